@@ -1,0 +1,268 @@
+/*
+ * naws.h — C ABI of the MI355X-native NA-fWebSOD hot path (libnaws_hip.so).
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes + a
+ * `void* stream` (a hipStream_t; NULL = the null stream), allocates nothing,
+ * launches asynchronously on that stream and returns 0 (NAWS_OK) or a
+ * negative NAWS_ERR_* code.  Shape / argument violations return an error
+ * where the reference op's CAFFE_ENFORCE* would throw (sites cited per
+ * function).  There is no global state: the two stateful reference ops
+ * (Stat: cur_iter_/init_; ACMWeightDecayMomentumSGDUpdate: iter_count_) take
+ * the state as explicit caller-owned arguments.
+ *
+ * All tensors are dense fp32 unless noted.  "ref:" citations are relative to
+ * the upstream repository root (shenyunhang/NA-fWebSOD).
+ */
+#ifndef NAWS_H_
+#define NAWS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAWS_OK 0
+#define NAWS_ERR_SHAPE (-1)       /* a dimension is inconsistent / non-positive */
+#define NAWS_ERR_ARG (-2)         /* an argument value is out of range */
+#define NAWS_ERR_NULL (-3)        /* a required pointer is NULL */
+#define NAWS_ERR_LAUNCH (-4)      /* hipGetLastError() != hipSuccess after launch */
+#define NAWS_ERR_UNSUPPORTED (-5) /* valid in the reference, not built here */
+
+#define NAWS_LAYOUT_NCHW 0
+#define NAWS_LAYOUT_NHWC 1
+
+/* Library identification; also used by the CPU-side "does it load" test. */
+const char* naws_version(void);
+/* hipError_t of the most recent failed launch in this thread (0 if none). */
+int naws_last_hip_error(void);
+
+/* ------------------------------------------------------------------------ *
+ * a-1  VGG-16 conv body   ref: detectron/modeling/VGG16.py:9-48 (Caffe2
+ *      Conv / Relu / MaxPool built-ins, pytorch v1.3.0 caffe2/operators).
+ * Activations are NHWC inside the body (channel-contiguous rows feed the
+ * implicit-GEMM MFMA kernel); the two boundary transposes are explicit.
+ * ------------------------------------------------------------------------ */
+
+/* conv1_1: X NCHW [N,3,H,W] -> Y NHWC [N,H,W,Cout]; 3x3, pad 1, stride 1,
+ * optional fused ReLU.  Wt is the reference blob layout [Cout,3,3,3] (OIHW). */
+int naws_conv3x3_c3_nchw_to_nhwc_fwd(const float* X, const float* Wt, const float* bias,
+                                     int N, int H, int W, int Cout, int relu,
+                                     float* Y, void* stream);
+
+/* Repack a reference conv weight blob [Cout,Cin,3,3] (OIHW) into the
+ * K-contiguous implicit-GEMM operand [Cout][kh][kw][Cin]. */
+int naws_conv3x3_pack_weight(const float* W_oihw, int Cout, int Cin, float* W_packed,
+                             void* stream);
+
+/* 3x3 conv, stride 1, pad == dilation (1 or 2), NHWC in/out, MFMA implicit
+ * GEMM (M = N*H*W pixels, N = Cout, K = 9*Cin), bias + optional ReLU fused.
+ * Requires Cin % 32 == 0 and Cout % 32 == 0 (true for every VGG layer but
+ * conv1_1).  Wp is the packed weight from naws_conv3x3_pack_weight. */
+int naws_conv3x3_nhwc_fwd(const float* X, const float* Wp, const float* bias,
+                          int N, int H, int W, int Cin, int Cout, int dilation, int relu,
+                          float* Y, void* stream);
+
+/* MaxPool kernel 2, pad 0, stride 1 or 2, floor output size (Caffe2 legacy
+ * pooling rule: Ho = (H - 2) / stride + 1).  NHWC in/out. */
+int naws_maxpool2x2_nhwc_fwd(const float* X, int N, int H, int W, int C, int stride,
+                             float* Y, void* stream);
+
+int naws_nchw_to_nhwc(const float* X, int N, int C, int H, int W, float* Y, void* stream);
+int naws_nhwc_to_nchw(const float* X, int N, int H, int W, int C, float* Y, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * a-2 / a-3  RoIPoolF (+ RoIFeatureBoost)
+ *   ref: detectron/modeling/detector.py:268-331 (op emission),
+ *        detectron/ops/roi_loop_pool_op.cu:31-101 (in-tree statement of the
+ *        Caffe2 RoIPoolF arithmetic; :72 holds the original empty-bin rule),
+ *        detectron/ops/roi_feature_boost_op.cc:8-35.
+ * X: [N,C,H,W] (layout NCHW) or [N,H,W,C] (layout NHWC).  rois: [R,5] =
+ * (batch_idx, x1, y1, x2, y2) in input-image pixels.  Y: [R,C,ph,pw].
+ * argmax (int32, same shape as Y, value h*W+w or -1) may be NULL.
+ * boost may be NULL; otherwise [R] and Y[r,...] *= boost[r] (fused a-3).
+ * Errors: R<0, C/H/W/ph/pw<=0 -> SHAPE; layout unknown -> ARG.
+ * ------------------------------------------------------------------------ */
+int naws_roi_pool_f_fwd(const float* X, int layout, int N, int C, int H, int W,
+                        const float* rois, int R, const float* boost,
+                        int pooled_h, int pooled_w, float spatial_scale,
+                        float* Y, int32_t* argmax, void* stream);
+
+/* Y[r,f] = X[r,f] * S[r]   (in place allowed)  ref: roi_feature_boost_op.cc:8-35 */
+int naws_roi_feature_boost_fwd(const float* X, const float* S, int R, int F, float* Y,
+                               void* stream);
+/* dX[r,f] = dY[r,f] * S[r]                     ref: roi_feature_boost_op.cc:37-66 */
+int naws_roi_feature_boost_bwd(const float* dY, const float* S, int R, int F, float* dX,
+                               void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * a-7  RoIIoU   ref: detectron/ops/roi_iou_op.cu:27-62 (kernel), :65-84 (op).
+ * rois [R,5] -> J [R,R]; coordinates truncated to int, diagonal forced to 1.
+ * ------------------------------------------------------------------------ */
+int naws_roi_iou_fwd(const float* rois, int R, float* J, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * a-4  FC layers as fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32)
+ *   ref: detectron/modeling/wsl_heads.py:654-681, webly_heads.py:463-502
+ *        (Caffe2 FC: Y = X W^T + b with W [out,in]; Relu; Dropout scale
+ *        1/(1-ratio)).
+ * ------------------------------------------------------------------------ */
+
+/* Epilogues of naws_gemm_f32 */
+#define NAWS_EPI_NONE 0          /* C = acc                                   */
+#define NAWS_EPI_BIAS 1          /* C = acc + bias[n]                         */
+#define NAWS_EPI_BIAS_RELU 2     /* C = max(acc + bias[n], 0)                 */
+#define NAWS_EPI_BIAS_RELU_DROP 3 /* C = max(acc+bias[n],0) * keep(m,n)/(1-p) */
+#define NAWS_EPI_GATE_POS 4      /* C = aux[m,n] > 0 ? acc * alpha : 0        */
+
+/* General row-major fp32 GEMM:  C[M,N] (+)= op(A)[M,K] * op(B)[K,N].
+ *   transA == 0: A is [M,K] (lda >= K);  transA == 1: A is stored [K,M] (lda >= M)
+ *   transB == 0: B is [K,N] (ldb >= N);  transB == 1: B is stored [N,K] (ldb >= K)
+ * `batch` independent problems with element strides strideA/B/C (bias and
+ * aux stride by strideBias / strideC).  accumulate != 0 adds to C.
+ * Dropout keep(m,n) is a counter-based hash of (seed, m*N+n); ratio in [0,1).
+ * Alignment: every leading dimension and pointer offset must be a multiple
+ * of 4 floats (16 B) -> NAWS_ERR_ARG otherwise. */
+int naws_gemm_f32(int transA, int transB, int M, int N, int K,
+                  const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+                  int epilogue, const float* bias, int64_t strideBias,
+                  const float* aux, int ldaux, float alpha,
+                  float drop_ratio, uint64_t seed, int accumulate, void* stream);
+
+/* The dropout keep-mask the GEMM epilogue applies, materialised (tests and
+ * the op-level Dropout API): mask[i] = keep(seed, i) ? 1 : 0, i in [0,n). */
+int naws_dropout_mask(uint64_t seed, float drop_ratio, int64_t n, float* mask, void* stream);
+
+/* db[n] (+)= sum_m dY[m,n]   (FC bias gradient) */
+int naws_colsum_f32(const float* dY, int M, int N, int ld, float* db, int accumulate,
+                    void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * a-5 / a-6  WSDDN two-stream outputs, both branches, per-image segments
+ *   ref: detectron/modeling/wsl_heads.py:23-56 (add_wsl_outputs),
+ *        detectron/modeling/webly_heads.py:32-74 (add_webly_outputs),
+ *        detectron/modeling/wsl_heads.py:213-227 (add_cls_pred).
+ * Inputs: four logit matrices [Rt,C] with row stride ld (floats).  Branch 0
+ * ("clean") uses (fc8c, fc8d); branch 1 ("noise") uses (fc8c + noisy_fc8c,
+ * fc8d + noisy_fc8d).  noisy_* may both be NULL -> only branch 0 is built.
+ * seg_off: int32 DEVICE array [nseg+1]; rows seg_off[s]..seg_off[s+1]-1 are
+ * image s (the reference is nseg == 1).  Softmax over classes is per row;
+ * softmax over proposals and the ReduceSum are per segment.
+ * Outputs (branch-major): alpha_cls, alpha_det, rois_pred [nb,Rt,C];
+ * cls_prob [nb,nseg,C];  nb = 1 or 2.
+ * ------------------------------------------------------------------------ */
+int naws_wsddn_outputs_fwd(const float* fc8c, const float* fc8d,
+                           const float* noisy_fc8c, const float* noisy_fc8d, int ld,
+                           const int32_t* seg_off, int nseg, int Rt, int C,
+                           float* alpha_cls, float* alpha_det, float* rois_pred,
+                           float* cls_prob, void* stream);
+
+/* a-11 (head part): backward of the above through Mul, both Softmaxes,
+ * ReduceSum and the residual Add.
+ * d_cls_prob [nb,nseg,C] -> d_fc8c, d_fc8d, d_noisy_fc8c, d_noisy_fc8d
+ * [Rt,C] with row stride ldd.  d_fc8c/d_fc8d receive clean + noise
+ * gradients (fan-in of the Add, webly_heads.py:57-61). */
+int naws_wsddn_outputs_bwd(const float* alpha_cls, const float* alpha_det,
+                           const float* rois_pred, const float* cls_prob,
+                           const float* d_cls_prob, const int32_t* seg_off, int nseg,
+                           int Rt, int C, int nb,
+                           float* d_fc8c, float* d_fc8d, float* d_noisy_fc8c,
+                           float* d_noisy_fc8d, int ldd, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * a-8  Spatial (IoU-graph) entropy gate
+ *   ref: detectron/modeling/webly_heads.py:265-391 (add_spatial_entropy_weight)
+ * rois [Rt,5], rois_pred [Rt,C] (branch 0), cls_prob [nseg,C], labels_oh
+ * [nseg,C] -> class_weight, class_weight_noise [nseg,C]; also exports
+ * hatE_sum and hatE_sum_norm [nseg,C] (inputs of the Stat ops).  J is never
+ * materialised: IoU is recomputed per (r,j) pair inside the J@E product.
+ * workspace: fp32, at least naws_entropy_gate_workspace_floats(Rt,C,nseg,max_seg).
+ * ------------------------------------------------------------------------ */
+int64_t naws_entropy_gate_workspace_floats(int Rt, int C, int nseg, int max_seg_len);
+int naws_entropy_gate_fwd(const float* rois, const float* rois_pred, const float* cls_prob,
+                          const float* labels_oh, const int32_t* seg_off, int nseg,
+                          int Rt, int C, int max_seg_len, float* workspace,
+                          float* class_weight, float* class_weight_noise,
+                          float* hatE_sum, float* hatE_sum_norm, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * a-9  (Weighted)CrossEntropyWithLogits forward / gradient
+ *   ref: detectron/ops/cross_entropy_wsl_op.cc:7-45 (CE fwd), :47-85 (CE
+ *        grad), :87-132 (WCE fwd), :134-180 (WCE grad); thresholds
+ *        cross_entropy_wsl_op.h:90-110 (1e-20 / 1e+4).
+ * X, L, W: [N,C] (W NULL -> unweighted op).  Y: scalar.  The loss is
+ * accumulated serially in index order by one lane, as the CPU op does.
+ * nprob independent problems laid out back to back (X,L,W,dX: [nprob,N,C];
+ * Y,dY: [nprob]) run in one launch; the reference op is nprob == 1.
+ * Errors: N<=0 or C<=0 -> SHAPE (ENFORCE sites .cc:16-17, :98-104).
+ * ------------------------------------------------------------------------ */
+int naws_weighted_ce_fwd(const float* X, const float* L, const float* W, int N, int C,
+                         int is_mean, int nprob, float* Y, void* stream);
+int naws_weighted_ce_bwd(const float* X, const float* L, const float* W, const float* dY,
+                         int N, int C, int is_mean, int nprob, float* dX, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * a-12  ACMWeightDecayMomentumSGDUpdate (fused), one launch per arena
+ *   ref: detectron/ops/acm_weightdecay_momentum_sgd_op.h:48-112,
+ *        detectron/ops/acm_weightdecay_momentum_sgd_op_gpu.cu:7-33,
+ *        detectron/modeling/optimizer_wsl.py:96-137 (per-param wd / lr_mult).
+ * Parameters live in one contiguous arena of `total` floats cut into `nseg`
+ * segments; seg_end[i] (int64 DEVICE array, exclusive prefix ends),
+ * seg_lr_mult[i], seg_wd[i] (fp32 DEVICE arrays).  lr is a DEVICE scalar.
+ * iter_count is the op's caller-owned state BEFORE this call (the op zeroes
+ * momentum and acmgrad when it is 0, .h:62-69).  Semantics per element:
+ *   acm += g; if ((iter_count+1) % iter_size == 0) { acm *= 1/(iter_size*
+ *   gpu_num); acm += wd*p; m = lr*lr_mult*acm + mom*m; p -= m (or the
+ *   nesterov form); acm = 0 }.  The grad blob is read-only (the op's
+ *   update value goes to the acmgrad output, which is then cleared,
+ *   .h:94-108).  acmgrad may be NULL when iter_size == 1: the buffer is then
+ *   identically zero between calls and the 3-read/2-write form is exact.
+ * ------------------------------------------------------------------------ */
+int naws_acm_sgd_update(const float* grad, float* momentum_buf, const float* lr, float* param,
+                        float* acmgrad, int64_t total, const int64_t* seg_end,
+                        const float* seg_lr_mult, const float* seg_wd, int nseg,
+                        float momentum, int nesterov, int iter_size, int gpu_num,
+                        int64_t iter_count, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * a-14  Stat accumulate   ref: detectron/ops/stat_op.cu:14-20, :24-78
+ * AI += I*L; AL += L  (n elements).  init != 0 zeroes AI/AL first (the op's
+ * init_ flag).  Printing AI/AL is host-side (ops.Stat).
+ * ------------------------------------------------------------------------ */
+int naws_stat_accumulate(const float* I, const float* L, int n, int init, float* AI,
+                         float* AL, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Small Caffe2 built-ins used op-by-op by the graph executor
+ * ------------------------------------------------------------------------ */
+#define NAWS_UN_LOG 0
+#define NAWS_UN_SCALE 1      /* y = x * a              */
+#define NAWS_UN_REPLACE_NAN 2 /* y = isnan(x) ? a : x   */
+#define NAWS_UN_LEAKY_RELU 3 /* y = x >= 0 ? x : a*x   */
+#define NAWS_UN_CLIP 4       /* y = min(max(x,a),b)    */
+#define NAWS_UN_RELU 5
+int naws_unary_f32(int op, const float* X, int64_t n, float a, float b, float* Y, void* stream);
+
+#define NAWS_BIN_ADD 0
+#define NAWS_BIN_SUB 1
+#define NAWS_BIN_MUL 2
+#define NAWS_BIN_DIV 3
+/* Y[r,c] = A[ra,ca] op B[rb,cb], numpy-style broadcasting of two 2-D
+ * operands: each of (rowsA, colsA, rowsB, colsB) is either 1 or the output
+ * extent. */
+int naws_binary_f32(int op, const float* A, int rowsA, int colsA, const float* B, int rowsB,
+                    int colsB, float* Y, int rows, int cols, void* stream);
+
+/* Softmax along axis 1 of a [rows, cols] matrix (max-subtracted). */
+int naws_softmax_rows_fwd(const float* X, int rows, int cols, float* Y, void* stream);
+int naws_softmax_rows_bwd(const float* Y, const float* dY, int rows, int cols, float* dX,
+                          void* stream);
+int naws_transpose2d_f32(const float* X, int rows, int cols, float* Y, void* stream);
+/* Y[c] = sum_r X[r,c]  (ReduceSum axes=[0]) */
+int naws_reduce_sum_axis0(const float* X, int rows, int cols, float* Y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAWS_H_ */

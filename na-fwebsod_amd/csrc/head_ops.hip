@@ -1,0 +1,514 @@
+// WSDDN two-stream outputs (dual softmax, residual noise branch, per-image
+// proposal sums), their backward, the IoU-graph entropy gate, the weighted
+// cross-entropy loss, Stat accumulate and the fused ACM momentum-SGD update.
+//
+// ref: detectron/modeling/wsl_heads.py:23-56, :213-227
+//      detectron/modeling/webly_heads.py:32-74, :265-391
+//      detectron/ops/cross_entropy_wsl_op.cc:7-180, cross_entropy_wsl_op.h:90-110
+//      detectron/ops/roi_iou_op.cu:27-62
+//      detectron/ops/acm_weightdecay_momentum_sgd_op.h:48-112, _gpu.cu:7-33
+//      detectron/ops/stat_op.cu:14-20
+//
+// All of this is [R,C] / [1,C] sized (R ~ 2000, C = 20..80): latency-bound.
+// The kernels are therefore few, each embarrassingly parallel over rows or
+// over (class, image) columns, with fixed-order reductions so results are
+// bitwise reproducible run to run.
+#include <math.h>
+#include "naws_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+
+// Block-wide fixed-order tree reductions (TB threads).
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < TB / 64; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < TB / 64; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+__device__ __forceinline__ int find_segment(const int32_t* seg_off, int nseg, int r) {
+  int s = 0;
+  while (s + 1 < nseg && r >= seg_off[s + 1]) ++s;
+  return s;
+}
+
+// ---- softmax over the proposals of one image, one class (column) ----------
+// grid (C, nseg, nb): alpha_det[b][r][c] = exp(z - max_r z) / sum_r exp(..)
+__global__ __launch_bounds__(TB) void det_softmax_kernel(
+    const float* __restrict__ fc8d, const float* __restrict__ noisy_fc8d, int ld,
+    const int32_t* __restrict__ seg_off, int Rt, int C, float* __restrict__ alpha_det) {
+  __shared__ float red[TB / 64];
+  const int c = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+  const int lo = seg_off[s], hi = seg_off[s + 1];
+  const bool noise = (b == 1);
+  float m = -INFINITY;
+  for (int r = lo + threadIdx.x; r < hi; r += TB) {
+    float z = fc8d[(int64_t)r * ld + c];
+    if (noise) z += noisy_fc8d[(int64_t)r * ld + c];
+    m = fmaxf(m, z);
+  }
+  m = block_max(m, red);
+  float sum = 0.f;
+  for (int r = lo + threadIdx.x; r < hi; r += TB) {
+    float z = fc8d[(int64_t)r * ld + c];
+    if (noise) z += noisy_fc8d[(int64_t)r * ld + c];
+    sum += expf(z - m);
+  }
+  sum = block_sum(sum, red);
+  float* out = alpha_det + (int64_t)b * Rt * C;
+  for (int r = lo + threadIdx.x; r < hi; r += TB) {
+    float z = fc8d[(int64_t)r * ld + c];
+    if (noise) z += noisy_fc8d[(int64_t)r * ld + c];
+    out[(int64_t)r * C + c] = expf(z - m) / sum;
+  }
+}
+
+// ---- softmax over classes per row, product with alpha_det ------------------
+// one lane = one (row, branch)
+__global__ __launch_bounds__(TB) void cls_softmax_mul_kernel(
+    const float* __restrict__ fc8c, const float* __restrict__ noisy_fc8c, int ld, int Rt, int C,
+    int nb, const float* __restrict__ alpha_det, float* __restrict__ alpha_cls,
+    float* __restrict__ rois_pred) {
+  const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+  if (t >= (int64_t)Rt * nb) return;
+  const int b = (int)(t / Rt), r = (int)(t % Rt);
+  const bool noise = (b == 1);
+  const float* zc = fc8c + (int64_t)r * ld;
+  const float* zn = noise ? noisy_fc8c + (int64_t)r * ld : nullptr;
+  float m = -INFINITY;
+  for (int c = 0; c < C; ++c) {
+    float z = zc[c];
+    if (noise) z += zn[c];
+    m = fmaxf(m, z);
+  }
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float z = zc[c];
+    if (noise) z += zn[c];
+    sum += expf(z - m);
+  }
+  const int64_t o = ((int64_t)b * Rt + r) * C;
+  for (int c = 0; c < C; ++c) {
+    float z = zc[c];
+    if (noise) z += zn[c];
+    float a = expf(z - m) / sum;
+    alpha_cls[o + c] = a;
+    rois_pred[o + c] = a * alpha_det[o + c];
+  }
+}
+
+// ---- cls_prob[b][s][c] = sum over the image's proposals --------------------
+__global__ __launch_bounds__(TB) void seg_colsum_kernel(const float* __restrict__ X,
+                                                        const int32_t* __restrict__ seg_off,
+                                                        int nseg, int Rt, int C,
+                                                        float* __restrict__ out) {
+  __shared__ float red[TB / 64];
+  const int c = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+  const int lo = seg_off[s], hi = seg_off[s + 1];
+  const float* x = X + (int64_t)b * Rt * C;
+  float acc = 0.f;
+  for (int r = lo + threadIdx.x; r < hi; r += TB) acc += x[(int64_t)r * C + c];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) out[((int64_t)b * nseg + s) * C + c] = acc;
+}
+
+// ---- backward: one lane = one row, both branches ---------------------------
+// Row softmax:  dz = y * (dy - <dy, y>).  Column softmax: the inner product
+// <dy_col, y_col> = sum_r g[c]*alpha_cls*alpha_det = g[c] * cls_prob[c].
+__global__ __launch_bounds__(TB) void wsddn_bwd_kernel(
+    const float* __restrict__ alpha_cls, const float* __restrict__ alpha_det,
+    const float* __restrict__ cls_prob, const float* __restrict__ d_cls_prob,
+    const int32_t* __restrict__ seg_off, int nseg, int Rt, int C, int nb,
+    float* __restrict__ d_fc8c, float* __restrict__ d_fc8d, float* __restrict__ d_nfc8c,
+    float* __restrict__ d_nfc8d, int ldd) {
+  const int r = blockIdx.x * TB + threadIdx.x;
+  if (r >= Rt) return;
+  const int s = find_segment(seg_off, nseg, r);
+  for (int b = 0; b < nb; ++b) {
+    const float* ac = alpha_cls + ((int64_t)b * Rt + r) * C;
+    const float* ad = alpha_det + ((int64_t)b * Rt + r) * C;
+    const float* g = d_cls_prob + ((int64_t)b * nseg + s) * C;
+    const float* y = cls_prob + ((int64_t)b * nseg + s) * C;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += (g[c] * ad[c]) * ac[c];
+    for (int c = 0; c < C; ++c) {
+      float dzc = ac[c] * (g[c] * ad[c] - dot);
+      float dzd = ad[c] * (g[c] * ac[c] - g[c] * y[c]);
+      const int64_t o = (int64_t)r * ldd + c;
+      if (b == 0) {
+        d_fc8c[o] = dzc;
+        d_fc8d[o] = dzd;
+      } else {
+        d_fc8c[o] += dzc;  // fan-in of Add(fc8c, noisy_fc8c)
+        d_fc8d[o] += dzd;
+        d_nfc8c[o] = dzc;
+        d_nfc8d[o] = dzd;
+      }
+    }
+  }
+}
+
+// ---- entropy gate ----------------------------------------------------------
+__device__ __forceinline__ float entropy_term(float p) {
+  float e = -(p * logf(p));
+  return isnan(e) ? 0.f : e;  // ReplaceNaN(value=0)
+}
+
+__device__ __forceinline__ float iou_int(int ax0, int ay0, int ax1, int ay1, int bx0, int by0,
+                                         int bx1, int by1) {
+  int xmin = max(ax0, bx0), ymin = max(ay0, by0);
+  int xmax = min(ax1, bx1), ymax = min(ay1, by1);
+  int w = (int)fmax(xmax - xmin + 1., 0.);
+  int h = (int)fmax(ymax - ymin + 1., 0.);
+  float inters = (float)(w * h);
+  float uni = (float)((ax1 - ax0 + 1.) * (ay1 - ay0 + 1.) + (bx1 - bx0 + 1.) * (by1 - by0 + 1.) -
+                      (double)inters);
+  return inters / uni;
+}
+
+constexpr int GR = 64;    // rows per workgroup
+constexpr int GJ = 64;    // j-tile staged in LDS
+constexpr int GCC = 20;   // classes accumulated per pass (registers)
+
+// grid (ceil(max_seg/GR), nseg, JCH).  Dpart[q][r][c] = sum_{j in chunk q} J(r,j) E[j,c]
+__global__ __launch_bounds__(GR) void gate_D_kernel(const float* __restrict__ rois,
+                                                    const float* __restrict__ rois_pred,
+                                                    const int32_t* __restrict__ seg_off,
+                                                    int Rt, int C, int JCH,
+                                                    float* __restrict__ Dpart) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int* jbox = reinterpret_cast<int*>(smem_raw);            // [GJ][4]
+  float* jE = reinterpret_cast<float*>(smem_raw) + GJ * 4;  // [GJ][GCC]
+  const int s = blockIdx.y, q = blockIdx.z;
+  const int lo = seg_off[s], hi = seg_off[s + 1];
+  const int len = hi - lo;
+  const int per = (len + JCH - 1) / JCH;
+  const int jlo = lo + q * per, jhi = min(hi, jlo + per);
+  const int r = lo + blockIdx.x * GR + threadIdx.x;
+  const bool active = r < hi;
+  int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+  if (active) {
+    bx0 = (int)rois[r * 5 + 1]; by0 = (int)rois[r * 5 + 2];
+    bx1 = (int)rois[r * 5 + 3]; by1 = (int)rois[r * 5 + 4];
+  }
+  for (int c0 = 0; c0 < C; c0 += GCC) {
+    const int cc = min(GCC, C - c0);
+    float acc[GCC];
+#pragma unroll
+    for (int k = 0; k < GCC; ++k) acc[k] = 0.f;
+    for (int j0 = jlo; j0 < jhi; j0 += GJ) {
+      const int nj = min(GJ, jhi - j0);
+      __syncthreads();
+      if ((int)threadIdx.x < nj) {
+        const int j = j0 + threadIdx.x;
+        jbox[threadIdx.x * 4 + 0] = (int)rois[j * 5 + 1];
+        jbox[threadIdx.x * 4 + 1] = (int)rois[j * 5 + 2];
+        jbox[threadIdx.x * 4 + 2] = (int)rois[j * 5 + 3];
+        jbox[threadIdx.x * 4 + 3] = (int)rois[j * 5 + 4];
+      }
+      for (int i = threadIdx.x; i < nj * GCC; i += GR) {
+        const int jj = i / GCC, k = i % GCC;
+        jE[i] = (k < cc) ? entropy_term(rois_pred[(int64_t)(j0 + jj) * C + c0 + k]) : 0.f;
+      }
+      __syncthreads();
+      if (active) {
+        for (int jj = 0; jj < nj; ++jj) {
+          const float w = (j0 + jj == r)
+                              ? 1.0f
+                              : iou_int(jbox[jj * 4], jbox[jj * 4 + 1], jbox[jj * 4 + 2],
+                                        jbox[jj * 4 + 3], bx0, by0, bx1, by1);
+#pragma unroll
+          for (int k = 0; k < GCC; ++k) acc[k] += w * jE[jj * GCC + k];
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < GCC; ++k)
+        if (k < cc) Dpart[((int64_t)q * Rt + r) * C + c0 + k] = acc[k];
+    }
+  }
+}
+
+// grid (C, nseg): hatE_sum, norm, clip, class weights
+__global__ __launch_bounds__(TB) void gate_finish_kernel(
+    const float* __restrict__ rois_pred, const float* __restrict__ Dpart,
+    const float* __restrict__ cls_prob, const float* __restrict__ labels_oh,
+    const int32_t* __restrict__ seg_off, int Rt, int C, int JCH, float* __restrict__ cw,
+    float* __restrict__ cw_noise, float* __restrict__ hatE_sum, float* __restrict__ hatE_norm) {
+  __shared__ float red[TB / 64];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int lo = seg_off[s], hi = seg_off[s + 1];
+  float acc = 0.f;
+  for (int r = lo + threadIdx.x; r < hi; r += TB) {
+    const float e = entropy_term(rois_pred[(int64_t)r * C + c]);
+    float d = 0.f;
+    for (int q = 0; q < JCH; ++q) d += Dpart[((int64_t)q * Rt + r) * C + c];
+    d = d >= 0.f ? d : 0.01f * d;  // LeakyRelu(alpha=0.01)
+    const float g = e / d;         // Div
+    acc += e * g;                  // Mul, ReduceSum
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    const int o = s * C + c;
+    const float y = cls_prob[o];
+    const float n = (float)(hi - lo);
+    const float norm = (logf(n) - logf(y)) * y;
+    float v = acc / norm;
+    v = (v < 0.f) ? 0.f : v;  // Clip(min=0,max=1); NaN passes through
+    v = (v > 1.f) ? 1.f : v;
+    const float bg = 1.0f - labels_oh[o];
+    const float wn = v * bg;
+    hatE_sum[o] = acc;
+    hatE_norm[o] = v;
+    cw_noise[o] = wn;
+    cw[o] = 1.0f - wn;
+  }
+}
+
+// ---- (weighted) cross entropy: one lane per problem, serial in index order -
+__global__ void wce_fwd_kernel(const float* __restrict__ X, const float* __restrict__ L,
+                               const float* __restrict__ W, int N, int C, int is_mean,
+                               float* __restrict__ Y) {
+  if (threadIdx.x != 0) return;
+  const int n = N * C;
+  X += (int64_t)blockIdx.x * n; L += (int64_t)blockIdx.x * n;
+  if (W) W += (int64_t)blockIdx.x * n;
+  Y += blockIdx.x;
+  const float norm = is_mean ? (float)C : 1.0f;
+  float loss = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float prob = fmaxf(X[i], 1e-20f);
+    const float one_prob = fmaxf(1.0f - X[i], 1e-20f);
+    float t = L[i] * logf(prob) + (1.0f - L[i]) * logf(one_prob);
+    if (W) t *= W[i];
+    loss -= t;
+  }
+  float y = loss / norm;
+  Y[0] = y * (float)(1.0 / N);
+}
+
+__global__ void wce_bwd_kernel(const float* __restrict__ X, const float* __restrict__ L,
+                               const float* __restrict__ W, const float* __restrict__ dY, int N,
+                               int C, int is_mean, float* __restrict__ dX) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * C) return;
+  const int64_t i = (int64_t)blockIdx.y * N * C + e;
+  const float norm = is_mean ? (float)C : 1.0f;
+  const float grad = dY[blockIdx.y];
+  const float prob = fmaxf(X[i], 1e-20f);
+  const float one_prob = fmaxf(1.0f - X[i], 1e-20f);
+  float v = fminf(grad * (-1.0f * L[i] / prob - (-1.0f) * (1.0f - L[i]) / one_prob) / norm, 1e4f);
+  if (W) v *= W[i];
+  dX[i] = v * (float)(1.0 / N);
+}
+
+// ---- Stat -------------------------------------------------------------------
+__global__ void stat_kernel(const float* __restrict__ I, const float* __restrict__ L, int n,
+                            int init, float* __restrict__ AI, float* __restrict__ AL) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float ai = init ? 0.f : AI[i];
+  const float al = init ? 0.f : AL[i];
+  AI[i] = I[i] * L[i] + ai;
+  AL[i] = L[i] + al;
+}
+
+// ---- fused ACM weight-decay momentum SGD over a parameter arena ------------
+__global__ __launch_bounds__(TB) void acm_sgd_kernel(
+    const float4* __restrict__ grad, float4* __restrict__ mom, const float* __restrict__ lr,
+    float4* __restrict__ param, float4* __restrict__ acm, int64_t total4,
+    const int64_t* __restrict__ seg_end, const float* __restrict__ seg_lr_mult,
+    const float* __restrict__ seg_wd, int nseg, float momentum, int nesterov, float scale,
+    int do_update, int first) {
+  const float base_lr = lr[0];
+  for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * TB) {
+    const int64_t e = i * 4;
+    int lo = 0, hi = nseg - 1;  // first segment with seg_end > e
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (seg_end[mid] > e) hi = mid; else lo = mid + 1;
+    }
+    const float LR = base_lr * seg_lr_mult[lo];
+    const float wd = seg_wd[lo];
+    float4 g = grad[i];
+    float4 a = (first || acm == nullptr) ? make_float4(0.f, 0.f, 0.f, 0.f) : acm[i];
+    a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+    if (!do_update) { acm[i] = a; if (first) mom[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+    float4 p = param[i];
+    float4 m = first ? make_float4(0.f, 0.f, 0.f, 0.f) : mom[i];
+    float av[4] = {a.x, a.y, a.z, a.w}, pv[4] = {p.x, p.y, p.z, p.w};
+    float mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = av[k] * scale;  // Normalize
+      t = t + wd * pv[k];       // Regularize (Axpy)
+      if (!nesterov) {
+        const float adj = LR * t + momentum * mv[k];
+        mv[k] = adj;
+        pv[k] -= adj;
+      } else {
+        const float mi = mv[k];
+        const float mi_new = momentum * mi + LR * t;
+        mv[k] = mi_new;
+        pv[k] -= (1.0f + momentum) * mi_new - momentum * mi;
+      }
+    }
+    // the update value goes to the acmgrad OUTPUT, which is then cleared; the
+    // grad blob itself is not written (acm_weightdecay_momentum_sgd_op.h:94-108)
+    mom[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    param[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    if (acm) acm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int naws_wsddn_outputs_fwd(const float* fc8c, const float* fc8d,
+                                      const float* noisy_fc8c, const float* noisy_fc8d, int ld,
+                                      const int32_t* seg_off, int nseg, int Rt, int C,
+                                      float* alpha_cls, float* alpha_det, float* rois_pred,
+                                      float* cls_prob, void* stream) {
+  if (Rt <= 0 || C <= 0 || nseg <= 0 || ld < C) return NAWS_ERR_SHAPE;
+  if ((noisy_fc8c == nullptr) != (noisy_fc8d == nullptr)) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(fc8c); NAWS_REQUIRE_PTR(fc8d); NAWS_REQUIRE_PTR(seg_off);
+  NAWS_REQUIRE_PTR(alpha_cls); NAWS_REQUIRE_PTR(alpha_det); NAWS_REQUIRE_PTR(rois_pred);
+  NAWS_REQUIRE_PTR(cls_prob);
+  if (nseg > 65535 || C > 65535) return NAWS_ERR_UNSUPPORTED;
+  const int nb = noisy_fc8c ? 2 : 1;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(det_softmax_kernel, dim3(C, nseg, nb), dim3(TB), 0, s, fc8d, noisy_fc8d, ld,
+                     seg_off, Rt, C, alpha_det);
+  const int64_t rows = (int64_t)Rt * nb;
+  hipLaunchKernelGGL(cls_softmax_mul_kernel, dim3((unsigned)naws_cdiv(rows, TB)), dim3(TB), 0, s,
+                     fc8c, noisy_fc8c, ld, Rt, C, nb, alpha_det, alpha_cls, rois_pred);
+  hipLaunchKernelGGL(seg_colsum_kernel, dim3(C, nseg, nb), dim3(TB), 0, s, rois_pred, seg_off,
+                     nseg, Rt, C, cls_prob);
+  return naws_check_launch();
+}
+
+extern "C" int naws_wsddn_outputs_bwd(const float* alpha_cls, const float* alpha_det,
+                                      const float* rois_pred, const float* cls_prob,
+                                      const float* d_cls_prob, const int32_t* seg_off, int nseg,
+                                      int Rt, int C, int nb, float* d_fc8c, float* d_fc8d,
+                                      float* d_noisy_fc8c, float* d_noisy_fc8d, int ldd,
+                                      void* stream) {
+  (void)rois_pred;
+  if (Rt <= 0 || C <= 0 || nseg <= 0 || ldd < C) return NAWS_ERR_SHAPE;
+  if (nb != 1 && nb != 2) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(alpha_cls); NAWS_REQUIRE_PTR(alpha_det); NAWS_REQUIRE_PTR(cls_prob);
+  NAWS_REQUIRE_PTR(d_cls_prob); NAWS_REQUIRE_PTR(seg_off);
+  NAWS_REQUIRE_PTR(d_fc8c); NAWS_REQUIRE_PTR(d_fc8d);
+  if (nb == 2) { NAWS_REQUIRE_PTR(d_noisy_fc8c); NAWS_REQUIRE_PTR(d_noisy_fc8d); }
+  hipLaunchKernelGGL(wsddn_bwd_kernel, dim3((unsigned)naws_cdiv(Rt, TB)), dim3(TB), 0,
+                     (hipStream_t)stream, alpha_cls, alpha_det, cls_prob, d_cls_prob, seg_off, nseg,
+                     Rt, C, nb, d_fc8c, d_fc8d, d_noisy_fc8c, d_noisy_fc8d, ldd);
+  return naws_check_launch();
+}
+
+static int gate_chunks(int max_seg_len) {
+  int q = (max_seg_len + 255) / 256;
+  return q < 1 ? 1 : (q > 16 ? 16 : q);
+}
+
+extern "C" int64_t naws_entropy_gate_workspace_floats(int Rt, int C, int nseg, int max_seg_len) {
+  (void)nseg;
+  if (Rt <= 0 || C <= 0 || max_seg_len <= 0) return 0;
+  return (int64_t)gate_chunks(max_seg_len) * Rt * C;
+}
+
+extern "C" int naws_entropy_gate_fwd(const float* rois, const float* rois_pred,
+                                     const float* cls_prob, const float* labels_oh,
+                                     const int32_t* seg_off, int nseg, int Rt, int C,
+                                     int max_seg_len, float* workspace, float* class_weight,
+                                     float* class_weight_noise, float* hatE_sum,
+                                     float* hatE_sum_norm, void* stream) {
+  if (Rt <= 0 || C <= 0 || nseg <= 0 || max_seg_len <= 0 || max_seg_len > Rt)
+    return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(rois); NAWS_REQUIRE_PTR(rois_pred); NAWS_REQUIRE_PTR(cls_prob);
+  NAWS_REQUIRE_PTR(labels_oh); NAWS_REQUIRE_PTR(seg_off); NAWS_REQUIRE_PTR(workspace);
+  NAWS_REQUIRE_PTR(class_weight); NAWS_REQUIRE_PTR(class_weight_noise);
+  NAWS_REQUIRE_PTR(hatE_sum); NAWS_REQUIRE_PTR(hatE_sum_norm);
+  if (nseg > 65535 || C > 65535) return NAWS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int JCH = gate_chunks(max_seg_len);
+  const size_t lds = GJ * 4 * sizeof(int) + GJ * GCC * sizeof(float);
+  hipLaunchKernelGGL(gate_D_kernel, dim3((unsigned)naws_cdiv(max_seg_len, GR), nseg, JCH),
+                     dim3(GR), lds, s, rois, rois_pred, seg_off, Rt, C, JCH, workspace);
+  hipLaunchKernelGGL(gate_finish_kernel, dim3(C, nseg), dim3(TB), 0, s, rois_pred, workspace,
+                     cls_prob, labels_oh, seg_off, Rt, C, JCH, class_weight, class_weight_noise,
+                     hatE_sum, hatE_sum_norm);
+  return naws_check_launch();
+}
+
+extern "C" int naws_weighted_ce_fwd(const float* X, const float* L, const float* W, int N, int C,
+                                    int is_mean, int nprob, float* Y, void* stream) {
+  if (N <= 0 || C <= 0 || nprob <= 0 || nprob > 65535) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(L); NAWS_REQUIRE_PTR(Y);
+  hipLaunchKernelGGL(wce_fwd_kernel, dim3(nprob), dim3(64), 0, (hipStream_t)stream, X, L, W, N, C,
+                     is_mean, Y);
+  return naws_check_launch();
+}
+
+extern "C" int naws_weighted_ce_bwd(const float* X, const float* L, const float* W,
+                                    const float* dY, int N, int C, int is_mean, int nprob,
+                                    float* dX, void* stream) {
+  if (N <= 0 || C <= 0 || nprob <= 0 || nprob > 65535) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(L); NAWS_REQUIRE_PTR(dY); NAWS_REQUIRE_PTR(dX);
+  hipLaunchKernelGGL(wce_bwd_kernel, dim3((unsigned)naws_cdiv((int64_t)N * C, 64), nprob), dim3(64), 0,
+                     (hipStream_t)stream, X, L, W, dY, N, C, is_mean, dX);
+  return naws_check_launch();
+}
+
+extern "C" int naws_stat_accumulate(const float* I, const float* L, int n, int init, float* AI,
+                                    float* AL, void* stream) {
+  if (n <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(I); NAWS_REQUIRE_PTR(L); NAWS_REQUIRE_PTR(AI); NAWS_REQUIRE_PTR(AL);
+  hipLaunchKernelGGL(stat_kernel, dim3((unsigned)naws_cdiv(n, 64)), dim3(64), 0,
+                     (hipStream_t)stream, I, L, n, init, AI, AL);
+  return naws_check_launch();
+}
+
+extern "C" int naws_acm_sgd_update(const float* grad, float* momentum_buf, const float* lr,
+                                   float* param, float* acmgrad, int64_t total,
+                                   const int64_t* seg_end, const float* seg_lr_mult,
+                                   const float* seg_wd, int nseg, float momentum, int nesterov,
+                                   int iter_size, int gpu_num, int64_t iter_count, void* stream) {
+  if (total <= 0 || nseg <= 0 || iter_size <= 0 || gpu_num <= 0 || iter_count < 0)
+    return NAWS_ERR_SHAPE;
+  if (total % 4 != 0) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(grad); NAWS_REQUIRE_PTR(momentum_buf); NAWS_REQUIRE_PTR(lr);
+  NAWS_REQUIRE_PTR(param); NAWS_REQUIRE_PTR(seg_end);
+  if (acmgrad == nullptr && iter_size != 1) return NAWS_ERR_NULL;
+  NAWS_REQUIRE_PTR(seg_lr_mult); NAWS_REQUIRE_PTR(seg_wd);
+  if ((((uintptr_t)grad | (uintptr_t)momentum_buf | (uintptr_t)param | (uintptr_t)acmgrad) % 16))
+    return NAWS_ERR_ARG;
+  const int64_t total4 = total / 4;
+  const int do_update = ((iter_count + 1) % iter_size == 0) ? 1 : 0;
+  const float scale = (float)(1.0 / ((double)iter_size * (double)gpu_num));
+  const int blocks = (int)std::min<int64_t>(naws_cdiv(total4, TB), 256 * 16);
+  hipLaunchKernelGGL(acm_sgd_kernel, dim3(blocks), dim3(TB), 0, (hipStream_t)stream,
+                     (const float4*)grad, (float4*)momentum_buf, lr, (float4*)param, (float4*)acmgrad,
+                     total4, seg_end, seg_lr_mult, seg_wd, nseg, momentum, nesterov, scale,
+                     do_update, iter_count == 0 ? 1 : 0);
+  return naws_check_launch();
+}

@@ -1,0 +1,365 @@
+// Memory-bound helpers of the conv body (conv1_1 direct, 2x2 max-pool, layout
+// transposes, weight repack) and the small Caffe2 built-ins the graph executor
+// runs op-by-op (unary / binary-broadcast / row softmax / transpose / column
+// sums / dropout mask).
+//
+// ref: detectron/modeling/VGG16.py:9-48 (Conv/Relu/MaxPool emission),
+//      SURVEY.md §2 #13 (Caffe2 built-ins on the path, pytorch v1.3.0).
+#include <float.h>
+#include <math.h>
+#include "naws_common.h"
+
+thread_local int g_naws_last_hip_error = 0;
+
+extern "C" const char* naws_version(void) { return "naws-hip 0.1 (gfx950)"; }
+extern "C" int naws_last_hip_error(void) { return g_naws_last_hip_error; }
+
+namespace {
+
+constexpr int TB = 256;
+
+// ---- conv1_1: NCHW (3 ch) -> NHWC (Cout), 3x3 pad 1 -------------------------
+// One lane = one pixel x 16 output channels; the 27 input taps are loaded once
+// into registers, weights come from LDS ([27][Cout], broadcast reads).
+template <int OC_PER>
+__global__ __launch_bounds__(TB) void conv_c3_kernel(const float* __restrict__ X,
+                                                     const float* __restrict__ Wt,
+                                                     const float* __restrict__ bias, int N, int H,
+                                                     int W, int Cout, int relu,
+                                                     float* __restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);  // [27][Cout]
+  float* bl = wl + 27 * Cout;
+  for (int i = threadIdx.x; i < 27 * Cout; i += TB) {
+    const int k = i / Cout, o = i % Cout;  // k = (c*3+kh)*3+kw : OIHW -> [k][o]
+    wl[i] = Wt[o * 27 + k];
+  }
+  for (int i = threadIdx.x; i < Cout; i += TB) bl[i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int groups = Cout / OC_PER;
+  const int64_t total = (int64_t)N * H * W * groups;
+  for (int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * TB) {
+    const int g = (int)(t % groups);
+    const int64_t pix = t / groups;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((int64_t)W * H));
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int yy = y + kh - 1, xx = x + kw - 1;
+          const bool ok = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+          in[(c * 3 + kh) * 3 + kw] =
+              ok ? X[(((int64_t)n * 3 + c) * H + yy) * W + xx] : 0.f;
+        }
+    float acc[OC_PER];
+#pragma unroll
+    for (int o = 0; o < OC_PER; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float v = in[k];
+      const float* wr = wl + k * Cout + g * OC_PER;
+#pragma unroll
+      for (int o = 0; o < OC_PER; ++o) acc[o] = fmaf(v, wr[o], acc[o]);
+    }
+    float* out = Y + pix * Cout + g * OC_PER;
+#pragma unroll
+    for (int o = 0; o < OC_PER; o += 4) {
+      float4 r;
+      r.x = acc[o + 0] + bl[g * OC_PER + o + 0];
+      r.y = acc[o + 1] + bl[g * OC_PER + o + 1];
+      r.z = acc[o + 2] + bl[g * OC_PER + o + 2];
+      r.w = acc[o + 3] + bl[g * OC_PER + o + 3];
+      if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+      *reinterpret_cast<float4*>(out + o) = r;
+    }
+  }
+}
+
+// ---- weight repack OIHW -> [O][kh][kw][I] ----------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ Wi, int Cout, int Cin,
+                                   float* __restrict__ Wo) {
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin);
+    const int tap = (int)((i / Cin) % 9);
+    const int o = (int)(i / ((int64_t)Cin * 9));
+    Wo[i] = Wi[((int64_t)o * Cin + c) * 9 + tap];
+  }
+}
+
+// ---- 2x2 max pool, NHWC, float4 lanes along channels -----------------------
+__global__ __launch_bounds__(TB) void maxpool2_kernel(const float4* __restrict__ X, int N, int H,
+                                                      int W, int C4, int stride, int Ho, int Wo,
+                                                      float4* __restrict__ Y) {
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * TB) {
+    const int c = (int)(t % C4);
+    const int xo = (int)((t / C4) % Wo);
+    const int yo = (int)((t / ((int64_t)C4 * Wo)) % Ho);
+    const int n = (int)(t / ((int64_t)C4 * Wo * Ho));
+    const int y = yo * stride, x = xo * stride;
+    const float4* p = X + (((int64_t)n * H + y) * W + x) * C4 + c;
+    const float4 a = p[0], b = p[C4], d = p[(int64_t)W * C4], e = p[(int64_t)W * C4 + C4];
+    float4 r;
+    r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x));
+    r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y));
+    r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z));
+    r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w));
+    Y[t] = r;
+  }
+}
+
+// ---- NCHW <-> NHWC via 32x32 LDS tiles over (C, HW) ------------------------
+// in: [batch][rows][cols] -> out: [batch][cols][rows]
+__global__ void transpose_batched_kernel(const float* __restrict__ X, int rows, int cols,
+                                         float* __restrict__ Y) {
+  __shared__ float tile[32][33];
+  const int64_t boff = (int64_t)blockIdx.z * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[i][threadIdx.x] = X[boff + (int64_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) Y[boff + (int64_t)c * rows + r] = tile[threadIdx.x][i];
+  }
+}
+
+// ---- small built-ins --------------------------------------------------------
+__global__ void unary_kernel(int op, const float* __restrict__ X, int64_t n, float a, float b,
+                             float* __restrict__ Y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = X[i];
+    float y;
+    switch (op) {
+      case NAWS_UN_LOG: y = logf(x); break;
+      case NAWS_UN_SCALE: y = x * a; break;
+      case NAWS_UN_REPLACE_NAN: y = isnan(x) ? a : x; break;
+      case NAWS_UN_LEAKY_RELU: y = x >= 0.f ? x : a * x; break;
+      case NAWS_UN_CLIP: y = (x < a) ? a : x; y = (y > b) ? b : y; break;
+      default: y = fmaxf(x, 0.f); break;
+    }
+    Y[i] = y;
+  }
+}
+
+__global__ void binary_kernel(int op, const float* __restrict__ A, int rowsA, int colsA,
+                              const float* __restrict__ B, int rowsB, int colsB,
+                              float* __restrict__ Y, int rows, int cols) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const float a = A[(int64_t)(rowsA == 1 ? 0 : r) * colsA + (colsA == 1 ? 0 : c)];
+    const float b = B[(int64_t)(rowsB == 1 ? 0 : r) * colsB + (colsB == 1 ? 0 : c)];
+    float y;
+    switch (op) {
+      case NAWS_BIN_ADD: y = a + b; break;
+      case NAWS_BIN_SUB: y = a - b; break;
+      case NAWS_BIN_MUL: y = a * b; break;
+      default: y = a / b; break;
+    }
+    Y[i] = y;
+  }
+}
+
+// one wave per row
+__global__ __launch_bounds__(TB) void softmax_rows_kernel(const float* __restrict__ X, int rows,
+                                                          int cols, float* __restrict__ Y) {
+  const int row = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* x = X + (int64_t)row * cols;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += expf(x[c] - m);
+  s = wave_sum(s);
+  float* y = Y + (int64_t)row * cols;
+  for (int c = lane; c < cols; c += 64) y[c] = expf(x[c] - m) / s;
+}
+
+__global__ __launch_bounds__(TB) void softmax_rows_bwd_kernel(const float* __restrict__ Y,
+                                                              const float* __restrict__ dY,
+                                                              int rows, int cols,
+                                                              float* __restrict__ dX) {
+  const int row = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* y = Y + (int64_t)row * cols;
+  const float* dy = dY + (int64_t)row * cols;
+  float d = 0.f;
+  for (int c = lane; c < cols; c += 64) d += y[c] * dy[c];
+  d = wave_sum(d);
+  float* dx = dX + (int64_t)row * cols;
+  for (int c = lane; c < cols; c += 64) dx[c] = y[c] * (dy[c] - d);
+}
+
+// Y[c] (+)= sum_r X[r*ld + c]; one workgroup per 64 columns, 4 row-lanes each
+__global__ __launch_bounds__(TB) void colsum_kernel(const float* __restrict__ X, int M, int N,
+                                                    int ld, float* __restrict__ Y,
+                                                    int accumulate) {
+  __shared__ float part[TB / 64][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < N)
+    for (int r = rl; r < M; r += TB / 64) acc += X[(int64_t)r * ld + c];
+  part[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float t = part[0][threadIdx.x];
+#pragma unroll
+    for (int i = 1; i < TB / 64; ++i) t += part[i][threadIdx.x];
+    Y[c] = accumulate ? Y[c] + t : t;
+  }
+}
+
+__global__ void dropout_mask_kernel(uint64_t seed, uint32_t thr, int64_t n,
+                                    float* __restrict__ mask) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    mask[i] = naws_keep(seed, (uint64_t)i, thr) ? 1.0f : 0.0f;
+}
+
+inline int grid_for(int64_t n, int tb = TB, int cap = 256 * 8) {
+  return (int)std::min<int64_t>(std::max<int64_t>(naws_cdiv(n, tb), 1), cap);
+}
+
+}  // namespace
+
+extern "C" int naws_conv3x3_c3_nchw_to_nhwc_fwd(const float* X, const float* Wt,
+                                                const float* bias, int N, int H, int W, int Cout,
+                                                int relu, float* Y, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (Cout % 16 != 0 || ((uintptr_t)Y % 16) != 0) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(Wt); NAWS_REQUIRE_PTR(Y);
+  const size_t lds = (size_t)(27 + 1) * Cout * sizeof(float);
+  const int64_t total = (int64_t)N * H * W * (Cout / 16);
+  hipLaunchKernelGGL(conv_c3_kernel<16>, dim3(grid_for(total, TB, 256 * 16)), dim3(TB), lds,
+                     (hipStream_t)stream, X, Wt, bias, N, H, W, Cout, relu, Y);
+  return naws_check_launch();
+}
+
+extern "C" int naws_conv3x3_pack_weight(const float* W_oihw, int Cout, int Cin, float* W_packed,
+                                        void* stream) {
+  if (Cout <= 0 || Cin <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(W_oihw); NAWS_REQUIRE_PTR(W_packed);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((int64_t)Cout * Cin * 9)), dim3(TB), 0,
+                     (hipStream_t)stream, W_oihw, Cout, Cin, W_packed);
+  return naws_check_launch();
+}
+
+extern "C" int naws_maxpool2x2_nhwc_fwd(const float* X, int N, int H, int W, int C, int stride,
+                                        float* Y, void* stream) {
+  if (N <= 0 || H < 2 || W < 2 || C <= 0) return NAWS_ERR_SHAPE;
+  if (stride != 1 && stride != 2) return NAWS_ERR_ARG;
+  if (C % 4 != 0 || (((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(Y);
+  const int Ho = (H - 2) / stride + 1, Wo = (W - 2) / stride + 1;
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total, TB, 256 * 16)), dim3(TB), 0,
+                     (hipStream_t)stream, (const float4*)X, N, H, W, C / 4, stride, Ho, Wo,
+                     (float4*)Y);
+  return naws_check_launch();
+}
+
+static int transpose_batched(const float* X, int batch, int rows, int cols, float* Y,
+                             void* stream) {
+  if (batch <= 0 || rows <= 0 || cols <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(Y);
+  if (batch > 65535 || naws_cdiv(rows, 32) > 65535) return NAWS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)naws_cdiv(cols, 32), (unsigned)naws_cdiv(rows, 32), batch);
+  hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, X,
+                     rows, cols, Y);
+  return naws_check_launch();
+}
+
+extern "C" int naws_nchw_to_nhwc(const float* X, int N, int C, int H, int W, float* Y,
+                                 void* stream) {
+  if (H <= 0 || W <= 0) return NAWS_ERR_SHAPE;
+  return transpose_batched(X, N, C, H * W, Y, stream);
+}
+extern "C" int naws_nhwc_to_nchw(const float* X, int N, int H, int W, int C, float* Y,
+                                 void* stream) {
+  if (H <= 0 || W <= 0) return NAWS_ERR_SHAPE;
+  return transpose_batched(X, N, H * W, C, Y, stream);
+}
+extern "C" int naws_transpose2d_f32(const float* X, int rows, int cols, float* Y, void* stream) {
+  return transpose_batched(X, 1, rows, cols, Y, stream);
+}
+
+extern "C" int naws_unary_f32(int op, const float* X, int64_t n, float a, float b, float* Y,
+                              void* stream) {
+  if (n < 0) return NAWS_ERR_SHAPE;
+  if (op < NAWS_UN_LOG || op > NAWS_UN_RELU) return NAWS_ERR_ARG;
+  if (n == 0) return NAWS_OK;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(Y);
+  hipLaunchKernelGGL(unary_kernel, dim3(grid_for(n)), dim3(TB), 0, (hipStream_t)stream, op, X, n,
+                     a, b, Y);
+  return naws_check_launch();
+}
+
+extern "C" int naws_binary_f32(int op, const float* A, int rowsA, int colsA, const float* B,
+                               int rowsB, int colsB, float* Y, int rows, int cols, void* stream) {
+  if (rows <= 0 || cols <= 0) return NAWS_ERR_SHAPE;
+  if (op < NAWS_BIN_ADD || op > NAWS_BIN_DIV) return NAWS_ERR_ARG;
+  if ((rowsA != 1 && rowsA != rows) || (rowsB != 1 && rowsB != rows) ||
+      (colsA != 1 && colsA != cols) || (colsB != 1 && colsB != cols))
+    return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(A); NAWS_REQUIRE_PTR(B); NAWS_REQUIRE_PTR(Y);
+  hipLaunchKernelGGL(binary_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(TB), 0,
+                     (hipStream_t)stream, op, A, rowsA, colsA, B, rowsB, colsB, Y, rows, cols);
+  return naws_check_launch();
+}
+
+extern "C" int naws_softmax_rows_fwd(const float* X, int rows, int cols, float* Y, void* stream) {
+  if (rows <= 0 || cols <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(Y);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)naws_cdiv(rows, TB / 64)), dim3(TB), 0,
+                     (hipStream_t)stream, X, rows, cols, Y);
+  return naws_check_launch();
+}
+extern "C" int naws_softmax_rows_bwd(const float* Y, const float* dY, int rows, int cols,
+                                     float* dX, void* stream) {
+  if (rows <= 0 || cols <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(Y); NAWS_REQUIRE_PTR(dY); NAWS_REQUIRE_PTR(dX);
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)naws_cdiv(rows, TB / 64)), dim3(TB),
+                     0, (hipStream_t)stream, Y, dY, rows, cols, dX);
+  return naws_check_launch();
+}
+
+extern "C" int naws_colsum_f32(const float* dY, int M, int N, int ld, float* db, int accumulate,
+                               void* stream) {
+  if (M <= 0 || N <= 0 || ld < N) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(dY); NAWS_REQUIRE_PTR(db);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)naws_cdiv(N, 64)), dim3(TB), 0,
+                     (hipStream_t)stream, dY, M, N, ld, db, accumulate);
+  return naws_check_launch();
+}
+extern "C" int naws_reduce_sum_axis0(const float* X, int rows, int cols, float* Y, void* stream) {
+  return naws_colsum_f32(X, rows, cols, cols, Y, 0, stream);
+}
+
+extern "C" int naws_dropout_mask(uint64_t seed, float drop_ratio, int64_t n, float* mask,
+                                 void* stream) {
+  if (n < 0) return NAWS_ERR_SHAPE;
+  if (!(drop_ratio >= 0.f && drop_ratio < 1.f)) return NAWS_ERR_ARG;
+  if (n == 0) return NAWS_OK;
+  NAWS_REQUIRE_PTR(mask);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(TB), 0, (hipStream_t)stream,
+                     seed, naws_drop_threshold(drop_ratio), n, mask);
+  return naws_check_launch();
+}

@@ -1,0 +1,256 @@
+// RoIPoolF (+ fused RoIFeatureBoost), RoIFeatureBoost fwd/bwd, RoIIoU for gfx950.
+//
+// ref: detectron/ops/roi_loop_pool_op.cu:31-101 (RoIPoolF arithmetic; :72 original
+//      empty-bin rule), detectron/ops/roi_feature_boost_op.cc:8-66,
+//      detectron/ops/roi_iou_op.cu:27-62.
+//
+// HBM-bound byte work: the NHWC kernel maps one lane to one channel so every
+// window pixel is one contiguous read per workgroup, stages the
+// [channels x bins] tile in LDS and writes the (c, ph, pw)-ordered output row
+// as one contiguous stream.
+#include <float.h>
+#include "naws_common.h"
+
+namespace {
+
+struct RoiBins {
+  int batch, start_w, start_h, roi_w, roi_h;
+};
+
+// Integer RoI frame: must stay bit-exact with the reference (roundf on the
+// fp32 product, max(.,1) on the extents).
+__device__ __forceinline__ RoiBins roi_frame(const float* roi, float spatial_scale) {
+  RoiBins b;
+  b.batch = (int)roi[0];
+  int start_w = (int)roundf(roi[1] * spatial_scale);
+  int start_h = (int)roundf(roi[2] * spatial_scale);
+  int end_w = (int)roundf(roi[3] * spatial_scale);
+  int end_h = (int)roundf(roi[4] * spatial_scale);
+  b.start_w = start_w;
+  b.start_h = start_h;
+  b.roi_w = max(end_w - start_w + 1, 1);
+  b.roi_h = max(end_h - start_h + 1, 1);
+  return b;
+}
+
+__device__ __forceinline__ void bin_range(int p, float bin_size, int roi_start, int limit,
+                                          int& lo, int& hi) {
+  int s = (int)floorf((float)p * bin_size);
+  int e = (int)ceilf((float)(p + 1) * bin_size);
+  lo = min(max(s + roi_start, 0), limit);
+  hi = min(max(e + roi_start, 0), limit);
+}
+
+// ---- NHWC: one workgroup = one RoI x CT channels -------------------------
+constexpr int CT = 256;
+
+template <bool WITH_ARGMAX>
+__global__ __launch_bounds__(CT) void roi_pool_nhwc_kernel(
+    const float* __restrict__ X, int C, int H, int W, const float* __restrict__ rois,
+    const float* __restrict__ boost, int PH, int PW, float spatial_scale,
+    float* __restrict__ Y, int32_t* __restrict__ argmax) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int nb = PH * PW;
+  float* tile = reinterpret_cast<float*>(smem_raw);
+  int32_t* itile = reinterpret_cast<int32_t*>(smem_raw) + CT * nb;
+
+  const int r = blockIdx.x;
+  const int c0 = blockIdx.y * CT;
+  const int c = c0 + threadIdx.x;
+  const bool active = c < C;
+
+  const RoiBins rb = roi_frame(rois + (int64_t)r * 5, spatial_scale);
+  const float bin_h = (float)rb.roi_h / (float)PH;
+  const float bin_w = (float)rb.roi_w / (float)PW;
+  const float scale = boost ? boost[r] : 1.0f;
+  const float* Xn = X + (int64_t)rb.batch * H * W * C + (active ? c : 0);
+
+  for (int ph = 0; ph < PH; ++ph) {
+    int hs, he;
+    bin_range(ph, bin_h, rb.start_h, H, hs, he);
+    for (int pw = 0; pw < PW; ++pw) {
+      int ws, we;
+      bin_range(pw, bin_w, rb.start_w, W, ws, we);
+      const bool empty = (he <= hs) || (we <= ws);
+      float best = empty ? 0.0f : -FLT_MAX;
+      int besti = -1;
+      if (active) {
+        for (int h = hs; h < he; ++h) {
+          const float* row = Xn + (int64_t)h * W * C;
+          int w = ws;
+          for (; w + 4 <= we; w += 4) {  // 4 independent loads in flight
+            float v0 = row[(int64_t)(w + 0) * C];
+            float v1 = row[(int64_t)(w + 1) * C];
+            float v2 = row[(int64_t)(w + 2) * C];
+            float v3 = row[(int64_t)(w + 3) * C];
+            if (v0 > best) { best = v0; besti = h * W + w; }
+            if (v1 > best) { best = v1; besti = h * W + w + 1; }
+            if (v2 > best) { best = v2; besti = h * W + w + 2; }
+            if (v3 > best) { best = v3; besti = h * W + w + 3; }
+          }
+          for (; w < we; ++w) {
+            float v = row[(int64_t)w * C];
+            if (v > best) { best = v; besti = h * W + w; }
+          }
+        }
+      }
+      const int bin = ph * PW + pw;
+      tile[threadIdx.x * nb + bin] = best * scale;
+      if (WITH_ARGMAX) itile[threadIdx.x * nb + bin] = besti;
+    }
+  }
+  __syncthreads();
+  const int nch = min(CT, C - c0);
+  const int count = nch * nb;
+  const int64_t base = ((int64_t)r * C + c0) * nb;
+  for (int i = threadIdx.x; i < count; i += CT) {
+    Y[base + i] = tile[i];
+    if (WITH_ARGMAX) argmax[base + i] = itile[i];
+  }
+}
+
+// ---- NCHW: one lane = one output element (op-level API on reference layout)
+__global__ void roi_pool_nchw_kernel(int64_t total, const float* __restrict__ X, int C, int H,
+                                     int W, const float* __restrict__ rois,
+                                     const float* __restrict__ boost, int PH, int PW,
+                                     float spatial_scale, float* __restrict__ Y,
+                                     int32_t* __restrict__ argmax) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int pw = (int)(idx % PW);
+    int ph = (int)((idx / PW) % PH);
+    int c = (int)((idx / PW / PH) % C);
+    int r = (int)(idx / PW / PH / C);
+    const RoiBins rb = roi_frame(rois + (int64_t)r * 5, spatial_scale);
+    const float bin_h = (float)rb.roi_h / (float)PH;
+    const float bin_w = (float)rb.roi_w / (float)PW;
+    int hs, he, ws, we;
+    bin_range(ph, bin_h, rb.start_h, H, hs, he);
+    bin_range(pw, bin_w, rb.start_w, W, ws, we);
+    const bool empty = (he <= hs) || (we <= ws);
+    float best = empty ? 0.0f : -FLT_MAX;
+    int besti = -1;
+    const float* Xc = X + ((int64_t)rb.batch * C + c) * H * W;
+    for (int h = hs; h < he; ++h)
+      for (int w = ws; w < we; ++w) {
+        float v = Xc[h * W + w];
+        if (v > best) { best = v; besti = h * W + w; }
+      }
+    Y[idx] = best * (boost ? boost[r] : 1.0f);
+    if (argmax) argmax[idx] = besti;
+  }
+}
+
+__global__ void row_scale_kernel(const float* __restrict__ X, const float* __restrict__ S,
+                                 int64_t total, int F, float* __restrict__ Y) {
+  // 16-byte lanes when F % 4 == 0 (rows then never straddle a float4)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    Y[i] = X[i] * S[i / F];
+  }
+}
+__global__ void row_scale4_kernel(const float4* __restrict__ X, const float* __restrict__ S,
+                                  int64_t total4, int F4, float4* __restrict__ Y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = S[i / F4];
+    float4 v = X[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    Y[i] = v;
+  }
+}
+
+// ---- RoIIoU --------------------------------------------------------------
+__global__ void roi_iou_kernel(const float* __restrict__ rois, int n, float* __restrict__ J) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // column
+  const int j = blockIdx.y;                              // row
+  if (i >= n) return;
+  const int64_t idx = (int64_t)j * n + i;
+  if (i == j) { J[idx] = 1.0f; return; }
+  int ixmin = (int)rois[i * 5 + 1], iymin = (int)rois[i * 5 + 2];
+  int ixmax = (int)rois[i * 5 + 3], iymax = (int)rois[i * 5 + 4];
+  int jxmin = (int)rois[j * 5 + 1], jymin = (int)rois[j * 5 + 2];
+  int jxmax = (int)rois[j * 5 + 3], jymax = (int)rois[j * 5 + 4];
+  int xmin = max(ixmin, jxmin), ymin = max(iymin, jymin);
+  int xmax = min(ixmax, jxmax), ymax = min(iymax, jymax);
+  int w = (int)fmax(xmax - xmin + 1., 0.);
+  int h = (int)fmax(ymax - ymin + 1., 0.);
+  float inters = (float)(w * h);
+  float uni = (float)((ixmax - ixmin + 1.) * (iymax - iymin + 1.) +
+                      (jxmax - jxmin + 1.) * (jymax - jymin + 1.) - (double)inters);
+  J[idx] = inters / uni;
+}
+
+}  // namespace
+
+extern "C" int naws_roi_pool_f_fwd(const float* X, int layout, int N, int C, int H, int W,
+                                   const float* rois, int R, const float* boost, int pooled_h,
+                                   int pooled_w, float spatial_scale, float* Y,
+                                   int32_t* argmax, void* stream) {
+  if (R < 0 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0)
+    return NAWS_ERR_SHAPE;
+  if (layout != NAWS_LAYOUT_NCHW && layout != NAWS_LAYOUT_NHWC) return NAWS_ERR_ARG;
+  if (R == 0) return NAWS_OK;
+  NAWS_REQUIRE_PTR(X);
+  NAWS_REQUIRE_PTR(rois);
+  NAWS_REQUIRE_PTR(Y);
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = pooled_h * pooled_w;
+  if (layout == NAWS_LAYOUT_NHWC) {
+    size_t lds = (size_t)CT * nb * sizeof(float) * (argmax ? 2 : 1);
+    if (lds > 160 * 1024) return NAWS_ERR_UNSUPPORTED;
+    dim3 grid(R, (unsigned)naws_cdiv(C, CT));
+    if (argmax)
+      hipLaunchKernelGGL(roi_pool_nhwc_kernel<true>, grid, dim3(CT), lds, s, X, C, H, W, rois,
+                         boost, pooled_h, pooled_w, spatial_scale, Y, argmax);
+    else
+      hipLaunchKernelGGL(roi_pool_nhwc_kernel<false>, grid, dim3(CT), lds, s, X, C, H, W, rois,
+                         boost, pooled_h, pooled_w, spatial_scale, Y, argmax);
+  } else {
+    int64_t total = (int64_t)R * C * nb;
+    int blocks = (int)std::min<int64_t>(naws_cdiv(total, 256), 256 * 32);
+    hipLaunchKernelGGL(roi_pool_nchw_kernel, dim3(blocks), dim3(256), 0, s, total, X, C, H, W,
+                       rois, boost, pooled_h, pooled_w, spatial_scale, Y, argmax);
+  }
+  return naws_check_launch();
+}
+
+static int row_scale(const float* X, const float* S, int R, int F, float* Y, void* stream) {
+  if (R < 0 || F <= 0) return NAWS_ERR_SHAPE;
+  if (R == 0) return NAWS_OK;
+  NAWS_REQUIRE_PTR(X);
+  NAWS_REQUIRE_PTR(S);
+  NAWS_REQUIRE_PTR(Y);
+  hipStream_t s = (hipStream_t)stream;
+  int64_t total = (int64_t)R * F;
+  bool vec = (F % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y) % 16 == 0);
+  if (vec) {
+    int64_t t4 = total / 4;
+    int blocks = (int)std::min<int64_t>(naws_cdiv(t4, 256), 2048);
+    hipLaunchKernelGGL(row_scale4_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)X, S, t4,
+                       F / 4, (float4*)Y);
+  } else {
+    int blocks = (int)std::min<int64_t>(naws_cdiv(total, 256), 2048);
+    hipLaunchKernelGGL(row_scale_kernel, dim3(blocks), dim3(256), 0, s, X, S, total, F, Y);
+  }
+  return naws_check_launch();
+}
+
+extern "C" int naws_roi_feature_boost_fwd(const float* X, const float* S, int R, int F, float* Y,
+                                          void* stream) {
+  return row_scale(X, S, R, F, Y, stream);
+}
+extern "C" int naws_roi_feature_boost_bwd(const float* dY, const float* S, int R, int F,
+                                          float* dX, void* stream) {
+  return row_scale(dY, S, R, F, dX, stream);
+}
+
+extern "C" int naws_roi_iou_fwd(const float* rois, int R, float* J, void* stream) {
+  if (R < 0) return NAWS_ERR_SHAPE;
+  if (R == 0) return NAWS_OK;
+  NAWS_REQUIRE_PTR(rois);
+  NAWS_REQUIRE_PTR(J);
+  dim3 grid((unsigned)naws_cdiv(R, 256), R);
+  hipLaunchKernelGGL(roi_iou_kernel, grid, dim3(256), 0, (hipStream_t)stream, rois, R, J);
+  return naws_check_launch();
+}

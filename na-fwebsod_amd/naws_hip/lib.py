@@ -1,0 +1,104 @@
+"""ctypes binding of libnaws_hip.so — the C ABI declared in include/naws.h.
+
+This is the ONLY way the host code reaches the kernels: plain pointers and
+sizes, no torch types cross the boundary.  The library must be built
+(`make -C na-fwebsod_amd/csrc`, or `__graft_entry__.build()`); there is no CPU
+fallback: a missing library raises at import of any op.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libnaws_hip.so')
+
+OK, ERR_SHAPE, ERR_ARG, ERR_NULL, ERR_LAUNCH, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+_ERR_NAMES = {
+    ERR_SHAPE: 'NAWS_ERR_SHAPE', ERR_ARG: 'NAWS_ERR_ARG', ERR_NULL: 'NAWS_ERR_NULL',
+    ERR_LAUNCH: 'NAWS_ERR_LAUNCH', ERR_UNSUPPORTED: 'NAWS_ERR_UNSUPPORTED',
+}
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_RELU_DROP, EPI_GATE_POS = range(5)
+UN_LOG, UN_SCALE, UN_REPLACE_NAN, UN_LEAKY_RELU, UN_CLIP, UN_RELU = range(6)
+BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV = range(4)
+
+p, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+
+# name -> argtypes; every function returns int except the two noted below.
+PROTOTYPES = {
+    'naws_conv3x3_c3_nchw_to_nhwc_fwd': [p, p, p, i32, i32, i32, i32, i32, p, p],
+    'naws_conv3x3_pack_weight': [p, i32, i32, p, p],
+    'naws_conv3x3_nhwc_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
+    'naws_maxpool2x2_nhwc_fwd': [p, i32, i32, i32, i32, i32, p, p],
+    'naws_nchw_to_nhwc': [p, i32, i32, i32, i32, p, p],
+    'naws_nhwc_to_nchw': [p, i32, i32, i32, i32, p, p],
+    'naws_roi_pool_f_fwd': [p, i32, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, p, p],
+    'naws_roi_feature_boost_fwd': [p, p, i32, i32, p, p],
+    'naws_roi_feature_boost_bwd': [p, p, i32, i32, p, p],
+    'naws_roi_iou_fwd': [p, i32, p, p],
+    'naws_gemm_f32': [i32, i32, i32, i32, i32, p, i32, p, i32, p, i32, i32, i64, i64, i64,
+                      i32, p, i64, p, i32, f32, f32, u64, i32, p],
+    'naws_dropout_mask': [u64, f32, i64, p, p],
+    'naws_colsum_f32': [p, i32, i32, i32, p, i32, p],
+    'naws_wsddn_outputs_fwd': [p, p, p, p, i32, p, i32, i32, i32, p, p, p, p, p],
+    'naws_wsddn_outputs_bwd': [p, p, p, p, p, p, i32, i32, i32, i32, p, p, p, p, i32, p],
+    'naws_entropy_gate_fwd': [p, p, p, p, p, i32, i32, i32, i32, p, p, p, p, p, p],
+    'naws_weighted_ce_fwd': [p, p, p, i32, i32, i32, i32, p, p],
+    'naws_weighted_ce_bwd': [p, p, p, p, i32, i32, i32, i32, p, p],
+    'naws_acm_sgd_update': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p],
+    'naws_stat_accumulate': [p, p, i32, i32, p, p, p],
+    'naws_unary_f32': [i32, p, i64, f32, f32, p, p],
+    'naws_binary_f32': [i32, p, i32, i32, p, i32, i32, p, i32, i32, p],
+    'naws_softmax_rows_fwd': [p, i32, i32, p, p],
+    'naws_softmax_rows_bwd': [p, p, i32, i32, p, p],
+    'naws_transpose2d_f32': [p, i32, i32, p, p],
+    'naws_reduce_sum_axis0': [p, i32, i32, p, p],
+}
+SPECIAL = {
+    'naws_version': ([], C.c_char_p),
+    'naws_last_hip_error': ([], i32),
+    'naws_entropy_gate_workspace_floats': ([i32, i32, i32, i32], i64),
+}
+ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(SPECIAL))
+
+
+class NawsError(RuntimeError):
+    """Raised where the reference op's CAFFE_ENFORCE would throw."""
+
+    def __init__(self, fn, code, hip_error=0):
+        self.fn, self.code, self.hip_error = fn, code, hip_error
+        msg = '%s failed: %s' % (fn, _ERR_NAMES.get(code, code))
+        if code == ERR_LAUNCH:
+            msg += ' (hipError %d)' % hip_error
+        super(NawsError, self).__init__(msg)
+
+
+_lib = None
+
+
+def load():
+    """Load the library once; loud failure if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libnaws_hip.so not found at %s — build it with `make -C na-fwebsod_amd/csrc` '
+            '(or __graft_entry__.build()); there is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = argtypes, i32
+    for name, (argtypes, restype) in SPECIAL.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = argtypes, restype
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise NawsError on a negative code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != OK:
+        raise NawsError(name, rc, lib.naws_last_hip_error() if rc == ERR_LAUNCH else 0)
+    return rc

@@ -1,0 +1,350 @@
+"""Tensor-level wrappers over the C ABI (include/naws.h).
+
+torch is plumbing only: it owns device memory and the current HIP stream; every
+computation below is one or more hand-written gfx950 kernels in libnaws_hip.so.
+Inputs must be CUDA(HIP) fp32 tensors; anything else raises (no CPU fallback).
+"""
+import torch
+
+from . import lib as L
+
+_f32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=_f32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError('%s must be a HIP device tensor (the naws ops have no CPU path)' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    return t
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------------------
+# conv body
+# ----------------------------------------------------------------------------
+def conv3x3_c3_nchw_to_nhwc(x, w_oihw, bias, relu=True, out=None):
+    _chk(x, 'x'); _chk(w_oihw, 'w')
+    n, c, h, w = x.shape
+    assert c == 3 and tuple(w_oihw.shape[1:]) == (3, 3, 3)
+    cout = w_oihw.shape[0]
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    L.call('naws_conv3x3_c3_nchw_to_nhwc_fwd', x.data_ptr(), w_oihw.data_ptr(), _ptr(bias),
+           n, h, w, cout, int(relu), y.data_ptr(), _stream())
+    return y
+
+
+def conv3x3_pack_weight(w_oihw):
+    _chk(w_oihw, 'w')
+    cout, cin = w_oihw.shape[:2]
+    wp = torch.empty((cout, 3, 3, cin), device=w_oihw.device, dtype=_f32)
+    L.call('naws_conv3x3_pack_weight', w_oihw.data_ptr(), cout, cin, wp.data_ptr(), _stream())
+    return wp
+
+
+def conv3x3_nhwc(x, w_packed, bias, dilation=1, relu=True, out=None):
+    _chk(x, 'x'); _chk(w_packed, 'w_packed')
+    n, h, w, cin = x.shape
+    cout = w_packed.shape[0]
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    L.call('naws_conv3x3_nhwc_fwd', x.data_ptr(), w_packed.data_ptr(), _ptr(bias), n, h, w, cin,
+           cout, dilation, int(relu), y.data_ptr(), _stream())
+    return y
+
+
+def maxpool2x2_nhwc(x, stride, out=None):
+    _chk(x, 'x')
+    n, h, w, c = x.shape
+    ho, wo = (h - 2) // stride + 1, (w - 2) // stride + 1
+    y = out if out is not None else torch.empty((n, ho, wo, c), device=x.device, dtype=_f32)
+    L.call('naws_maxpool2x2_nhwc_fwd', x.data_ptr(), n, h, w, c, stride, y.data_ptr(), _stream())
+    return y
+
+
+def nchw_to_nhwc(x):
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, c), device=x.device, dtype=_f32)
+    L.call('naws_nchw_to_nhwc', x.data_ptr(), n, c, h, w, y.data_ptr(), _stream())
+    return y
+
+
+def nhwc_to_nchw(x):
+    _chk(x, 'x')
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=_f32)
+    L.call('naws_nhwc_to_nchw', x.data_ptr(), n, h, w, c, y.data_ptr(), _stream())
+    return y
+
+
+# ----------------------------------------------------------------------------
+# RoI ops
+# ----------------------------------------------------------------------------
+def roi_pool_f(x, rois, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
+               layout='NCHW', with_argmax=False, out=None):
+    _chk(x, 'x'); _chk(rois, 'rois')
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise L.NawsError('naws_roi_pool_f_fwd', L.ERR_SHAPE)
+    if layout == 'NCHW':
+        n, c, h, w = x.shape
+        lay = L.LAYOUT_NCHW
+    elif layout == 'NHWC':
+        n, h, w, c = x.shape
+        lay = L.LAYOUT_NHWC
+    else:
+        raise L.NawsError('naws_roi_pool_f_fwd', L.ERR_ARG)
+    r = rois.shape[0]
+    if boost is not None:
+        _chk(boost, 'boost')
+        assert boost.numel() == r
+    y = out if out is not None else torch.empty((r, c, pooled_h, pooled_w), device=x.device,
+                                                dtype=_f32)
+    am = torch.empty((r, c, pooled_h, pooled_w), device=x.device, dtype=torch.int32) \
+        if with_argmax else None
+    L.call('naws_roi_pool_f_fwd', x.data_ptr(), lay, n, c, h, w, rois.data_ptr(), r, _ptr(boost),
+           pooled_h, pooled_w, float(spatial_scale), y.data_ptr(), _ptr(am), _stream())
+    return (y, am) if with_argmax else y
+
+
+def roi_feature_boost(x, s, out=None):
+    _chk(x, 'X'); _chk(s, 'S')
+    if s.shape[0] != s.numel() or x.shape[0] != s.shape[0]:
+        raise L.NawsError('naws_roi_feature_boost_fwd', L.ERR_SHAPE)
+    r = x.shape[0]
+    f = x.numel() // max(r, 1)
+    y = out if out is not None else torch.empty_like(x)
+    L.call('naws_roi_feature_boost_fwd', x.data_ptr(), s.data_ptr(), r, f, y.data_ptr(), _stream())
+    return y
+
+
+def roi_feature_boost_grad(dy, s):
+    _chk(dy, 'dY'); _chk(s, 'S')
+    if s.shape[0] != s.numel() or dy.shape[0] != s.shape[0]:
+        raise L.NawsError('naws_roi_feature_boost_bwd', L.ERR_SHAPE)
+    r = dy.shape[0]
+    f = dy.numel() // max(r, 1)
+    dx = torch.empty_like(dy)
+    L.call('naws_roi_feature_boost_bwd', dy.data_ptr(), s.data_ptr(), r, f, dx.data_ptr(),
+           _stream())
+    return dx
+
+
+def roi_iou(rois):
+    _chk(rois, 'rois')
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise L.NawsError('naws_roi_iou_fwd', L.ERR_SHAPE)
+    r = rois.shape[0]
+    j = torch.empty((r, r), device=rois.device, dtype=_f32)
+    L.call('naws_roi_iou_fwd', rois.data_ptr(), r, j.data_ptr(), _stream())
+    return j
+
+
+# ----------------------------------------------------------------------------
+# GEMM / FC
+# ----------------------------------------------------------------------------
+def gemm(a, b, trans_a=False, trans_b=False, out=None, epilogue=L.EPI_NONE, bias=None, aux=None,
+         alpha=1.0, drop_ratio=0.0, seed=0, accumulate=False):
+    """C[M,N] (+)= op(A) op(B) on row-major 2-D (or batched 3-D) tensors.  Inputs may be
+    row-strided views (last dim contiguous)."""
+    batched = a.dim() == 3
+    if batched:
+        batch = a.shape[0]
+        a2, b2 = a[0], b[0]
+    else:
+        batch, a2, b2 = 1, a, b
+    for t, nm in ((a2, 'A'), (b2, 'B')):
+        if not t.is_cuda or t.dtype != _f32 or t.stride(-1) != 1:
+            raise TypeError('%s must be a HIP fp32 tensor with a contiguous last dim' % nm)
+    m = a2.shape[1] if trans_a else a2.shape[0]
+    k = a2.shape[0] if trans_a else a2.shape[1]
+    kb = b2.shape[1] if trans_b else b2.shape[0]
+    n = b2.shape[0] if trans_b else b2.shape[1]
+    if k != kb:
+        raise L.NawsError('naws_gemm_f32', L.ERR_SHAPE)
+    if out is None:
+        out = torch.empty(((batch, m, n) if batched else (m, n)), device=a.device, dtype=_f32)
+    c2 = out[0] if batched else out
+    sa = a.stride(0) if batched else 0
+    sb = b.stride(0) if batched else 0
+    sc = out.stride(0) if batched else 0
+    sbias = 0
+    if bias is not None and bias.dim() == 2:
+        sbias = bias.stride(0)
+    L.call('naws_gemm_f32', int(trans_a), int(trans_b), m, n, k, a.data_ptr(), a2.stride(0),
+           b.data_ptr(), b2.stride(0), out.data_ptr(), c2.stride(0), batch, sa, sb, sc,
+           epilogue, _ptr(bias), sbias, _ptr(aux),
+           (aux.stride(-2) if aux is not None else 0), float(alpha), float(drop_ratio),
+           int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate), _stream())
+    return out
+
+
+def dropout_mask(seed, ratio, n, device):
+    m = torch.empty((n,), device=device, dtype=_f32)
+    L.call('naws_dropout_mask', int(seed) & 0xFFFFFFFFFFFFFFFF, float(ratio), n, m.data_ptr(),
+           _stream())
+    return m
+
+
+def colsum(x, out=None, accumulate=False):
+    assert x.dim() == 2 and x.stride(1) == 1
+    m, n = x.shape
+    y = out if out is not None else torch.empty((n,), device=x.device, dtype=_f32)
+    L.call('naws_colsum_f32', x.data_ptr(), m, n, x.stride(0), y.data_ptr(), int(accumulate),
+           _stream())
+    return y
+
+
+# ----------------------------------------------------------------------------
+# WSDDN head tail
+# ----------------------------------------------------------------------------
+def wsddn_outputs(fc8c, fc8d, noisy_fc8c, noisy_fc8d, seg_off):
+    """-> alpha_cls, alpha_det, rois_pred [nb,Rt,C], cls_prob [nb,nseg,C].  The four logit
+    matrices may be column slices of one wider row-major buffer (same row stride)."""
+    rt, c = fc8c.shape
+    ld = fc8c.stride(0)
+    for t in (fc8d, noisy_fc8c, noisy_fc8d):
+        if t is not None and (t.stride(0) != ld or t.stride(1) != 1):
+            raise ValueError('logit matrices must share one row stride')
+    nseg = seg_off.numel() - 1
+    nb = 2 if noisy_fc8c is not None else 1
+    dev = fc8c.device
+    ac = torch.empty((nb, rt, c), device=dev, dtype=_f32)
+    ad = torch.empty_like(ac)
+    rp = torch.empty_like(ac)
+    cp = torch.empty((nb, nseg, c), device=dev, dtype=_f32)
+    L.call('naws_wsddn_outputs_fwd', fc8c.data_ptr(), fc8d.data_ptr(), _ptr(noisy_fc8c),
+           _ptr(noisy_fc8d), ld, seg_off.data_ptr(), nseg, rt, c, ac.data_ptr(), ad.data_ptr(),
+           rp.data_ptr(), cp.data_ptr(), _stream())
+    return ac, ad, rp, cp
+
+
+def wsddn_outputs_grad(alpha_cls, alpha_det, rois_pred, cls_prob, d_cls_prob, seg_off, out=None):
+    """-> d_fc8c, d_fc8d, d_noisy_fc8c, d_noisy_fc8d as column slices of `out`
+    ([Rt, 4C]; allocated when None)."""
+    nb, rt, c = alpha_cls.shape
+    nseg = seg_off.numel() - 1
+    if out is None:
+        out = torch.empty((rt, 4 * c), device=alpha_cls.device, dtype=_f32)
+    ld = out.stride(0)
+    base = out.data_ptr()
+    ptrs = [base + 4 * c * i for i in range(4)]
+    L.call('naws_wsddn_outputs_bwd', alpha_cls.data_ptr(), alpha_det.data_ptr(),
+           rois_pred.data_ptr(), cls_prob.data_ptr(), d_cls_prob.data_ptr(), seg_off.data_ptr(),
+           nseg, rt, c, nb, ptrs[0], ptrs[1], ptrs[2] if nb == 2 else 0,
+           ptrs[3] if nb == 2 else 0, ld, _stream())
+    return out
+
+
+def entropy_gate(rois, rois_pred, cls_prob, labels_oh, seg_off, max_seg_len):
+    """-> class_weight, class_weight_noise, hatE_sum, hatE_sum_norm, each [nseg,C]."""
+    _chk(rois, 'rois'); _chk(rois_pred, 'rois_pred'); _chk(cls_prob, 'cls_prob')
+    _chk(labels_oh, 'labels_oh')
+    rt, c = rois_pred.shape
+    nseg = seg_off.numel() - 1
+    dev = rois.device
+    nws = L.load().naws_entropy_gate_workspace_floats(rt, c, nseg, max_seg_len)
+    ws = torch.empty((max(nws, 1),), device=dev, dtype=_f32)
+    outs = [torch.empty((nseg, c), device=dev, dtype=_f32) for _ in range(4)]
+    L.call('naws_entropy_gate_fwd', rois.data_ptr(), rois_pred.data_ptr(), cls_prob.data_ptr(),
+           labels_oh.data_ptr(), seg_off.data_ptr(), nseg, rt, c, max_seg_len, ws.data_ptr(),
+           outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
+           _stream())
+    return tuple(outs)
+
+
+def weighted_ce(x, l, w, is_mean, nprob=1):
+    _chk(x, 'X'); _chk(l, 'L')
+    if x.shape != l.shape or (w is not None and w.shape != x.shape):
+        raise L.NawsError('naws_weighted_ce_fwd', L.ERR_SHAPE)
+    c = x.shape[-1]
+    n = x.numel() // (c * nprob)
+    y = torch.empty((nprob,), device=x.device, dtype=_f32)
+    L.call('naws_weighted_ce_fwd', x.data_ptr(), l.data_ptr(), _ptr(w), n, c, int(is_mean), nprob,
+           y.data_ptr(), _stream())
+    return y
+
+
+def weighted_ce_grad(x, l, w, dy, is_mean, nprob=1):
+    _chk(x, 'X'); _chk(l, 'L'); _chk(dy, 'dY')
+    if x.shape != l.shape or (w is not None and w.shape != x.shape) or dy.numel() != nprob:
+        raise L.NawsError('naws_weighted_ce_bwd', L.ERR_SHAPE)
+    c = x.shape[-1]
+    n = x.numel() // (c * nprob)
+    dx = torch.empty_like(x)
+    L.call('naws_weighted_ce_bwd', x.data_ptr(), l.data_ptr(), _ptr(w), dy.data_ptr(), n, c,
+           int(is_mean), nprob, dx.data_ptr(), _stream())
+    return dx
+
+
+def acm_sgd_update(grad, momentum_buf, lr, param, acmgrad, seg_end, seg_lr_mult, seg_wd,
+                   momentum, nesterov, iter_size, gpu_num, iter_count):
+    total = param.numel()
+    L.call('naws_acm_sgd_update', grad.data_ptr(), momentum_buf.data_ptr(), lr.data_ptr(),
+           param.data_ptr(), _ptr(acmgrad), total, seg_end.data_ptr(), seg_lr_mult.data_ptr(),
+           seg_wd.data_ptr(), seg_end.numel(), float(momentum), int(nesterov), int(iter_size),
+           int(gpu_num), int(iter_count), _stream())
+
+
+def stat_accumulate(i, l, ai, al, init):
+    L.call('naws_stat_accumulate', i.data_ptr(), l.data_ptr(), i.numel(), int(init),
+           ai.data_ptr(), al.data_ptr(), _stream())
+
+
+# ----------------------------------------------------------------------------
+# small built-ins
+# ----------------------------------------------------------------------------
+def unary(op, x, a=0.0, b=0.0, out=None):
+    _chk(x, 'X')
+    y = out if out is not None else torch.empty_like(x)
+    L.call('naws_unary_f32', op, x.data_ptr(), x.numel(), float(a), float(b), y.data_ptr(),
+           _stream())
+    return y
+
+
+def binary(op, a, b):
+    _chk(a, 'A'); _chk(b, 'B')
+    a2 = a.reshape(-1, a.shape[-1]) if a.dim() >= 1 else a.reshape(1, 1)
+    b2 = b.reshape(-1, b.shape[-1]) if b.dim() >= 1 else b.reshape(1, 1)
+    rows, cols = max(a2.shape[0], b2.shape[0]), max(a2.shape[1], b2.shape[1])
+    y = torch.empty((rows, cols), device=a.device, dtype=_f32)
+    L.call('naws_binary_f32', op, a2.data_ptr(), a2.shape[0], a2.shape[1], b2.data_ptr(),
+           b2.shape[0], b2.shape[1], y.data_ptr(), rows, cols, _stream())
+    return y
+
+
+def softmax_rows(x):
+    _chk(x, 'X')
+    y = torch.empty_like(x)
+    L.call('naws_softmax_rows_fwd', x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), _stream())
+    return y
+
+
+def softmax_rows_grad(y, dy):
+    _chk(y, 'Y'); _chk(dy, 'dY')
+    dx = torch.empty_like(y)
+    L.call('naws_softmax_rows_bwd', y.data_ptr(), dy.data_ptr(), y.shape[0], y.shape[1],
+           dx.data_ptr(), _stream())
+    return dx
+
+
+def transpose2d(x):
+    _chk(x, 'X')
+    y = torch.empty((x.shape[1], x.shape[0]), device=x.device, dtype=_f32)
+    L.call('naws_transpose2d_f32', x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), _stream())
+    return y
+
+
+def reduce_sum_axis0(x):
+    _chk(x, 'X')
+    y = torch.empty((1, x.shape[1]), device=x.device, dtype=_f32)
+    L.call('naws_reduce_sum_axis0', x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), _stream())
+    return y

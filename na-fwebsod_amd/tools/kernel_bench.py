@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the hot-path kernels at the BASELINE config-2 shapes
+(2 images 600x1000, 2000 proposals each, fp32).  Prints one line per kernel with
+achieved TFLOP/s or GB/s.  Kernels run on torch's current stream, so
+torch.cuda.Event brackets them correctly."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from naws_hip import ops, lib  # noqa: E402
+
+
+def timeit(fn, iters=5, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters  # ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--images', type=int, default=2)
+    ap.add_argument('--rois', type=int, default=2000)
+    ap.add_argument('--what', default='gemm,conv,roi')
+    ap.add_argument('--iters', type=int, default=5)
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    R = a.images * a.rois
+    what = a.what.split(',')
+
+    def rnd(*shape):
+        return torch.empty(shape, device=dev).uniform_(-1, 1)
+
+    if 'gemm' in what:
+        shapes = [
+            ('fc6 fwd  NT', R, 8192, 25088, False, True, 1),
+            ('fc7 fwd  NT', R, 4096, 4096, False, True, 2),
+            ('fc7 dgrad NN', R, 4096, 4096, False, False, 2),
+            ('fc7 wgrad TN', 4096, 4096, R, True, False, 2),
+            ('fc6 wgrad TN', 8192, 25088, R, True, False, 1),
+        ]
+        for name, m, n, k, ta, tb, batch in shapes:
+            A = rnd(*((batch,) if batch > 1 else ()), *((k, m) if ta else (m, k)))
+            B = rnd(*((batch,) if batch > 1 else ()), *((n, k) if tb else (k, n)))
+            Cc = torch.empty(((batch, m, n) if batch > 1 else (m, n)), device=dev)
+            ms = timeit(lambda: ops.gemm(A, B, ta, tb, out=Cc), a.iters)
+            fl = 2.0 * m * n * k * batch
+            print('%-14s M=%6d N=%6d K=%6d b=%d  %8.3f ms  %7.1f TFLOP/s (%.1f%% of 157.3)' % (
+                name, m, n, k, batch, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
+            del A, B, Cc
+    if 'conv' in what:
+        layers = [(64, 64, 600, 1000, 1), (64, 128, 300, 500, 1), (128, 128, 300, 500, 1),
+                  (128, 256, 150, 250, 1), (256, 256, 150, 250, 1), (256, 512, 75, 125, 1),
+                  (512, 512, 75, 125, 1), (512, 512, 74, 124, 2)]
+        tot_ms, tot_fl = 0.0, 0.0
+        mult = {(256, 256, 150, 250, 1): 2, (512, 512, 75, 125, 1): 2, (512, 512, 74, 124, 2): 3}
+        for cin, cout, h, w, dil in layers:
+            x = rnd(a.images, h, w, cin)
+            wp = rnd(cout, 3, 3, cin)
+            b = rnd(cout)
+            y = torch.empty((a.images, h, w, cout), device=dev)
+            ms = timeit(lambda: ops.conv3x3_nhwc(x, wp, b, dil, True, out=y), a.iters)
+            fl = 2.0 * a.images * h * w * cout * 9 * cin
+            k = mult.get((cin, cout, h, w, dil), 1)
+            tot_ms += ms * k
+            tot_fl += fl * k
+            print('conv %3d->%3d %4dx%4d d%d  %8.3f ms  %7.1f TFLOP/s (%.1f%%)' % (
+                cin, cout, h, w, dil, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
+            del x, wp, b, y
+        x = rnd(a.images, 3, 600, 1000)
+        w1 = rnd(64, 3, 3, 3)
+        b1 = rnd(64)
+        ms = timeit(lambda: ops.conv3x3_c3_nchw_to_nhwc(x, w1, b1, True), a.iters)
+        print('conv1_1 direct            %8.3f ms' % ms)
+        tot_ms += ms
+        tot_fl += 2.0 * a.images * 600 * 1000 * 64 * 27
+        print('conv stack (MFMA layers + conv1_1, no pools): %.3f ms, %.1f TFLOP/s (%.1f%%)' % (
+            tot_ms, tot_fl / tot_ms / 1e9, tot_fl / tot_ms / 1e9 / 157.3 * 100))
+    if 'roi' in what:
+        import numpy as np
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..',
+                                        'tests'))
+        from helpers import make_rois
+        rois = torch.from_numpy(make_rois(np.random.default_rng(11), a.images, a.rois, 600, 1000,
+                                          degenerate=False)).to(dev)
+        feat = rnd(a.images, 74, 124, 512).abs_()
+        boost = torch.empty((R,), device=dev).uniform_(1, 2)
+        out = torch.empty((R, 512, 7, 7), device=dev)
+        ms = timeit(lambda: ops.roi_pool_f(feat, rois, 7, 7, 0.125, boost=boost, layout='NHWC',
+                                           out=out), a.iters)
+        by = out.numel() * 4 + feat.numel() * 4
+        print('roi_pool+boost NHWC R=%d  %8.3f ms  %7.1f GB/s algorithmic' % (R, ms, by / ms / 1e6))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,260 @@
+"""CPU oracle for the NA-fWebSOD hot path — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module, and only as the checker / the timed CPU baseline.  The product
+path (na-fwebsod_amd/) never imports it.
+
+Two layers:
+  * the custom operators: plain-C restatement in naws_oracle.c (ctypes), each C
+    function citing the reference file:line it follows;
+  * the Caffe2 built-ins on the path (Conv, MaxPool, FC, Relu, Dropout): these
+    live in the un-vendored third-party dependency pytorch v1.3.0
+    (caffe2/operators/*, pinned only in the reference's README.md:34-42), so
+    they are restated through torch-CPU fp32 ops with the Caffe2 defaults
+    (SURVEY.md §8c): legacy floor pooling, FC = X W^T + b with W [out,in],
+    Dropout scale 1/(1-ratio).
+
+PARITY UNPINNED by the reference's own tests (it has none for this path); see
+oracle/README.md for what pins the oracle instead.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, 'build', 'libnaws_oracle.so')
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+def _lib():
+    if not os.path.exists(_LIB):
+        build()
+    lib = C.CDLL(_LIB)
+    lib.oracle_acm_sgd.restype = C.c_int64
+    return lib
+
+
+_L = None
+
+
+def L():
+    global _L
+    if _L is None:
+        _L = _lib()
+    return _L
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_fp)
+
+
+# ---------------------------------------------------------------------------
+# custom operators (C restatement)
+# ---------------------------------------------------------------------------
+def roi_pool_f(x_nchw, rois, pooled_h=7, pooled_w=7, spatial_scale=0.125):
+    x, xp = _f(x_nchw)
+    r, rp = _f(rois)
+    n, c, h, w = x.shape
+    R = r.shape[0]
+    y = np.empty((R, c, pooled_h, pooled_w), np.float32)
+    am = np.empty((R, c, pooled_h, pooled_w), np.int32)
+    L().oracle_roi_pool_f(xp, n, c, h, w, rp, R, pooled_h, pooled_w, C.c_float(spatial_scale),
+                          y.ctypes.data_as(_fp), am.ctypes.data_as(_ip))
+    return y, am
+
+
+def roi_feature_boost(x, s):
+    x, xp = _f(x)
+    s, sp = _f(s)
+    R = x.shape[0]
+    F = x.size // max(R, 1)
+    y = np.empty_like(x)
+    L().oracle_roi_feature_boost(xp, sp, R, F, y.ctypes.data_as(_fp))
+    return y
+
+
+def roi_iou(rois):
+    r, rp = _f(rois)
+    n = r.shape[0]
+    j = np.empty((n, n), np.float32)
+    L().oracle_roi_iou(rp, n, j.ctypes.data_as(_fp))
+    return j
+
+
+def weighted_ce(x, l, w, is_mean):
+    x, xp = _f(x)
+    l, lp = _f(l)
+    wp = None
+    if w is not None:
+        w, wp = _f(w)
+    y = np.zeros((1,), np.float32)
+    L().oracle_wce_fwd(xp, lp, wp, x.shape[0], x.shape[1], int(is_mean), y.ctypes.data_as(_fp))
+    return y[0]
+
+
+def weighted_ce_grad(x, l, w, dy, is_mean):
+    x, xp = _f(x)
+    l, lp = _f(l)
+    wp = None
+    if w is not None:
+        w, wp = _f(w)
+    dy, dyp = _f(np.reshape(dy, (1,)))
+    dx = np.empty_like(x)
+    L().oracle_wce_bwd(xp, lp, wp, dyp, x.shape[0], x.shape[1], int(is_mean),
+                       dx.ctypes.data_as(_fp))
+    return dx
+
+
+def acm_sgd(grad, mom, lr, param, acm, momentum, nesterov, weight_decay, iter_size, gpu_num,
+            lr_mult, iter_count):
+    """In place on mom/param/acm (float32 C-contiguous numpy arrays). Returns new iter_count."""
+    for a in (grad, mom, param, acm):
+        assert a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
+    lr_a, lrp = _f(np.reshape(lr, (1,)))
+    return L().oracle_acm_sgd(grad.ctypes.data_as(_fp), mom.ctypes.data_as(_fp), lrp,
+                              param.ctypes.data_as(_fp), acm.ctypes.data_as(_fp),
+                              C.c_int64(grad.size), C.c_float(momentum), int(nesterov),
+                              C.c_float(weight_decay), int(iter_size), int(gpu_num),
+                              C.c_float(lr_mult), C.c_int64(iter_count))
+
+
+def stat(i, l, ai, al, init):
+    i, ip_ = _f(i)
+    l, lp = _f(l)
+    L().oracle_stat(ip_, lp, i.size, int(init), ai.ctypes.data_as(_fp), al.ctypes.data_as(_fp))
+
+
+def wsddn_outputs(fc8c, fc8d, noisy_fc8c=None, noisy_fc8d=None):
+    """One image. -> alpha_cls, alpha_det, rois_pred [R,C], cls_prob [1,C]."""
+    a, ap = _f(fc8c)
+    b, bp = _f(fc8d)
+    np_, dp_ = None, None
+    if noisy_fc8c is not None:
+        nc, np_ = _f(noisy_fc8c)
+        nd, dp_ = _f(noisy_fc8d)
+    R, Cc = a.shape
+    ac = np.empty((R, Cc), np.float32)
+    ad = np.empty((R, Cc), np.float32)
+    rp = np.empty((R, Cc), np.float32)
+    cp = np.empty((1, Cc), np.float32)
+    L().oracle_wsddn_outputs_fwd(ap, bp, np_, dp_, R, Cc, ac.ctypes.data_as(_fp),
+                                 ad.ctypes.data_as(_fp), rp.ctypes.data_as(_fp),
+                                 cp.ctypes.data_as(_fp))
+    return ac, ad, rp, cp
+
+
+def wsddn_outputs_grad(alpha_cls, alpha_det, d_cls_prob):
+    """One image, one branch. -> dzc, dzd [R,C] w.r.t. the branch's (summed) logits."""
+    ac, acp = _f(alpha_cls)
+    ad, adp = _f(alpha_det)
+    g, gp = _f(np.reshape(d_cls_prob, (-1,)))
+    R, Cc = ac.shape
+    dzc = np.empty((R, Cc), np.float32)
+    dzd = np.empty((R, Cc), np.float32)
+    L().oracle_wsddn_outputs_bwd(acp, adp, gp, R, Cc, dzc.ctypes.data_as(_fp),
+                                 dzd.ctypes.data_as(_fp))
+    return dzc, dzd
+
+
+def entropy_gate(rois, rois_pred, cls_prob, labels_oh):
+    """One image. -> class_weight, class_weight_noise, hatE_sum, hatE_sum_norm, each [1,C]."""
+    r, rp = _f(rois)
+    p, pp = _f(rois_pred)
+    y, yp = _f(np.reshape(cls_prob, (-1,)))
+    l, lp = _f(np.reshape(labels_oh, (-1,)))
+    R, Cc = p.shape
+    outs = [np.empty((1, Cc), np.float32) for _ in range(4)]
+    L().oracle_entropy_gate(rp, pp, yp, lp, R, Cc, *[o.ctypes.data_as(_fp) for o in outs])
+    return tuple(outs)
+
+
+# ---------------------------------------------------------------------------
+# Caffe2 built-ins through torch-CPU (third-party restatement)
+# ---------------------------------------------------------------------------
+VGG16_LAYERS = [
+    # name, cin, cout, dilation   ('P2' = MaxPool k2 s2, 'P1' = MaxPool k2 s1)
+    ('conv1_1', 3, 64, 1), ('conv1_2', 64, 64, 1), 'P2',
+    ('conv2_1', 64, 128, 1), ('conv2_2', 128, 128, 1), 'P2',
+    ('conv3_1', 128, 256, 1), ('conv3_2', 256, 256, 1), ('conv3_3', 256, 256, 1), 'P2',
+    ('conv4_1', 256, 512, 1), ('conv4_2', 512, 512, 1), ('conv4_3', 512, 512, 1), 'P1',
+    ('conv5_1', 512, 512, 2), ('conv5_2', 512, 512, 2), ('conv5_3', 512, 512, 2),
+]
+
+
+def vgg16_conv5_body(data, blobs):
+    """ref: detectron/modeling/VGG16.py:9-48 with WSL.DILATION == 2.
+    data: torch CPU [N,3,H,W]; blobs: {name_w: [O,I,3,3], name_b: [O]} -> conv5_3 NCHW."""
+    import torch
+    import torch.nn.functional as F
+    x = data
+    for item in VGG16_LAYERS:
+        if item == 'P2':
+            x = F.max_pool2d(x, 2, 2, 0, ceil_mode=False)
+        elif item == 'P1':
+            x = F.max_pool2d(x, 2, 1, 0, ceil_mode=False)
+        else:
+            name, _, _, dil = item
+            x = F.relu(F.conv2d(x, blobs[name + '_w'], blobs[name + '_b'], stride=1,
+                                padding=dil, dilation=dil))
+    return x
+
+
+def head_forward(roi_feat, blobs, masks, train=True):
+    """Both 2-fc branches + the four fc8 layers.
+    ref: detectron/modeling/wsl_heads.py:674-679, webly_heads.py:490-498, wsl_heads.py:29-46,
+    webly_heads.py:36-55.  masks: dict name -> keep mask (0/1) for drop6, drop7,
+    _[noisy]_drop6, _[noisy]_drop7 (Dropout ratio 0.5 -> scale 2), ignored when not train.
+    Returns a dict of every intermediate blob (torch CPU tensors)."""
+    import torch
+    import torch.nn.functional as F
+    out = {}
+    x = roi_feat.reshape(roi_feat.shape[0], -1)
+    for pre in ('', '_[noisy]_'):
+        h = F.relu(F.linear(x, blobs[pre + 'fc6_w'], blobs[pre + 'fc6_b']))
+        if train:
+            h = h * masks[pre + 'drop6'] * 2.0
+        out[pre + 'drop6'] = h
+        h = F.relu(F.linear(h, blobs[pre + 'fc7_w'], blobs[pre + 'fc7_b']))
+        if train:
+            h = h * masks[pre + 'drop7'] * 2.0
+        out[pre + 'drop7'] = h
+    out['fc8c'] = F.linear(out['drop7'], blobs['fc8c_w'], blobs['fc8c_b'])
+    out['fc8d'] = F.linear(out['drop7'], blobs['fc8d_w'], blobs['fc8d_b'])
+    out['noisy_fc8c'] = F.linear(out['_[noisy]_drop7'], blobs['noisy_fc8c_w'],
+                                 blobs['noisy_fc8c_b'])
+    out['noisy_fc8d'] = F.linear(out['_[noisy]_drop7'], blobs['noisy_fc8d_w'],
+                                 blobs['noisy_fc8d_b'])
+    return out
+
+
+def loss_tail(fc8, rois, labels_oh, is_mean=True):
+    """One image: WSDDN outputs, entropy gate, both weighted CE losses and the gradients
+    w.r.t. the four fc8 logit matrices (loss gradient seed 1.0 per loss,
+    ref: detectron/utils/blob.py:167-173, webly_heads.py:167-197)."""
+    fc8c, fc8d, nfc8c, nfc8d = [np.asarray(fc8[k], np.float32)
+                                for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
+    ac, ad, rp, cp = wsddn_outputs(fc8c, fc8d)
+    acn, adn, rpn, cpn = wsddn_outputs(fc8c, fc8d, nfc8c, nfc8d)
+    cw, cwn, hs, hsn = entropy_gate(rois, rp, cp, labels_oh)
+    lab = np.reshape(labels_oh, (1, -1)).astype(np.float32)
+    loss = weighted_ce(cp, lab, cw, is_mean)
+    loss_n = weighted_ce(cpn, lab, cwn, is_mean)
+    one = np.ones((1,), np.float32)
+    g = weighted_ce_grad(cp, lab, cw, one, is_mean)
+    gn = weighted_ce_grad(cpn, lab, cwn, one, is_mean)
+    dzc, dzd = wsddn_outputs_grad(ac, ad, g)
+    dzcn, dzdn = wsddn_outputs_grad(acn, adn, gn)
+    return dict(alpha_cls=ac, alpha_det=ad, rois_pred=rp, cls_prob=cp,
+                alpha_cls_noise=acn, alpha_det_noise=adn, rois_pred_noise=rpn, cls_prob_noise=cpn,
+                class_weight=cw, class_weight_noise=cwn, hatE_sum=hs, hatE_sum_norm=hsn,
+                loss_cls=loss, loss_cls_noise=loss_n, d_cls_prob=g, d_cls_prob_noise=gn,
+                d_fc8c=dzc + dzcn, d_fc8d=dzd + dzdn, d_noisy_fc8c=dzcn, d_noisy_fc8d=dzdn)

@@ -1,0 +1,375 @@
+"""GPU parity: every HIP operator (through the C ABI) against the CPU oracle.
+
+Bit-exact for index work (RoI bins/argmax, IoU ints); fp32 results within 1e-4
+relative (BASELINE.json north_star), usually far tighter.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_rois, seg_offsets
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _close(a, b, rtol=RTOL, atol=1e-6):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+# ---------------------------------------------------------------- RoIPoolF --
+@pytest.mark.parametrize('layout', ['NCHW', 'NHWC'])
+@pytest.mark.parametrize('with_boost', [False, True])
+def test_roi_pool_bitexact(dev, layout, with_boost):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(11)
+    n, c, h, w = 2, 300, 20, 30   # c not a multiple of the 256-channel tile
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    x[:, :, 3, 4] = x[:, :, 3, 5]  # ties -> first index must win
+    rois = make_rois(rng, n, 40, h * 8, w * 8)
+    y_ref, am_ref = oracle.roi_pool_f(x, rois, 7, 7, 0.125)
+    boost = (rng.uniform(0, 1, rois.shape[0]) + 1).astype(np.float32)
+    if with_boost:
+        y_ref = oracle.roi_feature_boost(y_ref, boost)
+    xd = _t(x, dev)
+    if layout == 'NHWC':
+        xd = xd.permute(0, 2, 3, 1).contiguous()
+    y, am = ops.roi_pool_f(xd, _t(rois, dev), 7, 7, 0.125, boost=_t(boost, dev) if with_boost
+                           else None, layout=layout, with_argmax=True)
+    assert np.array_equal(am.cpu().numpy(), am_ref)        # bit-exact index assignment
+    assert np.array_equal(y.cpu().numpy(), y_ref)           # max is exact, boost is one fp32 mul
+    y2 = ops.roi_pool_f(xd, _t(rois, dev), 7, 7, 0.125, boost=_t(boost, dev) if with_boost
+                        else None, layout=layout)
+    assert np.array_equal(y2.cpu().numpy(), y_ref)
+
+
+def test_roi_pool_empty_and_errors(dev):
+    from naws_hip import ops, lib
+    x = torch.zeros((1, 4, 5, 5), device=dev)
+    y = ops.roi_pool_f(x, torch.zeros((0, 5), device=dev))
+    assert y.shape == (0, 4, 7, 7)
+    with pytest.raises(lib.NawsError):
+        ops.roi_pool_f(x, torch.zeros((3, 4), device=dev))
+    with pytest.raises(TypeError):
+        ops.roi_pool_f(x.cpu(), torch.zeros((3, 5)))
+
+
+def test_roi_feature_boost(dev):
+    from naws_hip import ops, lib
+    from oracle import oracle
+    rng = np.random.default_rng(1)
+    for f in (25088, 37):
+        x = rng.standard_normal((17, f)).astype(np.float32)
+        s = rng.uniform(1, 2, (17, 1)).astype(np.float32)
+        ref = oracle.roi_feature_boost(x, s)
+        assert np.array_equal(ops.roi_feature_boost(_t(x, dev), _t(s, dev)).cpu().numpy(), ref)
+        assert np.array_equal(ops.roi_feature_boost_grad(_t(x, dev), _t(s, dev)).cpu().numpy(), ref)
+    with pytest.raises(lib.NawsError):
+        ops.roi_feature_boost(_t(x, dev), _t(np.ones((16, 1), np.float32), dev))
+
+
+def test_roi_iou_bitexact(dev):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(2)
+    rois = make_rois(rng, 1, 300, 600, 1000)
+    j = ops.roi_iou(_t(rois, dev)).cpu().numpy()
+    assert np.array_equal(j, oracle.roi_iou(rois), equal_nan=True)
+
+
+# ------------------------------------------------------------ WSDDN outputs --
+def _logits(rng, rt, c):
+    return [(rng.standard_normal((rt, c)) * s).astype(np.float32) for s in (2.0, 3.0, 0.5, 0.5)]
+
+
+@pytest.mark.parametrize('c', [20, 80])
+def test_wsddn_outputs_fwd_bwd(dev, c):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    lens = [257, 64, 301]
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rt = int(seg[-1])
+    fc8c, fc8d, nc, nd = _logits(rng, rt, c)
+    buf = _t(np.concatenate([fc8c, fc8d, nc, nd], 1), dev)      # [Rt, 4C] row-strided views
+    v = [buf[:, i * c:(i + 1) * c] for i in range(4)]
+    ac, ad, rp, cp = ops.wsddn_outputs(v[0], v[1], v[2], v[3], _t(seg, dev))
+    g = rng.standard_normal((2, len(lens), c)).astype(np.float32)
+    dl = ops.wsddn_outputs_grad(ac, ad, rp, cp, _t(g, dev), _t(seg, dev)).cpu().numpy()
+    for s, (lo, hi) in enumerate(zip(seg[:-1], seg[1:])):
+        sl = slice(lo, hi)
+        r0 = oracle.wsddn_outputs(fc8c[sl], fc8d[sl])
+        r1 = oracle.wsddn_outputs(fc8c[sl], fc8d[sl], nc[sl], nd[sl])
+        for b, ref in enumerate((r0, r1)):
+            _close(ac[b, sl], ref[0]); _close(ad[b, sl], ref[1], atol=1e-9)
+            _close(rp[b, sl], ref[2], atol=1e-10); _close(cp[b, s], ref[3][0])
+        dzc0, dzd0 = oracle.wsddn_outputs_grad(r0[0], r0[1], g[0, s])
+        dzc1, dzd1 = oracle.wsddn_outputs_grad(r1[0], r1[1], g[1, s])
+        scale = np.abs(g).max()
+        _close(dl[sl, 0:c], dzc0 + dzc1, atol=2e-6 * scale)
+        _close(dl[sl, c:2 * c], dzd0 + dzd1, atol=2e-6 * scale)
+        _close(dl[sl, 2 * c:3 * c], dzc1, atol=2e-6 * scale)
+        _close(dl[sl, 3 * c:4 * c], dzd1, atol=2e-6 * scale)
+
+
+# ------------------------------------------------------------- entropy gate --
+@pytest.mark.parametrize('c', [20, 27])
+def test_entropy_gate(dev, c):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(4)
+    rois = make_rois(rng, 2, 333, 600, 1000)
+    seg = seg_offsets(rois)
+    rt = rois.shape[0]
+    fc8c, fc8d, _, _ = _logits(rng, rt, c)
+    labels = np.zeros((2, c), np.float32)
+    labels[0, 3] = 1; labels[1, 5] = 1; labels[1, 7] = 0.4   # mixup-style fractional label
+    rp = np.empty((rt, c), np.float32); cp = np.empty((2, c), np.float32)
+    for s in range(2):
+        sl = slice(seg[s], seg[s + 1])
+        _, _, rp[sl], cps = oracle.wsddn_outputs(fc8c[sl], fc8d[sl])
+        cp[s] = cps[0]
+    rp[5, 2] = 0.0           # p = 0 -> 0*log 0 = NaN -> ReplaceNaN -> 0
+    outs = ops.entropy_gate(_t(rois, dev), _t(rp, dev), _t(cp, dev), _t(labels, dev),
+                            _t(seg, dev), int(np.diff(seg).max()))
+    for s in range(2):
+        sl = slice(seg[s], seg[s + 1])
+        ref = oracle.entropy_gate(rois[sl], rp[sl], cp[s], labels[s])
+        for o, r in zip(outs, ref):
+            _close(o[s], r[0], rtol=1e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------ WCE ------
+@pytest.mark.parametrize('weighted', [True, False])
+@pytest.mark.parametrize('is_mean', [True, False])
+def test_weighted_ce(dev, weighted, is_mean):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    for c in (20, 80):
+        x = rng.uniform(0, 1, (3, 1, c)).astype(np.float32)
+        x[0, 0, :4] = [0.0, 1.0, 1e-30, 0.9999999]
+        l = (rng.uniform(0, 1, (3, 1, c)) > 0.8).astype(np.float32)
+        l[1, 0, 2] = 0.37
+        w = rng.uniform(0, 1, (3, 1, c)).astype(np.float32) if weighted else None
+        dy = np.array([1.0, 0.5, 2.0], np.float32)
+        y = ops.weighted_ce(_t(x, dev), _t(l, dev), _t(w, dev) if weighted else None, is_mean, 3)
+        dx = ops.weighted_ce_grad(_t(x, dev), _t(l, dev), _t(w, dev) if weighted else None,
+                                  _t(dy, dev), is_mean, 3)
+        for p in range(3):
+            wp = w[p] if weighted else None
+            _close(y[p], oracle.weighted_ce(x[p], l[p], wp, is_mean), rtol=1e-6)
+            _close(dx[p], oracle.weighted_ce_grad(x[p], l[p], wp, dy[p:p + 1], is_mean), rtol=1e-6)
+
+
+def test_wce_known_answer(dev):
+    """The one reference output on record (reference .cc compiled by the survey)."""
+    from naws_hip import ops
+    x = np.array([[.9, .05, .3, 0.]], np.float32)
+    l = np.array([[1, 0, .4, 0]], np.float32)
+    w = np.array([[1, .5, 1, .25]], np.float32)
+    y = ops.weighted_ce(_t(x, dev), _t(l, dev), _t(w, dev), True)
+    assert abs(float(y[0]) - 0.206650317) < 1e-6
+
+
+# ------------------------------------------------------------------ SGD ------
+@pytest.mark.parametrize('iter_size,gpu_num,nesterov', [(1, 1, 0), (1, 8, 0), (2, 4, 0), (1, 2, 1)])
+def test_acm_sgd(dev, iter_size, gpu_num, nesterov):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(6)
+    sizes = [4096 * 8, 4096, 20 * 4096, 20]           # weight, bias, weight, bias
+    lr_mult = [1.0, 2.0, 1.0, 2.0]
+    wd = [5e-4, 0.0, 5e-4, 0.0]
+    total = sum(sizes)
+    ends = np.cumsum(sizes).astype(np.int64)
+    p = rng.standard_normal(total).astype(np.float32)
+    m = rng.standard_normal(total).astype(np.float32)     # garbage: first call must zero it
+    a = rng.standard_normal(total).astype(np.float32)
+    lr = np.array([1e-3], np.float32)
+    pd, md, ad = _t(p, dev), _t(m, dev), _t(a, dev)
+    use_acm = iter_size != 1
+    pr, mr, ar = p.copy(), m.copy(), a.copy()
+    it_ref = [0] * len(sizes)
+    for it in range(4):
+        g = rng.standard_normal(total).astype(np.float32)
+        gd = _t(g, dev)
+        ops.acm_sgd_update(gd, md, _t(lr, dev), pd, ad if use_acm else None, _t(ends, dev),
+                           _t(np.array(lr_mult, np.float32), dev), _t(np.array(wd, np.float32), dev),
+                           0.9, nesterov, iter_size, gpu_num, it)
+        assert np.array_equal(gd.cpu().numpy(), g)        # grad blob is read-only
+        lo = 0
+        for k, sz in enumerate(sizes):
+            sl = slice(lo, lo + sz)
+            gk, mk, pk, ak = g[sl].copy(), mr[sl].copy(), pr[sl].copy(), ar[sl].copy()
+            it_ref[k] = oracle.acm_sgd(gk, mk, lr, pk, ak, 0.9, nesterov, wd[k], iter_size,
+                                       gpu_num, lr_mult[k], it_ref[k])
+            mr[sl], pr[sl], ar[sl] = mk, pk, ak
+            lo += sz
+        _close(pd, pr, rtol=1e-6, atol=1e-7)
+        _close(md, mr, rtol=1e-5, atol=1e-8)
+        if use_acm:
+            _close(ad, ar, rtol=1e-6, atol=1e-7)
+
+
+def test_stat(dev):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(7)
+    ai = np.full(20, 7.0, np.float32); al = np.full(20, 3.0, np.float32)
+    aid, ald = _t(ai, dev), _t(al, dev)
+    for it in range(3):
+        i = rng.uniform(0, 1, 20).astype(np.float32)
+        l = (rng.uniform(0, 1, 20) > 0.5).astype(np.float32)
+        ops.stat_accumulate(_t(i, dev), _t(l, dev), aid, ald, it == 0)
+        oracle.stat(i, l, ai, al, it == 0)
+    assert np.array_equal(aid.cpu().numpy(), ai) and np.array_equal(ald.cpu().numpy(), al)
+
+
+# ------------------------------------------------------------------ GEMM -----
+def _ref_mm(a, b):
+    return (a.astype(np.float64) @ b.astype(np.float64))
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize('m,n,k', [(300, 200, 96), (128, 128, 32), (1000, 40, 4096),
+                                   (520, 8192, 64), (4000, 4096, 100), (40, 4096, 1000)])
+def test_gemm_layouts(dev, ta, tb, m, n, k):
+    from naws_hip import ops
+    rng = np.random.default_rng(8)
+    # operand dims that end up as vector-load (contiguous) dims must be multiples of 4
+    a = rng.uniform(-1, 1, (k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k) if tb else (k, n)).astype(np.float32)
+    ref = _ref_mm(a.T if ta else a, b.T if tb else b)
+    c = ops.gemm(_t(a, dev), _t(b, dev), bool(ta), bool(tb)).cpu().numpy()
+    err = np.abs(c - ref).max() / (np.abs(ref).max() + 1e-30)
+    assert err < 2e-6, err
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I with an asymmetric B catches a transposed C/D register map."""
+    from naws_hip import ops
+    n = 256
+    b = np.arange(n * n, dtype=np.float32).reshape(n, n) % 1013
+    c = ops.gemm(_t(np.eye(n, dtype=np.float32), dev), _t(b, dev)).cpu().numpy()
+    assert np.array_equal(c, b)
+
+
+def test_gemm_epilogues(dev):
+    from naws_hip import ops, lib
+    rng = np.random.default_rng(9)
+    m, n, k = 260, 384, 160
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    bias = rng.uniform(-1, 1, n).astype(np.float32)
+    z = _ref_mm(a, w.T) + bias
+    ad, wd, bd = _t(a, dev), _t(w, dev), _t(bias, dev)
+    _close(ops.gemm(ad, wd, False, True, epilogue=lib.EPI_BIAS, bias=bd), z, atol=1e-4)
+    _close(ops.gemm(ad, wd, False, True, epilogue=lib.EPI_BIAS_RELU, bias=bd), np.maximum(z, 0),
+           atol=1e-4)
+    y = ops.gemm(ad, wd, False, True, epilogue=lib.EPI_BIAS_RELU_DROP, bias=bd, drop_ratio=0.5,
+                 seed=1234)
+    mask = ops.dropout_mask(1234, 0.5, m * n, dev).reshape(m, n).cpu().numpy()
+    assert 0.45 < mask.mean() < 0.55
+    _close(y, np.maximum(z, 0) * mask * 2.0, atol=2e-4)
+    # gate epilogue (FC dgrad through ReLU + Dropout) and accumulate
+    aux = rng.standard_normal((m, n)).astype(np.float32)
+    g = ops.gemm(ad, wd, False, True, epilogue=lib.EPI_GATE_POS, aux=_t(aux, dev), alpha=2.0)
+    _close(g, np.where(aux > 0, _ref_mm(a, w.T) * 2.0, 0.0), atol=2e-4)
+    c0 = rng.standard_normal((m, n)).astype(np.float32)
+    cd = _t(c0, dev)
+    ops.gemm(ad, wd, False, True, out=cd, accumulate=True)
+    _close(cd, c0 + _ref_mm(a, w.T), atol=2e-4)
+
+
+def test_gemm_batched_and_errors(dev):
+    from naws_hip import ops, lib
+    rng = np.random.default_rng(10)
+    a = rng.uniform(-1, 1, (2, 130, 64)).astype(np.float32)
+    w = rng.uniform(-1, 1, (2, 72, 64)).astype(np.float32)
+    b = rng.uniform(-1, 1, (2, 72)).astype(np.float32)
+    y = ops.gemm(_t(a, dev), _t(w, dev), False, True, epilogue=lib.EPI_BIAS, bias=_t(b, dev))
+    for i in range(2):
+        _close(y[i], _ref_mm(a[i], w[i].T) + b[i], atol=1e-4)
+    with pytest.raises(lib.NawsError):          # K not a multiple of 4
+        ops.gemm(torch.zeros((8, 6), device=dev), torch.zeros((8, 6), device=dev), False, True)
+    with pytest.raises(lib.NawsError):          # inner dims differ
+        ops.gemm(torch.zeros((8, 8), device=dev), torch.zeros((8, 12), device=dev), False, True)
+
+
+def test_colsum(dev):
+    from naws_hip import ops
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((1000, 200)).astype(np.float32)
+    _close(ops.colsum(_t(x, dev)), x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------ conv -----
+@pytest.mark.parametrize('cin,cout,dil,h,w', [(64, 64, 1, 37, 53), (128, 256, 1, 19, 23),
+                                              (512, 512, 2, 20, 31), (64, 128, 1, 75, 125)])
+def test_conv3x3_nhwc(dev, cin, cout, dil, h, w):
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(13)
+    n = 2
+    x = rng.uniform(-1, 1, (n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    wp = ops.conv3x3_pack_weight(_t(wt, dev))
+    y = ops.nhwc_to_nchw(ops.conv3x3_nhwc(xd, wp, _t(b, dev), dil, True)).cpu().numpy()
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_conv1_1_and_pool(dev):
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(14)
+    x = rng.uniform(-120, 140, (2, 3, 41, 67)).astype(np.float32)
+    wt = (rng.standard_normal((64, 3, 3, 3)) * 0.1).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, 64).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=1))
+    y = ops.conv3x3_c3_nchw_to_nhwc(_t(x, dev), _t(wt, dev), _t(b, dev), True)
+    _close(ops.nhwc_to_nchw(y), ref.numpy(), rtol=1e-5, atol=1e-3)
+    for stride in (2, 1):
+        pr = F.max_pool2d(ref, 2, stride, 0, ceil_mode=False).float().numpy()
+        yp = ops.nhwc_to_nchw(ops.maxpool2x2_nhwc(y, stride))
+        assert yp.shape == pr.shape
+        _close(yp, pr, rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------ small built-ins
+def test_small_builtins(dev):
+    from naws_hip import ops, lib
+    rng = np.random.default_rng(15)
+    x = rng.uniform(0.01, 2, (37, 20)).astype(np.float32)
+    xd = _t(x, dev)
+    _close(ops.unary(lib.UN_LOG, xd), np.log(x), rtol=1e-6)
+    _close(ops.unary(lib.UN_SCALE, xd, -1.0), -x)
+    xn = x.copy(); xn[3, 4] = np.nan
+    _close(ops.unary(lib.UN_REPLACE_NAN, _t(xn, dev), 0.0), np.nan_to_num(xn, nan=0.0))
+    _close(ops.unary(lib.UN_LEAKY_RELU, _t(x - 1, dev), 0.01), np.where(x - 1 >= 0, x - 1, 0.01 * (x - 1)))
+    _close(ops.unary(lib.UN_CLIP, _t(xn, dev), 0.0, 1.0), np.clip(xn, 0, 1))   # NaN stays NaN
+    row = rng.uniform(1, 2, (1, 20)).astype(np.float32)
+    sc = np.array([[7.0]], np.float32)
+    _close(ops.binary(lib.BIN_DIV, xd, _t(row, dev)), x / row)
+    _close(ops.binary(lib.BIN_SUB, _t(sc, dev), _t(row, dev)), sc - row)
+    _close(ops.binary(lib.BIN_MUL, _t(row, dev), xd), row * x)
+    e = np.exp(x - x.max(1, keepdims=True)); sm = e / e.sum(1, keepdims=True)
+    y = ops.softmax_rows(xd)
+    _close(y, sm, rtol=1e-5)
+    dy = rng.standard_normal(x.shape).astype(np.float32)
+    _close(ops.softmax_rows_grad(y, _t(dy, dev)), sm * (dy - (sm * dy).sum(1, keepdims=True)),
+           rtol=1e-4, atol=1e-7)
+    assert np.array_equal(ops.transpose2d(xd).cpu().numpy(), x.T)
+    _close(ops.reduce_sum_axis0(xd), x.sum(0, keepdims=True), rtol=1e-5)
