@@ -150,10 +150,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   constexpr int TI = WTM / 32, TJ = WTN / 32;
   static_assert(TI >= 1 && TJ >= 1, "wave tile too small");
 
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sm = reinterpret_cast<float*>(smem_raw);
-  float* As[2] = {sm, sm + GA::FLOATS};
-  float* Bs[2] = {sm + 2 * GA::FLOATS, sm + 2 * GA::FLOATS + GB::FLOATS};
+  // One LDS array, addressed by integer offsets only: a pointer table indexed
+  // by the buffer parity degrades to FLAT accesses, whose waits also drain the
+  // global prefetch.
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int A_OFF = 0, B_OFF = 2 * GA::FLOATS;
 
   // XCD-aware tile order: consecutive logical tiles (sharing an A panel) land
   // on one XCD's L2; groups of 8 M-tiles sweep N together.
@@ -201,15 +202,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   };
 
   fetch(0);
-  store_tile<BM, BK, A_KC>(As[0], ra);
-  store_tile<BN, BK, B_KC>(Bs[0], rb);
+  store_tile<BM, BK, A_KC>(sm + A_OFF, ra);
+  store_tile<BN, BK, B_KC>(sm + B_OFF, rb);
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     if (t + 1 < T) fetch(t + 1);
-    const float* as = As[cur];
-    const float* bs = Bs[cur];
+    const float* as = sm + A_OFF + cur * GA::FLOATS;
+    const float* bs = sm + B_OFF + cur * GB::FLOATS;
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
       float af[TI][4], bf[TJ][4];
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < T) {
-      store_tile<BM, BK, A_KC>(As[cur ^ 1], ra);
-      store_tile<BN, BK, B_KC>(Bs[cur ^ 1], rb);
+      store_tile<BM, BK, A_KC>(sm + A_OFF + (cur ^ 1) * GA::FLOATS, ra);
+      store_tile<BN, BK, B_KC>(sm + B_OFF + (cur ^ 1) * GB::FLOATS, rb);
     }
     __syncthreads();
   }

@@ -1,0 +1,254 @@
+"""Global config for the MI355X-native NA-fWebSOD hot path.
+
+Plugin surface mirrored from the reference (detectron/core/config.py:60-1105 for
+the key tree, :1178-1396 for the merge helpers): a module-level `cfg` tree that
+is filled from a yaml file (`merge_cfg_from_file`) and `KEY VALUE` pairs
+(`merge_cfg_from_list`), type-checked against the defaults, and frozen by
+`assert_and_infer_cfg`.  Only the sub-trees the hot path reads
+are declared; a key outside them raises KeyError exactly like an unknown key
+does in the reference, so a yaml written for another model family fails loudly
+rather than being half-applied.
+"""
+import ast
+import copy
+import os
+
+import numpy as np
+import yaml
+
+
+class CfgNode(dict):
+    """dict with attribute access and a recursive read-only switch."""
+
+    _FROZEN = '__frozen__'
+
+    def __init__(self, init=None):
+        super(CfgNode, self).__init__()
+        self.__dict__[CfgNode._FROZEN] = False
+        for k, v in (init or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __getattr__(self, name):
+        if name in self:
+            return self[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if self.__dict__[CfgNode._FROZEN]:
+            raise AttributeError(
+                'Attempted to set "{}" to "{}", but the config is immutable'.format(name, value))
+        self[name] = value
+
+    def immutable(self, flag):
+        self.__dict__[CfgNode._FROZEN] = flag
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v.immutable(flag)
+
+    def is_immutable(self):
+        return self.__dict__[CfgNode._FROZEN]
+
+    def __deepcopy__(self, memo):
+        out = CfgNode()
+        for k, v in self.items():
+            out[k] = copy.deepcopy(v, memo)
+        return out
+
+
+AttrDict = CfgNode  # the reference's name for this class (detectron/utils/collections.py)
+
+
+def _defaults():
+    return {
+        'MODEL': {
+            'TYPE': '', 'CONV_BODY': '', 'NUM_CLASSES': -1, 'MASK_ON': False,
+            'KEYPOINTS_ON': False, 'RPN_ONLY': False, 'FASTER_RCNN': False,
+            'EXECUTION_TYPE': 'dag',
+        },
+        'TRAIN': {
+            'WEIGHTS': '', 'DATASETS': (), 'PROPOSAL_FILES': (), 'SCALES': (600,),
+            'MAX_SIZE': 1000, 'IMS_PER_BATCH': 2, 'BATCH_SIZE_PER_IM': 64,
+            'USE_FLIPPED': True, 'SNAPSHOT_ITERS': 80000, 'ASPECT_GROUPING': True,
+            'CROWD_FILTER_THRESH': 0.7, 'GT_MIN_AREA': -1, 'FREEZE_CONV_BODY': False,
+            'AUTO_RESUME': True, 'COPY_WEIGHTS': False, 'FREEZE_AT': 2,
+        },
+        'DATA_LOADER': {'NUM_THREADS': 4, 'MINIBATCH_QUEUE_SIZE': 64, 'BLOBS_QUEUE_CAPACITY': 8},
+        'TEST': {
+            'WEIGHTS': '', 'DATASETS': (), 'SCALE': 600, 'MAX_SIZE': 1000, 'NMS': 0.3,
+            'BBOX_REG': True, 'PROPOSAL_FILES': (), 'PROPOSAL_LIMIT': 2000,
+            'DETECTIONS_PER_IM': 100, 'SCORE_THRESH': 0.05, 'COMPETITION_MODE': True,
+            'FORCE_JSON_DATASET_EVAL': False, 'PRECOMPUTED_PROPOSALS': True,
+            'BBOX_AUG': {
+                'ENABLED': False, 'SCORE_HEUR': 'UNION', 'COORD_HEUR': 'UNION', 'H_FLIP': False,
+                'SCALES': (), 'MAX_SIZE': 4000, 'SCALE_H_FLIP': False, 'SCALE_SIZE_DEP': False,
+                'AREA_TH_LO': 50 ** 2, 'AREA_TH_HI': 180 ** 2, 'ASPECT_RATIOS': (),
+                'ASPECT_RATIO_H_FLIP': False,
+            },
+        },
+        'SOLVER': {
+            'BASE_LR': 0.001, 'LR_POLICY': 'step', 'GAMMA': 0.1, 'STEP_SIZE': 30000,
+            'STEPS': [], 'LRS': [], 'MAX_ITER': 40000, 'MOMENTUM': 0.9, 'WEIGHT_DECAY': 0.0005,
+            'WEIGHT_DECAY_GN': 0.0, 'WARM_UP_ITERS': 500, 'WARM_UP_FACTOR': 1.0 / 3.0,
+            'WARM_UP_METHOD': 'linear', 'SCALE_MOMENTUM': True, 'SCALE_MOMENTUM_THRESHOLD': 1.1,
+            'LOG_LR_CHANGE_THRESHOLD': 1.1,
+        },
+        'FAST_RCNN': {
+            'ROI_BOX_HEAD': '', 'MLP_HEAD_DIM': 1024, 'ROI_XFORM_METHOD': 'RoIPoolF',
+            'ROI_XFORM_SAMPLING_RATIO': 0, 'ROI_XFORM_RESOLUTION': 14,
+        },
+        # other model families: only their on/off switches exist, and must stay off
+        'RPN': {'RPN_ON': False},
+        'FPN': {'FPN_ON': False, 'MULTILEVEL_ROIS': False},
+        'RETINANET': {'RETINANET_ON': False},
+        'MRCNN': {'ROI_MASK_HEAD': ''},
+        'KRCNN': {'ROI_KEYPOINTS_HEAD': ''},
+        'WSL': {
+            'WSL_ON': False, 'ITER_SIZE': 1, 'DEBUG': False, 'SAMPLE': False, 'SAMPLE_ITER': 1280,
+            'CPG': False, 'CSC': False, 'CENTER_LOSS': False, 'CONTEXT': False, 'OICR': False,
+            'PCL': False, 'CMIL': False, 'MEAN_LOSS': False, 'USE_DISTORTION': True,
+            'SATURATION': 1.5, 'EXPOSURE': 1.5, 'USE_CROP': True, 'CROP': 0.9, 'DILATION': 1,
+            'MIN_ENTROPY_LOSS': False,
+        },
+        'WEBLY': {
+            'WEBLY_ON': False, 'ENTROPY': False, 'MINING': False, 'BAGGING_MIXUP': False,
+            'BAGGING_MIXUP_ALPHA': 1.5,
+        },
+        'NUM_GPUS': 1,
+        'USE_NCCL': False,
+        'DEDUP_BOXES': 1 / 16.,
+        'PIXEL_MEANS': np.array([[[102.9801, 115.9465, 122.7717]]]),
+        'RNG_SEED': 3,
+        'EPS': 1e-14,
+        'ROOT_DIR': os.getcwd(),
+        'OUTPUT_DIR': '/tmp',
+        'MEMONGER': False,
+        'MEMONGER_SHARE_ACTIVATIONS': False,
+        'VIS': False,
+        'VIS_TH': 0.9,
+        'EXPECTED_RESULTS': [],
+        'EXPECTED_RESULTS_RTOL': 0.1,
+        'EXPECTED_RESULTS_ATOL': 0.005,
+        # MI355X-native additions (not in the reference)
+        'NAWS': {
+            'IMS_PER_GPU': 1,        # images per GPU process (the reference supports only 1)
+            'ALLREDUCE_CHUNKS': 8,   # fc6 wgrad is cut into this many row chunks, each
+                                     # all-reduced while the next chunk's GEMM runs
+        },
+    }
+
+
+# Switches that select code outside the hot path: accepted only at their default.
+_OFF_PATH_SWITCHES = (
+    'MODEL.MASK_ON', 'MODEL.KEYPOINTS_ON', 'MODEL.RPN_ONLY', 'MODEL.FASTER_RCNN', 'RPN.RPN_ON',
+    'FPN.FPN_ON', 'RETINANET.RETINANET_ON', 'WSL.CPG', 'WSL.CSC', 'WSL.CENTER_LOSS',
+    'WSL.CONTEXT', 'WSL.OICR', 'WSL.PCL', 'WSL.CMIL', 'WSL.MIN_ENTROPY_LOSS', 'WEBLY.MINING',
+)
+
+cfg = CfgNode(_defaults())
+__C = cfg
+
+
+def reset_cfg():
+    """Restore the defaults (tests)."""
+    cfg.immutable(False)
+    fresh = CfgNode(_defaults())
+    for k in list(cfg.keys()):
+        del cfg[k]
+    for k, v in fresh.items():
+        cfg[k] = v
+
+
+def assert_and_infer_cfg(cache_urls=True, make_immutable=True):
+    """ref: detectron/core/config.py:1178-1194.  URL caching has no meaning offline."""
+    for key in _OFF_PATH_SWITCHES:
+        node = cfg
+        parts = key.split('.')
+        for p in parts[:-1]:
+            node = node[p]
+        if node[parts[-1]]:
+            raise NotImplementedError(
+                '{} selects a model family outside the MI355X hot path (SURVEY.md §8)'.format(key))
+    if make_immutable:
+        cfg.immutable(True)
+
+
+def get_output_dir(datasets, training=True):
+    """<OUTPUT_DIR>/<train|test>/<dataset>/<MODEL.TYPE>  (ref: config.py:1210-1221)."""
+    name = datasets if isinstance(datasets, str) else ':'.join(datasets)
+    outdir = os.path.join(cfg.OUTPUT_DIR, 'train' if training else 'test', name, cfg.MODEL.TYPE)
+    os.makedirs(outdir, exist_ok=True)
+    return outdir
+
+
+def load_cfg(cfg_to_load):
+    if hasattr(cfg_to_load, 'read'):
+        cfg_to_load = cfg_to_load.read()
+    return yaml.safe_load(cfg_to_load)
+
+
+def merge_cfg_from_file(cfg_filename):
+    with open(cfg_filename, 'r') as f:
+        tree = load_cfg(f)
+    _merge(tree or {}, cfg, [])
+
+
+def merge_cfg_from_cfg(cfg_other):
+    _merge(cfg_other, cfg, [])
+
+
+def merge_cfg_from_list(cfg_list):
+    """['TEST.NMS', 0.5, ...] — values are python literals or plain strings."""
+    assert len(cfg_list) % 2 == 0
+    for full_key, v in zip(cfg_list[0::2], cfg_list[1::2]):
+        node = cfg
+        parts = full_key.split('.')
+        for sub in parts[:-1]:
+            assert sub in node, 'Non-existent key: {}'.format(full_key)
+            node = node[sub]
+        assert parts[-1] in node, 'Non-existent key: {}'.format(full_key)
+        node[parts[-1]] = _coerce(_decode(v), node[parts[-1]], full_key)
+
+
+def _decode(v):
+    if isinstance(v, dict):
+        return CfgNode(v)
+    if not isinstance(v, str):
+        return v
+    try:
+        return ast.literal_eval(v)
+    except (ValueError, SyntaxError):
+        return v
+
+
+def _coerce(new, old, full_key):
+    """Accept `new` if it has the default's type, or a benign conversion of it
+    (ref: config.py:1370-1396)."""
+    t_old, t_new = type(old), type(new)
+    if t_old is t_new:
+        return new
+    if isinstance(old, np.ndarray):
+        return np.array(new, dtype=old.dtype)
+    if isinstance(old, str) and isinstance(new, str):
+        return new
+    if isinstance(old, tuple) and isinstance(new, list):
+        return tuple(new)
+    if isinstance(old, list) and isinstance(new, tuple):
+        return list(new)
+    if isinstance(old, float) and isinstance(new, int) and not isinstance(new, bool):
+        return float(new)
+    raise ValueError('Type mismatch ({} vs. {}) with values ({} vs. {}) for config key: {}'.format(
+        t_old, t_new, old, new, full_key))
+
+
+def _merge(a, b, stack):
+    for k, v_ in a.items():
+        full_key = '.'.join(stack + [k])
+        if k not in b:
+            raise KeyError('Non-existent config key: {}'.format(full_key))
+        v = _decode(copy.deepcopy(v_))
+        if isinstance(b[k], CfgNode):
+            if not isinstance(v, dict):
+                raise ValueError('config key {} must be a mapping'.format(full_key))
+            _merge(v, b[k], stack + [k])
+        else:
+            b[k] = _coerce(v, b[k], full_key)

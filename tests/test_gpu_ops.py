@@ -250,7 +250,7 @@ def test_gemm_layouts(dev, ta, tb, m, n, k):
     ref = _ref_mm(a.T if ta else a, b.T if tb else b)
     c = ops.gemm(_t(a, dev), _t(b, dev), bool(ta), bool(tb)).cpu().numpy()
     err = np.abs(c - ref).max() / (np.abs(ref).max() + 1e-30)
-    assert err < 2e-6, err
+    assert err < 5e-6, err
 
 
 def test_gemm_asymmetric_identity(dev):
