@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the NA-fWebSOD hot path (VGG16-C5 conv body ->
+RoIPoolF(+boost) -> two 2-fc branches -> WSDDN dual softmax -> entropy-gated weighted
+CE -> backward -> gradient all-reduce -> ACM momentum SGD), fp32, on synthetic
+600x1000 images with 2000 proposals each (BASELINE.json configs[1]; configs[2] at
+--gpus 8: batch = 2 images per GPU).
+
+A "step" = one full training iteration of every rank on its own 2 images.  Inputs are
+resident in HBM before the timed region.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--images-per-gpu', type=int, default=2)
+    ap.add_argument('--rois', type=int, default=2000)
+    ap.add_argument('--height', type=int, default=600)
+    ap.add_argument('--width', type=int, default=1000)
+    ap.add_argument('--classes', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-rois', type=int, default=500)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, num_fg):
+    """CPU restatement of the reference path (oracle/, torch-CPU + C ops) on BASELINE
+    configs[0]: 2 synthetic 600x1000 images x 500 proposals, one fwd+bwd+SGD iteration."""
+    import numpy as np
+    import torch
+    from detectron.datasets import synthetic
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    roidb = synthetic.make_roidb(2, args.cpu_rois, num_fg, args.height, args.width, seed=11)
+    mb = synthetic.make_minibatch(roidb, num_fg)
+    blobs = synthetic.init_blobs(num_fg, seed=11)
+    rt = mb['rois'].shape[0]
+    rng = np.random.default_rng(0)
+    masks = {k: (rng.uniform(size=(rt, 4096)) > 0.5).astype(np.float32)
+             for k in ('drop6', 'drop7', '_[noisy]_drop6', '_[noisy]_drop7')}
+    t0 = time.time()
+    ref = oracle.full_forward_backward(blobs, mb, masks, num_fg)
+    lr = np.array([1e-3], np.float32)
+    for name, g in ref['grads'].items():
+        p = blobs[name].numpy().reshape(-1)
+        m = np.zeros_like(p)
+        a = np.zeros_like(p)
+        bias = name.endswith('_b')
+        oracle.acm_sgd(np.ascontiguousarray(g.reshape(-1)), m, lr, p, a, 0.9, 0,
+                       0.0 if bias else 5e-4, 1, 2, 2.0 if bias else 1.0, 0)
+    dt = time.time() - t0
+    return {'value': round(2.0 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '1 iteration (fwd+bwd+SGD) of 2 images %dx%d x %d proposals, fp32, '
+                      'torch-CPU conv/fc + C oracle ops, %.1f s' % (args.height, args.width,
+                                                                    args.cpu_rois, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+        pg = dist.group.WORLD
+    from detectron.datasets import synthetic
+    from naws_hip.engine import WsddnEngine
+
+    num_fg = args.classes
+    B = args.images_per_gpu
+    eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
+                      weight_decay=5e-4, iter_size=1, gpu_num=world * B, seed=11,
+                      process_group=pg, world_size=world, allreduce_chunks=8)
+    blobs = synthetic.init_blobs(num_fg, seed=11)     # identical on every rank (= broadcast)
+    eng.set_conv_blobs(blobs)
+    eng.set_head_blobs(blobs)
+    del blobs
+    roidb = synthetic.make_roidb(B, args.rois, num_fg, args.height, args.width, seed=11 + rank)
+    mb = synthetic.make_minibatch(roidb, num_fg)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    eng.set_lr(1e-3)
+
+    # live timing of the dominant kernel (fc6 forward GEMM, N = 8192) with HIP events on
+    # the launch stream
+    ev = []
+
+    def step(timed):
+        if timed:
+            eng.timing_events = ev
+        else:
+            eng.timing_events = None
+        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+        eng.sgd_step()
+        return out
+
+    for _ in range(args.warmup):
+        out = step(False)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        td = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(td, op=torch.distributed.ReduceOp.MAX)
+        dt = float(td.item())
+    loss = float(out['loss_cls'].sum().item() + out['loss_cls_noise'].sum().item())
+
+    if rank == 0:
+        rt = mb['rois'].shape[0]
+        k6 = 512 * 49
+        fc6_flops = 2.0 * rt * (2 * 4096) * k6
+        kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+        achieved = fc6_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
+        res = {
+            'metric': 'images/sec (600px, 2000 proposals) VGG16-C5 WSDDN fwd+bwd',
+            'value': round(world * B * args.steps / dt, 3),
+            'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'flickr_voc na_wsddn_V-16-C5_1x (C=%d): %d images %dx%d per '
+                                   'GPU x %d proposals, fwd+bwd+allreduce+SGD, fp32 MFMA' % (
+                                       num_fg, B, args.height, args.width, args.rois),
+                       'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
+                       'final_loss': round(loss, 5)},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128,128,32,KC,KC> (fc6 fwd, '
+                                                    'both branches, M=%d N=8192 K=%d)' % (rt, k6),
+                         'achieved': round(achieved, 2) if achieved else None,
+                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                         'traffic': None, 'kernel_ms': round(kern_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args, num_fg)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,387 @@
+"""Fused execution plan of the na_wsddn graph (VGG16-C5 -> RoIPoolF -> two 2-fc
+branches -> WSDDN dual softmax -> entropy-gated weighted CE -> backward ->
+all-reduce -> ACM momentum SGD) on one MI355X.
+
+This is the plan the graph executor (detectron/modeling/detector.py) selects when
+the recorded op list is the reference's na_wsddn graph; it runs
+the same named blobs through a handful of fused HIP kernels instead of 103 ops:
+
+  * conv body in NHWC, bias+ReLU in the implicit-GEMM epilogue (frozen, fwd only);
+  * RoIPoolF fused with RoIFeatureBoost, written straight in (c,ph,pw) order;
+  * fc6 of BOTH branches as ONE GEMM (N = 8192): `fc6_w` and `_[noisy]_fc6_w` are
+    adjacent in one parameter arena, so the shared 400 MB `roi_feat` is read once;
+  * fc7 / fc8 as batch-2 GEMMs over the interleaved [Rt, 8192] activations;
+  * ReLU + Dropout in the GEMM epilogues (counter-based mask, never stored: the
+    backward gate is `drop_out > 0`);
+  * the whole loss tail in ~8 small kernels, per-image segments keyed on rois[:,0];
+  * fc6 wgrad cut into row chunks, each all-reduced (RCCL) while the next runs;
+  * one fused SGD launch over the whole parameter arena.
+
+Blob names, shapes and update rule follow the reference:
+  detectron/modeling/VGG16.py:9-48, wsl_heads.py:23-56,213-227,654-681,
+  webly_heads.py:32-74,123-216,265-391,463-502, optimizer_wsl.py:52-137,
+  detectron/ops/acm_weightdecay_momentum_sgd_op.h:48-112.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+
+VGG16_CONVS = [
+    # (name, cin, cout, dilation) and pool markers
+    ('conv1_1', 3, 64, 1), ('conv1_2', 64, 64, 1), ('pool', 2),
+    ('conv2_1', 64, 128, 1), ('conv2_2', 128, 128, 1), ('pool', 2),
+    ('conv3_1', 128, 256, 1), ('conv3_2', 256, 256, 1), ('conv3_3', 256, 256, 1), ('pool', 2),
+    ('conv4_1', 256, 512, 1), ('conv4_2', 512, 512, 1), ('conv4_3', 512, 512, 1), ('pool4',),
+    ('conv5_1', 512, 512, None), ('conv5_2', 512, 512, None), ('conv5_3', 512, 512, None),
+]
+
+HIDDEN = 4096
+
+
+def head_param_specs(num_fg_classes, dim_in=512, roi_size=7):
+    """Arena order.  Adjacent pairs form the fused GEMM operands."""
+    k6, c = dim_in * roi_size * roi_size, num_fg_classes
+    return [
+        ('fc6_w', (HIDDEN, k6)), ('_[noisy]_fc6_w', (HIDDEN, k6)),
+        ('fc6_b', (HIDDEN,)), ('_[noisy]_fc6_b', (HIDDEN,)),
+        ('fc7_w', (HIDDEN, HIDDEN)), ('_[noisy]_fc7_w', (HIDDEN, HIDDEN)),
+        ('fc7_b', (HIDDEN,)), ('_[noisy]_fc7_b', (HIDDEN,)),
+        ('fc8c_w', (c, HIDDEN)), ('fc8d_w', (c, HIDDEN)),
+        ('noisy_fc8c_w', (c, HIDDEN)), ('noisy_fc8d_w', (c, HIDDEN)),
+        ('fc8c_b', (c,)), ('fc8d_b', (c,)), ('noisy_fc8c_b', (c,)), ('noisy_fc8d_b', (c,)),
+    ]
+
+
+class ParamArena(object):
+    """One flat fp32 buffer cut into named blobs (params / grads / momentum share the cut)."""
+
+    def __init__(self, specs, device):
+        self.specs = specs
+        self.offsets = {}
+        off = 0
+        for name, shape in specs:
+            n = int(np.prod(shape))
+            if n % 4 != 0:
+                raise NotImplementedError('blob %s has %d elements; arena segments must be a '
+                                          'multiple of 4 floats' % (name, n))
+            self.offsets[name] = (off, n, shape)
+            off += n
+        self.total = off
+        self.device = device
+
+    def alloc(self, zero=True):
+        return (torch.zeros if zero else torch.empty)((self.total,), device=self.device,
+                                                      dtype=torch.float32)
+
+    def view(self, flat, name):
+        off, n, shape = self.offsets[name]
+        return flat[off:off + n].view(shape)
+
+    def span(self, flat, first, last):
+        """Contiguous slice covering blobs first..last (inclusive, arena order)."""
+        o0 = self.offsets[first][0]
+        o1, n1, _ = self.offsets[last]
+        return flat[o0:o1 + n1]
+
+
+class WsddnEngine(object):
+    def __init__(self, num_classes, device, dilation=2, roi_size=7, dropout=0.5, is_mean=True,
+                 momentum=0.9, weight_decay=5e-4, iter_size=1, gpu_num=1, seed=11,
+                 process_group=None, world_size=1, allreduce_chunks=8, freeze_conv_body=True):
+        if not freeze_conv_body:
+            raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
+                                      '(SURVEY.md fact 2): the conv body has no backward')
+        L.load()
+        self.C = num_classes - 1
+        self.device = device
+        self.dilation = dilation
+        self.roi_size = roi_size
+        self.spatial_scale = 1.0 / 8.0 if dilation == 2 else 1.0 / 16.0
+        self.dropout = float(dropout)
+        self.is_mean = bool(is_mean)
+        self.momentum = float(momentum)
+        self.iter_size = int(iter_size)
+        self.gpu_num = int(gpu_num)
+        self.seed = int(seed)
+        self.pg, self.world_size = process_group, int(world_size)
+        self.allreduce_chunks = max(1, int(allreduce_chunks))
+        self.k6 = 512 * roi_size * roi_size
+
+        self.arena = ParamArena(head_param_specs(self.C, 512, roi_size), device)
+        self.params = self.arena.alloc()
+        self.grads = self.arena.alloc()
+        self.momentum_buf = self.arena.alloc()
+        self.acmgrad = self.arena.alloc() if self.iter_size != 1 else None
+        ends, lr_mult, wd = [], [], []
+        for name, _ in self.arena.specs:
+            off, n, _s = self.arena.offsets[name]
+            ends.append(off + n)
+            is_bias = name.endswith('_b')
+            # biases: no weight decay, 2x lr (optimizer_wsl.py:106-123); '_lrm10_' -> x10 (:125)
+            lm = 2.0 if is_bias else 1.0
+            if '_lrm10_' in name:
+                lm *= 10.0
+            lr_mult.append(lm)
+            wd.append(0.0 if is_bias else float(weight_decay))
+        self.seg_end = torch.tensor(ends, dtype=torch.int64, device=device)
+        self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=device)
+        self.seg_wd = torch.tensor(wd, dtype=torch.float32, device=device)
+        self.lr = torch.zeros((1,), dtype=torch.float32, device=device)
+        self.sgd_iter_count = 0      # the SGD op's iter_count_ state
+        self.step_count = 0          # forward/backward passes run (dropout stream)
+        self.conv = {}               # name -> (weight (OIHW or packed), bias)
+        self.stat_state = None
+        self.saved = None
+
+    # ------------------------------------------------------------------ params
+    def blob(self, name):
+        return self.arena.view(self.params, name)
+
+    def grad_blob(self, name):
+        return self.arena.view(self.grads, name)
+
+    def momentum_blob(self, name):
+        return self.arena.view(self.momentum_buf, name)
+
+    def set_conv_blobs(self, blobs):
+        """blobs: name_w [O,I,3,3], name_b [O] (reference layout).  Packs once."""
+        for item in VGG16_CONVS:
+            if item[0].startswith('pool'):
+                continue
+            name = item[0]
+            w = blobs[name + '_w'].to(self.device, torch.float32).contiguous()
+            b = blobs[name + '_b'].to(self.device, torch.float32).contiguous()
+            self.conv[name] = (w if name == 'conv1_1' else ops.conv3x3_pack_weight(w), b, w)
+
+    def set_head_blobs(self, blobs):
+        for name, shape in self.arena.specs:
+            if name in blobs:
+                self.blob(name).copy_(blobs[name].to(self.device, torch.float32).view(shape))
+
+    def export_blobs(self, with_momentum=True):
+        out = {}
+        for name, (wp, b, w) in self.conv.items():
+            out[name + '_w'], out[name + '_b'] = w, b
+        for name, _ in self.arena.specs:
+            out[name] = self.blob(name)
+            if with_momentum:
+                out[name + '_momentum'] = self.momentum_blob(name)
+        return out
+
+    # ---------------------------------------------------------------- forward
+    def conv_body(self, data):
+        """data NCHW [B,3,H,W] -> conv5_3 NHWC [B,H/8-1,W/8-1,512]."""
+        x = None
+        for item in VGG16_CONVS:
+            if item[0] == 'pool':
+                x = ops.maxpool2x2_nhwc(x, 2)
+            elif item[0] == 'pool4':
+                x = ops.maxpool2x2_nhwc(x, 1 if self.dilation == 2 else 2)
+            else:
+                name, _, _, dil = item
+                wp, b, _w = self.conv[name]
+                if name == 'conv1_1':
+                    x = ops.conv3x3_c3_nchw_to_nhwc(data, wp, b, True)
+                else:
+                    d = dil if dil is not None else (2 if self.dilation == 2 else 1)
+                    x = ops.conv3x3_nhwc(x, wp, b, d, True)
+        return x
+
+    @staticmethod
+    def segments(rois, n_img):
+        """seg_off (host list) from rois[:,0]; rows must be grouped by image in order."""
+        b = rois[:, 0].to(torch.int64)
+        counts = torch.bincount(b, minlength=n_img).cpu().tolist()
+        seg = [0]
+        for c in counts:
+            seg.append(seg[-1] + c)
+        return seg
+
+    def _seed(self, layer):
+        return (self.seed * 0x9E3779B1 + self.step_count * 1000003 + layer * 7919) & ((1 << 62) - 1)
+
+    def head_forward(self, roi_feat, train, both_branches=True):
+        """roi_feat [Rt, k6] -> H6, H7 [Rt, nb*4096], logits L [Rt, nb*2C]."""
+        rt = roi_feat.shape[0]
+        nb = 2 if both_branches else 1
+        C = self.C
+        w6 = self.arena.span(self.params, 'fc6_w', '_[noisy]_fc6_w').view(2 * HIDDEN, self.k6)
+        b6 = self.arena.span(self.params, 'fc6_b', '_[noisy]_fc6_b')
+        w7 = self.arena.span(self.params, 'fc7_w', '_[noisy]_fc7_w').view(2, HIDDEN, HIDDEN)
+        b7 = self.arena.span(self.params, 'fc7_b', '_[noisy]_fc7_b').view(2, HIDDEN)
+        w8 = self.arena.span(self.params, 'fc8c_w', 'noisy_fc8d_w').view(2, 2 * C, HIDDEN)
+        b8 = self.arena.span(self.params, 'fc8c_b', 'noisy_fc8d_b').view(2, 2 * C)
+        drop = train and self.dropout > 0
+        epi = L.EPI_BIAS_RELU_DROP if drop else L.EPI_BIAS_RELU
+        tev = getattr(self, 'timing_events', None)
+        if tev is not None:     # bench.py: HIP events around the dominant kernel, same stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        h6 = ops.gemm(roi_feat, w6[:nb * HIDDEN], False, True, epilogue=epi, bias=b6,
+                      drop_ratio=self.dropout if drop else 0.0, seed=self._seed(6))
+        if tev is not None:
+            e1.record()
+            tev.append((e0, e1))
+        h6v = h6.view(rt, nb, HIDDEN).permute(1, 0, 2)       # [nb, Rt, 4096] strided views
+        h7 = torch.empty((rt, nb * HIDDEN), device=self.device, dtype=torch.float32)
+        h7v = h7.view(rt, nb, HIDDEN).permute(1, 0, 2)
+        ops.gemm(h6v, w7[:nb], False, True, out=h7v, epilogue=epi, bias=b7,
+                 drop_ratio=self.dropout if drop else 0.0, seed=self._seed(7))
+        lg = torch.empty((rt, nb * 2 * C), device=self.device, dtype=torch.float32)
+        lgv = lg.view(rt, nb, 2 * C).permute(1, 0, 2)
+        ops.gemm(h7v, w8[:nb], False, True, out=lgv, epilogue=L.EPI_BIAS, bias=b8)
+        return h6, h7, lg
+
+    def forward_backward(self, data, rois, obn_scores, labels_oh, compute_grads=True):
+        """One training pass over this GPU's images.  Returns dict of loss tensors
+        (per image) and keeps what backward / stats need."""
+        C = self.C
+        n_img = data.shape[0]
+        seg = self.segments(rois, n_img)
+        rt = rois.shape[0]
+        max_seg = max(seg[i + 1] - seg[i] for i in range(n_img))
+        seg_off = torch.tensor(seg, dtype=torch.int32, device=self.device)
+        conv5 = self.conv_body(data)
+        roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
+                                  boost=obn_scores.reshape(-1), layout='NHWC')
+        del conv5
+        x = roi_feat.view(rt, self.k6)
+        h6, h7, lg = self.head_forward(x, train=True)
+        lv = [lg[:, i * C:(i + 1) * C] for i in range(4)]    # fc8c, fc8d, noisy_fc8c, noisy_fc8d
+        ac, ad, rp, cp = ops.wsddn_outputs(lv[0], lv[1], lv[2], lv[3], seg_off)
+        cw, cwn, hs, hsn = ops.entropy_gate(rois, rp[0], cp[0], labels_oh, seg_off, max_seg)
+        wts = torch.stack([cw, cwn])                           # [2, nseg, C]
+        lab2 = labels_oh.unsqueeze(0).expand(2, n_img, C).contiguous()
+        losses = ops.weighted_ce(cp, lab2, wts, self.is_mean, 2 * n_img)   # [2*nseg]
+        out = dict(loss_cls=losses[:n_img], loss_cls_noise=losses[n_img:], cls_prob=cp[0],
+                   cls_prob_noise=cp[1], class_weight=cw, class_weight_noise=cwn,
+                   hatE_sum=hs, hatE_sum_norm=hsn, rois_pred=rp[0])
+        self.step_count += 1
+        if not compute_grads:
+            return out
+        # ---- backward (loss gradient seed 1.0 per loss, blob.py:167-173)
+        ones = torch.ones((2 * n_img,), device=self.device, dtype=torch.float32)
+        g = ops.weighted_ce_grad(cp, lab2, wts, ones, self.is_mean, 2 * n_img)
+        dl = ops.wsddn_outputs_grad(ac, ad, rp, cp, g, seg_off)          # [Rt, 4C]
+        self._head_backward(x, h6, h7, dl)
+        out['d_logits'] = dl
+        return out
+
+    def _head_backward(self, x, h6, h7, dl):
+        C, rt = self.C, x.shape[0]
+        G = self.grads
+        scale = 1.0 / (1.0 - self.dropout) if self.dropout > 0 else 1.0
+        w7 = self.arena.span(self.params, 'fc7_w', '_[noisy]_fc7_w').view(2, HIDDEN, HIDDEN)
+        w8 = self.arena.span(self.params, 'fc8c_w', 'noisy_fc8d_w').view(2, 2 * C, HIDDEN)
+        gw6 = self.arena.span(G, 'fc6_w', '_[noisy]_fc6_w').view(2 * HIDDEN, self.k6)
+        gb6 = self.arena.span(G, 'fc6_b', '_[noisy]_fc6_b')
+        gw7 = self.arena.span(G, 'fc7_w', '_[noisy]_fc7_w').view(2, HIDDEN, HIDDEN)
+        gb7 = self.arena.span(G, 'fc7_b', '_[noisy]_fc7_b')
+        gw8 = self.arena.span(G, 'fc8c_w', 'noisy_fc8d_w').view(2, 2 * C, HIDDEN)
+        gb8 = self.arena.span(G, 'fc8c_b', 'noisy_fc8d_b')
+        dlv = dl.view(rt, 2, 2 * C).permute(1, 0, 2)           # [2, Rt, 2C]
+        h7v = h7.view(rt, 2, HIDDEN).permute(1, 0, 2)
+        h6v = h6.view(rt, 2, HIDDEN).permute(1, 0, 2)
+        # fc8: dW = dL^T H7, db = colsum(dL), dH7 = dL W8 gated by ReLU/Dropout of fc7
+        ops.gemm(dlv, h7v, True, False, out=gw8)
+        ops.colsum(dl, out=gb8)
+        dz7 = torch.empty_like(h7)
+        dz7v = dz7.view(rt, 2, HIDDEN).permute(1, 0, 2)
+        ops.gemm(dlv, w8, False, False, out=dz7v, epilogue=L.EPI_GATE_POS, aux=h7v, alpha=scale)
+        # fc7
+        ops.gemm(dz7v, h6v, True, False, out=gw7)
+        ops.colsum(dz7, out=gb7)
+        dz6 = torch.empty_like(h6)
+        dz6v = dz6.view(rt, 2, HIDDEN).permute(1, 0, 2)
+        ops.gemm(dz7v, w7, False, False, out=dz6v, epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
+        ops.colsum(dz6, out=gb6)
+        # everything except fc6_w is ready: start its all-reduce, then stream fc6 wgrad chunks
+        works = []
+        dist_on = self.pg is not None and self.world_size > 1
+        if dist_on:
+            import torch.distributed as dist
+            tail = self.arena.span(G, 'fc6_b', 'noisy_fc8d_b')
+            works.append(dist.all_reduce(tail, group=self.pg, async_op=True))
+        nch = self.allreduce_chunks if dist_on else 1
+        rows = 2 * HIDDEN
+        step = (rows // nch + 127) // 128 * 128
+        for r0 in range(0, rows, step):
+            r1 = min(rows, r0 + step)
+            ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
+            if dist_on:
+                works.append(dist.all_reduce(gw6[r0:r1], group=self.pg, async_op=True))
+        self._pending = works
+
+    def wait_allreduce(self):
+        for w in getattr(self, '_pending', []):
+            w.wait()
+        self._pending = []
+
+    # -------------------------------------------------------------------- SGD
+    def set_lr(self, new_lr):
+        """UpdateWorkspaceLr + momentum correction (detector.py:509-559)."""
+        new_lr = float(np.float32(new_lr))
+        cur = float(self.lr.item())
+        if cur != new_lr:
+            ratio = max(new_lr / max(cur, 1e-10), cur / max(new_lr, 1e-10))
+            self.lr.fill_(new_lr)
+            if cur > 1e-7 and ratio > 1.1:
+                ops.unary(L.UN_SCALE, self.momentum_buf, new_lr / cur, out=self.momentum_buf)
+        return new_lr
+
+    def sgd_step(self):
+        self.wait_allreduce()
+        ops.acm_sgd_update(self.grads, self.momentum_buf, self.lr, self.params, self.acmgrad,
+                           self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
+                           self.iter_size, self.gpu_num, self.sgd_iter_count)
+        self.sgd_iter_count += 1
+
+    # -------------------------------------------------------------- inference
+    def infer(self, data, rois, obn_scores):
+        """Test-mode forward: cls_prob [R, C+1] = Concat(rois_pred[:, :1], rois_pred)
+        (wsl_heads.py:58-67); no dropout; only the clean branch is fetched (test_wsl.py:151)."""
+        n_img = data.shape[0]
+        seg = self.segments(rois, n_img)
+        seg_off = torch.tensor(seg, dtype=torch.int32, device=self.device)
+        conv5 = self.conv_body(data)
+        roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
+                                  boost=obn_scores.reshape(-1), layout='NHWC')
+        x = roi_feat.view(rois.shape[0], self.k6)
+        _h6, _h7, lg = self.head_forward(x, train=False, both_branches=False)
+        C = self.C
+        _ac, _ad, rp, _cp = ops.wsddn_outputs(lg[:, :C], lg[:, C:2 * C], None, None, seg_off)
+        return torch.cat([rp[0][:, :1], rp[0]], dim=1)
+
+    # ------------------------------------------------------------------ Stat
+    def stat_update(self, out, labels_oh, display, printer=print):
+        """The six Stat ops of webly_heads.py:400-440 (image 0 of this process)."""
+        C = self.C
+        if self.stat_state is None:
+            self.stat_state = dict(AI=torch.zeros((6, C), device=self.device),
+                                   AL=torch.zeros((6, C), device=self.device), it=0, init=True)
+        st = self.stat_state
+        lab = labels_oh[0].contiguous()
+        bg = ops.unary(L.UN_SCALE, lab, -1.0)
+        bg = ops.binary(L.BIN_ADD, bg.view(1, C), torch.ones((1, 1), device=self.device)).view(C)
+        pairs = [('class_weight      ', out['class_weight'][0], bg),
+                 ('class_weight_noise', out['class_weight_noise'][0], bg),
+                 ('hatE_sum bg       ', out['hatE_sum'][0], bg),
+                 ('hatE_sum fg       ', out['hatE_sum'][0], lab),
+                 ('hatE_sum_norm bg  ', out['hatE_sum_norm'][0], bg),
+                 ('hatE_sum_norm fg  ', out['hatE_sum_norm'][0], lab)]
+        for k, (_p, i_, l_) in enumerate(pairs):
+            ops.stat_accumulate(i_.contiguous(), l_, st['AI'][k], st['AL'][k], st['init'])
+        st['init'] = False
+        st['it'] += 1
+        if st['it'] % display == 0 or st['it'] == 1:
+            ai, al = st['AI'].cpu().numpy(), st['AL'].cpu().numpy()
+            with np.errstate(divide='ignore', invalid='ignore'):
+                ratio = ai / al
+            for k, (p, _i, _l) in enumerate(pairs):
+                printer('\t' + p + ' Stat #iter_: ' + str(st['it']) + ''.join(
+                    ' %.2f' % v for v in ratio[k]))
+            st['init'] = True

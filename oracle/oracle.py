@@ -258,3 +258,43 @@ def loss_tail(fc8, rois, labels_oh, is_mean=True):
                 class_weight=cw, class_weight_noise=cwn, hatE_sum=hs, hatE_sum_norm=hsn,
                 loss_cls=loss, loss_cls_noise=loss_n, d_cls_prob=g, d_cls_prob_noise=gn,
                 d_fc8c=dzc + dzcn, d_fc8d=dzd + dzdn, d_noisy_fc8c=dzcn, d_noisy_fc8d=dzdn)
+
+
+def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatial_scale=0.125,
+                          roi_size=7, train=True):
+    """Whole hot path on the CPU for a minibatch of B images (each image is one reference
+    'GPU': per-image softmax-over-proposals / ReduceSum / gate / loss; gradients summed over
+    images, exactly what the all-reduce does).
+    blobs: torch CPU tensors in the reference layouts; mb: dict of numpy loader blobs;
+    masks: dict of 0/1 keep masks [Rt,4096] for drop6, drop7, _[noisy]_drop6, _[noisy]_drop7.
+    Returns dict(losses per image, grads per trainable blob, intermediates)."""
+    import torch
+    data = torch.from_numpy(mb['data'])
+    with torch.no_grad():
+        conv5 = vgg16_conv5_body(data, blobs)                # StopGradient: forward only
+    rois = mb['rois']
+    pooled, _ = roi_pool_f(conv5.numpy(), rois, roi_size, roi_size, spatial_scale)
+    roi_feat = roi_feature_boost(pooled, mb['obn_scores'].reshape(-1))
+    x = torch.from_numpy(roi_feat.reshape(rois.shape[0], -1))
+    names = ['fc6_w', 'fc6_b', 'fc7_w', 'fc7_b', '_[noisy]_fc6_w', '_[noisy]_fc6_b',
+             '_[noisy]_fc7_w', '_[noisy]_fc7_b', 'fc8c_w', 'fc8c_b', 'fc8d_w', 'fc8d_b',
+             'noisy_fc8c_w', 'noisy_fc8c_b', 'noisy_fc8d_w', 'noisy_fc8d_b']
+    params = {n: blobs[n].clone().requires_grad_(True) for n in names}
+    tmasks = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in (masks or {}).items()}
+    act = head_forward(x, params, tmasks, train=train)
+    fc8 = {k: act[k].detach().numpy() for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')}
+    b = rois[:, 0].astype(np.int64)
+    n_img = mb['data'].shape[0]
+    tails, dl = [], {k: np.zeros_like(v) for k, v in fc8.items()}
+    for i in range(n_img):
+        sel = np.where(b == i)[0]
+        t = loss_tail({k: v[sel] for k, v in fc8.items()}, rois[sel], mb['labels_oh'][i], is_mean)
+        tails.append(t)
+        for k in dl:
+            dl[k][sel] = t['d_' + k]
+    outs = [act[k] for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
+    gouts = [torch.from_numpy(dl[k]) for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
+    grads = torch.autograd.grad(outs, [params[n] for n in names], gouts)
+    return dict(conv5_3=conv5.numpy(), roi_feat=roi_feat, act={k: v.detach().numpy()
+                                                               for k, v in act.items()},
+                tails=tails, d_logits=dl, grads={n: g.numpy() for n, g in zip(names, grads)})

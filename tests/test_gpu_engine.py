@@ -1,0 +1,108 @@
+"""GPU parity of the fused execution plan (naws_hip.engine) against the CPU oracle on a
+tiny end-to-end case: 2 synthetic 64x96 images, 24 / 16 rois, random weights -> conv5_3,
+roi_feat, logits, loss_cls, loss_cls_noise, all 16 parameter gradients, 3 SGD steps."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _setup(dev, c=20, dropout=0.5, seed=11):
+    from detectron.datasets import synthetic
+    from naws_hip.engine import WsddnEngine
+    roidb = synthetic.make_roidb(2, 24, c, 64, 96, seed=seed)
+    roidb[1]['boxes'] = roidb[1]['boxes'][:16]
+    roidb[1]['obn_scores'] = roidb[1]['obn_scores'][:16]
+    roidb[1]['gt_classes'] = roidb[1]['gt_classes'][:16]
+    mb = synthetic.make_minibatch(roidb, c)
+    blobs = synthetic.init_blobs(c, seed=seed)
+    for k in list(blobs):     # non-zero biases so the bias paths are exercised
+        if k.endswith('_b'):
+            blobs[k] = torch.randn(blobs[k].shape, generator=torch.Generator().manual_seed(1)) * 0.05
+    eng = WsddnEngine(c + 1, dev, dropout=dropout, gpu_num=2, seed=seed)
+    eng.set_conv_blobs(blobs)
+    eng.set_head_blobs(blobs)
+    return eng, mb, blobs
+
+
+def _masks(eng, rt, dev):
+    from naws_hip import ops
+    if eng.dropout <= 0:
+        return None
+    m6 = ops.dropout_mask(eng._seed(6), eng.dropout, rt * 8192, dev).view(rt, 8192).cpu().numpy()
+    m7 = ops.dropout_mask(eng._seed(7), eng.dropout, 2 * rt * 4096, dev).view(2, rt, 4096).cpu().numpy()
+    return {'drop6': m6[:, :4096], '_[noisy]_drop6': m6[:, 4096:],
+            'drop7': m7[0], '_[noisy]_drop7': m7[1]}
+
+
+@pytest.mark.parametrize('dropout', [0.5, 0.0])
+def test_engine_matches_oracle(dev, dropout):
+    from oracle import oracle
+    eng, mb, blobs = _setup(dev, dropout=dropout)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    rt = mb['rois'].shape[0]
+    masks = _masks(eng, rt, dev)
+    out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+    ref = oracle.full_forward_backward(blobs, mb, masks, 20, train=dropout > 0)
+    conv5 = eng.conv_body(t['data']).permute(0, 3, 1, 2)
+    assert _rel(conv5, ref['conv5_3']) < 1e-4
+    for i in range(2):
+        tl = ref['tails'][i]
+        assert abs(float(out['loss_cls'][i]) - tl['loss_cls']) <= 1e-4 * abs(tl['loss_cls'])
+        assert abs(float(out['loss_cls_noise'][i]) - tl['loss_cls_noise']) <= \
+            1e-4 * abs(tl['loss_cls_noise'])
+        np.testing.assert_allclose(out['cls_prob'][i].cpu().numpy(), tl['cls_prob'][0], rtol=1e-4)
+        np.testing.assert_allclose(out['class_weight'][i].cpu().numpy(), tl['class_weight'][0],
+                                   rtol=1e-4, atol=1e-6)
+    dl = np.concatenate([ref['d_logits'][k] for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')], 1)
+    assert _rel(out['d_logits'], dl) < 1e-4
+    for name, g in ref['grads'].items():
+        assert _rel(eng.grad_blob(name), g) < 2e-4, name
+
+
+def test_engine_sgd_steps(dev):
+    """3 iterations of fwd+bwd+SGD vs the oracle (dropout masks replayed)."""
+    from oracle import oracle
+    eng, mb, blobs = _setup(dev)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    rt = mb['rois'].shape[0]
+    cur = {k: v.clone() for k, v in blobs.items()}
+    state = {}
+    lr = np.float32(1e-3)
+    eng.set_lr(lr)
+    for it in range(3):
+        masks = _masks(eng, rt, dev)
+        eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+        eng.sgd_step()
+        ref = oracle.full_forward_backward(cur, mb, masks, 20)
+        for name, g in ref['grads'].items():
+            p = cur[name].numpy().reshape(-1).copy()
+            st = state.setdefault(name, dict(m=np.ones_like(p), a=np.ones_like(p), it=0))
+            bias = name.endswith('_b')
+            st['it'] = oracle.acm_sgd(np.ascontiguousarray(g.reshape(-1)), st['m'],
+                                      np.array([lr], np.float32), p, st['a'], 0.9, 0,
+                                      0.0 if bias else 5e-4, 1, 2, 2.0 if bias else 1.0, st['it'])
+            cur[name] = torch.from_numpy(p.reshape(cur[name].shape))
+    for name in ref['grads']:
+        assert _rel(eng.blob(name), cur[name].numpy()) < 1e-5, name
+        assert _rel(eng.momentum_blob(name), state[name]['m'].reshape(cur[name].shape)) < 5e-4, name
+
+
+def test_engine_infer(dev):
+    from oracle import oracle
+    eng, mb, blobs = _setup(dev, dropout=0.5)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    one = {k: v[:1] if k in ('data', 'labels_oh') else v for k, v in mb.items()}
+    sel = mb['rois'][:, 0] == 0
+    cls_prob = eng.infer(t['data'][:1], t['rois'][sel], t['obn_scores'][sel])
+    one['rois'], one['obn_scores'] = mb['rois'][sel], mb['obn_scores'][sel]
+    ref = oracle.full_forward_backward(blobs, one, None, 20, train=False)
+    rp = ref['tails'][0]['rois_pred']
+    np.testing.assert_allclose(cls_prob.cpu().numpy(), np.concatenate([rp[:, :1], rp], 1),
+                               rtol=1e-4, atol=1e-8)
