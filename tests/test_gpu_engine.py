@@ -62,8 +62,12 @@ def test_engine_matches_oracle(dev, dropout):
                                    rtol=1e-4, atol=1e-6)
     dl = np.concatenate([ref['d_logits'][k] for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')], 1)
     assert _rel(out['d_logits'], dl) < 1e-4
+    # fc8d_b's gradient is identically zero in exact arithmetic (a softmax-over-proposals
+    # gradient sums to 0 down each column): compare against the rounding floor instead
+    floor = 1e-6 * float(np.abs(dl).max()) * rt
     for name, g in ref['grads'].items():
-        assert _rel(eng.grad_blob(name), g) < 2e-4, name
+        got = eng.grad_blob(name).cpu().numpy()
+        assert np.abs(got - g).max() <= 2e-4 * np.abs(g).max() + floor, name
 
 
 def test_engine_sgd_steps(dev):
