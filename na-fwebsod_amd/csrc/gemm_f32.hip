@@ -9,20 +9,26 @@
 //      detectron/modeling/VGG16.py:9-48 (Caffe2 FC / Conv semantics).
 //
 // Design (MI355X, 64-wide waves): 256-thread workgroup = 4 waves in a 2x2 grid,
-// each wave owns TI x TJ tiles of 32x32 accumulators.  Operand tiles are staged
-// global -> registers -> LDS (two LDS buffers, one barrier per K-step; the next
-// tile's global loads are in flight during the current tile's MFMAs).
+// each wave owns TI x TJ tiles of 32x32 accumulators, 2 workgroups per CU.
+// Operand tiles go global -> registers -> LDS (two LDS buffers, one barrier per
+// K-step).  Global loads are branch-free buffer loads (out-of-range lanes use
+// an out-of-bounds offset and read 0), issued right after the K-step's first
+// LDS fragment reads so their issue hides in the MFMA shadow; the LDS writes of
+// the next tile are placed in the middle of the last k-group's MFMAs.
 // K-contiguous operands sit in LDS as [row][BK+4] (pad 4 floats => the 16-lane
 // ds_read_b128 groups hit 16 distinct 16-B slots) and each lane fetches FOUR
 // k-values with one ds_read_b128; M/N-contiguous operands sit as [k][row] and
 // are fetched with conflict-free ds_read_b32.  Both forms use the same k
 // assignment inside an 8-deep group (MFMA step s, lane half h -> k = 4h + s),
 // so any A/B layout pair multiplies matching k's.
+#include <stdlib.h>
+#include <type_traits>
 #include "naws_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
   const float* A;
@@ -31,6 +37,7 @@ struct GemmArgs {
   int M, N, K;
   int lda, ldb, ldc;
   long long sA, sB, sC, sBias;
+  unsigned bytesA, bytesB;  // extent of one batch slice (for the buffer descriptors)
   const float* bias;
   const float* aux;
   int ldaux;
@@ -45,101 +52,115 @@ struct GemmArgs {
   int H, W, Cin, dil;
 };
 
-constexpr int NT = 256;  // threads per workgroup
-constexpr int PADK = 4;  // K-contiguous LDS row pad (floats)
+constexpr int NT = 256;                // threads per workgroup
+constexpr int PADK = 4;                // K-contiguous LDS row pad (floats)
+constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any descriptor range
 
 template <int ROWS, int BK, bool KC>
 struct TileGeom {
   static constexpr int LD = KC ? (BK + PADK) : ROWS;          // LDS leading dim
   static constexpr int FLOATS = KC ? ROWS * (BK + PADK) : BK * ROWS;
-  static constexpr int VEC_PER_THREAD = ROWS * BK / 4 / NT;   // float4 per thread
+  static constexpr int VPT = ROWS * BK / 4 / NT;              // float4 per thread
   static_assert(ROWS * BK / 4 % NT == 0, "tile must divide over the workgroup");
 };
 
-// ---- global -> registers ---------------------------------------------------
-template <int ROWS, int BK, bool KC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int row0,
-                                          int nrows, int k0, int K, float4* __restrict__ r) {
-  using G = TileGeom<ROWS, BK, KC>;
-#pragma unroll
-  for (int i = 0; i < G::VEC_PER_THREAD; ++i) {
-    const int f = threadIdx.x + i * NT;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KC) {
-      const int row = f / (BK / 4), c4 = f % (BK / 4);
-      const int gr = row0 + row, gk = k0 + c4 * 4;
-      if (gr < nrows && gk < K) v = *reinterpret_cast<const float4*>(P + (long long)gr * ld + gk);
-    } else {
-      const int kr = f / (ROWS / 4), m4 = f % (ROWS / 4);
-      const int gk = k0 + kr, gr = row0 + m4 * 4;
-      if (gk < K && gr < nrows) v = *reinterpret_cast<const float4*>(P + (long long)gk * ld + gr);
-    }
-    r[i] = v;
-  }
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+  float4 f;
+  f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y);
+  f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+  return f;
 }
 
+// Per-thread staging state of one operand tile: the K-invariant part of each
+// 16-byte load's byte offset (or OOB when the row is outside the matrix).
 template <int ROWS, int BK, bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4* __restrict__ r) {
+struct Stage {
   using G = TileGeom<ROWS, BK, KC>;
+  unsigned base[G::VPT];
+  unsigned kstep;  // bytes added per K-step
+
+  __device__ __forceinline__ void init(int ld, int row0, int nrows) {
 #pragma unroll
-  for (int i = 0; i < G::VEC_PER_THREAD; ++i) {
-    const int f = threadIdx.x + i * NT;
-    if (KC) {
-      const int row = f / (BK / 4), c4 = f % (BK / 4);
-      *reinterpret_cast<float4*>(S + row * G::LD + c4 * 4) = r[i];
-    } else {
-      const int kr = f / (ROWS / 4), m4 = f % (ROWS / 4);
-      *reinterpret_cast<float4*>(S + kr * G::LD + m4 * 4) = r[i];
+    for (int i = 0; i < G::VPT; ++i) {
+      const int f = threadIdx.x + i * NT;
+      if (KC) {
+        const int row = f / (BK / 4), c4 = f % (BK / 4);
+        const int gr = row0 + row;
+        base[i] = gr < nrows ? ((unsigned)gr * (unsigned)ld + c4 * 4) * 4u : OOB;
+      } else {
+        const int kr = f / (ROWS / 4), m4 = f % (ROWS / 4);
+        const int gr = row0 + m4 * 4;
+        base[i] = gr < nrows ? ((unsigned)kr * (unsigned)ld + gr) * 4u : OOB;
+      }
+    }
+    kstep = KC ? BK * 4u : (unsigned)BK * (unsigned)ld * 4u;
+  }
+
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int t, int K,
+                                       float4* __restrict__ r) const {
+#pragma unroll
+    for (int i = 0; i < G::VPT; ++i) {
+      const int f = threadIdx.x + i * NT;
+      const int kk = KC ? (f % (BK / 4)) * 4 : f / (ROWS / 4);
+      const bool ok = (base[i] != OOB) && (t * BK + kk < K);
+      r[i] = buf_load4(rsrc, ok ? base[i] + (unsigned)t * kstep : OOB);
     }
   }
-}
 
-// conv A tile: rows are output pixels, the K-step lies inside one 3x3 tap.
-template <int ROWS, int BK>
-struct ConvRows {
-  static constexpr int VPT = TileGeom<ROWS, BK, true>::VEC_PER_THREAD;
-  int y[VPT], x[VPT];
-  long long base[VPT];  // pixel offset (n*H + y)*W + x, or -1 when the row is out of range
+  __device__ __forceinline__ static void store(float* __restrict__ S,
+                                               const float4* __restrict__ r) {
+#pragma unroll
+    for (int i = 0; i < G::VPT; ++i) {
+      const int f = threadIdx.x + i * NT;
+      if (KC) {
+        const int row = f / (BK / 4), c4 = f % (BK / 4);
+        *reinterpret_cast<float4*>(S + row * G::LD + c4 * 4) = r[i];
+      } else {
+        const int kr = f / (ROWS / 4), m4 = f % (ROWS / 4);
+        *reinterpret_cast<float4*>(S + kr * G::LD + m4 * 4) = r[i];
+      }
+    }
+  }
 };
 
+// conv A tile: rows are output pixels, a K-step lies inside one 3x3 tap.
 template <int ROWS, int BK>
-__device__ __forceinline__ void conv_rows_init(ConvRows<ROWS, BK>& cr, int row0, int M, int H,
-                                               int W) {
+struct ConvStage {
+  using G = TileGeom<ROWS, BK, true>;
+  int y[G::VPT], x[G::VPT];
+  unsigned base[G::VPT];  // byte offset of (pixel, channel chunk) or OOB
+
+  __device__ __forceinline__ void init(int row0, int M, int H, int W, int Cin) {
 #pragma unroll
-  for (int i = 0; i < ConvRows<ROWS, BK>::VPT; ++i) {
-    const int f = threadIdx.x + i * NT;
-    const int row = f / (BK / 4);
-    const int gm = row0 + row;
-    if (gm < M) {
-      const int xx = gm % W;
-      const int t = gm / W;
-      cr.x[i] = xx;
-      cr.y[i] = t % H;
-      cr.base[i] = gm;
-    } else {
-      cr.x[i] = 0; cr.y[i] = 0; cr.base[i] = -1;
+    for (int i = 0; i < G::VPT; ++i) {
+      const int f = threadIdx.x + i * NT;
+      const int row = f / (BK / 4), c4 = f % (BK / 4);
+      const int gm = row0 + row;
+      if (gm < M) {
+        x[i] = gm % W;
+        y[i] = (gm / W) % H;
+        base[i] = ((unsigned)gm * (unsigned)Cin + c4 * 4) * 4u;
+      } else {
+        x[i] = 0; y[i] = 0; base[i] = OOB;
+      }
     }
   }
-}
 
-template <int ROWS, int BK>
-__device__ __forceinline__ void load_tile_conv(const float* __restrict__ X,
-                                               const ConvRows<ROWS, BK>& cr, int k0, int H, int W,
-                                               int Cin, int dil, float4* __restrict__ r) {
-  const int tap = k0 / Cin, c0 = k0 - tap * Cin;
-  const int dy = (tap / 3 - 1) * dil, dx = (tap % 3 - 1) * dil;
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int t, int H, int W, int Cin,
+                                       int dil, float4* __restrict__ r) const {
+    const int k0 = t * BK;
+    const int tap = k0 / Cin, c0 = k0 - tap * Cin;
+    const int dy = (tap / 3 - 1) * dil, dx = (tap % 3 - 1) * dil;
+    const int delta = ((dy * W + dx) * Cin + c0) * 4;  // bytes, may be negative
 #pragma unroll
-  for (int i = 0; i < ConvRows<ROWS, BK>::VPT; ++i) {
-    const int f = threadIdx.x + i * NT;
-    const int c4 = f % (BK / 4);
-    const int yy = cr.y[i] + dy, xx = cr.x[i] + dx;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cr.base[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W)
-      v = *reinterpret_cast<const float4*>(X + (cr.base[i] + (long long)dy * W + dx) * Cin + c0 +
-                                           c4 * 4);
-    r[i] = v;
+    for (int i = 0; i < G::VPT; ++i) {
+      const int yy = y[i] + dy, xx = x[i] + dx;
+      const bool ok = (base[i] != OOB) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      r[i] = buf_load4(rsrc, ok ? (unsigned)((int)base[i] + delta) : OOB);
+    }
   }
-}
+};
 
 // ---- the kernel --------------------------------------------------------------
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool CONV>
@@ -148,6 +169,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   using GB = TileGeom<BN, BK, B_KC>;
   constexpr int WTM = BM / 2, WTN = BN / 2;  // per-wave output
   constexpr int TI = WTM / 32, TJ = WTN / 32;
+  constexpr int NKG = BK / 8;
   static_assert(TI >= 1 && TJ >= 1, "wave tile too small");
 
   // One LDS array, addressed by integer offsets only: a pointer table indexed
@@ -174,8 +196,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   const long long bz = blockIdx.z;
-  const float* A = g.A + bz * g.sA;
-  const float* B = g.B + bz * g.sB;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(g.A + bz * g.sA), 0, (int)g.bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(g.B + bz * g.sB), 0, (int)g.bytesB, 0x00020000);
   float* C = g.C + bz * g.sC;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -190,29 +214,39 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[GA::VEC_PER_THREAD], rb[GB::VEC_PER_THREAD];
-  ConvRows<BM, BK> cr;
-  if (CONV) conv_rows_init<BM, BK>(cr, m0, g.M, g.H, g.W);
+  float4 ra[GA::VPT], rb[GB::VPT];
+  Stage<BM, BK, A_KC> stA;
+  ConvStage<BM, BK> cvA;
+  Stage<BN, BK, B_KC> stB;
+  if constexpr (CONV) cvA.init(m0, g.M, g.H, g.W, g.Cin);
+  else stA.init(g.lda, m0, g.M);
+  stB.init(g.ldb, n0, g.N);
 
   const int T = (g.K + BK - 1) / BK;
   auto fetch = [&](int t) {
-    if (CONV) load_tile_conv<BM, BK>(A, cr, t * BK, g.H, g.W, g.Cin, g.dil, ra);
-    else load_tile<BM, BK, A_KC>(A, g.lda, m0, g.M, t * BK, g.K, ra);
-    load_tile<BN, BK, B_KC>(B, g.ldb, n0, g.N, t * BK, g.K, rb);
+    if constexpr (CONV) cvA.load(rsA, t, g.H, g.W, g.Cin, g.dil, ra);
+    else stA.load(rsA, t, g.K, ra);
+    stB.load(rsB, t, g.K, rb);
+  };
+  auto stash = [&](int buf) {
+    Stage<BM, BK, A_KC>::store(sm + A_OFF + buf * GA::FLOATS, ra);
+    Stage<BN, BK, B_KC>::store(sm + B_OFF + buf * GB::FLOATS, rb);
   };
 
   fetch(0);
-  store_tile<BM, BK, A_KC>(sm + A_OFF, ra);
-  store_tile<BN, BK, B_KC>(sm + B_OFF, rb);
+  stash(0);
   __syncthreads();
 
-  for (int t = 0; t < T; ++t) {
+  // One K-step.  MORE (compile-time) = a following tile exists: the main loop body
+  // is then a single basic block and the staging instructions stay where they
+  // are written, between the MFMAs.
+  auto kstep = [&](int t, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
     const int cur = t & 1;
-    if (t + 1 < T) fetch(t + 1);
     const float* as = sm + A_OFF + cur * GA::FLOATS;
     const float* bs = sm + B_OFF + cur * GB::FLOATS;
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
+    for (int kg = 0; kg < NKG; ++kg) {
       float af[TI][4], bf[TJ][4];
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
@@ -236,50 +270,55 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
           for (int s = 0; s < 4; ++s) bf[j][s] = bs[(kg * 8 + h * 4 + s) * GB::LD + col];
         }
       }
+      if (MORE && kg == 0) {
+        // next tile's global loads: issued behind this step's first LDS reads,
+        // ahead of the MFMAs that cover their latency
+        fetch(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
+        if (MORE && kg == NKG - 1 && s == 2) {
+          // land the next tile in the other LDS buffer while the last MFMAs run
+          __builtin_amdgcn_sched_barrier(0);
+          stash(cur ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int j = 0; j < TJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (t + 1 < T) {
-      store_tile<BM, BK, A_KC>(sm + A_OFF + (cur ^ 1) * GA::FLOATS, ra);
-      store_tile<BN, BK, B_KC>(sm + B_OFF + (cur ^ 1) * GB::FLOATS, rb);
+      }
     }
     __syncthreads();
-  }
+  };
+  for (int t = 0; t + 1 < T; ++t) kstep(t, std::true_type{});
+  kstep(T - 1, std::false_type{});
 
   // ---- epilogue: C/D map col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
+  const int epi = g.epilogue;
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int col = n0 + wn * WTN + j * 32 + l31;
     if (col >= g.N) continue;
-    const float bv = (bias && g.epilogue >= NAWS_EPI_BIAS && g.epilogue <= NAWS_EPI_BIAS_RELU_DROP)
-                         ? bias[col] : 0.f;
+    const float bv = (bias && epi >= NAWS_EPI_BIAS && epi <= NAWS_EPI_BIAS_RELU_DROP) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (row >= g.M) continue;
-        float v = acc[i][j][e];
-        switch (g.epilogue) {
-          case NAWS_EPI_BIAS: v += bv; break;
-          case NAWS_EPI_BIAS_RELU: v = fmaxf(v + bv, 0.f); break;
-          case NAWS_EPI_BIAS_RELU_DROP: {
-            v = fmaxf(v + bv, 0.f);
-            const unsigned long long idx =
-                (unsigned long long)bz * g.M * g.N + (unsigned long long)row * g.N + col;
-            v = naws_keep(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
-          } break;
-          case NAWS_EPI_GATE_POS:
-            v = (aux[(long long)row * g.ldaux + col] > 0.f) ? v * g.alpha : 0.f;
-            break;
-          default: break;
+        float v = acc[i][j][e] + bv;
+        if (epi == NAWS_EPI_BIAS_RELU || epi == NAWS_EPI_BIAS_RELU_DROP) v = fmaxf(v, 0.f);
+        if (epi == NAWS_EPI_BIAS_RELU_DROP) {
+          const unsigned long long idx =
+              (unsigned long long)bz * g.M * g.N + (unsigned long long)row * g.N + col;
+          v = naws_keep(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+        } else if (epi == NAWS_EPI_GATE_POS) {
+          v = (aux[(long long)row * g.ldaux + col] > 0.f) ? v * g.alpha : 0.f;
         }
         float* dst = C + (long long)row * g.ldc + col;
         if (g.accumulate) v += *dst;
@@ -289,18 +328,30 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// Tuning knob for A/B experiments (tools/kernel_bench.py): NAWS_GEMM_VARIANT
+//   0 default, 1: BK=16 (3 workgroups per CU), 2: pad LDS so only 1 workgroup fits a CU
+int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NAWS_GEMM_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool CONV>
 int launch(GemmArgs& g, int batch, hipStream_t s) {
   using GA = TileGeom<BM, BK, A_KC>;
   using GB = TileGeom<BN, BK, B_KC>;
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
-  const size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float);
+  size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float);
+  if (gemm_variant() == 2) lds = std::max<size_t>(lds, 84 * 1024);
   auto kern = gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, batch);
@@ -317,7 +368,10 @@ int dispatch(GemmArgs& g, int batch, hipStream_t s) {
     if (naws_cdiv(g.M, 128) * batch >= 512) return launch<128, 64, 32, A_KC, B_KC, CONV>(g, batch, s);
     return launch<64, 64, 32, A_KC, B_KC, CONV>(g, batch, s);
   }
-  if (t128 >= 1024) return launch<128, 128, 32, A_KC, B_KC, CONV>(g, batch, s);
+  if (t128 >= 1024) {
+    if (gemm_variant() == 1) return launch<128, 128, 16, A_KC, B_KC, CONV>(g, batch, s);
+    return launch<128, 128, 32, A_KC, B_KC, CONV>(g, batch, s);
+  }
   if (naws_cdiv(g.M, 64) * naws_cdiv(g.N, 128) * batch >= 768)
     return launch<64, 128, 32, A_KC, B_KC, CONV>(g, batch, s);
   return launch<64, 64, 32, A_KC, B_KC, CONV>(g, batch, s);
@@ -325,6 +379,12 @@ int dispatch(GemmArgs& g, int batch, hipStream_t s) {
 
 bool aligned4(long long v) { return (v & 3) == 0; }
 bool ptr16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// bytes spanned by one [rows, cols] row-major slice with leading dimension ld
+long long extent_bytes(long long rows, long long cols, long long ld) {
+  return ((rows - 1) * ld + cols) * 4;
+}
+constexpr long long MAX_EXTENT = 0xFFFFFFF0LL - 64;  // 32-bit buffer byte offsets
 
 }  // namespace
 
@@ -347,11 +407,15 @@ extern "C" int naws_gemm_f32(int transA, int transB, int M, int N, int K, const 
     return NAWS_ERR_ARG;
   if (!aligned4(transA ? M : K) || !aligned4(transB ? K : N)) return NAWS_ERR_ARG;
   if (batch > 65535) return NAWS_ERR_UNSUPPORTED;
+  const long long exA = transA ? extent_bytes(K, M, lda) : extent_bytes(M, K, lda);
+  const long long exB = transB ? extent_bytes(N, K, ldb) : extent_bytes(K, N, ldb);
+  if (exA > MAX_EXTENT || exB > MAX_EXTENT) return NAWS_ERR_UNSUPPORTED;
 
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sBias = strideBias;
+  g.bytesA = (unsigned)exA; g.bytesB = (unsigned)exB;
   g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.alpha = alpha;
   g.drop_thr = naws_drop_threshold(drop_ratio);
   g.drop_scale = (float)(1.0 / (1.0 - (double)drop_ratio));
@@ -372,11 +436,14 @@ extern "C" int naws_conv3x3_nhwc_fwd(const float* X, const float* Wp, const floa
   if (Cin % 32 != 0 || Cout % 4 != 0) return NAWS_ERR_UNSUPPORTED;
   NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(Wp); NAWS_REQUIRE_PTR(Y);
   if (!ptr16(X) || !ptr16(Wp)) return NAWS_ERR_ARG;
-  if ((long long)N * H * W > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  const long long pix = (long long)N * H * W;
+  if (pix > 0x7fffffffLL || pix * Cin * 4 > MAX_EXTENT) return NAWS_ERR_UNSUPPORTED;
   GemmArgs g{};
   g.A = X; g.B = Wp; g.C = Y;
-  g.M = N * H * W; g.N = Cout; g.K = 9 * Cin;
+  g.M = (int)pix; g.N = Cout; g.K = 9 * Cin;
   g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
+  g.bytesA = (unsigned)(pix * Cin * 4);
+  g.bytesB = (unsigned)((long long)Cout * 9 * Cin * 4);
   g.bias = bias; g.epilogue = bias ? (relu ? NAWS_EPI_BIAS_RELU : NAWS_EPI_BIAS) : NAWS_EPI_NONE;
   if (!bias && relu) return NAWS_ERR_ARG;
   g.H = H; g.W = W; g.Cin = Cin; g.dil = dilation;
