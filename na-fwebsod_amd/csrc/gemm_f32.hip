@@ -278,12 +278,16 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if (MORE && kg == NKG - 1 && s == 2) {
+        if (MORE && kg == NKG - 1 && s == 0) {
           // land the next tile in the other LDS buffer while the last MFMAs run
           __builtin_amdgcn_sched_barrier(0);
           stash(cur ^ 1);
           __builtin_amdgcn_sched_barrier(0);
         }
+        // keep the barrier (and its wait for the LDS writes) behind most of
+        // this group's MFMAs; the final ones may sink below it and cover the
+        // next step's first fragment reads
+        if (MORE && kg == NKG - 1 && s == 3) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll

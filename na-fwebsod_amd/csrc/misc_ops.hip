@@ -207,7 +207,51 @@ __global__ __launch_bounds__(TB) void softmax_rows_bwd_kernel(const float* __res
   for (int c = lane; c < cols; c += 64) dx[c] = y[c] * (dy[c] - d);
 }
 
-// Y[c] (+)= sum_r X[r*ld + c]; one workgroup per 64 columns, 4 row-lanes each
+// Y[c] (+)= sum_r X[r*ld + c].  One workgroup per 32 columns: 8 float4 column
+// groups x 32 row lanes, fixed-order LDS tree over the row lanes (deterministic).
+__global__ __launch_bounds__(TB) void colsum4_kernel(const float* __restrict__ X, int M, int N,
+                                                     int ld, float* __restrict__ Y,
+                                                     int accumulate) {
+  __shared__ float4 part[32][8];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 32 + cg * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < N) {
+    const float* p = X + c;
+    int r = rl;
+    for (; r + 96 < M; r += 128) {  // 4 independent loads in flight
+      const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
+      const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)(r + 32) * ld);
+      const float4 d = *reinterpret_cast<const float4*>(p + (int64_t)(r + 64) * ld);
+      const float4 e = *reinterpret_cast<const float4*>(p + (int64_t)(r + 96) * ld);
+      acc.x += (a.x + b.x) + (d.x + e.x); acc.y += (a.y + b.y) + (d.y + e.y);
+      acc.z += (a.z + b.z) + (d.z + e.z); acc.w += (a.w + b.w) + (d.w + e.w);
+    }
+    for (; r < M; r += 32) {
+      const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+  }
+  part[rl][cg] = acc;
+  __syncthreads();
+  for (int s = 16; s > 0; s >>= 1) {
+    if (rl < s) {
+      float4 a = part[rl][cg];
+      const float4 b = part[rl + s][cg];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      part[rl][cg] = a;
+    }
+    __syncthreads();
+  }
+  if (rl == 0 && c < N) {
+    float4 t = part[0][cg];
+    float* y = Y + c;
+    if (accumulate) { t.x += y[0]; t.y += y[1]; t.z += y[2]; t.w += y[3]; }
+    y[0] = t.x; y[1] = t.y; y[2] = t.z; y[3] = t.w;
+  }
+}
+
+// scalar fallback (N or ld not a multiple of 4): one workgroup per 64 columns
 __global__ __launch_bounds__(TB) void colsum_kernel(const float* __restrict__ X, int M, int N,
                                                     int ld, float* __restrict__ Y,
                                                     int accumulate) {
@@ -345,8 +389,12 @@ extern "C" int naws_colsum_f32(const float* dY, int M, int N, int ld, float* db,
                                void* stream) {
   if (M <= 0 || N <= 0 || ld < N) return NAWS_ERR_SHAPE;
   NAWS_REQUIRE_PTR(dY); NAWS_REQUIRE_PTR(db);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)naws_cdiv(N, 64)), dim3(TB), 0,
-                     (hipStream_t)stream, dY, M, N, ld, db, accumulate);
+  if (N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)dY % 16) == 0)
+    hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)naws_cdiv(N, 32)), dim3(TB), 0,
+                       (hipStream_t)stream, dY, M, N, ld, db, accumulate);
+  else
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)naws_cdiv(N, 64)), dim3(TB), 0,
+                       (hipStream_t)stream, dY, M, N, ld, db, accumulate);
   return naws_check_launch();
 }
 extern "C" int naws_reduce_sum_axis0(const float* X, int rows, int cols, float* Y, void* stream) {

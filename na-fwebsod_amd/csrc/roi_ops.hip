@@ -109,6 +109,148 @@ __global__ __launch_bounds__(CT) void roi_pool_nhwc_kernel(
   }
 }
 
+// ---- NHWC fast path (no argmax, C % 4 == 0): one WAVE = one RoI x 256 channels,
+// each lane owns 4 consecutive channels (16-byte loads: 1 KiB per pixel per wave,
+// 4 pixels in flight).  Only one row of bins is staged in LDS (7 KB), so the
+// kernel runs at full wave occupancy: this gather is bytes-in-flight bound.
+__global__ __launch_bounds__(64) void roi_pool_nhwc_v4_kernel(
+    const float* __restrict__ X, int C, int H, int W, const float* __restrict__ rois,
+    const float* __restrict__ boost, int PH, int PW, float spatial_scale,
+    float* __restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);  // [4][64][PW]
+  const int r = blockIdx.x;
+  const int c0 = blockIdx.y * 256;
+  const int lane = threadIdx.x;
+  const int c = c0 + lane * 4;
+  const bool active = c < C;
+  const RoiBins rb = roi_frame(rois + (int64_t)r * 5, spatial_scale);
+  const float bin_h = (float)rb.roi_h / (float)PH;
+  const float bin_w = (float)rb.roi_w / (float)PW;
+  const float scale = boost ? boost[r] : 1.0f;
+  const float* Xn = X + (int64_t)rb.batch * H * W * C + (active ? c : 0);
+  const int nb = PH * PW;
+  const int nch = min(256, C - c0);
+  const int64_t obase = ((int64_t)r * C + c0) * nb;
+
+  for (int ph = 0; ph < PH; ++ph) {
+    int hs, he;
+    bin_range(ph, bin_h, rb.start_h, H, hs, he);
+    for (int pw = 0; pw < PW; ++pw) {
+      int ws, we;
+      bin_range(pw, bin_w, rb.start_w, W, ws, we);
+      const bool empty = (he <= hs) || (we <= ws);
+      const float init = empty ? 0.0f : -FLT_MAX;
+      float4 best = make_float4(init, init, init, init);
+      if (active) {
+        for (int h = hs; h < he; ++h) {
+          const float* row = Xn + (int64_t)h * W * C;
+          int w = ws;
+          for (; w + 4 <= we; w += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 0) * C);
+            const float4 v1 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 1) * C);
+            const float4 v2 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 2) * C);
+            const float4 v3 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 3) * C);
+#define NAWS_UPD(v) \
+  best.x = (v.x > best.x) ? v.x : best.x; best.y = (v.y > best.y) ? v.y : best.y; \
+  best.z = (v.z > best.z) ? v.z : best.z; best.w = (v.w > best.w) ? v.w : best.w;
+            NAWS_UPD(v0) NAWS_UPD(v1) NAWS_UPD(v2) NAWS_UPD(v3)
+          }
+          for (; w < we; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(row + (int64_t)w * C);
+            NAWS_UPD(v)
+          }
+#undef NAWS_UPD
+        }
+      }
+      tile[(0 * 64 + lane) * PW + pw] = best.x * scale;
+      tile[(1 * 64 + lane) * PW + pw] = best.y * scale;
+      tile[(2 * 64 + lane) * PW + pw] = best.z * scale;
+      tile[(3 * 64 + lane) * PW + pw] = best.w * scale;
+    }
+    __syncthreads();
+    const int count = nch * PW;
+    for (int i = lane; i < count; i += 64) {
+      const int cl = i / PW, pw = i - cl * PW;
+      Y[obase + (int64_t)cl * nb + ph * PW + pw] = tile[((cl & 3) * 64 + (cl >> 2)) * PW + pw];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- NHWC, XCD-sliced (no argmax, C % 64 == 0): one wave = one RoI x 64 channels.
+// blockIdx.x = slice + nslices * roi, so with the round-robin workgroup->XCD
+// placement every XCD keeps gathering from the same 64-channel slice of the feature
+// map (2.3 MB per 74x124 image: L2-resident) instead of all 8 L2s thrashing over the
+// whole map.  Placement only affects speed.  Lane = (bin group g = lane>>4, channel
+// quad cg = lane&15): four bins of a bin row are pooled concurrently, each 16-lane
+// group reading 256 contiguous bytes per pixel.
+__global__ __launch_bounds__(64) void roi_pool_nhwc_xcd_kernel(
+    const float* __restrict__ X, int C, int H, int W, const float* __restrict__ rois,
+    const float* __restrict__ boost, int PH, int PW, float spatial_scale, int nslices,
+    float* __restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);  // [4][16][PW]
+  const int slice = blockIdx.x % nslices;
+  const int r = blockIdx.x / nslices;
+  const int lane = threadIdx.x;
+  const int cg = lane & 15, g = lane >> 4;
+  const int c0 = slice * 64;
+  const RoiBins rb = roi_frame(rois + (int64_t)r * 5, spatial_scale);
+  const float bin_h = (float)rb.roi_h / (float)PH;
+  const float bin_w = (float)rb.roi_w / (float)PW;
+  const float scale = boost ? boost[r] : 1.0f;
+  const float* Xn = X + (int64_t)rb.batch * H * W * C + c0 + cg * 4;
+  const int nb = PH * PW;
+  const int64_t obase = ((int64_t)r * C + c0) * nb;
+
+  for (int ph = 0; ph < PH; ++ph) {
+    int hs, he;
+    bin_range(ph, bin_h, rb.start_h, H, hs, he);
+    for (int pw0 = 0; pw0 < PW; pw0 += 4) {
+      const int pw = pw0 + g;
+      const bool lane_on = pw < PW;
+      int ws = 0, we = 0;
+      if (lane_on) bin_range(pw, bin_w, rb.start_w, W, ws, we);
+      const bool empty = (he <= hs) || (we <= ws);
+      const float init = empty ? 0.0f : -FLT_MAX;
+      float4 best = make_float4(init, init, init, init);
+      for (int h = hs; h < he; ++h) {
+        const float* row = Xn + (int64_t)h * W * C;
+        int w = ws;
+        for (; w + 4 <= we; w += 4) {
+          const float4 v0 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 0) * C);
+          const float4 v1 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 1) * C);
+          const float4 v2 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 2) * C);
+          const float4 v3 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 3) * C);
+#define NAWS_UPD(v) \
+  best.x = (v.x > best.x) ? v.x : best.x; best.y = (v.y > best.y) ? v.y : best.y; \
+  best.z = (v.z > best.z) ? v.z : best.z; best.w = (v.w > best.w) ? v.w : best.w;
+          NAWS_UPD(v0) NAWS_UPD(v1) NAWS_UPD(v2) NAWS_UPD(v3)
+        }
+        for (; w < we; ++w) {
+          const float4 v = *reinterpret_cast<const float4*>(row + (int64_t)w * C);
+          NAWS_UPD(v)
+        }
+#undef NAWS_UPD
+      }
+      if (lane_on) {
+        tile[(0 * 16 + cg) * PW + pw] = best.x * scale;
+        tile[(1 * 16 + cg) * PW + pw] = best.y * scale;
+        tile[(2 * 16 + cg) * PW + pw] = best.z * scale;
+        tile[(3 * 16 + cg) * PW + pw] = best.w * scale;
+      }
+    }
+    __syncthreads();
+    const int count = 64 * PW;
+    for (int i = lane; i < count; i += 64) {
+      const int cl = i / PW, pw = i - cl * PW;
+      Y[obase + (int64_t)cl * nb + ph * PW + pw] = tile[((cl & 3) * 16 + (cl >> 2)) * PW + pw];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- NCHW: one lane = one output element (op-level API on reference layout)
 __global__ void roi_pool_nchw_kernel(int64_t total, const float* __restrict__ X, int C, int H,
                                      int W, const float* __restrict__ rois,
@@ -203,6 +345,15 @@ extern "C" int naws_roi_pool_f_fwd(const float* X, int layout, int N, int C, int
     if (argmax)
       hipLaunchKernelGGL(roi_pool_nhwc_kernel<true>, grid, dim3(CT), lds, s, X, C, H, W, rois,
                          boost, pooled_h, pooled_w, spatial_scale, Y, argmax);
+    else if (C % 64 == 0 && ((uintptr_t)X % 16) == 0 && pooled_w <= 64 &&
+             (int64_t)R * (C / 64) < 0x7fffffffLL)
+      hipLaunchKernelGGL(roi_pool_nhwc_xcd_kernel, dim3((unsigned)(R * (C / 64))), dim3(64),
+                         (size_t)64 * pooled_w * sizeof(float), s, X, C, H, W, rois, boost,
+                         pooled_h, pooled_w, spatial_scale, C / 64, Y);
+    else if (C % 4 == 0 && ((uintptr_t)X % 16) == 0 && pooled_w <= 64)
+      hipLaunchKernelGGL(roi_pool_nhwc_v4_kernel, dim3(R, (unsigned)naws_cdiv(C, 256)), dim3(64),
+                         (size_t)4 * 64 * pooled_w * sizeof(float), s, X, C, H, W, rois, boost,
+                         pooled_h, pooled_w, spatial_scale, Y);
     else
       hipLaunchKernelGGL(roi_pool_nhwc_kernel<false>, grid, dim3(CT), lds, s, X, C, H, W, rois,
                          boost, pooled_h, pooled_w, spatial_scale, Y, argmax);

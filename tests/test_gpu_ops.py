@@ -24,13 +24,13 @@ def _close(a, b, rtol=RTOL, atol=1e-6):
 
 
 # ---------------------------------------------------------------- RoIPoolF --
-@pytest.mark.parametrize('layout', ['NCHW', 'NHWC'])
+@pytest.mark.parametrize('layout,c', [('NCHW', 300), ('NHWC', 300), ('NHWC', 128), ('NHWC', 30)])
 @pytest.mark.parametrize('with_boost', [False, True])
-def test_roi_pool_bitexact(dev, layout, with_boost):
+def test_roi_pool_bitexact(dev, layout, c, with_boost):
     from naws_hip import ops
     from oracle import oracle
     rng = np.random.default_rng(11)
-    n, c, h, w = 2, 300, 20, 30   # c not a multiple of the 256-channel tile
+    n, h, w = 2, 20, 30   # c = 300: float4 kernel with a ragged tile; 128: XCD-sliced; 30: scalar
     x = rng.standard_normal((n, c, h, w)).astype(np.float32)
     x[:, :, 3, 4] = x[:, :, 3, 5]  # ties -> first index must win
     rois = make_rois(rng, n, 40, h * 8, w * 8)
