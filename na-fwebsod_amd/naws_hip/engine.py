@@ -29,6 +29,7 @@ import torch
 
 from . import lib as L
 from . import ops
+from .reducer import ArenaReducer, row_chunks
 
 VGG16_CONVS = [
     # (name, cin, cout, dilation) and pool markers
@@ -108,6 +109,7 @@ class WsddnEngine(object):
         self.gpu_num = int(gpu_num)
         self.seed = int(seed)
         self.pg, self.world_size = process_group, int(world_size)
+        self.reducer = ArenaReducer(process_group, world_size)
         self.allreduce_chunks = max(1, int(allreduce_chunks))
         self.k6 = 512 * roi_size * roi_size
 
@@ -300,26 +302,14 @@ class WsddnEngine(object):
         ops.gemm(dz7v, w7, False, False, out=dz6v, epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
         ops.colsum(dz6, out=gb6)
         # everything except fc6_w is ready: start its all-reduce, then stream fc6 wgrad chunks
-        works = []
-        dist_on = self.pg is not None and self.world_size > 1
-        if dist_on:
-            import torch.distributed as dist
-            tail = self.arena.span(G, 'fc6_b', 'noisy_fc8d_b')
-            works.append(dist.all_reduce(tail, group=self.pg, async_op=True))
-        nch = self.allreduce_chunks if dist_on else 1
-        rows = 2 * HIDDEN
-        step = (rows // nch + 127) // 128 * 128
-        for r0 in range(0, rows, step):
-            r1 = min(rows, r0 + step)
+        red = self.reducer
+        red.reduce_async(self.arena.span(G, 'fc6_b', 'noisy_fc8d_b'))
+        for r0, r1 in row_chunks(2 * HIDDEN, self.allreduce_chunks if red.active else 1):
             ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
-            if dist_on:
-                works.append(dist.all_reduce(gw6[r0:r1], group=self.pg, async_op=True))
-        self._pending = works
+            red.reduce_async(gw6[r0:r1].reshape(-1))
 
     def wait_allreduce(self):
-        for w in getattr(self, '_pending', []):
-            w.wait()
-        self._pending = []
+        self.reducer.wait()
 
     # -------------------------------------------------------------------- SGD
     def set_lr(self, new_lr):

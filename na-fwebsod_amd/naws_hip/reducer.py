@@ -1,0 +1,49 @@
+"""Gradient all-reduce schedule over the parameter arena (reference:
+detectron/modeling/optimizer_wsl.py:52-72 issues one NCCLAllreduce per parameter blob).
+
+One process per GPU; the backend is whatever the process group was created with ("nccl" =
+RCCL over xGMI on MI355X, "gloo" in the CPU tests).  Two kinds of message:
+  * one slice for every gradient except fc6_w (ready early in backward), and
+  * fc6_w's gradient in row chunks, each handed over while the next chunk's wgrad GEMM runs,
+so the 822 MB that backward produces last never sits exposed behind the compute.
+"""
+
+
+def row_chunks(rows, n_chunks, align=128):
+    """[(r0, r1)) covering [0, rows) in at most n_chunks pieces whose size is a multiple of
+    `align` (the GEMM's M-tile), so every piece is a full-tile wgrad launch."""
+    n_chunks = max(1, int(n_chunks))
+    step = (rows + n_chunks - 1) // n_chunks
+    step = (step + align - 1) // align * align
+    out, r0 = [], 0
+    while r0 < rows:
+        out.append((r0, min(rows, r0 + step)))
+        r0 += step
+    return out
+
+
+class ArenaReducer(object):
+    def __init__(self, process_group=None, world_size=1):
+        self.pg = process_group
+        self.world_size = int(world_size)
+        self._pending = []
+
+    @property
+    def active(self):
+        return self.pg is not None and self.world_size > 1
+
+    def reduce_async(self, flat_slice):
+        """Sum `flat_slice` (a contiguous view of the gradient arena) over all ranks, in place.
+        Returns immediately; the collective is ordered after the work already queued on the
+        caller's current stream."""
+        if not self.active:
+            return
+        import torch.distributed as dist
+        assert flat_slice.is_contiguous()
+        self._pending.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.pg,
+                                             async_op=True))
+
+    def wait(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
