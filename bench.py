@@ -160,6 +160,13 @@ def main():
                          'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
                          'traffic': None, 'kernel_ms': round(kern_ms, 4)},
         }
+        # HBM traffic of that kernel comes from the rocprofv3 PMC passes of this same command
+        # (profiles/rNN_bench_traffic.json, written by tools/summarize_profile.py)
+        import glob
+        tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_traffic.json')))
+        if tj and args.rois == 2000 and B == 2:
+            res['roofline']['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
+            res['roofline']['traffic_source'] = os.path.relpath(tj[-1], ROOT)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, num_fg)
         print(json.dumps(res))

@@ -248,6 +248,7 @@ int naws_unary_f32(int op, const float* X, int64_t n, float a, float b, float* Y
 #define NAWS_BIN_SUB 1
 #define NAWS_BIN_MUL 2
 #define NAWS_BIN_DIV 3
+#define NAWS_BIN_GATE_POS 4 /* Y = B > 0 ? A : 0   (ReluGradient: A = dY, B = Y) */
 /* Y[r,c] = A[ra,ca] op B[rb,cb], numpy-style broadcasting of two 2-D
  * operands: each of (rowsA, colsA, rowsB, colsB) is either 1 or the output
  * extent. */

@@ -168,7 +168,8 @@ __global__ void binary_kernel(int op, const float* __restrict__ A, int rowsA, in
       case NAWS_BIN_ADD: y = a + b; break;
       case NAWS_BIN_SUB: y = a - b; break;
       case NAWS_BIN_MUL: y = a * b; break;
-      default: y = a / b; break;
+      case NAWS_BIN_DIV: y = a / b; break;
+      default: y = b > 0.f ? a : 0.f; break;
     }
     Y[i] = y;
   }
@@ -359,7 +360,7 @@ extern "C" int naws_unary_f32(int op, const float* X, int64_t n, float a, float 
 extern "C" int naws_binary_f32(int op, const float* A, int rowsA, int colsA, const float* B,
                                int rowsB, int colsB, float* Y, int rows, int cols, void* stream) {
   if (rows <= 0 || cols <= 0) return NAWS_ERR_SHAPE;
-  if (op < NAWS_BIN_ADD || op > NAWS_BIN_DIV) return NAWS_ERR_ARG;
+  if (op < NAWS_BIN_ADD || op > NAWS_BIN_GATE_POS) return NAWS_ERR_ARG;
   if ((rowsA != 1 && rowsA != rows) || (rowsB != 1 && rowsB != rows) ||
       (colsA != 1 && colsA != cols) || (colsB != 1 && colsB != cols))
     return NAWS_ERR_SHAPE;

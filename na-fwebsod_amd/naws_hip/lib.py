@@ -19,7 +19,7 @@ _ERR_NAMES = {
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_RELU_DROP, EPI_GATE_POS = range(5)
 UN_LOG, UN_SCALE, UN_REPLACE_NAN, UN_LEAKY_RELU, UN_CLIP, UN_RELU = range(6)
-BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV = range(4)
+BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV, BIN_GATE_POS = range(5)
 
 p, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
 

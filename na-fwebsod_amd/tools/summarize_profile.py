@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel-trace stats + separate FETCH_SIZE / WRITE_SIZE PMC
+passes) into the small summaries kept under profiles/.
+
+  summarize_profile.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <out_prefix>
+
+HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, so
+read bytes = 2 * FETCH_SIZE * 1024 (upper estimate for narrow accesses)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+
+def short(name):
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    return name.split('(')[0][:70]
+
+
+def main():
+    stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
+    rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, '*', '*_kernel_stats.csv'))[0])))
+    lines = ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
+    for r in rows[:24]:
+        lines.append('| %s | %s | %.3f | %.1f | %.2f |' % (
+            short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
+            float(r['AverageNs']) / 1e3, float(r['Percentage'])))
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d, cname in ((fetch_dir, 'FETCH_SIZE'), (write_dir, 'WRITE_SIZE')):
+        f = glob.glob(os.path.join(d, '*', '*_counter_collection.csv'))
+        if not f:
+            continue
+        for r in csv.DictReader(open(f[0])):
+            if r['Counter_Name'] == cname:
+                pmc[short(r['Kernel_Name'])][cname].append(float(r['Counter_Value']))
+    lines += ['', '| kernel | launches | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | '
+              'HBM traffic MB/launch (2*FETCH+WRITE) |', '|---|---|---|---|---|']
+    for k, v in sorted(pmc.items(), key=lambda kv: -sum(kv[1].get('FETCH_SIZE', [0]))):
+        f = v.get('FETCH_SIZE', [])
+        w = v.get('WRITE_SIZE', [])
+        fa = sum(f) / len(f) if f else 0.0
+        wa = sum(w) / len(w) if w else 0.0
+        lines.append('| %s | %d | %.0f | %.0f | %.1f |' % (k, max(len(f), len(w)), fa, wa,
+                                                          (2 * fa + wa) * 1024 / 1e6))
+    # the dominant kernel of bench.py: fc6 forward = the K-contiguous x K-contiguous GEMM with the
+    # largest grid (M=4000 N=8192 -> 2048 workgroups)
+    dom = {}
+    for d, cname in ((fetch_dir, 'FETCH_SIZE'), (write_dir, 'WRITE_SIZE')):
+        f = glob.glob(os.path.join(d, '*', '*_counter_collection.csv'))
+        vals = []
+        if f:
+            rws = [r for r in csv.DictReader(open(f[0])) if r['Counter_Name'] == cname and
+                   'gemm_f32_kernel<128, 128, 32, true, true, false>' in r['Kernel_Name']]
+            if rws:
+                gmax = max(int(r['Grid_Size']) for r in rws)
+                vals = [float(r['Counter_Value']) for r in rws if int(r['Grid_Size']) == gmax]
+        dom[cname] = sum(vals) / len(vals) if vals else None
+    if dom.get('FETCH_SIZE') is not None and dom.get('WRITE_SIZE') is not None:
+        import json
+        tb = (2 * dom['FETCH_SIZE'] + dom['WRITE_SIZE']) * 1024
+        json.dump({'kernel': 'gemm_f32_kernel<128,128,32,KC,KC> fc6 fwd',
+                   'FETCH_SIZE_KiB_per_launch': dom['FETCH_SIZE'],
+                   'WRITE_SIZE_KiB_per_launch': dom['WRITE_SIZE'],
+                   'hbm_bytes_per_launch': tb,
+                   'note': 'separate --pmc passes of `bench.py --steps 2 --warmup 1`; read bytes = '
+                           '2*FETCH_SIZE*1024 (gfx950 FETCH_SIZE counts 64 B per 128-B request; '
+                           'Infinity-Cache hits are included in the memory-side counters)'},
+                  open(out + '_traffic.json', 'w'), indent=1)
+        lines += ['', 'fc6 fwd GEMM: FETCH %.0f KiB, WRITE %.0f KiB per launch -> %.2f GB fabric '
+                  'traffic per launch (algorithmic 1.354 GB)' % (dom['FETCH_SIZE'], dom['WRITE_SIZE'],
+                                                                 tb / 1e9)]
+    open(out + '.md', 'w').write('\n'.join(lines) + '\n')
+    import shutil
+    shutil.copy(glob.glob(os.path.join(stats_dir, '*', '*_kernel_stats.csv'))[0], out + '_kernel_stats.csv')
+    print('\n'.join(lines))
+
+
+if __name__ == '__main__':
+    main()

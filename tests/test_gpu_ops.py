@@ -365,6 +365,7 @@ def test_small_builtins(dev):
     _close(ops.binary(lib.BIN_DIV, xd, _t(row, dev)), x / row)
     _close(ops.binary(lib.BIN_SUB, _t(sc, dev), _t(row, dev)), sc - row)
     _close(ops.binary(lib.BIN_MUL, _t(row, dev), xd), row * x)
+    _close(ops.binary(lib.BIN_GATE_POS, xd, _t(x - 1, dev)), np.where(x - 1 > 0, x, 0))
     e = np.exp(x - x.max(1, keepdims=True)); sm = e / e.sum(1, keepdims=True)
     y = ops.softmax_rows(xd)
     _close(y, sm, rtol=1e-5)
