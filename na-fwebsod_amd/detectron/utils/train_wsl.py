@@ -1,0 +1,140 @@
+"""Training loop.  Mirrors detectron/utils/train_wsl.py: `train_model` (:33-102),
+`create_model` with auto-resume (:112-189), `setup_model_for_training` (:192-222).
+One process per GPU (torchrun): RANK / WORLD_SIZE / LOCAL_RANK from the environment."""
+import logging
+import os
+import re
+
+import numpy as np
+import torch
+
+from detectron.core.config import cfg, get_output_dir
+from detectron.core.executor import NetExecutor
+from detectron.utils import lr_policy
+from detectron.utils.training_stats_wsl import TrainingStats
+import detectron.modeling.model_builder_wsl as model_builder
+import detectron.utils.net_wsl as nu
+
+logger = logging.getLogger(__name__)
+
+
+def dist_env():
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    return rank, world, local
+
+
+def train_model(roidb=None, max_iter=None, printer=print):
+    rank, world, local = dist_env()
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group('nccl', device_id=device)
+        pg = dist.group.WORLD
+    model, weights_file, start_iter, checkpoints, output_dir = create_model()
+    if 'final' in checkpoints:
+        return checkpoints
+    executor = setup_model_for_training(model, weights_file, output_dir, device, pg, world, rank,
+                                        roidb)
+    stats = TrainingStats(model, printer)
+    period = max(1, int(cfg.TRAIN.SNAPSHOT_ITERS / max(cfg.NUM_GPUS, 1)))
+    last = cfg.SOLVER.MAX_ITER if max_iter is None else min(cfg.SOLVER.MAX_ITER, max_iter)
+    loader = model.roi_data_loader
+    for cur_iter in range(start_iter, last):
+        if loader.has_stopped():
+            handle_critical_error(model, 'roi_data_loader failed')
+        stats.IterTic()
+        lr = model.UpdateWorkspaceLr(cur_iter, lr_policy.get_lr_at_iter(cur_iter))
+        executor.feed(loader.next_device_batch(device, cfg.NAWS.IMS_PER_GPU))
+        executor.run()
+        vals = iteration_values(executor, model, pg, world)
+        stats.IterToc()
+        stats.UpdateIterStats(vals)
+        if rank == 0:
+            stats.LogIterStats(cur_iter, lr, loader.queue_size(),
+                               torch.cuda.max_memory_allocated(device) // (1 << 20))
+        if (cur_iter + 1) % period == 0 and cur_iter > start_iter and rank == 0:
+            checkpoints[cur_iter] = os.path.join(output_dir, 'model_iter{}.pkl'.format(cur_iter))
+            nu.save_model_to_weights_file(checkpoints[cur_iter], model, executor)
+        if cur_iter == start_iter + stats.LOG_PERIOD:
+            stats.ResetIterTimer()
+        if np.isnan(stats.iter_total_loss):
+            handle_critical_error(model, 'Loss is NaN')
+    if rank == 0:
+        checkpoints['final'] = os.path.join(output_dir, 'model_final.pkl')
+        nu.save_model_to_weights_file(checkpoints['final'], model, executor)
+    loader.shutdown()
+    return checkpoints
+
+
+def iteration_values(executor, model, pg, world):
+    """Scalar losses / metrics of this iteration, averaged over this process's images and over
+    ranks (the reference averages the per-GPU scalars on the host, net_wsl.py:210-220)."""
+    ws = executor.ws
+    vals = []
+    for k in model.losses:
+        vals.append(ws[k].reshape(-1).float().mean())
+    t = torch.stack(vals)
+    if pg is not None and world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=pg)
+        t = t / world
+    out = {k: float(v) for k, v in zip(model.losses, t.cpu().tolist())}
+    labels = ws['labels_int32'].reshape(-1).cpu().numpy()
+    for k, blob in (('accuracy_cls', 'cls_prob'), ('accuracy_cls_noise', 'cls_prob_noise')):
+        if k in model.metrics and blob in ws:
+            p = ws[blob].reshape(len(labels), -1).cpu().numpy()
+            out[k] = float((p.argmax(1) == labels).mean())
+    return out
+
+
+def handle_critical_error(model, msg):
+    logger.critical(msg)
+    model.roi_data_loader.shutdown()
+    raise Exception(msg)
+
+
+def create_model():
+    """Build the training model; with TRAIN.AUTO_RESUME pick up the newest model_iter*.pkl."""
+    start_iter, checkpoints = 0, {}
+    output_dir = get_output_dir(cfg.TRAIN.DATASETS, training=True)
+    weights_file = cfg.TRAIN.WEIGHTS
+    if cfg.TRAIN.AUTO_RESUME:
+        final_path = os.path.join(output_dir, 'model_final.pkl')
+        if os.path.exists(final_path):
+            logger.info('model_final.pkl exists; no need to train!')
+            return None, None, None, {'final': final_path}, output_dir
+        best = -1
+        for f in os.listdir(output_dir):
+            m = re.match(r'model_iter(\d+)\.pkl$', f)
+            if m and int(m.group(1)) > best:
+                best = int(m.group(1))
+                weights_file = os.path.join(output_dir, f)
+        if best >= 0:
+            start_iter = best + 1
+            logger.info('Resuming from checkpoint {} at start iter {}'.format(weights_file, start_iter))
+    model = model_builder.create(cfg.MODEL.TYPE, train=True)
+    return model, weights_file, start_iter, checkpoints, output_dir
+
+
+def setup_model_for_training(model, weights_file, output_dir, device, pg, world, rank, roidb=None):
+    executor = NetExecutor(model, device, process_group=pg, world_size=world, rank=rank,
+                           images_per_process=cfg.NAWS.IMS_PER_GPU)
+    executor.init_params()
+    if weights_file and os.path.exists(weights_file):
+        nu.initialize_from_weights_file(model, weights_file, executor, broadcast=True)
+    else:
+        if weights_file:
+            logger.warning('weights file {} not found: training from random init'.format(weights_file))
+        executor.broadcast_parameters()
+    if roidb is None:
+        from detectron.datasets import synthetic
+        roidb = synthetic.make_roidb(64, cfg.TRAIN.BATCH_SIZE_PER_IM, cfg.MODEL.NUM_CLASSES - 1,
+                                     seed=cfg.RNG_SEED)
+    model_builder.add_training_inputs(model, roidb=roidb, rank=rank, world_size=world)
+    model.roi_data_loader.start(prefill=False)
+    return executor

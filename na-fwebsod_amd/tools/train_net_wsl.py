@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Train the noise-aware WSDDN on MI355X.  Same CLI as the reference tool
+(tools/train_net_wsl.py:52-84):
+
+    python tools/train_net_wsl.py --cfg configs/flickr_voc/na_wsddn_V-16-C5_1x.yaml \
+        [--multi-gpu-testing] [--skip-test] KEY VALUE ...
+
+Multi-GPU: one process per GPU, e.g.
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_net_wsl.py --cfg ...
+(NUM_GPUS in the yaml is overridden by WORLD_SIZE x NAWS.IMS_PER_GPU for the SGD normaliser).
+"""
+import argparse
+import logging
+import os
+import pprint
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+import numpy as np  # noqa: E402
+
+from detectron.core.config import (assert_and_infer_cfg, cfg, merge_cfg_from_file,  # noqa: E402
+                                   merge_cfg_from_list)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='Train a network with Detectron (MI355X hot path)')
+    p.add_argument('--cfg', dest='cfg_file', help='Config file for training (and optionally testing)',
+                   default=None, type=str)
+    p.add_argument('--multi-gpu-testing', dest='multi_gpu_testing', action='store_true',
+                   help='Use cfg.NUM_GPUS GPUs for inference')
+    p.add_argument('--skip-test', dest='skip_test', action='store_true',
+                   help='Do not test the final model')
+    p.add_argument('--max-iter', dest='max_iter', type=int, default=None,
+                   help='stop after this many iterations (smoke runs)')
+    p.add_argument('opts', help='See detectron/core/config.py for all options', default=None,
+                   nargs=argparse.REMAINDER)
+    if argv is None and len(sys.argv) == 1:
+        p.print_help()
+        sys.exit(1)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    logging.basicConfig(level=logging.INFO, format='%(levelname)s %(filename)s:%(lineno)4d: %(message)s')
+    logger = logging.getLogger(__name__)
+    args = parse_args(argv)
+    if args.cfg_file is not None:
+        merge_cfg_from_file(args.cfg_file)
+    if args.opts:
+        merge_cfg_from_list(args.opts)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    merge_cfg_from_list(['NUM_GPUS', world * cfg.NAWS.IMS_PER_GPU])
+    assert_and_infer_cfg()
+    logger.info('Training with config:')
+    logger.info(pprint.pformat(cfg))
+    np.random.seed(cfg.RNG_SEED)
+    from detectron.utils import train_wsl
+    checkpoints = train_wsl.train_model(max_iter=args.max_iter)
+    if not args.skip_test and int(os.environ.get('RANK', '0')) == 0:
+        logger.info('final checkpoint: %s (evaluation needs the VOC/COCO datasets, which are '
+                    'outside the hot path; use tools/test_net_wsl.py)', checkpoints.get('final'))
+
+
+if __name__ == '__main__':
+    main()
