@@ -35,6 +35,9 @@ def parse():
                     help='synthetic Kaiming weights collapse the MIL softmax within a few '
                          'iterations at the schedule lr 1e-3 (entropy gate -> 0/0, as in the '
                          'reference); the SGD work is lr-independent')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise RCCL and run the all-reduce schedule even with one rank '
+                         '(exercises the N>1 code path on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rois', type=int, default=500)
     return ap.parse_args()
@@ -82,9 +85,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
     from detectron.datasets import synthetic
     from naws_hip.engine import WsddnEngine
@@ -93,7 +98,9 @@ def main():
     B = args.images_per_gpu
     eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
                       weight_decay=5e-4, iter_size=1, gpu_num=world * B, seed=11,
-                      process_group=pg, world_size=world, allreduce_chunks=8)
+                      process_group=pg, world_size=world, allreduce_chunks=1)
+    if args.force_dist:
+        eng.reducer.force = True
     blobs = synthetic.init_blobs(num_fg, seed=11)     # identical on every rank (= broadcast)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)
@@ -118,13 +125,15 @@ def main():
 
     for _ in range(args.warmup):
         out = step(False)
-    if world > 1:
+    eng.flush()
+    if pg is not None:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(True)
-    if world > 1:
+    eng.flush()          # the last iteration's (deferred) all-reduce + SGD belongs to the K steps
+    if pg is not None:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -170,7 +179,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, num_fg)
         print(json.dumps(res))
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

@@ -131,8 +131,9 @@ def _defaults():
         # MI355X-native additions (not in the reference)
         'NAWS': {
             'IMS_PER_GPU': 1,        # images per GPU process (the reference supports only 1)
-            'ALLREDUCE_CHUNKS': 8,   # fc6 wgrad is cut into this many row chunks, each
-                                     # all-reduced while the next chunk's GEMM runs
+            'ALLREDUCE_CHUNKS': 1,   # >1: cut fc6 wgrad into row chunks, each all-reduced while
+                                     # the next chunk's GEMM runs (default: one launch; the
+                                     # collective hides under the next iteration's conv body)
         },
     }
 

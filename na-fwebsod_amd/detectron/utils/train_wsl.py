@@ -64,6 +64,8 @@ def train_model(roidb=None, max_iter=None, printer=print):
             stats.ResetIterTimer()
         if np.isnan(stats.iter_total_loss):
             handle_critical_error(model, 'Loss is NaN')
+    if executor.engine is not None:
+        executor.engine.flush()
     if rank == 0:
         checkpoints['final'] = os.path.join(output_dir, 'model_final.pkl')
         nu.save_model_to_weights_file(checkpoints['final'], model, executor)

@@ -92,7 +92,7 @@ class ParamArena(object):
 class WsddnEngine(object):
     def __init__(self, num_classes, device, dilation=2, roi_size=7, dropout=0.5, is_mean=True,
                  momentum=0.9, weight_decay=5e-4, iter_size=1, gpu_num=1, seed=11,
-                 process_group=None, world_size=1, allreduce_chunks=8, freeze_conv_body=True):
+                 process_group=None, world_size=1, allreduce_chunks=1, freeze_conv_body=True):
         if not freeze_conv_body:
             raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
                                       '(SURVEY.md fact 2): the conv body has no backward')
@@ -133,11 +133,18 @@ class WsddnEngine(object):
         self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=device)
         self.seg_wd = torch.tensor(wd, dtype=torch.float32, device=device)
         self.lr = torch.zeros((1,), dtype=torch.float32, device=device)
+        self._lr_host = 0.0
         self.sgd_iter_count = 0      # the SGD op's iter_count_ state
         self.step_count = 0          # forward/backward passes run (dropout stream)
         self.conv = {}               # name -> (weight (OIHW or packed), bias)
         self.stat_state = None
-        self.saved = None
+        # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
+        # parameters: when gradients are all-reduced the SGD update is deferred until that
+        # (parameter-free) prefix of the next iteration has been queued, so the collective runs
+        # under ~10 ms of conv work instead of in front of it.  Same arithmetic, same order of
+        # updates; flush() applies a pending update (checkpoints, lr changes, end of run).
+        self.defer_update = None     # None -> follow reducer.active
+        self._update_pending = False
 
     # ------------------------------------------------------------------ params
     def blob(self, name):
@@ -165,6 +172,7 @@ class WsddnEngine(object):
                 self.blob(name).copy_(blobs[name].to(self.device, torch.float32).view(shape))
 
     def export_blobs(self, with_momentum=True):
+        self.flush()
         out = {}
         for name, (wp, b, w) in self.conv.items():
             out[name + '_w'], out[name + '_b'] = w, b
@@ -251,6 +259,7 @@ class WsddnEngine(object):
         roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
                                   boost=obn_scores.reshape(-1), layout='NHWC')
         del conv5
+        self.flush()                 # previous iteration's all-reduce + SGD, now overlapped
         x = roi_feat.view(rt, self.k6)
         h6, h7, lg = self.head_forward(x, train=True)
         lv = [lg[:, i * C:(i + 1) * C] for i in range(4)]    # fc8c, fc8d, noisy_fc8c, noisy_fc8d
@@ -315,7 +324,11 @@ class WsddnEngine(object):
     def set_lr(self, new_lr):
         """UpdateWorkspaceLr + momentum correction (detector.py:509-559)."""
         new_lr = float(np.float32(new_lr))
-        cur = float(self.lr.item())
+        if self._lr_host == new_lr:
+            return new_lr
+        self.flush()                 # a pending update must see the lr it was computed under
+        cur = self._lr_host
+        self._lr_host = new_lr
         if cur != new_lr:
             ratio = max(new_lr / max(cur, 1e-10), cur / max(new_lr, 1e-10))
             self.lr.fill_(new_lr)
@@ -324,6 +337,18 @@ class WsddnEngine(object):
         return new_lr
 
     def sgd_step(self):
+        defer = self.reducer.active if self.defer_update is None else self.defer_update
+        if defer:
+            self._update_pending = True
+        else:
+            self._apply_update()
+
+    def flush(self):
+        if self._update_pending:
+            self._update_pending = False
+            self._apply_update()
+
+    def _apply_update(self):
         self.wait_allreduce()
         ops.acm_sgd_update(self.grads, self.momentum_buf, self.lr, self.params, self.acmgrad,
                            self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
@@ -332,6 +357,7 @@ class WsddnEngine(object):
 
     # -------------------------------------------------------------- inference
     def infer(self, data, rois, obn_scores):
+        self.flush()
         """Test-mode forward: cls_prob [R, C+1] = Concat(rois_pred[:, :1], rois_pred)
         (wsl_heads.py:58-67); no dropout; only the clean branch is fetched (test_wsl.py:151)."""
         n_img = data.shape[0]

@@ -120,3 +120,22 @@ def test_engine_infer(dev):
     rp = ref['tails'][0]['rois_pred']
     np.testing.assert_allclose(cls_prob.cpu().numpy(), np.concatenate([rp[:, :1], rp], 1),
                                rtol=1e-4, atol=1e-8)
+
+
+def test_deferred_update_is_equivalent(dev):
+    """The N>1 schedule (all-reduce launched after backward, SGD applied after the NEXT
+    iteration's conv body) gives bit-identical parameters to the immediate update."""
+    res = []
+    for defer in (False, True):
+        eng, mb, _blobs = _setup(dev)
+        eng.defer_update = defer
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        eng.set_lr(1e-3)
+        for it in range(3):
+            if it == 2:
+                eng.set_lr(1e-4)           # lr change must not leak into the pending update
+            eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+            eng.sgd_step()
+        eng.flush()
+        res.append((eng.params.clone(), eng.momentum_buf.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
