@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
 }
 
 // Tuning knob for A/B experiments (tools/kernel_bench.py): NAWS_GEMM_VARIANT
-//   0 default, 1: BK=16 (3 workgroups per CU), 2: pad LDS so only 1 workgroup fits a CU
+//   0 default, 2: pad LDS so only 1 workgroup fits a CU, 4: BK=32 tile forms
 int gemm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -363,21 +363,26 @@ int launch(GemmArgs& g, int batch, hipStream_t s) {
   return naws_check_launch();
 }
 
-// Tile choice: 128x128 by default; narrower N tile for N <= 64; when the grid
-// would leave CUs idle (fewer than ~2 tiles per CU) fall back to 64-row tiles.
+// Tile choice.  BK = 16 keeps a workgroup's LDS at <= 40 KB so 3-5 workgroups share a CU:
+// more independent barrier domains per SIMD fill each other's staging gaps (measured
+// +3-5% over BK = 32 at 2 workgroups/CU), and finer granularity when a layer has only a
+// few tiles per CU.  NAWS_GEMM_VARIANT=4 selects the BK = 32 forms for A/B runs.
 template <bool A_KC, bool B_KC, bool CONV>
 int dispatch(GemmArgs& g, int batch, hipStream_t s) {
   const long long t128 = naws_cdiv(g.M, 128) * naws_cdiv(g.N, 128) * batch;
+  const bool bk32 = gemm_variant() == 4;
   if (g.N <= 64) {
-    if (naws_cdiv(g.M, 128) * batch >= 512) return launch<128, 64, 32, A_KC, B_KC, CONV>(g, batch, s);
+    if (naws_cdiv(g.M, 128) * batch >= 512)
+      return bk32 ? launch<128, 64, 32, A_KC, B_KC, CONV>(g, batch, s)
+                  : launch<128, 64, 16, A_KC, B_KC, CONV>(g, batch, s);
     return launch<64, 64, 32, A_KC, B_KC, CONV>(g, batch, s);
   }
-  if (t128 >= 1024) {
-    if (gemm_variant() == 1) return launch<128, 128, 16, A_KC, B_KC, CONV>(g, batch, s);
-    return launch<128, 128, 32, A_KC, B_KC, CONV>(g, batch, s);
-  }
+  if (t128 >= 2048 || (!CONV && t128 >= 1024))
+    return bk32 ? launch<128, 128, 32, A_KC, B_KC, CONV>(g, batch, s)
+                : launch<128, 128, 16, A_KC, B_KC, CONV>(g, batch, s);
   if (naws_cdiv(g.M, 64) * naws_cdiv(g.N, 128) * batch >= 768)
-    return launch<64, 128, 32, A_KC, B_KC, CONV>(g, batch, s);
+    return bk32 ? launch<64, 128, 32, A_KC, B_KC, CONV>(g, batch, s)
+                : launch<64, 128, 16, A_KC, B_KC, CONV>(g, batch, s);
   return launch<64, 64, 32, A_KC, B_KC, CONV>(g, batch, s);
 }
 
