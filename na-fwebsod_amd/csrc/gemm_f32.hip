@@ -13,8 +13,9 @@
 // Operand tiles go global -> registers -> LDS (two LDS buffers, one barrier per
 // K-step).  Global loads are branch-free buffer loads (out-of-range lanes use
 // an out-of-bounds offset and read 0), issued right after the K-step's first
-// LDS fragment reads so their issue hides in the MFMA shadow; the LDS writes of
-// the next tile are placed in the middle of the last k-group's MFMAs.
+// LDS fragment reads so their issue hides in the MFMA shadow, one or two tiles
+// ahead (DIST); the LDS writes of the next tile sit among the last k-group's
+// MFMAs; BK = 16 keeps LDS small enough for 3-5 workgroups per CU.
 // K-contiguous operands sit in LDS as [row][BK+4] (pad 4 floats => the 16-lane
 // ds_read_b128 groups hit 16 distinct 16-B slots) and each lane fetches FOUR
 // k-values with one ds_read_b128; M/N-contiguous operands sit as [k][row] and
@@ -163,13 +164,29 @@ struct ConvStage {
 };
 
 // ---- the kernel --------------------------------------------------------------
+// Occupancy target (waves per SIMD = workgroups per CU): what the LDS footprint admits, capped
+// at 4 (128 VGPRs); the register allocator is held to it.
+template <int BM, int BN, int BK>
+constexpr int occupancy_target() {
+  constexpr int lds = 2 * (BM + BN) * (BK + PADK) * 4;
+  constexpr int by_lds = 160 * 1024 / lds;
+  return (BM * BN >= 128 * 128 || BK != 16) ? 1 : (by_lds > 5 ? 5 : by_lds);
+}
+
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool CONV>
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NT, (occupancy_target<BM, BN, BK>())) void gemm_f32_kernel(GemmArgs g) {
   using GA = TileGeom<BM, BK, A_KC>;
   using GB = TileGeom<BN, BK, B_KC>;
   constexpr int WTM = BM / 2, WTN = BN / 2;  // per-wave output
   constexpr int TI = WTM / 32, TJ = WTN / 32;
   constexpr int NKG = BK / 8;
+  // Prefetch distance in K-steps.  2 = two register sets: the loads of tile t+2 are issued
+  // in step t and written to LDS in step t+1, so the wait in front of the LDS writes never
+  // sees memory latency (+1..4% on the N-contiguous / conv forms, interleaved A/B).  The
+  // K-contiguous x K-contiguous 128x128 form keeps one set: its 116 VGPRs admit 4 workgroups
+  // per CU, which is worth more there than the longer distance (-2% with two sets).
+  constexpr int DIST = (BM * BN >= 128 * 128 && A_KC && B_KC && !CONV) ? 1 : 2;
+  constexpr int STASH_AT = (DIST == 1 && BK == 16) ? 2 : 0;  // MFMA step of the last k-group
   static_assert(TI >= 1 && TJ >= 1, "wave tile too small");
 
   // One LDS array, addressed by integer offsets only: a pointer table indexed
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[GA::VPT], rb[GB::VPT];
+  float4 ra0[GA::VPT], rb0[GB::VPT], ra1[GA::VPT], rb1[GB::VPT];
   Stage<BM, BK, A_KC> stA;
   ConvStage<BM, BK> cvA;
   Stage<BN, BK, B_KC> stB;
@@ -223,26 +240,26 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   stB.init(g.ldb, n0, g.N);
 
   const int T = (g.K + BK - 1) / BK;
-  auto fetch = [&](int t) {
+  auto fetch = [&](int t, float4* ra, float4* rb) {
     if constexpr (CONV) cvA.load(rsA, t, g.H, g.W, g.Cin, g.dil, ra);
     else stA.load(rsA, t, g.K, ra);
     stB.load(rsB, t, g.K, rb);
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const float4* ra, const float4* rb) {
     Stage<BM, BK, A_KC>::store(sm + A_OFF + buf * GA::FLOATS, ra);
     Stage<BN, BK, B_KC>::store(sm + B_OFF + buf * GB::FLOATS, rb);
   };
 
-  fetch(0);
-  stash(0);
-  __syncthreads();
-
-  // One K-step.  MORE (compile-time) = a following tile exists: the main loop body
-  // is then a single basic block and the staging instructions stay where they
-  // are written, between the MFMAs.
-  auto kstep = [&](int t, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value;
+  // One K-step on LDS buffer t&1: compute tile t, load tile t+2 into (lra, lrb), write tile
+  // t+1 from (sra, srb) into the other buffer.  PIPE (compile-time) = steady state, no
+  // bounds on t: the body is then a single basic block and the staging instructions stay
+  // where they are written, between the MFMAs.
+  auto kstep = [&](int t, auto pipe_tag, float4* lra, float4* lrb, const float4* sra,
+                   const float4* srb) {
+    constexpr bool PIPE = decltype(pipe_tag)::value;
     const int cur = t & 1;
+    const bool load2 = PIPE || (t + DIST < T);
+    const bool store1 = PIPE || (t + 1 < T);
     const float* as = sm + A_OFF + cur * GA::FLOATS;
     const float* bs = sm + B_OFF + cur * GB::FLOATS;
 #pragma unroll
@@ -270,24 +287,20 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
           for (int s = 0; s < 4; ++s) bf[j][s] = bs[(kg * 8 + h * 4 + s) * GB::LD + col];
         }
       }
-      if (MORE && kg == 0) {
-        // next tile's global loads: issued behind this step's first LDS reads,
-        // ahead of the MFMAs that cover their latency
-        fetch(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
+      if (kg == 0) {
+        if (load2) fetch(t + DIST, lra, lrb);
+        if (PIPE) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if (MORE && kg == NKG - 1 && s == 0) {
-          // land the next tile in the other LDS buffer while the last MFMAs run
-          __builtin_amdgcn_sched_barrier(0);
-          stash(cur ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
+        if (kg == NKG - 1 && s == STASH_AT) {
+          if (PIPE) __builtin_amdgcn_sched_barrier(0);
+          if (store1) stash(cur ^ 1, sra, srb);
+          if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
-        // keep the barrier (and its wait for the LDS writes) behind most of
-        // this group's MFMAs; the final ones may sink below it and cover the
-        // next step's first fragment reads
-        if (MORE && kg == NKG - 1 && s == 3) __builtin_amdgcn_sched_barrier(0);
+        // keep the barrier (and its wait for the LDS writes) behind most of this group's
+        // MFMAs; the final ones may sink below it and cover the next step's first reads
+        if (PIPE && kg == NKG - 1 && s == 3 && STASH_AT < 3) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -297,8 +310,26 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
     }
     __syncthreads();
   };
-  for (int t = 0; t + 1 < T; ++t) kstep(t, std::true_type{});
-  kstep(T - 1, std::false_type{});
+
+  fetch(0, ra0, rb0);
+  stash(0, ra0, rb0);
+  if constexpr (DIST == 2) {
+    if (T > 1) fetch(1, ra1, rb1);
+    __syncthreads();
+    int t = 0;
+    for (; t + 3 < T; t += 2) {
+      kstep(t, std::true_type{}, ra0, rb0, ra1, rb1);
+      kstep(t + 1, std::true_type{}, ra1, rb1, ra0, rb0);
+    }
+    if (t < T) kstep(t, std::false_type{}, ra0, rb0, ra1, rb1);
+    if (t + 1 < T) kstep(t + 1, std::false_type{}, ra1, rb1, ra0, rb0);
+    if (t + 2 < T) kstep(t + 2, std::false_type{}, ra0, rb0, ra1, rb1);
+  } else {
+    __syncthreads();
+    int t = 0;
+    for (; t + 1 < T; ++t) kstep(t, std::true_type{}, ra0, rb0, ra0, rb0);
+    kstep(T - 1, std::false_type{}, ra0, rb0, ra0, rb0);
+  }
 
   // ---- epilogue: C/D map col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
