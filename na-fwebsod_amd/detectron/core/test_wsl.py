@@ -36,3 +36,125 @@ def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_score
     if inv_index is not None:
         scores = scores[inv_index, :]
     return scores, boxes
+
+
+# ---------------------------------------------------------------------------------------
+# Test-time augmentation and post-processing (reference: core/test_wsl.py:29-99 im_detect_all,
+# :181-281 im_detect_bbox_aug, :284-352 hflip / scale variants, :803-863
+# box_results_with_nms_and_limit).  Host logic over the same forward pass; NMS is the plain
+# greedy CPU algorithm (the reference uses a cython CPU NMS; a GPU NMS is SURVEY.md §8f-2).
+# ---------------------------------------------------------------------------------------
+def flip_boxes(boxes, im_width):
+    """Horizontal flip of [n,4] boxes (utils/boxes.py `flip_boxes`)."""
+    out = boxes.copy()
+    out[:, 0::4] = im_width - boxes[:, 2::4] - 1
+    out[:, 2::4] = im_width - boxes[:, 0::4] - 1
+    return out
+
+
+def im_detect_bbox_hflip(executor, im, target_scale, target_max_size, boxes, obn_scores):
+    im_hf = np.ascontiguousarray(im[:, ::-1, :])
+    scores_hf, _ = im_detect_bbox(executor, im_hf, target_scale, target_max_size,
+                                  flip_boxes(boxes, im.shape[1]), obn_scores)
+    return scores_hf, boxes        # scores refer to the un-flipped proposals, in order
+
+
+def im_detect_bbox_scale(executor, im, target_scale, target_max_size, boxes, obn_scores,
+                         hflip=False):
+    fn = im_detect_bbox_hflip if hflip else im_detect_bbox
+    return fn(executor, im, target_scale, target_max_size, boxes, obn_scores)
+
+
+def im_detect_bbox_aug(executor, im, boxes, obn_scores):
+    """hflip at TEST.SCALE, each BBOX_AUG.SCALES (+flip), identity last; scores combined by
+    BBOX_AUG.SCORE_HEUR ('ID' | 'AVG' | 'UNION'), boxes by COORD_HEUR."""
+    aug = cfg.TEST.BBOX_AUG
+    assert not aug.SCALE_SIZE_DEP, 'Size dependent scaling not implemented'
+    assert (aug.SCORE_HEUR == 'UNION') == (aug.COORD_HEUR == 'UNION'), \
+        'Score and coord heuristics must be UNION together'
+    if aug.ASPECT_RATIOS:
+        raise NotImplementedError('aspect-ratio augmentation is not used by the na_wsddn configs')
+    scores_ts, boxes_ts = [], []
+
+    def add(s, b):
+        scores_ts.append(s)
+        boxes_ts.append(b)
+        if aug.COORD_HEUR == 'ID':
+            assert np.array_equal(boxes_ts[0], b), 'boxes at each scale should be the same'
+
+    if aug.H_FLIP:
+        add(*im_detect_bbox_hflip(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes, obn_scores))
+    for scale in aug.SCALES:
+        add(*im_detect_bbox_scale(executor, im, scale, aug.MAX_SIZE, boxes, obn_scores))
+        if aug.SCALE_H_FLIP:
+            add(*im_detect_bbox_scale(executor, im, scale, aug.MAX_SIZE, boxes, obn_scores,
+                                      hflip=True))
+    scores_i, boxes_i = im_detect_bbox(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes,
+                                       obn_scores)
+    add(scores_i, boxes_i)
+    if aug.SCORE_HEUR == 'ID':
+        scores_c = scores_i
+    elif aug.SCORE_HEUR == 'AVG':
+        scores_c = np.mean(scores_ts, axis=0)
+    elif aug.SCORE_HEUR == 'UNION':
+        scores_c = np.vstack(scores_ts)
+    else:
+        raise NotImplementedError('Score heur {} not supported'.format(aug.SCORE_HEUR))
+    if aug.COORD_HEUR == 'ID':
+        boxes_c = boxes_i
+    elif aug.COORD_HEUR == 'AVG':
+        boxes_c = np.mean(boxes_ts, axis=0)
+    elif aug.COORD_HEUR == 'UNION':
+        boxes_c = np.vstack(boxes_ts)
+    else:
+        raise NotImplementedError('Coord heur {} not supported'.format(aug.COORD_HEUR))
+    return scores_c, boxes_c
+
+
+def nms(dets, thresh):
+    """Greedy NMS on [n,5] (x1,y1,x2,y2,score); returns kept indices (cython_nms.pyx `nms`)."""
+    if dets.shape[0] == 0:
+        return []
+    x1, y1, x2, y2, sc = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3], dets[:, 4]
+    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = sc.argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        xx1, yy1 = np.maximum(x1[i], x1[order[1:]]), np.maximum(y1[i], y1[order[1:]])
+        xx2, yy2 = np.minimum(x2[i], x2[order[1:]]), np.minimum(y2[i], y2[order[1:]])
+        inter = np.maximum(0.0, xx2 - xx1 + 1) * np.maximum(0.0, yy2 - yy1 + 1)
+        ovr = inter / (areas[i] + areas[order[1:]] - inter)
+        order = order[1:][ovr <= thresh]
+    return keep
+
+
+def box_results_with_nms_and_limit(scores, boxes):
+    """Per-class score threshold, NMS, then keep the DETECTIONS_PER_IM best over all classes.
+    -> (scores, boxes, cls_boxes) with cls_boxes[j] = [n_j,5] for class j (0 = background)."""
+    num_classes = cfg.MODEL.NUM_CLASSES
+    cls_boxes = [np.zeros((0, 5), np.float32) for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        inds = np.where(scores[:, j] > cfg.TEST.SCORE_THRESH)[0]
+        dets = np.hstack((boxes[inds, :], scores[inds, j][:, np.newaxis])).astype(np.float32,
+                                                                                  copy=False)
+        cls_boxes[j] = dets[nms(dets, cfg.TEST.NMS), :]
+    if cfg.TEST.DETECTIONS_PER_IM > 0:
+        all_scores = np.hstack([cls_boxes[j][:, -1] for j in range(1, num_classes)])
+        if len(all_scores) > cfg.TEST.DETECTIONS_PER_IM:
+            th = np.sort(all_scores)[-cfg.TEST.DETECTIONS_PER_IM]
+            for j in range(1, num_classes):
+                cls_boxes[j] = cls_boxes[j][cls_boxes[j][:, -1] >= th, :]
+    im_results = np.vstack([cls_boxes[j] for j in range(1, num_classes)])
+    return im_results[:, -1], im_results[:, :-1], cls_boxes
+
+
+def im_detect_all(executor, im, box_proposals, obn_scores):
+    if cfg.TEST.BBOX_AUG.ENABLED:
+        scores, boxes = im_detect_bbox_aug(executor, im, box_proposals, obn_scores)
+    else:
+        scores, boxes = im_detect_bbox(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE,
+                                       box_proposals, obn_scores)
+    scores, boxes, cls_boxes = box_results_with_nms_and_limit(scores, boxes)
+    return cls_boxes

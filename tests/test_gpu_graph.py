@@ -138,3 +138,30 @@ def test_train_cli_two_iterations(dev, cfgmod, tmp_path, capsys):
     assert 'class_weight       Stat #iter_: 1' in out
     assert os.path.exists(os.path.join(str(tmp_path), 'train', 'flickr_voc', 'generalized_wsl',
                                        'model_final.pkl'))
+
+
+def test_tta_inference_and_nms(dev, cfgmod):
+    """BASELINE configs[4] shape of work, scaled down: multi-scale + flip TTA, AVG scores, NMS."""
+    from detectron.core import test_wsl
+    from detectron.datasets import synthetic
+    c = cfgmod
+    c.merge_cfg_from_list(['TEST.SCALE', 64, 'TEST.MAX_SIZE', 200, 'TEST.BBOX_AUG.ENABLED', True,
+                           'TEST.BBOX_AUG.SCALES', '(48, 80)', 'TEST.BBOX_AUG.MAX_SIZE', 200,
+                           'TEST.DETECTIONS_PER_IM', 20])
+    blobs = synthetic.init_blobs(20, seed=3)
+    _m, ex = _build(dev, False, False, blobs)
+    e = synthetic.make_roidb(1, 40, 20, 64, 96, seed=9)[0]
+    e['boxes'][1] = e['boxes'][0]                       # a duplicate proposal: dedup + scatter back
+    im = (synthetic.make_image(e).transpose(1, 2, 0) + synthetic.PIXEL_MEANS_BGR).astype(np.float32)
+    scores, boxes = test_wsl.im_detect_bbox_aug(ex, im, e['boxes'], e['obn_scores'])
+    assert scores.shape == (40, 21) and np.isfinite(scores).all()
+    s1, _ = test_wsl.im_detect_bbox(ex, im, 64, 200, e['boxes'], e['obn_scores'])
+    assert np.array_equal(boxes, e['boxes']) and not np.allclose(scores, s1)   # 6 passes averaged
+    cls_boxes = test_wsl.im_detect_all(ex, im, e['boxes'], e['obn_scores'])
+    assert len(cls_boxes) == 21 and sum(len(b) for b in cls_boxes[1:]) <= 20
+    # dedup hash: rows 0 and 1 collapse to one roi in the forward pass
+    rois = np.hstack((np.zeros((40, 1), np.float32), e['boxes'])).astype(np.float32)
+    u, idx, inv = test_wsl.dedup_rois(rois, 0.125)
+    assert u.shape[0] == 39 and np.array_equal(u[inv], rois)
+    assert test_wsl.nms(np.array([[0, 0, 10, 10, .9], [1, 1, 10, 10, .8], [20, 20, 30, 30, .7]],
+                                 np.float32), 0.5) == [0, 2]
