@@ -70,6 +70,11 @@ def test_engine_matches_oracle(dev, dropout, c):
     floor = 1e-6 * float(np.abs(dl).max()) * rt
     for name, g in ref['grads'].items():
         got = eng.grad_blob(name).cpu().numpy()
+        if name.endswith('fc8d_b'):
+            # exactly 0 in exact arithmetic: both sides are sums of rt rounding residues
+            bound = 2e-3 * float(np.abs(dl).max()) * np.sqrt(rt)
+            assert np.abs(got).max() <= bound and np.abs(g).max() <= bound, name
+            continue
         # A pre-activation within rounding of 0 can land on opposite sides of the ReLU gate in
         # two fp32 evaluations (seen: 1 of 160k units), which changes one row/column of a
         # weight gradient by O(1): bound the Frobenius error and the share of outliers
