@@ -138,6 +138,8 @@ class WsddnEngine(object):
         self.step_count = 0          # forward/backward passes run (dropout stream)
         self.conv = {}               # name -> (weight (OIHW or packed), bias)
         self.stat_state = None
+        self.conv_streams = True     # one HIP stream per image for the conv body
+        self._streams = []
         # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
         # parameters: when gradients are all-reduced the SGD update is deferred until that
         # (parameter-free) prefix of the next iteration has been queued, so the collective runs
@@ -183,9 +185,10 @@ class WsddnEngine(object):
         return out
 
     # ---------------------------------------------------------------- forward
-    def conv_body(self, data):
-        """data NCHW [B,3,H,W] -> conv5_3 NHWC [B,H/8-1,W/8-1,512]."""
+    def _conv_chain(self, data, out=None):
+        """data NCHW [b,3,H,W] -> conv5_3 NHWC, on the current stream."""
         x = None
+        last = VGG16_CONVS[-1][0]
         for item in VGG16_CONVS:
             if item[0] == 'pool':
                 x = ops.maxpool2x2_nhwc(x, 2)
@@ -198,8 +201,39 @@ class WsddnEngine(object):
                     x = ops.conv3x3_c3_nchw_to_nhwc(data, wp, b, True)
                 else:
                     d = dil if dil is not None else (2 if self.dilation == 2 else 1)
-                    x = ops.conv3x3_nhwc(x, wp, b, d, True)
+                    x = ops.conv3x3_nhwc(x, wp, b, d, True, out=out if name == last else None)
         return x
+
+    def conv_body(self, data):
+        """data NCHW [B,3,H,W] -> conv5_3 NHWC [B,H/8-1,W/8-1,512].
+
+        The 13 layers of one image are a dependent chain, and the deep layers have only a
+        couple of workgroup-tiles per CU, so every layer ends on a partially filled chip.
+        Images are independent: each image's chain is queued on its own HIP stream and the
+        hardware packs the tail of one image's layer with the head of the other's."""
+        n = data.shape[0]
+        if n == 1 or not self.conv_streams:
+            return self._conv_chain(data)
+        h, w = data.shape[2], data.shape[3]
+        for _ in range(3):
+            h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+        if self.dilation == 2:
+            h, w = h - 1, w - 1
+        else:
+            h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+        out = torch.empty((n, h, w, 512), device=self.device, dtype=torch.float32)
+        main = torch.cuda.current_stream(self.device)
+        start = main.record_event()
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        for i in range(n):
+            st = self._streams[i]
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                self._conv_chain(data[i:i + 1], out=out[i:i + 1])
+                done = st.record_event()
+            main.wait_event(done)
+        return out
 
     @staticmethod
     def segments(rois, n_img):
