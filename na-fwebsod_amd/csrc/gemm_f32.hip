@@ -53,11 +53,10 @@ struct GemmArgs {
   int H, W, Cin, dil;
 };
 
-constexpr int NT = 256;                // threads per workgroup
 constexpr int PADK = 4;                // K-contiguous LDS row pad (floats)
 constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any descriptor range
 
-template <int ROWS, int BK, bool KC>
+template <int ROWS, int BK, bool KC, int NT>
 struct TileGeom {
   static constexpr int LD = KC ? (BK + PADK) : ROWS;          // LDS leading dim
   static constexpr int FLOATS = KC ? ROWS * (BK + PADK) : BK * ROWS;
@@ -75,9 +74,9 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigne
 
 // Per-thread staging state of one operand tile: the K-invariant part of each
 // 16-byte load's byte offset (or OOB when the row is outside the matrix).
-template <int ROWS, int BK, bool KC>
+template <int ROWS, int BK, bool KC, int NT>
 struct Stage {
-  using G = TileGeom<ROWS, BK, KC>;
+  using G = TileGeom<ROWS, BK, KC, NT>;
   unsigned base[G::VPT];
   unsigned kstep;  // bytes added per K-step
 
@@ -126,9 +125,9 @@ struct Stage {
 };
 
 // conv A tile: rows are output pixels, a K-step lies inside one 3x3 tap.
-template <int ROWS, int BK>
+template <int ROWS, int BK, int NT>
 struct ConvStage {
-  using G = TileGeom<ROWS, BK, true>;
+  using G = TileGeom<ROWS, BK, true, NT>;
   int y[G::VPT], x[G::VPT];
   unsigned base[G::VPT];  // byte offset of (pixel, channel chunk) or OOB
 
@@ -173,11 +172,13 @@ constexpr int occupancy_target() {
   return (BM * BN >= 128 * 128 || BK != 16) ? 1 : (by_lds > 5 ? 5 : by_lds);
 }
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool CONV>
-__global__ __launch_bounds__(NT, (occupancy_target<BM, BN, BK>())) void gemm_f32_kernel(GemmArgs g) {
-  using GA = TileGeom<BM, BK, A_KC>;
-  using GB = TileGeom<BN, BK, B_KC>;
-  constexpr int WTM = BM / 2, WTN = BN / 2;  // per-wave output
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool CONV, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, (occupancy_target<BM, BN, BK>()))
+void gemm_f32_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WM * WN;
+  using GA = TileGeom<BM, BK, A_KC, NT>;
+  using GB = TileGeom<BN, BK, B_KC, NT>;
+  constexpr int WTM = BM / WM, WTN = BN / WN;  // per-wave output
   constexpr int TI = WTM / 32, TJ = WTN / 32;
   constexpr int NKG = BK / 8;
   // Prefetch distance in K-steps.  2 = two register sets: the loads of tile t+2 are issued
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(NT, (occupancy_target<BM, BN, BK>())) void gemm_f32
   float* C = g.C + bz * g.sC;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
   f32x16 acc[TI][TJ];
@@ -232,9 +233,9 @@ __global__ __launch_bounds__(NT, (occupancy_target<BM, BN, BK>())) void gemm_f32
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float4 ra0[GA::VPT], rb0[GB::VPT], ra1[GA::VPT], rb1[GB::VPT];
-  Stage<BM, BK, A_KC> stA;
-  ConvStage<BM, BK> cvA;
-  Stage<BN, BK, B_KC> stB;
+  Stage<BM, BK, A_KC, NT> stA;
+  ConvStage<BM, BK, NT> cvA;
+  Stage<BN, BK, B_KC, NT> stB;
   if constexpr (CONV) cvA.init(m0, g.M, g.H, g.W, g.Cin);
   else stA.init(g.lda, m0, g.M);
   stB.init(g.ldb, n0, g.N);
@@ -246,8 +247,8 @@ __global__ __launch_bounds__(NT, (occupancy_target<BM, BN, BK>())) void gemm_f32
     stB.load(rsB, t, g.K, rb);
   };
   auto stash = [&](int buf, const float4* ra, const float4* rb) {
-    Stage<BM, BK, A_KC>::store(sm + A_OFF + buf * GA::FLOATS, ra);
-    Stage<BN, BK, B_KC>::store(sm + B_OFF + buf * GB::FLOATS, rb);
+    Stage<BM, BK, A_KC, NT>::store(sm + A_OFF + buf * GA::FLOATS, ra);
+    Stage<BN, BK, B_KC, NT>::store(sm + B_OFF + buf * GB::FLOATS, rb);
   };
 
   // One K-step on LDS buffer t&1: compute tile t, load tile t+2 into (lra, lrb), write tile
@@ -374,15 +375,16 @@ int gemm_variant() {
   return v;
 }
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool CONV>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool CONV, int WM = 2, int WN = 2>
 int launch(GemmArgs& g, int batch, hipStream_t s) {
-  using GA = TileGeom<BM, BK, A_KC>;
-  using GB = TileGeom<BN, BK, B_KC>;
+  constexpr int NT = 64 * WM * WN;
+  using GA = TileGeom<BM, BK, A_KC, NT>;
+  using GB = TileGeom<BN, BK, B_KC, NT>;
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float);
   if (gemm_variant() == 2) lds = std::max<size_t>(lds, 84 * 1024);
-  auto kern = gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, CONV>;
+  auto kern = gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, CONV, WM, WN>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -408,6 +410,11 @@ int dispatch(GemmArgs& g, int batch, hipStream_t s) {
                   : launch<128, 64, 16, A_KC, B_KC, CONV>(g, batch, s);
     return launch<64, 64, 32, A_KC, B_KC, CONV>(g, batch, s);
   }
+  // FC forward (both operands K-contiguous): a 256x128 tile on 8 waves moves 25% fewer bytes
+  // per MFMA through L2/LDS, worth +1.6% there (interleaved A/B); the N-contiguous forms
+  // lose 1-7% with it and keep 128x128.  NAWS_GEMM_VARIANT=5 disables it.
+  if (!CONV && A_KC && B_KC && gemm_variant() != 5 && !bk32 && t128 >= 2048)
+    return launch<256, 128, 16, A_KC, B_KC, CONV, 4, 2>(g, batch, s);
   if (t128 >= 2048 || (!CONV && t128 >= 1024))
     return bk32 ? launch<128, 128, 32, A_KC, B_KC, CONV>(g, batch, s)
                 : launch<128, 128, 16, A_KC, B_KC, CONV>(g, batch, s);

@@ -28,6 +28,9 @@ def main():
     ap.add_argument('libs', nargs='+')
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--rows', type=int, default=4000)
+    ap.add_argument('--env', nargs='*', default=[],
+                    help='NAME=VALUE applied while lib i makes its FIRST call (one per lib, "-" = none): '
+                         'the variant knob is latched per library on first use')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     libs = [bind(p) for p in a.libs]
@@ -58,10 +61,20 @@ def main():
                 y.data_ptr(), st)
         cases.append(('conv %d->%d %dx%d d%d' % (cin, cout, h, w, dil), 'naws_conv3x3_nhwc_fwd',
                       args, 2.0 * 2 * h * w * cout * 9 * cin, (x, wp, b, y)))
+    first = [True] * len(libs)
     for name, fn, args, flops, _keep in cases:
         times = [[] for _ in libs]
         for r in range(a.rounds + 1):
             for i, l in enumerate(libs):
+                if first[i] and i < len(a.env) and a.env[i] != '-':
+                    k, v = a.env[i].split('=')
+                    os.environ[k] = v
+                    g0 = cases[0][2]   # a tiny launch on the first case's buffers latches the knob
+                    rc = l.naws_gemm_f32(0, 1, 256, 256, 32, g0[5], 32, g0[7], 32, g0[9], 256, 1,
+                                         0, 0, 0, 0, None, 0, None, 0, 1.0, 0.0, 0, 0, st)
+                    assert rc == 0, rc
+                    del os.environ[k]
+                first[i] = False
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 rc = getattr(l, fn)(*args)
