@@ -141,21 +141,24 @@ class WsddnEngine(object):
         self.conv_streams = True     # one HIP stream per image for the conv body
         self._streams = []
         # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
-        # parameters: when gradients are all-reduced the SGD update is deferred until that
-        # (parameter-free) prefix of the next iteration has been queued, so the collective runs
-        # under ~10 ms of conv work instead of in front of it.  Same arithmetic, same order of
-        # updates; flush() applies a pending update (checkpoints, lr changes, end of run).
-        self.defer_update = None     # None -> follow reducer.active
+        # parameters: the all-reduce wait and the SGD kernel run on a side stream underneath
+        # them (see sgd_step).  Same arithmetic, same order of updates; flush() joins the
+        # streams (before the head, checkpoints, lr changes, end of run).
+        self.defer_update = None     # None/True -> side stream; False -> inline on the main stream
         self._update_pending = False
+        self._upd_stream = None
+        self._upd_event = None
 
     # ------------------------------------------------------------------ params
     def blob(self, name):
+        self.flush()
         return self.arena.view(self.params, name)
 
     def grad_blob(self, name):
         return self.arena.view(self.grads, name)
 
     def momentum_blob(self, name):
+        self.flush()
         return self.arena.view(self.momentum_buf, name)
 
     def set_conv_blobs(self, blobs):
@@ -371,16 +374,27 @@ class WsddnEngine(object):
         return new_lr
 
     def sgd_step(self):
-        defer = self.reducer.active if self.defer_update is None else self.defer_update
-        if defer:
-            self._update_pending = True
-        else:
+        """Queue this iteration's update.  By default it goes to a side stream: it waits there
+        for the gradient all-reduce and runs the (HBM-bound) fused SGD kernel while the main
+        stream already runs the next iteration's (MFMA-bound, parameter-free) conv body + RoIPool;
+        `flush()` — called before the head touches the parameters — joins the two streams."""
+        defer = True if self.defer_update is None else self.defer_update
+        if not defer:
             self._apply_update()
+            return
+        main = torch.cuda.current_stream(self.device)
+        if self._upd_stream is None:
+            self._upd_stream = torch.cuda.Stream(device=self.device)
+        self._upd_stream.wait_event(main.record_event())
+        with torch.cuda.stream(self._upd_stream):
+            self._apply_update()
+            self._upd_event = self._upd_stream.record_event()
+        self._update_pending = True
 
     def flush(self):
         if self._update_pending:
             self._update_pending = False
-            self._apply_update()
+            torch.cuda.current_stream(self.device).wait_event(self._upd_event)
 
     def _apply_update(self):
         self.wait_allreduce()

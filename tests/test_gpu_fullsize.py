@@ -59,6 +59,7 @@ def test_run_to_run_bitwise_reproducible(setup):
         eng = make()
         out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
         eng.sgd_step()
+        eng.flush()
         res.append((out['loss_cls'].clone(), eng.grads.clone(), eng.params.clone()))
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
