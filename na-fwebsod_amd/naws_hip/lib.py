@@ -29,6 +29,8 @@ PROTOTYPES = {
     'naws_conv3x3_pack_weight': [p, i32, i32, p, p],
     'naws_conv3x3_nhwc_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
     'naws_maxpool2x2_nhwc_fwd': [p, i32, i32, i32, i32, i32, p, p],
+    'naws_winograd_weight_transform': [p, i32, i32, p, p],
+    'naws_conv3x3_winograd_nhwc_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p],
     'naws_nchw_to_nhwc': [p, i32, i32, i32, i32, p, p],
     'naws_nhwc_to_nchw': [p, i32, i32, i32, i32, p, p],
     'naws_roi_pool_f_fwd': [p, i32, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, p, p],
@@ -57,6 +59,7 @@ SPECIAL = {
     'naws_version': ([], C.c_char_p),
     'naws_last_hip_error': ([], i32),
     'naws_entropy_gate_workspace_floats': ([i32, i32, i32, i32], i64),
+    'naws_winograd_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(SPECIAL))
 

@@ -61,6 +61,26 @@ def conv3x3_nhwc(x, w_packed, bias, dilation=1, relu=True, out=None):
     return y
 
 
+def winograd_weight_transform(w_oihw):
+    _chk(w_oihw, 'w')
+    cout, cin = w_oihw.shape[:2]
+    u = torch.empty((16, cout, cin), device=w_oihw.device, dtype=_f32)
+    L.call('naws_winograd_weight_transform', w_oihw.data_ptr(), cout, cin, u.data_ptr(), _stream())
+    return u
+
+
+def conv3x3_winograd_nhwc(x, u, bias, dilation=1, relu=True, out=None):
+    _chk(x, 'x'); _chk(u, 'U')
+    n, h, w, cin = x.shape
+    cout = u.shape[1]
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    nws = L.load().naws_winograd_workspace_floats(n, h, w, cin, cout, dilation)
+    ws = torch.empty((nws,), device=x.device, dtype=_f32)
+    L.call('naws_conv3x3_winograd_nhwc_fwd', x.data_ptr(), u.data_ptr(), _ptr(bias), n, h, w, cin,
+           cout, dilation, int(relu), ws.data_ptr(), y.data_ptr(), _stream())
+    return y
+
+
 def maxpool2x2_nhwc(x, stride, out=None):
     _chk(x, 'x')
     n, h, w, c = x.shape

@@ -70,6 +70,10 @@ def main():
             b = rnd(cout)
             y = torch.empty((a.images, h, w, cout), device=dev)
             ms = timeit(lambda: ops.conv3x3_nhwc(x, wp, b, dil, True, out=y), a.iters)
+            if cin >= 128:
+                u = rnd(16, cout, cin)
+                msw = timeit(lambda: ops.conv3x3_winograd_nhwc(x, u, b, dil, True, out=y), a.iters)
+                print('   winograd F(2x2,3x3): %8.3f ms (direct %8.3f ms)' % (msw, ms))
             fl = 2.0 * a.images * h * w * cout * 9 * cin
             k = mult.get((cin, cout, h, w, dil), 1)
             tot_ms += ms * k

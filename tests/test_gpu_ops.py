@@ -330,6 +330,28 @@ def test_conv3x3_nhwc(dev, cin, cout, dil, h, w):
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('cin,cout,dil,h,w', [(256, 256, 1, 37, 53), (128, 256, 1, 19, 24),
+                                              (512, 512, 2, 21, 31), (512, 512, 2, 74, 124)])
+def test_conv3x3_winograd(dev, cin, cout, dil, h, w):
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(16)
+    n = 2
+    x = rng.uniform(-1, 1, (n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    u = ops.winograd_weight_transform(_t(wt, dev))
+    y = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc(xd, u, _t(b, dev), dil, True)).cpu().numpy()
+    assert np.abs(y - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+    # and against the direct implicit-GEMM kernel
+    yd = ops.nhwc_to_nchw(ops.conv3x3_nhwc(xd, ops.conv3x3_pack_weight(_t(wt, dev)), _t(b, dev),
+                                           dil, True)).cpu().numpy()
+    assert np.abs(y - yd).max() < 1e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_conv1_1_and_pool(dev):
     from naws_hip import ops
     import torch.nn.functional as F
