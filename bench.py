@@ -162,7 +162,7 @@ def main():
                                        num_fg, B, args.height, args.width, args.rois),
                        'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
                        'lr': args.lr, 'final_loss': round(loss, 5)},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<256,128,16,KC,KC,4x2 waves> (fc6 fwd, '
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves> (fc6 fwd, '
                                                     'both branches, M=%d N=8192 K=%d)' % (rt, k6),
                          'achieved': round(achieved, 2) if achieved else None,
                          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

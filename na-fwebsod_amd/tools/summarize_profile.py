@@ -52,7 +52,7 @@ def main():
         vals = []
         if f:
             rws = [r for r in csv.DictReader(open(f[0])) if r['Counter_Name'] == cname and
-                   'gemm_f32_kernel<256, 128, 16, true, true, false, 4, 2>' in r['Kernel_Name']]
+                   'gemm_f32_kernel<256, 256, 16, true, true, false, 4, 4>' in r['Kernel_Name']]
             if rws:
                 # fc7 fwd (batch 2) has the same thread count; fc6 launches are the ones that
                 # move the most bytes
@@ -62,7 +62,7 @@ def main():
     if dom.get('FETCH_SIZE') is not None and dom.get('WRITE_SIZE') is not None:
         import json
         tb = (2 * dom['FETCH_SIZE'] + dom['WRITE_SIZE']) * 1024
-        json.dump({'kernel': 'gemm_f32_kernel<256,128,16,KC,KC,4x2> fc6 fwd',
+        json.dump({'kernel': 'gemm_f32_kernel<256,256,16,KC,KC,4x4> fc6 fwd',
                    'FETCH_SIZE_KiB_per_launch': dom['FETCH_SIZE'],
                    'WRITE_SIZE_KiB_per_launch': dom['WRITE_SIZE'],
                    'hbm_bytes_per_launch': tb,
