@@ -108,6 +108,9 @@ def main():
     roidb = synthetic.make_roidb(B, args.rois, num_fg, args.height, args.width, seed=11 + rank)
     mb = synthetic.make_minibatch(roidb, num_fg)
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    import numpy as np
+    counts = np.bincount(mb['rois'][:, 0].astype(np.int64), minlength=B)
+    seg = [0] + np.cumsum(counts).tolist()        # per-image row offsets, known on the host
     eng.set_lr(args.lr)
 
     # live timing of the dominant kernel (fc6 forward GEMM, N = 8192) with HIP events on
@@ -119,7 +122,7 @@ def main():
             eng.timing_events = ev
         else:
             eng.timing_events = None
-        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
         eng.sgd_step()
         return out
 

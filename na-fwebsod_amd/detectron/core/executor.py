@@ -155,6 +155,7 @@ class NetExecutor(object):
 
     # -------------------------------------------------------------------- run
     def feed(self, blobs):
+        self.ws.pop('_seg', None)      # host-side row offsets only ever describe the current rois
         for k, v in blobs.items():
             self.ws[k] = v
 
@@ -172,7 +173,8 @@ class NetExecutor(object):
     def _run_fused(self):
         ws, eng = self.ws, self.engine
         if self.model.train:
-            out = eng.forward_backward(ws['data'], ws['rois'], ws['obn_scores'], ws['labels_oh'])
+            out = eng.forward_backward(ws['data'], ws['rois'], ws['obn_scores'], ws['labels_oh'],
+                                       seg=ws.get('_seg'))
             eng.sgd_step()
             ws['loss_cls'], ws['loss_cls_noise'] = out['loss_cls'], out['loss_cls_noise']
             ws['cls_prob'], ws['cls_prob_noise'] = out['cls_prob'], out['cls_prob_noise']
@@ -182,7 +184,7 @@ class NetExecutor(object):
             if self.rank == 0:
                 eng.stat_update(out, ws['labels_oh'], max(1, int(1280 / cfg.NUM_GPUS)))
         else:
-            ws['cls_prob'] = eng.infer(ws['data'], ws['rois'], ws['obn_scores'])
+            ws['cls_prob'] = eng.infer(ws['data'], ws['rois'], ws['obn_scores'], seg=ws.get('_seg'))
 
     # ------------------------------------------------------ op-by-op plan
     def _run_interpreted(self):

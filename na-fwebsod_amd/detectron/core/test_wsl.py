@@ -29,7 +29,7 @@ def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_score
         obn = obn[index, :]
     dev = executor.device
     executor.feed(dict(data=torch.from_numpy(data).to(dev), rois=torch.from_numpy(rois).to(dev),
-                       obn_scores=torch.from_numpy(obn).to(dev)))
+                       obn_scores=torch.from_numpy(obn).to(dev), _seg=[0, rois.shape[0]]))
     executor.run()
     scores = executor.fetch('cls_prob').cpu().numpy()
     scores = scores.reshape([-1, scores.shape[-1]])

@@ -165,12 +165,15 @@ class RoIDataLoader(object):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=device)
         out = {}
+        counts = np.bincount(host['rois'][:, 0].astype(np.int64), minlength=host['data'].shape[0])
+        seg = [0] + np.cumsum(counts).tolist()
         with torch.cuda.stream(self._copy_stream):
             for k, v in host.items():
                 out[k] = torch.from_numpy(v).pin_memory().to(device, non_blocking=True)
         torch.cuda.current_stream(device).wait_stream(self._copy_stream)
         for v in out.values():
             v.record_stream(torch.cuda.current_stream(device))
+        out['_seg'] = seg            # host-side per-image row offsets (no device sync needed)
         return out
 
 

@@ -297,12 +297,15 @@ class WsddnEngine(object):
         ops.gemm(h7v, w8[:nb], False, True, out=lgv, epilogue=L.EPI_BIAS, bias=b8)
         return h6, h7, lg
 
-    def forward_backward(self, data, rois, obn_scores, labels_oh, compute_grads=True):
+    def forward_backward(self, data, rois, obn_scores, labels_oh, compute_grads=True, seg=None):
         """One training pass over this GPU's images.  Returns dict of loss tensors
-        (per image) and keeps what backward / stats need."""
+        (per image) and keeps what backward / stats need.  `seg` = host list of per-image row
+        offsets [0, R0, R0+R1, ...] (the loader knows it); when omitted it is derived from
+        rois[:,0] on the device, which costs a device->host sync per iteration."""
         C = self.C
         n_img = data.shape[0]
-        seg = self.segments(rois, n_img)
+        if seg is None:
+            seg = self.segments(rois, n_img)
         rt = rois.shape[0]
         max_seg = max(seg[i + 1] - seg[i] for i in range(n_img))
         seg_off = torch.tensor(seg, dtype=torch.int32, device=self.device)
@@ -418,12 +421,13 @@ class WsddnEngine(object):
         self.sgd_iter_count += 1
 
     # -------------------------------------------------------------- inference
-    def infer(self, data, rois, obn_scores):
+    def infer(self, data, rois, obn_scores, seg=None):
         self.flush()
         """Test-mode forward: cls_prob [R, C+1] = Concat(rois_pred[:, :1], rois_pred)
         (wsl_heads.py:58-67); no dropout; only the clean branch is fetched (test_wsl.py:151)."""
         n_img = data.shape[0]
-        seg = self.segments(rois, n_img)
+        if seg is None:
+            seg = self.segments(rois, n_img)
         seg_off = torch.tensor(seg, dtype=torch.int32, device=self.device)
         conv5 = self.conv_body(data)
         roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
