@@ -413,7 +413,9 @@ int dispatch(GemmArgs& g, int batch, hipStream_t s) {
   // FC forward (both operands K-contiguous): a 256x128 tile on 8 waves moves 25% fewer bytes
   // per MFMA through L2/LDS, worth +1.6% there (interleaved A/B); the N-contiguous forms
   // lose 1-7% with it and keep 128x128.  NAWS_GEMM_VARIANT=5 disables it.
-  if (!CONV && A_KC && B_KC && gemm_variant() != 5 && !bk32) {
+  // (long K only: with one or two workgroups per CU nothing covers a tile's prologue/epilogue,
+  // which short-K problems such as the Winograd batch GEMMs, K = Cin, cannot amortise)
+  if (!CONV && A_KC && B_KC && gemm_variant() != 5 && !bk32 && g.K >= 2048) {
     // 256x256 on 16 waves (one workgroup per CU): another +1.5% when it fills the chip twice
     if (naws_cdiv(g.M, 256) * naws_cdiv(g.N, 256) * batch >= 512)
       return launch<256, 256, 16, A_KC, B_KC, CONV, 4, 4>(g, batch, s);

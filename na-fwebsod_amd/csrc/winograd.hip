@@ -8,10 +8,18 @@
 // result within ~1e-6 relative of the direct sum (well inside the 1e-4 parity bar).
 // Dilation 2 (conv5_x) = four independent dense convolutions on the (y%2, x%2) sub-grids.
 //
-// Workspace layout: V [16][P][Cin] | M [16][P][Cout], P = N * d*d * ceil(Hs/2) * ceil(Ws/2).
+// Workspace layout: V [16][P*Cin + PAD] | M [16][P*Cout + PAD], P = N * d*d * ceil(Hs/2) *
+// ceil(Ws/2); PAD floats keep the 16 slabs a lane touches off one HBM channel.
+#include <stdlib.h>
 #include "naws_common.h"
 
 namespace {
+
+int wino_pad() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NAWS_WINO_PAD"); v = e ? atoi(e) : 0; }
+  return v;
+}
 
 struct WinoGeom {
   int N, H, W, d, Hs, Ws, th, tw;
@@ -43,7 +51,8 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 
 // V[xi][p][c] = (B^T d B)[xi];  one lane = one tile x 4 channels
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ X, WinoGeom g,
-                                                         int Cin, float* __restrict__ V) {
+                                                         int Cin, long long slab,
+                                                         float* __restrict__ V) {
   const int c4n = Cin / 4;
   const long long total = g.P * c4n;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
@@ -76,7 +85,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       tt[3][j] = f4sub(dd[1][j], dd[3][j]);
     }
     float* out = V + p * Cin + c4 * 4;
-    const long long slab = g.P * Cin;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {       // (.) B
       *reinterpret_cast<float4*>(out + (i * 4 + 0) * slab) = f4sub(tt[i][0], tt[i][2]);
@@ -89,11 +97,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 
 // Y tile = A^T m A (+ bias, ReLU);  one lane = one tile x 4 output channels
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, WinoGeom g,
-                                                          int Cout, const float* __restrict__ bias,
+                                                          int Cout, long long slab,
+                                                          const float* __restrict__ bias,
                                                           int relu, float* __restrict__ Y) {
   const int c4n = Cout / 4;
   const long long total = g.P * c4n;
-  const long long slab = g.P * Cout;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
        t += (long long)gridDim.x * 256) {
     const int c4 = (int)(t % c4n);
@@ -173,7 +181,7 @@ extern "C" int64_t naws_winograd_workspace_floats(int N, int H, int W, int Cin, 
                                                   int dilation) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation < 1) return 0;
   const WinoGeom g = wino_geom(N, H, W, dilation);
-  return 16 * g.P * ((int64_t)Cin + Cout);
+  return 16 * (g.P * ((int64_t)Cin + Cout) + 2 * 4096);
 }
 
 extern "C" int naws_winograd_weight_transform(const float* W_oihw, int Cout, int Cin, float* U,
@@ -198,23 +206,25 @@ extern "C" int naws_conv3x3_winograd_nhwc_fwd(const float* X, const float* U, co
   const WinoGeom g = wino_geom(N, H, W, dilation);
   if (g.P > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  const long long pad = wino_pad();
+  const long long slabV = g.P * Cin + pad, slabM = g.P * Cout + pad;
   float* V = workspace;
-  float* Mb = workspace + 16 * g.P * Cin;
+  float* Mb = workspace + 16 * slabV;
   {
     const long long total = g.P * (Cin / 4);
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, X, g, Cin, V);
+                       dim3(256), 0, s, X, g, Cin, slabV, V);
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
   }
-  int rc = naws_gemm_f32(0, 1, (int)g.P, Cout, Cin, V, Cin, U, Cin, Mb, Cout, 16, g.P * Cin,
-                         (int64_t)Cout * Cin, g.P * Cout, NAWS_EPI_NONE, nullptr, 0, nullptr, 0, 1.0f,
+  int rc = naws_gemm_f32(0, 1, (int)g.P, Cout, Cin, V, Cin, U, Cin, Mb, Cout, 16, slabV,
+                         (int64_t)Cout * Cin, slabM, NAWS_EPI_NONE, nullptr, 0, nullptr, 0, 1.0f,
                          0.0f, 0, 0, stream);
   if (rc != NAWS_OK) return rc;
   {
     const long long total = g.P * (Cout / 4);
     hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, Mb, g, Cout, bias, relu, Y);
+                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y);
   }
   return naws_check_launch();
 }
