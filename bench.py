@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense v_mfma_f32_32x32x16_bf16
 
 
 def parse():
@@ -39,6 +40,9 @@ def parse():
                     help='initialise RCCL and run the all-reduce schedule even with one rank '
                          '(exercises the N>1 code path on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mfma-dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help="fp32 = BASELINE configs[1]/[2] (the headline metric); bf16 = the "
+                         "configs[3] option (bf16 MFMA conv/fc, fp32 storage + loss)")
     ap.add_argument('--cpu-rois', type=int, default=500)
     return ap.parse_args()
 
@@ -98,7 +102,8 @@ def main():
     B = args.images_per_gpu
     eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
                       weight_decay=5e-4, iter_size=1, gpu_num=world * B, seed=11,
-                      process_group=pg, world_size=world, allreduce_chunks=1)
+                      process_group=pg, world_size=world, allreduce_chunks=1,
+                      mfma_dtype=args.mfma_dtype)
     if args.force_dist:
         eng.reducer.force = True
     blobs = synthetic.init_blobs(num_fg, seed=11)     # identical on every rank (= broadcast)
@@ -152,6 +157,10 @@ def main():
         fc6_flops = 2.0 * rt * (2 * 4096) * k6
         kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
         achieved = fc6_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
+        bf = args.mfma_dtype == 'bf16'
+        peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
+        kname = ('gemm_bf16_kernel<256,128,4x2 waves,fp32 sources>' if bf else
+                 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
         res = {
             'metric': 'images/sec (600px, 2000 proposals) VGG16-C5 WSDDN fwd+bwd',
             'value': round(world * B * args.steps / dt, 3),
@@ -159,24 +168,26 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'bf16' if bf else 'f32', 'data': 'synthetic',
             'config': {'workload': 'flickr_voc na_wsddn_V-16-C5_1x (C=%d): %d images %dx%d per '
-                                   'GPU x %d proposals, fwd+bwd+allreduce+SGD, fp32 MFMA' % (
-                                       num_fg, B, args.height, args.width, args.rois),
+                                   'GPU x %d proposals, fwd+bwd+allreduce+SGD, %s' % (
+                                       num_fg, B, args.height, args.width, args.rois,
+                                       'bf16 MFMA conv/fc6/fc7, fp32 storage/fc8/loss/SGD'
+                                       if bf else 'fp32 MFMA'),
                        'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
                        'lr': args.lr, 'final_loss': round(loss, 5)},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves> (fc6 fwd, '
-                                                    'both branches, M=%d N=8192 K=%d)' % (rt, k6),
+            'roofline': {'bound': 'mfma', 'kernel': '%s (fc6 fwd, both branches, M=%d N=8192 K=%d)' % (
+                kname, rt, k6),
                          'achieved': round(achieved, 2) if achieved else None,
-                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                         'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / peak, 4) if achieved else None,
                          'traffic': None, 'kernel_ms': round(kern_ms, 4)},
         }
         # HBM traffic of that kernel comes from the rocprofv3 PMC passes of this same command
         # (profiles/rNN_bench_traffic.json, written by tools/summarize_profile.py)
         import glob
         tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_traffic.json')))
-        if tj and args.rois == 2000 and B == 2:
+        if tj and args.rois == 2000 and B == 2 and not bf:
             res['roofline']['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
             res['roofline']['traffic_source'] = os.path.relpath(tj[-1], ROOT)
         if world == 1 and not args.no_cpu_baseline:

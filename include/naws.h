@@ -274,6 +274,31 @@ int naws_transpose2d_f32(const float* X, int rows, int cols, float* Y, void* str
 /* Y[c] = sum_r X[r,c]  (ReduceSum axes=[0]) */
 int naws_reduce_sum_axis0(const float* X, int rows, int cols, float* Y, void* stream);
 
+/* ---- bf16 MFMA option (BASELINE.json configs[3]: "bf16 MFMA conv/fc with fp32 loss") ----------
+ * Replaces the same Caffe2 FC / FCGradient / Conv operators as naws_gemm_f32 and
+ * naws_conv3x3_nhwc_fwd (reference: detectron/modeling/wsl_heads.py:33-47 model.FC calls,
+ * detectron/modeling/VGG16.py:37-130 model.Conv calls), computing in
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 results.
+ *
+ * C[M,N] (+)= A[M,K] * B[N,K]^T ; both operands K-contiguous.  Each operand is read either as
+ * fp32 (rounded to bf16, round-to-nearest-even, inside the kernel) or as bf16 (uint16 storage).
+ * lda/ldb/strideA/strideB are in elements of the operand's own type and, like K, must be
+ * multiples of 8; A and B must be 16-byte aligned.  Epilogue arguments as naws_gemm_f32. */
+int naws_gemm_bf16_nt(int M, int N, int K, const void* A, int a_is_bf16, int lda, const void* B,
+                      int b_is_bf16, int ldb, float* C, int ldc, int batch, int64_t strideA,
+                      int64_t strideB, int64_t strideC, int epilogue, const float* bias,
+                      int64_t strideBias, const float* aux, int ldaux, float alpha,
+                      float drop_ratio, uint64_t seed, int accumulate, void* stream);
+/* 3x3 / stride 1 / pad = dilation convolution on NHWC fp32 activations with the packed weight of
+ * naws_conv3x3_pack_weight, bf16 MFMA inner product (Cin % 32 == 0). */
+int naws_conv3x3_nhwc_bf16_fwd(const float* X, const float* Wp, const float* bias, int N, int H,
+                               int W, int Cin, int Cout, int dilation, int relu, float* Y,
+                               void* stream);
+/* Y[b][c][r] = bf16(X[b][r][c]) for r < rows, 0 for rows <= r < rows_pad: the K-contiguous bf16
+ * copies the backward FC GEMMs (dX = dY W, dW = dY^T X) take as operands. */
+int naws_transpose_to_bf16(const float* X, int batch, int rows, int cols, int ld, int rows_pad,
+                           void* Y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

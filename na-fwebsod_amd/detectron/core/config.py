@@ -134,6 +134,8 @@ def _defaults():
             'ALLREDUCE_CHUNKS': 1,   # >1: cut fc6 wgrad into row chunks, each all-reduced while
                                      # the next chunk's GEMM runs (default: one launch; the
                                      # collective hides under the next iteration's conv body)
+            'MFMA_DTYPE': 'fp32',    # 'bf16': conv2..conv5 + fc6/fc7 multiply in bf16 MFMA with
+                                     # fp32 accumulation; storage, fc8, loss and SGD stay fp32
         },
     }
 

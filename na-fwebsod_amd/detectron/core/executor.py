@@ -83,7 +83,8 @@ class NetExecutor(object):
                 is_mean=cfg.WSL.MEAN_LOSS, momentum=cfg.SOLVER.MOMENTUM,
                 weight_decay=cfg.SOLVER.WEIGHT_DECAY, iter_size=cfg.WSL.ITER_SIZE,
                 gpu_num=self.world * self.ims, seed=cfg.RNG_SEED, process_group=process_group,
-                world_size=world_size, allreduce_chunks=cfg.NAWS.ALLREDUCE_CHUNKS)
+                world_size=world_size, allreduce_chunks=cfg.NAWS.ALLREDUCE_CHUNKS,
+                mfma_dtype=cfg.NAWS.MFMA_DTYPE)
         else:
             if self.ims != 1:
                 raise NotImplementedError('the op-by-op plan follows the reference: one image '

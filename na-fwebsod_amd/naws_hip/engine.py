@@ -92,11 +92,19 @@ class ParamArena(object):
 class WsddnEngine(object):
     def __init__(self, num_classes, device, dilation=2, roi_size=7, dropout=0.5, is_mean=True,
                  momentum=0.9, weight_decay=5e-4, iter_size=1, gpu_num=1, seed=11,
-                 process_group=None, world_size=1, allreduce_chunks=1, freeze_conv_body=True):
+                 process_group=None, world_size=1, allreduce_chunks=1, freeze_conv_body=True,
+                 mfma_dtype='fp32'):
         if not freeze_conv_body:
             raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
                                       '(SURVEY.md fact 2): the conv body has no backward')
+        if mfma_dtype not in ('fp32', 'bf16'):
+            raise ValueError("mfma_dtype must be 'fp32' or 'bf16'")
         L.load()
+        # 'bf16': conv2..conv5 and fc6/fc7 (forward, dgrad, wgrad) multiply in
+        # v_mfma_f32_32x32x16_bf16 with fp32 accumulation; parameters, activations, gradients,
+        # fc8, the dual softmax, the loss and the SGD update stay fp32 (BASELINE.json configs[3]:
+        # "bf16 MFMA conv/fc with fp32 loss")
+        self.mfma_dtype = mfma_dtype
         self.C = num_classes - 1
         self.device = device
         self.dilation = dilation
@@ -174,7 +182,8 @@ class WsddnEngine(object):
             name = item[0]
             w = blobs[name + '_w'].to(self.device, torch.float32).contiguous()
             b = blobs[name + '_b'].to(self.device, torch.float32).contiguous()
-            use_wino = self.winograd and w.shape[1] >= 128 and w.shape[0] >= 256
+            use_wino = (self.winograd and self.mfma_dtype == 'fp32' and w.shape[1] >= 128
+                        and w.shape[0] >= 256)
             if name == 'conv1_1':
                 packed = w
             elif use_wino:
@@ -217,7 +226,11 @@ class WsddnEngine(object):
                     x = ops.conv3x3_c3_nchw_to_nhwc(data, wp, b, True)
                 else:
                     d = dil if dil is not None else (2 if self.dilation == 2 else 1)
-                    conv = ops.conv3x3_winograd_nhwc if self.conv_wino[name] else ops.conv3x3_nhwc
+                    if self.mfma_dtype == 'bf16':
+                        conv = ops.conv3x3_nhwc_bf16
+                    else:
+                        conv = (ops.conv3x3_winograd_nhwc if self.conv_wino[name]
+                                else ops.conv3x3_nhwc)
                     x = conv(x, wp, b, d, True, out=out if name == last else None)
         return x
 
@@ -282,16 +295,25 @@ class WsddnEngine(object):
         if tev is not None:     # bench.py: HIP events around the dominant kernel, same stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        h6 = ops.gemm(roi_feat, w6[:nb * HIDDEN], False, True, epilogue=epi, bias=b6,
-                      drop_ratio=self.dropout if drop else 0.0, seed=self._seed(6))
+        bf = self.mfma_dtype == 'bf16'
+        if bf:
+            h6 = ops.gemm_bf16_nt(roi_feat, w6[:nb * HIDDEN], epilogue=epi, bias=b6,
+                                  drop_ratio=self.dropout if drop else 0.0, seed=self._seed(6))
+        else:
+            h6 = ops.gemm(roi_feat, w6[:nb * HIDDEN], False, True, epilogue=epi, bias=b6,
+                          drop_ratio=self.dropout if drop else 0.0, seed=self._seed(6))
         if tev is not None:
             e1.record()
             tev.append((e0, e1))
         h6v = h6.view(rt, nb, HIDDEN).permute(1, 0, 2)       # [nb, Rt, 4096] strided views
         h7 = torch.empty((rt, nb * HIDDEN), device=self.device, dtype=torch.float32)
         h7v = h7.view(rt, nb, HIDDEN).permute(1, 0, 2)
-        ops.gemm(h6v, w7[:nb], False, True, out=h7v, epilogue=epi, bias=b7,
-                 drop_ratio=self.dropout if drop else 0.0, seed=self._seed(7))
+        if bf:
+            ops.gemm_bf16_nt(h6v, w7[:nb], out=h7v, epilogue=epi, bias=b7,
+                             drop_ratio=self.dropout if drop else 0.0, seed=self._seed(7))
+        else:
+            ops.gemm(h6v, w7[:nb], False, True, out=h7v, epilogue=epi, bias=b7,
+                     drop_ratio=self.dropout if drop else 0.0, seed=self._seed(7))
         lg = torch.empty((rt, nb * 2 * C), device=self.device, dtype=torch.float32)
         lgv = lg.view(rt, nb, 2 * C).permute(1, 0, 2)
         ops.gemm(h7v, w8[:nb], False, True, out=lgv, epilogue=L.EPI_BIAS, bias=b8)
@@ -358,17 +380,38 @@ class WsddnEngine(object):
         dz7v = dz7.view(rt, 2, HIDDEN).permute(1, 0, 2)
         ops.gemm(dlv, w8, False, False, out=dz7v, epilogue=L.EPI_GATE_POS, aux=h7v, alpha=scale)
         # fc7
-        ops.gemm(dz7v, h6v, True, False, out=gw7)
-        ops.colsum(dz7, out=gb7)
+        bf = self.mfma_dtype == 'bf16'
         dz6 = torch.empty_like(h6)
         dz6v = dz6.view(rt, 2, HIDDEN).permute(1, 0, 2)
-        ops.gemm(dz7v, w7, False, False, out=dz6v, epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
+        if bf:
+            # the bf16 kernel takes K-contiguous operands: dW = dZ^T H needs dZ^T and H^T
+            # ([2*4096, Rt] bf16, the zero-padded Rt is the K dim), dX = dZ W needs W^T
+            rp8 = (rt + 7) // 8 * 8
+            dz7t = ops.transpose_to_bf16(dz7, rp8).view(2, HIDDEN, rp8)
+            h6t = ops.transpose_to_bf16(h6, rp8).view(2, HIDDEN, rp8)
+            ops.gemm_bf16_nt(dz7t, h6t, out=gw7)
+            del h6t
+            ops.colsum(dz7, out=gb7)
+            w7t = ops.transpose_to_bf16(w7)                    # [2, in, out]
+            ops.gemm_bf16_nt(dz7v, w7t, out=dz6v, epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
+            del w7t, dz7t
+        else:
+            ops.gemm(dz7v, h6v, True, False, out=gw7)
+            ops.colsum(dz7, out=gb7)
+            ops.gemm(dz7v, w7, False, False, out=dz6v, epilogue=L.EPI_GATE_POS, aux=h6v,
+                     alpha=scale)
         ops.colsum(dz6, out=gb6)
         # everything except fc6_w is ready: start its all-reduce, then stream fc6 wgrad chunks
         red = self.reducer
         red.reduce_async(self.arena.span(G, 'fc6_b', 'noisy_fc8d_b'))
+        if bf:
+            dz6t = ops.transpose_to_bf16(dz6, rp8)             # [8192, Rt]
+            xt = ops.transpose_to_bf16(x, rp8)                 # [25088, Rt]
         for r0, r1 in row_chunks(2 * HIDDEN, self.allreduce_chunks if red.active else 1):
-            ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
+            if bf:
+                ops.gemm_bf16_nt(dz6t[r0:r1], xt, out=gw6[r0:r1])
+            else:
+                ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
             red.reduce_async(gw6[r0:r1].reshape(-1))
 
     def wait_allreduce(self):

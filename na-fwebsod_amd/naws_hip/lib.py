@@ -54,6 +54,10 @@ PROTOTYPES = {
     'naws_softmax_rows_bwd': [p, p, i32, i32, p, p],
     'naws_transpose2d_f32': [p, i32, i32, p, p],
     'naws_reduce_sum_axis0': [p, i32, i32, p, p],
+    'naws_gemm_bf16_nt': [i32, i32, i32, p, i32, i32, p, i32, i32, p, i32, i32, i64, i64, i64,
+                          i32, p, i64, p, i32, f32, f32, u64, i32, p],
+    'naws_conv3x3_nhwc_bf16_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
+    'naws_transpose_to_bf16': [p, i32, i32, i32, i32, i32, p, p],
 }
 SPECIAL = {
     'naws_version': ([], C.c_char_p),

@@ -207,6 +207,60 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, epilogue=L.EPI_NONE, bias
     return out
 
 
+def gemm_bf16_nt(a, b, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, alpha=1.0,
+                 drop_ratio=0.0, seed=0, accumulate=False):
+    """C[M,N] (+)= A[M,K] B[N,K]^T with bf16 MFMA / fp32 accumulate.  a and b are 2-D (or batched
+    3-D) row-strided views, each fp32 (rounded in-kernel) or bf16."""
+    batched = a.dim() == 3
+    a2, b2 = (a[0], b[0]) if batched else (a, b)
+    batch = a.shape[0] if batched else 1
+    for t, nm in ((a2, 'A'), (b2, 'B')):
+        if not t.is_cuda or t.dtype not in (_f32, torch.bfloat16) or t.stride(-1) != 1:
+            raise TypeError('%s must be a HIP fp32/bf16 tensor with a contiguous last dim' % nm)
+    m, k = a2.shape
+    n, kb = b2.shape
+    if k != kb:
+        raise L.NawsError('naws_gemm_bf16_nt', L.ERR_SHAPE)
+    if out is None:
+        out = torch.empty(((batch, m, n) if batched else (m, n)), device=a.device, dtype=_f32)
+    c2 = out[0] if batched else out
+    sbias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    L.call('naws_gemm_bf16_nt', m, n, k, a.data_ptr(), int(a.dtype == torch.bfloat16),
+           a2.stride(0), b.data_ptr(), int(b.dtype == torch.bfloat16), b2.stride(0),
+           out.data_ptr(), c2.stride(0), batch, (a.stride(0) if batched else 0),
+           (b.stride(0) if batched else 0), (out.stride(0) if batched else 0), epilogue,
+           _ptr(bias), sbias, _ptr(aux), (aux.stride(-2) if aux is not None else 0),
+           float(alpha), float(drop_ratio), int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate),
+           _stream())
+    return out
+
+
+def transpose_to_bf16(x, rows_pad=None, out=None):
+    """fp32 [rows, cols] (or [b, rows, cols], batch-contiguous) -> bf16 [cols, rows_pad]."""
+    batched = x.dim() == 3
+    x2 = x[0] if batched else x
+    batch = x.shape[0] if batched else 1
+    rows, cols = x2.shape
+    if x2.stride(1) != 1 or (batched and x.stride(0) != rows * x2.stride(0)):
+        raise TypeError('x must be row-major with batch stride rows*ld')
+    rp = rows_pad if rows_pad is not None else (rows + 7) // 8 * 8
+    shape = (batch, cols, rp) if batched else (cols, rp)
+    y = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.bfloat16)
+    L.call('naws_transpose_to_bf16', x.data_ptr(), batch, rows, cols, x2.stride(0), rp,
+           y.data_ptr(), _stream())
+    return y
+
+
+def conv3x3_nhwc_bf16(x, w_packed, bias, dilation=1, relu=True, out=None):
+    _chk(x, 'x'); _chk(w_packed, 'w_packed')
+    n, h, w, cin = x.shape
+    cout = w_packed.shape[0]
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    L.call('naws_conv3x3_nhwc_bf16_fwd', x.data_ptr(), w_packed.data_ptr(), _ptr(bias), n, h, w,
+           cin, cout, dilation, int(relu), y.data_ptr(), _stream())
+    return y
+
+
 def dropout_mask(seed, ratio, n, device):
     m = torch.empty((n,), device=device, dtype=_f32)
     L.call('naws_dropout_mask', int(seed) & 0xFFFFFFFFFFFFFFFF, float(ratio), n, m.data_ptr(),

@@ -58,6 +58,45 @@ def main():
             print('%-14s M=%6d N=%6d K=%6d b=%d  %8.3f ms  %7.1f TFLOP/s (%.1f%% of 157.3)' % (
                 name, m, n, k, batch, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
             del A, B, Cc
+    if 'bf16' in what:
+        PEAK = 2500.0
+        shapes = [('fc6 fwd ', R, 8192, 25088, 1, False, False),
+                  ('fc7 fwd ', R, 4096, 4096, 2, False, False),
+                  ('fc7 dgrad', R, 4096, 4096, 2, False, True),
+                  ('fc7 wgrad', 4096, 4096, R, 2, True, True),
+                  ('fc6 wgrad', 8192, 25088, R, 1, True, True)]
+        for name, m, n, k, batch, a16, b16 in shapes:
+            bs = (batch,) if batch > 1 else ()
+            A = rnd(*bs, m, k)
+            B = rnd(*bs, n, k)
+            if a16:
+                A = A.bfloat16()
+            if b16:
+                B = B.bfloat16()
+            Cc = torch.empty((*bs, m, n), device=dev)
+            ms = timeit(lambda: ops.gemm_bf16_nt(A, B, out=Cc), a.iters)
+            fl = 2.0 * m * n * k * batch
+            by = A.numel() * A.element_size() + B.numel() * B.element_size() + Cc.numel() * 4
+            print('bf16 %-10s M=%6d N=%6d K=%6d b=%d A16=%d B16=%d %8.3f ms %7.1f TFLOP/s (%.1f%% of 2500) '
+                  '%6.0f GB/s min-traffic' % (name, m, n, k, batch, a16, b16, ms, fl / ms / 1e9,
+                                              fl / ms / 1e9 / PEAK * 100, by / ms / 1e6))
+            del A, B, Cc
+        x = rnd(2, R, 4096)
+        ms = timeit(lambda: ops.transpose_to_bf16(x, rows_pad=(R + 7) // 8 * 8), a.iters)
+        print('transpose_to_bf16 [2,%d,4096]  %8.3f ms  %6.0f GB/s' % (R, ms, x.numel() * 6 / ms / 1e6))
+        del x
+        for cin, cout, h, w, dil in [(64, 64, 600, 1000, 1), (128, 128, 300, 500, 1),
+                                     (256, 256, 150, 250, 1), (512, 512, 75, 125, 1),
+                                     (512, 512, 74, 124, 2)]:
+            x = rnd(a.images, h, w, cin)
+            wp = rnd(cout, 3, 3, cin)
+            b = rnd(cout)
+            y = torch.empty((a.images, h, w, cout), device=dev)
+            ms = timeit(lambda: ops.conv3x3_nhwc_bf16(x, wp, b, dil, True, out=y), a.iters)
+            fl = 2.0 * a.images * h * w * cout * 9 * cin
+            print('bf16 conv %3d->%3d %4dx%4d d%d  %8.3f ms  %7.1f TFLOP/s' % (
+                cin, cout, h, w, dil, ms, fl / ms / 1e9))
+            del x, wp, b, y
     if 'conv' in what:
         layers = [(64, 64, 600, 1000, 1), (64, 128, 300, 500, 1), (128, 128, 300, 500, 1),
                   (128, 256, 150, 250, 1), (256, 256, 150, 250, 1), (256, 512, 75, 125, 1),

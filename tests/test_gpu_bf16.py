@@ -1,0 +1,117 @@
+"""GPU parity for the bf16 MFMA option (BASELINE.json configs[3]).
+
+The kernels round their fp32 operands to bf16 (round-to-nearest-even) and accumulate in
+fp32, so against a float64 product of the *same rounded operands* they must agree to fp32
+accumulation error (tight test); against the unrounded fp32 oracle result they agree to
+bf16 operand precision (2^-8 per operand, random-sign error ~ 2^-8 * |a||b| / sqrt(K)).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _bf(a):
+    """fp32 ndarray -> bf16-rounded values as float64 (torch's RNE conversion on the CPU)."""
+    return torch.from_numpy(a).bfloat16().double().numpy()
+
+
+@pytest.mark.parametrize('m,n,k', [(128, 128, 32), (130, 72, 64), (517, 260, 1000), (64, 4000, 264),
+                                   (2100, 140, 96)])
+@pytest.mark.parametrize('a16,b16', [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_bf16_nt(dev, m, n, k, a16, b16):
+    from naws_hip import ops
+    rng = np.random.default_rng(21)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    ref = _bf(a) @ _bf(b).T
+    ad, bd = _t(a, dev), _t(b, dev)
+    if a16:
+        ad = ad.bfloat16()
+    if b16:
+        bd = bd.bfloat16()
+    c = ops.gemm_bf16_nt(ad, bd).cpu().numpy()
+    err = np.abs(c - ref).max() / np.abs(ref).max()
+    assert err < 5e-6, err
+    # and against the unrounded product: bf16 operand precision
+    full = a.astype(np.float64) @ b.astype(np.float64).T
+    assert np.abs(c - full).max() / np.abs(full).max() < 2e-2
+
+
+def test_gemm_bf16_identity_and_map(dev):
+    """A = I with an asymmetric B (small integers are exact in bf16) catches a wrong
+    operand lane map or a transposed C/D register map."""
+    from naws_hip import ops
+    n = 256
+    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 251)
+    c = ops.gemm_bf16_nt(_t(np.eye(n, dtype=np.float32), dev), _t(b.T.copy(), dev)).cpu().numpy()
+    assert np.array_equal(c, b)
+
+
+def test_gemm_bf16_epilogues_batched(dev):
+    from naws_hip import ops, lib
+    rng = np.random.default_rng(22)
+    m, n, k = 260, 384, 160
+    a = rng.uniform(-1, 1, (2, m, k)).astype(np.float32)
+    w = rng.uniform(-1, 1, (2, n, k)).astype(np.float32)
+    bias = rng.uniform(-1, 1, (2, n)).astype(np.float32)
+    z = np.stack([_bf(a[i]) @ _bf(w[i]).T + bias[i] for i in range(2)])
+    ad, wd, bd = _t(a, dev), _t(w, dev), _t(bias, dev)
+    y = ops.gemm_bf16_nt(ad, wd, epilogue=lib.EPI_BIAS, bias=bd).cpu().numpy()
+    np.testing.assert_allclose(y, z, rtol=1e-5, atol=1e-4)
+    y = ops.gemm_bf16_nt(ad, wd, epilogue=lib.EPI_BIAS_RELU, bias=bd).cpu().numpy()
+    np.testing.assert_allclose(y, np.maximum(z, 0), rtol=1e-5, atol=1e-4)
+    y = ops.gemm_bf16_nt(ad, wd, epilogue=lib.EPI_BIAS_RELU_DROP, bias=bd, drop_ratio=0.5,
+                         seed=77).cpu().numpy()
+    mask = ops.dropout_mask(77, 0.5, 2 * m * n, dev).reshape(2, m, n).cpu().numpy()
+    np.testing.assert_allclose(y, np.maximum(z, 0) * mask * 2.0, rtol=1e-5, atol=2e-4)
+    aux = rng.standard_normal((2, m, n)).astype(np.float32)
+    g = ops.gemm_bf16_nt(ad, wd, epilogue=lib.EPI_GATE_POS, aux=_t(aux, dev), alpha=2.0)
+    zz = np.stack([_bf(a[i]) @ _bf(w[i]).T for i in range(2)])
+    np.testing.assert_allclose(g.cpu().numpy(), np.where(aux > 0, zz * 2.0, 0.0), rtol=1e-5,
+                               atol=2e-4)
+    c0 = rng.standard_normal((2, m, n)).astype(np.float32)
+    cd = _t(c0, dev)
+    ops.gemm_bf16_nt(ad, wd, out=cd, accumulate=True)
+    np.testing.assert_allclose(cd.cpu().numpy(), c0 + zz, rtol=1e-5, atol=2e-4)
+    with pytest.raises(lib.NawsError):      # K not a multiple of 8
+        ops.gemm_bf16_nt(torch.zeros((8, 12), device=dev), torch.zeros((8, 12), device=dev))
+
+
+def test_transpose_to_bf16(dev):
+    from naws_hip import ops
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((2, 101, 70)).astype(np.float32)
+    y = ops.transpose_to_bf16(_t(x, dev), rows_pad=104)
+    assert y.shape == (2, 70, 104) and y.dtype == torch.bfloat16
+    ref = torch.from_numpy(x).bfloat16().transpose(1, 2)
+    assert torch.equal(y[:, :, :101].cpu(), ref)
+    assert (y[:, :, 101:] == 0).all()
+    # strided (column-slice) source
+    xs = _t(x, dev)[0][:, 8:40]
+    ys = ops.transpose_to_bf16(xs)
+    assert torch.equal(ys[:, :101].cpu(), torch.from_numpy(x[0][:, 8:40]).bfloat16().t())
+
+
+@pytest.mark.parametrize('cin,cout,dil,h,w', [(64, 64, 1, 37, 53), (128, 256, 1, 19, 23),
+                                              (512, 512, 2, 20, 31)])
+def test_conv3x3_bf16(dev, cin, cout, dil, h, w):
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(24)
+    n = 2
+    x = rng.uniform(-1, 1, (n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).bfloat16().double(),
+                          torch.from_numpy(wt).bfloat16().double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    wp = ops.conv3x3_pack_weight(_t(wt, dev))
+    y = ops.nhwc_to_nchw(ops.conv3x3_nhwc_bf16(xd, wp, _t(b, dev), dil, True)).cpu().numpy()
+    assert np.abs(y - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
