@@ -299,6 +299,28 @@ int naws_conv3x3_nhwc_bf16_fwd(const float* X, const float* Wp, const float* bia
 int naws_transpose_to_bf16(const float* X, int batch, int rows, int cols, int ld, int rows_pad,
                            void* Y, void* stream);
 
+/* ---- fp32 GEMM on the bf16 matrix cores ("3 x bf16" split, fp32-accurate) ----------------------
+ * Same operators as naws_gemm_f32 (Caffe2 FC / FCGradient of fc6 / fc7; reference
+ * detectron/modeling/wsl_heads.py:674-679, webly_heads.py:490-498).  An fp32 value is exactly
+ * a1 + a2 + a3 with three bf16 values; the GEMM keeps the six products a_p*b_q with p+q <= 4
+ * (dropped terms < 2^-26 |ab|) and accumulates them in fp32 inside v_mfma_f32_32x32x16_bf16.
+ *
+ * naws_split_bf16x3: X fp32 [batch][rows][ld] -> P bf16 [3][batch][kpad/16][outer][16]
+ * ("K-slab-major": the 16-deep K-step of any run of rows is contiguous), where
+ *   transpose == 0: outer = rows, K = cols;   transpose != 0: outer = cols, K = rows
+ * (the K-contiguous operand of dW = dY^T X).  kpad = K rounded up to 16, the pad is zero-filled.
+ * X == P[0] + P[1] + P[2] exactly for |x| >= 2^-109 (below, residues are denormal and flushed).
+ * naws_gemm_f32x3_nt: C[M,N] (+)= A[M,K] B[N,K]^T on such planes; slabA/slabB = elements
+ * between K slabs (outer * 16; A3/B3 may point at a row offset inside a larger operand),
+ * planeA/planeB = elements between planes, K % 16 == 0.  Epilogue arguments as naws_gemm_f32. */
+int naws_split_bf16x3(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
+                      int transpose, int kpad, void* P, void* stream);
+int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t slabA, int64_t planeA,
+                       const void* B3, int64_t slabB, int64_t planeB, float* C, int ldc, int batch,
+                       int64_t strideA, int64_t strideB, int64_t strideC, int epilogue,
+                       const float* bias, int64_t strideBias, const float* aux, int ldaux,
+                       float alpha, float drop_ratio, uint64_t seed, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

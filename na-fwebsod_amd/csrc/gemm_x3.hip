@@ -1,0 +1,363 @@
+// fp32 GEMM on the bf16 matrix cores: the "3 x bf16" split.
+//
+// gfx950 has no fast fp32 MFMA path (v_mfma_f32_32x32x2_f32: 157 TFLOP/s) but a 16x faster
+// bf16 one (v_mfma_f32_32x32x16_bf16: 2.5 PFLOP/s, fp32 accumulate).  An fp32 number is EXACTLY
+// the sum of three bf16 numbers (8 + 8 + 8 significand bits, round-to-nearest residues):
+//      a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
+// so  a*b = sum_{p,q} a_p b_q  and keeping the six terms with p + q <= 4
+//      a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1)
+// drops only terms below 2^-26 |ab| - a quarter of an fp32 ulp of the product, less than the
+// rounding an fp32 FMA chain commits anyway.  Each bf16 x bf16 product is exact (16-bit
+// significand) and is accumulated in fp32 by the MFMA, exactly like the fp32 MFMA accumulates.
+// Six bf16 MFMA passes cost 6/16 of one fp32 MFMA pass: an fp32-accurate GEMM at up to 2.67x the
+// fp32 MFMA peak.  tests/test_gpu_x3.py pins the claim: against a float64 product the error of
+// this kernel is not larger than that of the fp32-MFMA kernel (gemm_f32.hip) on the same data.
+//
+// Operands arrive pre-split ("planes": P[3][rows][K] bf16, K-contiguous, K % 16 == 0, made by
+// naws_split_bf16x3, which also transposes for the dW = dY^T X form).  With 48 MFMAs (1536
+// cycles) per wave per 16-deep K-step the staging pipeline can be the simplest correct one:
+// LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) of K-step t+1 into the other LDS stage
+// while step t multiplies, one barrier per step; two 4-wave workgroups per CU (72 KB LDS each)
+// drift against each other and keep the MFMA pipe fed.
+//
+// replaces: Caffe2 FC / FCGradient for fc6 / fc7 (reference detectron/modeling/wsl_heads.py:
+// 674-679, webly_heads.py:490-498), same as gemm_f32.hip.
+#include <stdlib.h>
+#include "naws_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct XArgs {
+  const unsigned short* A;   // planes [3][K/16][rowsA][16]
+  const unsigned short* B;   // planes [3][K/16][rowsB][16]
+  float* C;
+  int M, N, K;
+  int ldc;
+  long long planeA, planeB;  // elements between planes
+  long long slabA, slabB;    // elements between 16-deep K slabs (= rows * 16)
+  long long sA, sB, sC, sBias;
+  const float* bias;
+  const float* aux;
+  int ldaux;
+  float alpha;
+  unsigned drop_thr;
+  float drop_scale;
+  unsigned long long seed;
+  int epilogue, accumulate;
+  int tiles_m, tiles_n;
+};
+
+#define NAWS_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define NAWS_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Operand planes are stored K-slab-major, P[plane][k/16][row][k%16]: the 16-deep K-step of a
+// BM-row tile is ONE contiguous BM*32-byte run per plane, so every LDS-DMA wave-instruction
+// reads 1 KB of consecutive HBM bytes.  LDS image of a plane-stage: [row][2 slots of 16 B]; the
+// slot of k-half h of row r is h ^ ((r >> 3) & 1), which spreads the 16 lanes of a ds_read_b128
+// group over all 64 banks.  The DMA writes lane-linearly, so the swizzle is applied to the
+// global source address (it only permutes 16-byte halves inside one 32-byte row record).
+//
+// Pipeline: ring of STAGES LDS stages, DMA runs STAGES-1 K-steps ahead.  Per step: counted
+// s_waitcnt vmcnt (retires this wave's pieces of step t, leaves the younger steps in flight),
+// one raw s_barrier (everybody's pieces landed; everybody is done reading the stage about to be
+// refilled), issue step t+STAGES-1, then 6 x TI x TJ MFMAs on step t.
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_kernel(XArgs g) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TI = WTM / 32, TJ = WTN / 32;
+  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;       // bytes per plane per stage
+  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  constexpr int PIECE_ROWS = NT / 2;                        // rows one DMA round covers
+  constexpr int PA = BM / PIECE_ROWS, PB = BN / PIECE_ROWS;
+  constexpr int G = 3 * (PA + PB);                          // DMA instructions per thread per step
+  static_assert(BM % PIECE_ROWS == 0 && BN % PIECE_ROWS == 0, "tile vs workgroup");
+  static_assert((STAGES - 2) * G <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int lid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, rem = ntiles & 7, xcd = lid & 7, within = lid >> 3;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * g.tiles_n;
+  const int grp = lid / per_group;
+  const int first_m = grp * GM;
+  const int gsz = min(g.tiles_m - first_m, GM);
+  const int tm = first_m + (lid % per_group) % gsz;
+  const int tn = (lid % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const long long bz = blockIdx.z;
+  const unsigned short* A = g.A + bz * g.sA;
+  const unsigned short* B = g.B + bz * g.sB;
+  float* C = g.C + bz * g.sC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // DMA sources: thread -> (row = piece*PIECE_ROWS + tid/2, physical slot = tid&1); rows past
+  // the edge re-read the last row (their products land in accumulator rows never stored)
+  const int lrow = tid >> 1;
+  const int kslot = ((tid & 1) ^ ((lrow >> 3) & 1)) * 8;
+  const unsigned short* srcA[PA];
+  const unsigned short* srcB[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p)
+    srcA[p] = A + (long long)min(m0 + p * PIECE_ROWS + lrow, g.M - 1) * 16 + kslot;
+#pragma unroll
+  for (int p = 0; p < PB; ++p)
+    srcB[p] = B + (long long)min(n0 + p * PIECE_ROWS + lrow, g.N - 1) * 16 + kslot;
+
+  auto issue = [&](int t, int st) {
+    unsigned char* base = smx + st * STAGE + wid * 1024;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int p = 0; p < PA; ++p)
+        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcA[p] + pl * g.planeA + t * g.slabA),
+                                         NAWS_LDS_PTR(base + pl * A_PLANE + p * (NT * 16)), 16, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PB; ++p)
+        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcB[p] + pl * g.planeB + t * g.slabB),
+                                         NAWS_LDS_PTR(base + 3 * A_PLANE + pl * B_PLANE + p * (NT * 16)),
+                                         16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int rd_a = (wm * WTM + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+  const int rd_b = 3 * A_PLANE + (wn * WTN + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+
+  const int T = g.K / 16;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < T) issue(s, s);
+  int st_cur = 0, st_fill = STAGES - 1;
+  for (int t = 0; t < T; ++t) {
+    if (t + STAGES - 2 < T) wait_vmcnt<(STAGES - 2) * G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + STAGES - 1 < T) issue(t + STAGES - 1, st_fill);
+    const unsigned char* st = smx + st_cur * STAGE;
+    bf16x8 a[3][TI], b[3][TJ];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        a[pl][i] = *reinterpret_cast<const bf16x8*>(st + rd_a + pl * A_PLANE + i * 1024);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        b[pl][j] = *reinterpret_cast<const bf16x8*>(st + rd_b + pl * B_PLANE + j * 1024);
+    }
+    // consecutive MFMAs go to different accumulators
+#define NAWS_X3_TERM(P, Q)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][i], b[Q][j], acc[i][j], 0, 0, 0);
+    NAWS_X3_TERM(0, 0)
+    NAWS_X3_TERM(0, 1)
+    NAWS_X3_TERM(1, 0)
+    NAWS_X3_TERM(1, 1)
+    NAWS_X3_TERM(0, 2)
+    NAWS_X3_TERM(2, 0)
+#undef NAWS_X3_TERM
+    st_cur = (st_cur + 1 == STAGES) ? 0 : st_cur + 1;
+    st_fill = (st_fill + 1 == STAGES) ? 0 : st_fill + 1;
+  }
+
+  const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
+  const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
+  const int epi = g.epilogue;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+    if (col >= g.N) continue;
+    const float bv = (bias && epi >= NAWS_EPI_BIAS && epi <= NAWS_EPI_BIAS_RELU_DROP) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        float v = acc[i][j][e] + bv;
+        if (epi == NAWS_EPI_BIAS_RELU || epi == NAWS_EPI_BIAS_RELU_DROP) v = fmaxf(v, 0.f);
+        if (epi == NAWS_EPI_BIAS_RELU_DROP) {
+          const unsigned long long idx =
+              (unsigned long long)bz * g.M * g.N + (unsigned long long)row * g.N + col;
+          v = naws_keep(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+        } else if (epi == NAWS_EPI_GATE_POS) {
+          v = (aux[row * g.ldaux + col] > 0.f) ? v * g.alpha : 0.f;
+        }
+        const int idx = row * g.ldc + col;      // < 2^31, checked on the host
+        if (g.accumulate) v += C[idx];
+        C[idx] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+int launch_x3(XArgs& g, int batch, hipStream_t s) {
+  g.tiles_m = (int)naws_cdiv(g.M, BM);
+  g.tiles_n = (int)naws_cdiv(g.N, BN);
+  const size_t lds = (size_t)STAGES * 3 * (BM + BN) * 32;
+  auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
+  return naws_check_launch();
+}
+
+__device__ __forceinline__ void split3(float a, unsigned short& p1, unsigned short& p2,
+                                       unsigned short& p3) {
+  const __bf16 h1 = (__bf16)a;
+  float r = a - (float)h1;
+  if (!(fabsf(a) <= 3.4028234e38f)) r = 0.f;        // inf / NaN live in plane 1 only
+  const __bf16 h2 = (__bf16)r;
+  const __bf16 h3 = (__bf16)(r - (float)h2);
+  p1 = *reinterpret_cast<const unsigned short*>(&h1);
+  p2 = *reinterpret_cast<const unsigned short*>(&h2);
+  p3 = *reinterpret_cast<const unsigned short*>(&h3);
+}
+
+// X fp32 [rows][ld] -> P[3][slabs][outer][16] through 64 x 64 LDS tiles.
+//   TRANS == false: outer = rows, K = cols;  TRANS == true: outer = cols, K = rows.
+// Each workgroup writes, per plane, 4 runs of 64 * 32 contiguous bytes.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X, int rows, int cols,
+                                                     int ld, int outer, int slabs, long long sx,
+                                                     long long plane, long long sp,
+                                                     unsigned short* __restrict__ P) {
+  __shared__ float tile[64][65];
+  const float* Xb = X + blockIdx.z * sx;
+  unsigned short* Pb = P + blockIdx.z * sp;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + i * 4 + tr, c = c0 + tc;
+    tile[i * 4 + tr][tc] = (r < rows && c < cols) ? Xb[(long long)r * ld + c] : 0.f;
+  }
+  __syncthreads();
+  const int o0 = TRANS ? c0 : r0;          // first outer index of this tile
+  const int k0 = TRANS ? r0 : c0;          // first K index (multiple of 64)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int u = threadIdx.x + it * 256;  // (slab s, outer o, half hh), hh fastest
+    const int hh = u & 1, o = (u >> 1) & 63, s = u >> 7;
+    if (o0 + o >= outer || k0 / 16 + s >= slabs) continue;
+    unsigned short q[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = s * 16 + hh * 8 + e;
+      split3(TRANS ? tile[kk][o] : tile[o][kk], q[0][e], q[1][e], q[2][e]);
+    }
+    const long long dst = ((long long)(k0 / 16 + s) * outer + (o0 + o)) * 16 + hh * 8;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      u32x4 w;
+      w.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+      w.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+      w.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+      w.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+      *reinterpret_cast<u32x4*>(Pb + pl * plane + dst) = w;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int naws_split_bf16x3(const float* X, int batch, int rows, int cols, int ld,
+                                 int64_t strideX, int transpose, int kpad, void* P, void* stream) {
+  if (batch <= 0 || rows <= 0 || cols <= 0 || ld < cols) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(P);
+  const int kdim = transpose ? rows : cols;
+  if (kpad != (kdim + 15) / 16 * 16) return NAWS_ERR_ARG;
+  if (((uintptr_t)P & 15) != 0) return NAWS_ERR_ARG;
+  const int outer = transpose ? cols : rows;
+  const long long sp = (long long)kpad * outer;              // one batch item of one plane
+  const long long plane = (long long)batch * sp;             // P[3][batch][kpad/16][outer][16]
+  const long long gy = naws_cdiv(transpose ? kpad : rows, 64);
+  if (batch > 65535 || gy > 65535) return NAWS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (!transpose) {
+    dim3 grid((unsigned)naws_cdiv(kpad, 64), (unsigned)gy, batch);
+    hipLaunchKernelGGL(split3_kernel<false>, grid, dim3(256), 0, s, X, rows, cols, ld, outer,
+                       kpad / 16, (long long)strideX, plane, sp, (unsigned short*)P);
+  } else {
+    dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, batch);
+    hipLaunchKernelGGL(split3_kernel<true>, grid, dim3(256), 0, s, X, rows, cols, ld, outer,
+                       kpad / 16, (long long)strideX, plane, sp, (unsigned short*)P);
+  }
+  return naws_check_launch();
+}
+
+static int g_x3_variant = -1;
+
+extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t slabA,
+                                  int64_t planeA, const void* B3, int64_t slabB, int64_t planeB,
+                                  float* C, int ldc, int batch, int64_t strideA, int64_t strideB,
+                                  int64_t strideC, int epilogue, const float* bias,
+                                  int64_t strideBias, const float* aux, int ldaux, float alpha,
+                                  float drop_ratio, uint64_t seed, int accumulate, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(A3); NAWS_REQUIRE_PTR(B3); NAWS_REQUIRE_PTR(C);
+  if (epilogue < NAWS_EPI_NONE || epilogue > NAWS_EPI_GATE_POS) return NAWS_ERR_ARG;
+  if (epilogue == NAWS_EPI_GATE_POS && aux == nullptr) return NAWS_ERR_NULL;
+  if (epilogue == NAWS_EPI_BIAS_RELU_DROP && !(drop_ratio >= 0.f && drop_ratio < 1.f)) return NAWS_ERR_ARG;
+  if (slabA < (int64_t)M * 16 || slabB < (int64_t)N * 16 || ldc < N) return NAWS_ERR_SHAPE;
+  if (K % 16 != 0 || slabA % 8 != 0 || slabB % 8 != 0 || planeA % 8 != 0 || planeB % 8 != 0 ||
+      strideA % 8 != 0 || strideB % 8 != 0)
+    return NAWS_ERR_ARG;
+  if ((((uintptr_t)A3 | (uintptr_t)B3) & 15) != 0) return NAWS_ERR_ARG;
+  if (batch > 65535) return NAWS_ERR_UNSUPPORTED;
+  if ((long long)(M - 1) * ldc + N > 0x7fffffffLL ||
+      (aux && (long long)(M - 1) * ldaux + N > 0x7fffffffLL))
+    return NAWS_ERR_UNSUPPORTED;
+  XArgs g{};
+  g.A = (const unsigned short*)A3; g.B = (const unsigned short*)B3; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+  g.planeA = planeA; g.planeB = planeB; g.slabA = slabA; g.slabB = slabB;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sBias = strideBias;
+  g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.alpha = alpha;
+  g.drop_thr = naws_drop_threshold(drop_ratio);
+  g.drop_scale = (float)(1.0 / (1.0 - (double)drop_ratio));
+  g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
+  hipStream_t s = (hipStream_t)stream;
+  if (g_x3_variant < 0) {
+    const char* e = getenv("NAWS_X3_VARIANT");
+    g_x3_variant = e ? atoi(e) : 0;
+  }
+  if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2>(g, batch, s);
+  switch (g_x3_variant) {
+    case 1: return launch_x3<256, 128, 2, 2, 2>(g, batch, s);
+    case 2: return launch_x3<256, 256, 2, 4, 2>(g, batch, s);
+    case 3: return launch_x3<256, 128, 2, 2, 3>(g, batch, s);
+    default: return launch_x3<256, 256, 2, 4, 3>(g, batch, s);
+  }
+}

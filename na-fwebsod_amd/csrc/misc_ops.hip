@@ -81,6 +81,82 @@ __global__ __launch_bounds__(TB) void conv_c3_kernel(const float* __restrict__ X
   }
 }
 
+
+// ---- conv1_1, Cout = 64: LDS-tiled sliding-window kernel ------------------------------------
+// 3 input channels give the MFMA nothing to contract over (K = 27), so this layer runs on the
+// vector ALU, whose floor (1.04 G lane-FMA per 600x1000 image) is ~26 us and equals the time to
+// write the 154 MB NHWC result.  A workgroup owns an 8-row x 64-column pixel tile: the 3x10x66
+// input halo is staged in LDS once (zero-filled outside the image, so the inner loop is
+// branch-free).  Sixteen adjacent lanes own one pixel: lane q keeps the 27x4 weights of output
+// channels 4q..4q+3 in registers for the whole tile and the group stores 256 contiguous bytes
+// per pixel.  Each 16-lane group walks a 32-pixel strip of one row, keeping the 3x3x3 input
+// window in registers and reading only the 9 new values per step (LDS broadcast reads).
+constexpr int C3_TW = 64, C3_TH = 8, C3_STRIP = 32, C3_LD = C3_TW + 4;  // row stride 68 floats
+__global__ __launch_bounds__(256) void conv_c3_tile_kernel(const float* __restrict__ X,
+                                                           const float* __restrict__ Wt,
+                                                           const float* __restrict__ bias, int H,
+                                                           int W, int relu, float* __restrict__ Y) {
+  __shared__ float tile[3][C3_TH + 2][C3_LD];
+  __shared__ __attribute__((aligned(16))) float wl[27][64];
+  const int x0 = blockIdx.x * C3_TW, y0 = blockIdx.y * C3_TH, n = blockIdx.z;
+  const float* Xn = X + (int64_t)n * 3 * H * W;
+  for (int i = threadIdx.x; i < 3 * (C3_TH + 2) * (C3_TW + 2); i += 256) {
+    const int col = i % (C3_TW + 2);
+    const int r = (i / (C3_TW + 2)) % (C3_TH + 2);
+    const int c = i / ((C3_TW + 2) * (C3_TH + 2));
+    const int yy = y0 + r - 1, xx = x0 + col - 1;
+    const bool ok = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+    const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+    const float v = Xn[((int64_t)c * H + yc) * W + xc];
+    tile[c][r][col] = ok ? v : 0.f;
+  }
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) wl[i % 27][i / 27] = Wt[i];  // OIHW -> [k][o]
+  __syncthreads();
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int row = grp & 7, strip = grp >> 3;
+  float w[27][4];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float4 t = *reinterpret_cast<const float4*>(&wl[k][4 * q]);
+    w[k][0] = t.x; w[k][1] = t.y; w[k][2] = t.z; w[k][3] = t.w;
+  }
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * q);
+  const int y = y0 + row;
+  const int cx = strip * C3_STRIP;                 // tile column of this strip's first window
+  float win[3][3][3];                              // [c][kh][slot], slot = tile column mod 3
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      win[c][kh][0] = tile[c][row + kh][cx];
+      win[c][kh][1] = tile[c][row + kh][cx + 1];
+    }
+  float* yrow = Y + (((int64_t)n * H + y) * W + x0 + cx) * 64 + 4 * q;
+#pragma unroll
+  for (int i = 0; i < C3_STRIP; ++i) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) win[c][kh][(i + 2) % 3] = tile[c][row + kh][cx + i + 2];
+    float a0 = bv.x, a1 = bv.y, a2 = bv.z, a3 = bv.w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float v = win[c][kh][(i + kw) % 3];
+          const int k = (c * 3 + kh) * 3 + kw;
+          a0 = fmaf(v, w[k][0], a0); a1 = fmaf(v, w[k][1], a1);
+          a2 = fmaf(v, w[k][2], a2); a3 = fmaf(v, w[k][3], a3);
+        }
+    if (relu) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); a2 = fmaxf(a2, 0.f); a3 = fmaxf(a3, 0.f); }
+    if (y < H && x0 + cx + i < W)
+      *reinterpret_cast<float4*>(yrow + (int64_t)i * 64) = make_float4(a0, a1, a2, a3);
+  }
+}
+
 // ---- weight repack OIHW -> [O][kh][kw][I] ----------------------------------
 __global__ void pack_weight_kernel(const float* __restrict__ Wi, int Cout, int Cin,
                                    float* __restrict__ Wo) {
@@ -291,6 +367,12 @@ extern "C" int naws_conv3x3_c3_nchw_to_nhwc_fwd(const float* X, const float* Wt,
   if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
   if (Cout % 16 != 0 || ((uintptr_t)Y % 16) != 0) return NAWS_ERR_ARG;
   NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(Wt); NAWS_REQUIRE_PTR(Y);
+  if (Cout == 64 && N <= 65535 && naws_cdiv(H, C3_TH) <= 65535) {
+    dim3 grid((unsigned)naws_cdiv(W, C3_TW), (unsigned)naws_cdiv(H, C3_TH), (unsigned)N);
+    hipLaunchKernelGGL(conv_c3_tile_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, Wt, bias,
+                       H, W, relu, Y);
+    return naws_check_launch();
+  }
   const size_t lds = (size_t)(27 + 1) * Cout * sizeof(float);
   const int64_t total = (int64_t)N * H * W * (Cout / 16);
   hipLaunchKernelGGL(conv_c3_kernel<16>, dim3(grid_for(total, TB, 256 * 16)), dim3(TB), lds,

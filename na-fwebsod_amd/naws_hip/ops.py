@@ -261,6 +261,60 @@ def conv3x3_nhwc_bf16(x, w_packed, bias, dilation=1, relu=True, out=None):
     return y
 
 
+def split_bf16x3(x, transpose=False, out=None):
+    """fp32 [rows, cols] or [b, rows, cols] (last dim contiguous) -> bf16 planes
+    [3, (b,) K/16, outer, 16] ("K-slab-major"): outer/K = rows/cols, or cols/rows when
+    `transpose`; K is rounded up to 16 (zero-filled).  x == P[0] + P[1] + P[2] exactly."""
+    batched = x.dim() == 3
+    x2 = x[0] if batched else x
+    if not x.is_cuda or x.dtype != _f32 or x2.stride(1) != 1:
+        raise TypeError('x must be a HIP fp32 tensor with a contiguous last dim')
+    batch = x.shape[0] if batched else 1
+    rows, cols = x2.shape
+    outer, k = (cols, rows) if transpose else (rows, cols)
+    kpad = (k + 15) // 16 * 16
+    shape = (3, batch, kpad // 16, outer, 16) if batched else (3, kpad // 16, outer, 16)
+    p = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.bfloat16)
+    L.call('naws_split_bf16x3', x.data_ptr(), batch, rows, cols, x2.stride(0),
+           (x.stride(0) if batched else 0), int(transpose), kpad, p.data_ptr(), _stream())
+    return p
+
+
+def planes_to_dense(p):
+    """[3, (b,) K/16, outer, 16] planes -> float64 [(b,) outer, K] (test / debug helper)."""
+    s = p[0].double() + p[1].double() + p[2].double()
+    s = s.transpose(-3, -2)
+    return s.reshape(*s.shape[:-2], -1)
+
+
+def gemm_f32x3_nt(a3, b3, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, alpha=1.0,
+                  drop_ratio=0.0, seed=0, accumulate=False):
+    """C[M,N] (+)= A B^T from split planes a3 [3,(b,)K/16,M,16], b3 [3,(b,)K/16,N,16]
+    (split_bf16x3); fp32-accurate, runs on the bf16 MFMA.  Row-sliced plane views
+    (a3[..., r0:r1, :]) are fine."""
+    batched = a3.dim() == 5
+    for t in (a3, b3):
+        if (not t.is_cuda or t.dtype != torch.bfloat16 or t.shape[0] != 3 or t.shape[-1] != 16
+                or t.stride(-1) != 1 or t.stride(-2) != 16):
+            raise TypeError('operands must be bf16 split planes [3, ..., K/16, rows, 16]')
+    batch = a3.shape[1] if batched else 1
+    mm, k = a3.shape[-2], a3.shape[-3] * 16
+    nn, kb = b3.shape[-2], b3.shape[-3] * 16
+    if k != kb:
+        raise L.NawsError('naws_gemm_f32x3_nt', L.ERR_SHAPE)
+    if out is None:
+        out = torch.empty(((batch, mm, nn) if batched else (mm, nn)), device=a3.device, dtype=_f32)
+    c2 = out[0] if batched else out
+    sbias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    L.call('naws_gemm_f32x3_nt', mm, nn, k, a3.data_ptr(), a3.stride(-3), a3.stride(0),
+           b3.data_ptr(), b3.stride(-3), b3.stride(0), out.data_ptr(), c2.stride(0), batch,
+           (a3.stride(1) if batched else 0), (b3.stride(1) if batched else 0),
+           (out.stride(0) if batched else 0), epilogue, _ptr(bias), sbias, _ptr(aux),
+           (aux.stride(-2) if aux is not None else 0), float(alpha), float(drop_ratio),
+           int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate), _stream())
+    return out
+
+
 def dropout_mask(seed, ratio, n, device):
     m = torch.empty((n,), device=device, dtype=_f32)
     L.call('naws_dropout_mask', int(seed) & 0xFFFFFFFFFFFFFFFF, float(ratio), n, m.data_ptr(),

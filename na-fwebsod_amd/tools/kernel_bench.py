@@ -58,6 +58,32 @@ def main():
             print('%-14s M=%6d N=%6d K=%6d b=%d  %8.3f ms  %7.1f TFLOP/s (%.1f%% of 157.3)' % (
                 name, m, n, k, batch, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
             del A, B, Cc
+    if 'x3' in what:
+        shapes = [('fc6 fwd ', R, 8192, 25088, 1), ('fc7 fwd ', R, 4096, 4096, 2),
+                  ('fc7 wgrad', 4096, 4096, (R + 15) // 16 * 16, 2),
+                  ('fc6 wgrad', 8192, 25088, (R + 15) // 16 * 16, 1)]
+        for name, m, n, k, batch in shapes:
+            bs = (batch,) if batch > 1 else ()
+            A3 = torch.empty((3, *bs, k // 16, m, 16), device=dev).uniform_(-1, 1).bfloat16()
+            B3 = torch.empty((3, *bs, k // 16, n, 16), device=dev).uniform_(-1, 1).bfloat16()
+            Cc = torch.empty((*bs, m, n), device=dev)
+            ms = timeit(lambda: ops.gemm_f32x3_nt(A3, B3, out=Cc), a.iters)
+            fl = 2.0 * m * n * k * batch
+            print('x3 %-10s M=%6d N=%6d K=%6d b=%d %8.3f ms %7.1f TFLOP/s fp32-equivalent '
+                  '(%.1f%% of 416.7 = 2500/6; bf16 MFMA %.0f TFLOP/s)' % (
+                      name, m, n, k, batch, ms, fl / ms / 1e9, fl / ms / 1e9 / 416.7 * 100,
+                      6 * fl / ms / 1e9))
+            del A3, B3, Cc
+        x = rnd(R, 25088)
+        ms = timeit(lambda: ops.split_bf16x3(x), a.iters)
+        print('split_bf16x3      [%d,25088]  %8.3f ms  %6.0f GB/s' % (R, ms, x.numel() * 10 / ms / 1e6))
+        ms = timeit(lambda: ops.split_bf16x3(x, transpose=True), a.iters)
+        print('split_bf16x3 (T)  [%d,25088]  %8.3f ms  %6.0f GB/s' % (R, ms, x.numel() * 10 / ms / 1e6))
+        del x
+        w = rnd(8192, 25088)
+        ms = timeit(lambda: ops.split_bf16x3(w), a.iters)
+        print('split_bf16x3   [8192,25088]  %8.3f ms  %6.0f GB/s' % (ms, w.numel() * 10 / ms / 1e6))
+        del w
     if 'bf16' in what:
         PEAK = 2500.0
         shapes = [('fc6 fwd ', R, 8192, 25088, 1, False, False),

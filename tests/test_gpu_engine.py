@@ -90,7 +90,7 @@ def test_engine_matches_oracle(dev, dropout, c):
 def test_engine_bf16_mode(dev, c):
     """BASELINE configs[3]: bf16 MFMA conv/fc with fp32 storage and loss.  Operands are rounded
     to 8 significant bits, so conv5_3 / logits / gradients agree with the fp32 oracle to a few
-    1e-3 .. 1e-2 (norm-wise), the dropout-free loss to 2e-2, gradients to 15% / cosine 0.99
+    1e-3 .. 1e-2 (norm-wise), the dropout-free loss to 5e-2, gradients to 15% / cosine 0.99
     (the tight check of the bf16 kernels themselves is tests/test_gpu_bf16.py: 5e-6 against a
     float64 product of the same rounded operands)."""
     from oracle import oracle
@@ -102,9 +102,9 @@ def test_engine_bf16_mode(dev, c):
     assert np.linalg.norm(conv5 - ref['conv5_3']) <= 1e-2 * np.linalg.norm(ref['conv5_3'])
     for i in range(2):
         tl = ref['tails'][i]
-        assert abs(float(out['loss_cls'][i]) - tl['loss_cls']) <= 2e-2 * abs(tl['loss_cls'])
-        assert abs(float(out['loss_cls_noise'][i]) - tl['loss_cls_noise']) <= \
-            2e-2 * abs(tl['loss_cls_noise'])
+        for k in ('loss_cls', 'loss_cls_noise'):
+            got, want = float(out[k][i]), float(tl[k])
+            assert abs(got - want) <= 5e-2 * abs(want), (k, i, got, want)
     for name, g in ref['grads'].items():
         if name.endswith('fc8d_b'):
             continue          # identically zero in exact arithmetic (see the fp32 test)

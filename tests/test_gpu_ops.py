@@ -363,6 +363,13 @@ def test_conv1_1_and_pool(dev):
                           torch.from_numpy(b).double(), padding=1))
     y = ops.conv3x3_c3_nchw_to_nhwc(_t(x, dev), _t(wt, dev), _t(b, dev), True)
     _close(ops.nhwc_to_nchw(y), ref.numpy(), rtol=1e-5, atol=1e-3)
+    # no bias / no ReLU, a tile-aligned shape, and the generic (Cout != 64) kernel
+    x2 = rng.uniform(-1, 1, (1, 3, 16, 128)).astype(np.float32)
+    for cout in (64, 32):
+        w2 = (rng.standard_normal((cout, 3, 3, 3)) * 0.1).astype(np.float32)
+        r2 = F.conv2d(torch.from_numpy(x2).double(), torch.from_numpy(w2).double(), None, padding=1)
+        y2 = ops.conv3x3_c3_nchw_to_nhwc(_t(x2, dev), _t(w2, dev), None, False)
+        _close(ops.nhwc_to_nchw(y2), r2.numpy(), rtol=1e-5, atol=1e-5)
     for stride in (2, 1):
         pr = F.max_pool2d(ref, 2, stride, 0, ceil_mode=False).float().numpy()
         yp = ops.nhwc_to_nchw(ops.maxpool2x2_nhwc(y, stride))
