@@ -40,9 +40,12 @@ def parse():
                     help='initialise RCCL and run the all-reduce schedule even with one rank '
                          '(exercises the N>1 code path on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mfma-dtype', default='fp32', choices=['fp32', 'bf16'],
-                    help="fp32 = BASELINE configs[1]/[2] (the headline metric); bf16 = the "
-                         "configs[3] option (bf16 MFMA conv/fc, fp32 storage + loss)")
+    ap.add_argument('--mfma-dtype', default='fp32x3', choices=['fp32x3', 'fp32', 'bf16'],
+                    help="fp32x3 (default) and fp32 are both fp32 arithmetic (BASELINE configs[1]/[2]): "
+                         "fp32 = v_mfma_f32_32x32x2_f32 everywhere; fp32x3 = fc6/fc7 GEMMs as exact "
+                         "3-way bf16 splits, 6 bf16-MFMA passes, fp32 accumulate (fp32-accurate, "
+                         "tests/test_gpu_x3.py).  bf16 = the configs[3] option (operands rounded to "
+                         "bf16, fp32 storage + loss)")
     ap.add_argument('--cpu-rois', type=int, default=500)
     return ap.parse_args()
 
@@ -158,9 +161,14 @@ def main():
         kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
         achieved = fc6_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
         bf = args.mfma_dtype == 'bf16'
-        peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
+        x3 = args.mfma_dtype == 'fp32x3'
+        # fp32x3 executes 6 bf16 MFMA flops per algorithmic fp32 flop: its ceiling in algorithmic
+        # TFLOP/s is the bf16 dense peak / 6 (frac = executed MFMA flops / bf16 peak)
+        peak = (BF16_MFMA_PEAK_TFLOPS if bf else
+                round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if x3 else FP32_MFMA_PEAK_TFLOPS)
         kname = ('gemm_bf16_kernel<256,128,4x2 waves,fp32 sources>' if bf else
-                 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
+                 'gemm_x3_kernel<256,256,2x4 waves,3 stages> = 6 x v_mfma_f32_32x32x16_bf16 per '
+                 'fp32 product' if x3 else 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
         res = {
             'metric': 'images/sec (600px, 2000 proposals) VGG16-C5 WSDDN fwd+bwd',
             'value': round(world * B * args.steps / dt, 3),
@@ -173,7 +181,9 @@ def main():
                                    'GPU x %d proposals, fwd+bwd+allreduce+SGD, %s' % (
                                        num_fg, B, args.height, args.width, args.rois,
                                        'bf16 MFMA conv/fc6/fc7, fp32 storage/fc8/loss/SGD'
-                                       if bf else 'fp32 MFMA'),
+                                       if bf else 'fp32; fc6/fc7 GEMMs as exact 3xbf16 splits on '
+                                       'the bf16 MFMA (fp32-accurate), conv/fc8 on the fp32 MFMA'
+                                       if x3 else 'fp32 MFMA'),
                        'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
                        'lr': args.lr, 'final_loss': round(loss, 5)},
             'roofline': {'bound': 'mfma', 'kernel': '%s (fc6 fwd, both branches, M=%d N=8192 K=%d)' % (
@@ -187,7 +197,7 @@ def main():
         # (profiles/rNN_bench_traffic.json, written by tools/summarize_profile.py)
         import glob
         tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_traffic.json')))
-        if tj and args.rois == 2000 and B == 2 and not bf:
+        if tj and args.rois == 2000 and B == 2 and args.mfma_dtype == 'fp32':
             res['roofline']['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
             res['roofline']['traffic_source'] = os.path.relpath(tj[-1], ROOT)
         if world == 1 and not args.no_cpu_baseline:

@@ -134,7 +134,9 @@ def _defaults():
             'ALLREDUCE_CHUNKS': 1,   # >1: cut fc6 wgrad into row chunks, each all-reduced while
                                      # the next chunk's GEMM runs (default: one launch; the
                                      # collective hides under the next iteration's conv body)
-            'MFMA_DTYPE': 'fp32',    # 'bf16': conv2..conv5 + fc6/fc7 multiply in bf16 MFMA with
+            'MFMA_DTYPE': 'fp32x3',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact
+                                     # 3-way bf16 splits on the bf16 MFMA (fp32-accurate, faster);
+                                     # 'bf16': conv2..conv5 + fc6/fc7 operands rounded to bf16,
                                      # fp32 accumulation; storage, fc8, loss and SGD stay fp32
         },
     }

@@ -97,9 +97,14 @@ class WsddnEngine(object):
         if not freeze_conv_body:
             raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
                                       '(SURVEY.md fact 2): the conv body has no backward')
-        if mfma_dtype not in ('fp32', 'bf16'):
-            raise ValueError("mfma_dtype must be 'fp32' or 'bf16'")
+        if mfma_dtype not in ('fp32', 'fp32x3', 'bf16'):
+            raise ValueError("mfma_dtype must be 'fp32', 'fp32x3' or 'bf16'")
         L.load()
+        # 'fp32'  : every GEMM on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
+        # 'fp32x3': fc6/fc7 forward, dgrad and wgrad on the bf16 matrix cores with each fp32
+        #           operand split exactly into three bf16 planes and six MFMA passes
+        #           (csrc/gemm_x3.hip): fp32-accurate (tests/test_gpu_x3.py), ~1.65x faster.
+        #           The weight planes are re-split after every SGD update, on the update stream.
         # 'bf16': conv2..conv5 and fc6/fc7 (forward, dgrad, wgrad) multiply in
         # v_mfma_f32_32x32x16_bf16 with fp32 accumulation; parameters, activations, gradients,
         # fc8, the dual softmax, the loss and the SGD update stay fp32 (BASELINE.json configs[3]:
@@ -161,11 +166,31 @@ class WsddnEngine(object):
         self._update_pending = False
         self._upd_stream = None
         self._upd_event = None
+        self._wplanes = None         # fp32x3: split planes of fc6_w / fc7_w / fc7_w^T
+        self._planes_dirty = True
 
     # ------------------------------------------------------------------ params
     def blob(self, name):
         self.flush()
+        self._planes_dirty = True     # the caller may write through the view
         return self.arena.view(self.params, name)
+
+    def _weight_views(self):
+        w6 = self.arena.span(self.params, 'fc6_w', '_[noisy]_fc6_w').view(2 * HIDDEN, self.k6)
+        w7 = self.arena.span(self.params, 'fc7_w', '_[noisy]_fc7_w').view(2, HIDDEN, HIDDEN)
+        return w6, w7
+
+    def _refresh_weight_planes(self):
+        """fp32x3: re-split fc6_w / fc7_w (and fc7_w^T for the dgrad) into bf16 planes."""
+        w6, w7 = self._weight_views()
+        if self._wplanes is None:
+            self._wplanes = dict(w6=ops.split_bf16x3(w6), w7=ops.split_bf16x3(w7),
+                                 w7t=ops.split_bf16x3(w7, transpose=True))
+        else:
+            ops.split_bf16x3(w6, out=self._wplanes['w6'])
+            ops.split_bf16x3(w7, out=self._wplanes['w7'])
+            ops.split_bf16x3(w7, transpose=True, out=self._wplanes['w7t'])
+        self._planes_dirty = False
 
     def grad_blob(self, name):
         return self.arena.view(self.grads, name)
@@ -296,7 +321,16 @@ class WsddnEngine(object):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         bf = self.mfma_dtype == 'bf16'
-        if bf:
+        x3 = self.mfma_dtype == 'fp32x3'
+        if x3:
+            if self._planes_dirty:
+                self._refresh_weight_planes()
+            xp = roi_feat if roi_feat.dtype == torch.bfloat16 else ops.split_bf16x3(roi_feat)
+            h6 = ops.gemm_f32x3_nt(xp, self._wplanes['w6'][:, :, :nb * HIDDEN], epilogue=epi,
+                                   bias=b6, drop_ratio=self.dropout if drop else 0.0,
+                                   seed=self._seed(6))
+            del xp
+        elif bf:
             h6 = ops.gemm_bf16_nt(roi_feat, w6[:nb * HIDDEN], epilogue=epi, bias=b6,
                                   drop_ratio=self.dropout if drop else 0.0, seed=self._seed(6))
         else:
@@ -308,7 +342,11 @@ class WsddnEngine(object):
         h6v = h6.view(rt, nb, HIDDEN).permute(1, 0, 2)       # [nb, Rt, 4096] strided views
         h7 = torch.empty((rt, nb * HIDDEN), device=self.device, dtype=torch.float32)
         h7v = h7.view(rt, nb, HIDDEN).permute(1, 0, 2)
-        if bf:
+        if x3:
+            ops.gemm_f32x3_nt(ops.split_bf16x3(h6v), self._wplanes['w7'][:, :nb], out=h7v,
+                              epilogue=epi, bias=b7, drop_ratio=self.dropout if drop else 0.0,
+                              seed=self._seed(7))
+        elif bf:
             ops.gemm_bf16_nt(h6v, w7[:nb], out=h7v, epilogue=epi, bias=b7,
                              drop_ratio=self.dropout if drop else 0.0, seed=self._seed(7))
         else:
@@ -381,9 +419,18 @@ class WsddnEngine(object):
         ops.gemm(dlv, w8, False, False, out=dz7v, epilogue=L.EPI_GATE_POS, aux=h7v, alpha=scale)
         # fc7
         bf = self.mfma_dtype == 'bf16'
+        x3 = self.mfma_dtype == 'fp32x3'
         dz6 = torch.empty_like(h6)
         dz6v = dz6.view(rt, 2, HIDDEN).permute(1, 0, 2)
-        if bf:
+        if x3:
+            # dW = dZ^T H: both operands K(=rows)-contiguous through the transposing split;
+            # dX = dZ W: W^T planes are kept beside the W planes
+            ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v, transpose=True),
+                              ops.split_bf16x3(h6v, transpose=True), out=gw7)
+            ops.colsum(dz7, out=gb7)
+            ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v), self._wplanes['w7t'], out=dz6v,
+                              epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
+        elif bf:
             # the bf16 kernel takes K-contiguous operands: dW = dZ^T H needs dZ^T and H^T
             # ([2*4096, Rt] bf16, the zero-padded Rt is the K dim), dX = dZ W needs W^T
             rp8 = (rt + 7) // 8 * 8
@@ -404,11 +451,16 @@ class WsddnEngine(object):
         # everything except fc6_w is ready: start its all-reduce, then stream fc6 wgrad chunks
         red = self.reducer
         red.reduce_async(self.arena.span(G, 'fc6_b', 'noisy_fc8d_b'))
-        if bf:
+        if x3:
+            dz6t = ops.split_bf16x3(dz6, transpose=True)       # [3, Rt/16, 8192, 16]
+            xt = ops.split_bf16x3(x, transpose=True)           # [3, Rt/16, 25088, 16]
+        elif bf:
             dz6t = ops.transpose_to_bf16(dz6, rp8)             # [8192, Rt]
             xt = ops.transpose_to_bf16(x, rp8)                 # [25088, Rt]
         for r0, r1 in row_chunks(2 * HIDDEN, self.allreduce_chunks if red.active else 1):
-            if bf:
+            if x3:
+                ops.gemm_f32x3_nt(dz6t[:, :, r0:r1], xt, out=gw6[r0:r1])
+            elif bf:
                 ops.gemm_bf16_nt(dz6t[r0:r1], xt, out=gw6[r0:r1])
             else:
                 ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
@@ -462,6 +514,8 @@ class WsddnEngine(object):
                            self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
                            self.iter_size, self.gpu_num, self.sgd_iter_count)
         self.sgd_iter_count += 1
+        if self.mfma_dtype == 'fp32x3' and self._wplanes is not None:
+            self._refresh_weight_planes()      # same stream as the update: hidden with it
 
     # -------------------------------------------------------------- inference
     def infer(self, data, rois, obn_scores, seg=None):

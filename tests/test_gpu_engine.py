@@ -41,10 +41,13 @@ def _masks(eng, rt, dev):
             'drop7': m7[0], '_[noisy]_drop7': m7[1]}
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
 @pytest.mark.parametrize('dropout,c', [(0.5, 20), (0.0, 20), (0.5, 80)])
-def test_engine_matches_oracle(dev, dropout, c):
+def test_engine_matches_oracle(dev, dropout, c, mode):
+    """Both fp32 plans (fp32 MFMA everywhere / fc6+fc7 as exact 3xbf16 splits on the bf16 MFMA)
+    are held to the same fp32 tolerances."""
     from oracle import oracle
-    eng, mb, blobs = _setup(dev, c=c, dropout=dropout)
+    eng, mb, blobs = _setup(dev, c=c, dropout=dropout, mfma_dtype=mode)
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
     rt = mb['rois'].shape[0]
     masks = _masks(eng, rt, dev)
@@ -119,10 +122,11 @@ def test_engine_bf16_mode(dev, c):
     assert torch.equal(out['loss_cls'], out2['loss_cls'])
 
 
-def test_engine_sgd_steps(dev):
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+def test_engine_sgd_steps(dev, mode):
     """3 iterations of fwd+bwd+SGD vs the oracle (dropout masks replayed)."""
     from oracle import oracle
-    eng, mb, blobs = _setup(dev)
+    eng, mb, blobs = _setup(dev, mfma_dtype=mode)
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
     rt = mb['rois'].shape[0]
     cur = {k: v.clone() for k, v in blobs.items()}
@@ -150,9 +154,10 @@ def test_engine_sgd_steps(dev):
         assert np.abs(m_got - m_ref).max() <= 2e-3 * np.abs(m_ref).max() + 1e-9, name
 
 
-def test_engine_infer(dev):
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+def test_engine_infer(dev, mode):
     from oracle import oracle
-    eng, mb, blobs = _setup(dev, dropout=0.5)
+    eng, mb, blobs = _setup(dev, dropout=0.5, mfma_dtype=mode)
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
     one = {k: v[:1] if k in ('data', 'labels_oh') else v for k, v in mb.items()}
     sel = mb['rois'][:, 0] == 0
@@ -164,12 +169,14 @@ def test_engine_infer(dev):
                                rtol=1e-4, atol=1e-8)
 
 
-def test_deferred_update_is_equivalent(dev):
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+def test_deferred_update_is_equivalent(dev, mode):
     """The N>1 schedule (all-reduce launched after backward, SGD applied after the NEXT
-    iteration's conv body) gives bit-identical parameters to the immediate update."""
+    iteration's conv body) gives bit-identical parameters to the immediate update (fp32x3: the
+    weight planes are re-split on the update stream, the head must see the new ones)."""
     res = []
     for defer in (False, True):
-        eng, mb, _blobs = _setup(dev)
+        eng, mb, _blobs = _setup(dev, mfma_dtype=mode)
         eng.defer_update = defer
         t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
         eng.set_lr(1e-3)
