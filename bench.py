@@ -196,8 +196,9 @@ def main():
         # HBM traffic of that kernel comes from the rocprofv3 PMC passes of this same command
         # (profiles/rNN_bench_traffic.json, written by tools/summarize_profile.py)
         import glob
-        tj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_traffic.json')))
-        if tj and args.rois == 2000 and B == 2 and args.mfma_dtype == 'fp32':
+        tj = [f for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench*traffic*.json')))
+              if json.load(open(f)).get('mfma_dtype', 'fp32') == args.mfma_dtype]
+        if tj and args.rois == 2000 and B == 2:
             res['roofline']['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
             res['roofline']['traffic_source'] = os.path.relpath(tj[-1], ROOT)
         if world == 1 and not args.no_cpu_baseline:

@@ -207,7 +207,7 @@ class WsddnEngine(object):
             name = item[0]
             w = blobs[name + '_w'].to(self.device, torch.float32).contiguous()
             b = blobs[name + '_b'].to(self.device, torch.float32).contiguous()
-            use_wino = (self.winograd and self.mfma_dtype == 'fp32' and w.shape[1] >= 128
+            use_wino = (self.winograd and self.mfma_dtype != 'bf16' and w.shape[1] >= 128
                         and w.shape[0] >= 256)
             if name == 'conv1_1':
                 packed = w

@@ -2,7 +2,9 @@
 """Condense rocprofv3 CSV output (kernel-trace stats + separate FETCH_SIZE / WRITE_SIZE PMC
 passes) into the small summaries kept under profiles/.
 
-  summarize_profile.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <out_prefix>
+  summarize_profile.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <out_prefix> [mfma_dtype]
+
+mfma_dtype (fp32x3 default | fp32 | bf16) selects which kernel is bench.py's dominant one.
 
 HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, so
@@ -19,9 +21,24 @@ def short(name):
     return name.split('(')[0][:70]
 
 
+def _find(d, pat):
+    return glob.glob(os.path.join(d, pat)) + glob.glob(os.path.join(d, '*', pat))
+
+
 def main():
     stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
-    rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, '*', '*_kernel_stats.csv'))[0])))
+    mode = sys.argv[5] if len(sys.argv) > 5 else 'fp32x3'
+    # (kernel-name substring, label, algorithmic GB per launch, Grid_Size of the fc6-fwd launch:
+    #  other launches of the same template - fc6 wgrad - have another grid)
+    dom_sub, dom_name, alg_gb, dom_grid = {
+        'fp32': ('gemm_f32_kernel<256, 256, 16, true, true, false, 4, 4>',
+                 'gemm_f32_kernel<256,256,16,KC,KC,4x4> fc6 fwd', 1.354, None),
+        'fp32x3': ('gemm_x3_kernel<256, 256, 2, 4, 3>', 'gemm_x3_kernel<256,256,2x4,3 stages> fc6 fwd',
+                   1.966, '262144'),
+        'bf16': ('gemm_bf16_kernel<256, 128, 4, 2, false, false, false>',
+                 'gemm_bf16_kernel<256,128,4x2,fp32 sources> fc6 fwd', 1.354, None),
+    }[mode]
+    rows = list(csv.DictReader(open(_find(stats_dir, '*_kernel_stats.csv')[0])))
     lines = ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
     for r in rows[:24]:
         lines.append('| %s | %s | %.3f | %.1f | %.2f |' % (
@@ -29,7 +46,7 @@ def main():
             float(r['AverageNs']) / 1e3, float(r['Percentage'])))
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d, cname in ((fetch_dir, 'FETCH_SIZE'), (write_dir, 'WRITE_SIZE')):
-        f = glob.glob(os.path.join(d, '*', '*_counter_collection.csv'))
+        f = _find(d, '*_counter_collection.csv')
         if not f:
             continue
         for r in csv.DictReader(open(f[0])):
@@ -48,11 +65,11 @@ def main():
     # largest grid (M=4000 N=8192 -> 2048 workgroups)
     dom = {}
     for d, cname in ((fetch_dir, 'FETCH_SIZE'), (write_dir, 'WRITE_SIZE')):
-        f = glob.glob(os.path.join(d, '*', '*_counter_collection.csv'))
+        f = _find(d, '*_counter_collection.csv')
         vals = []
         if f:
             rws = [r for r in csv.DictReader(open(f[0])) if r['Counter_Name'] == cname and
-                   'gemm_f32_kernel<256, 256, 16, true, true, false, 4, 4>' in r['Kernel_Name']]
+                   dom_sub in r['Kernel_Name'] and (dom_grid is None or r['Grid_Size'] == dom_grid)]
             if rws:
                 # fc7 fwd (batch 2) has the same thread count; fc6 launches are the ones that
                 # move the most bytes
@@ -62,7 +79,7 @@ def main():
     if dom.get('FETCH_SIZE') is not None and dom.get('WRITE_SIZE') is not None:
         import json
         tb = (2 * dom['FETCH_SIZE'] + dom['WRITE_SIZE']) * 1024
-        json.dump({'kernel': 'gemm_f32_kernel<256,256,16,KC,KC,4x4> fc6 fwd',
+        json.dump({'kernel': dom_name, 'mfma_dtype': mode, 'algorithmic_bytes_per_launch': alg_gb * 1e9,
                    'FETCH_SIZE_KiB_per_launch': dom['FETCH_SIZE'],
                    'WRITE_SIZE_KiB_per_launch': dom['WRITE_SIZE'],
                    'hbm_bytes_per_launch': tb,
@@ -71,11 +88,11 @@ def main():
                            'Infinity-Cache hits are included in the memory-side counters)'},
                   open(out + '_traffic.json', 'w'), indent=1)
         lines += ['', 'fc6 fwd GEMM: FETCH %.0f KiB, WRITE %.0f KiB per launch -> %.2f GB fabric '
-                  'traffic per launch (algorithmic 1.354 GB)' % (dom['FETCH_SIZE'], dom['WRITE_SIZE'],
-                                                                 tb / 1e9)]
+                  'traffic per launch (algorithmic %.3f GB)' % (dom['FETCH_SIZE'], dom['WRITE_SIZE'],
+                                                               tb / 1e9, alg_gb)]
     open(out + '.md', 'w').write('\n'.join(lines) + '\n')
     import shutil
-    shutil.copy(glob.glob(os.path.join(stats_dir, '*', '*_kernel_stats.csv'))[0], out + '_kernel_stats.csv')
+    shutil.copy(_find(stats_dir, '*_kernel_stats.csv')[0], out + '_kernel_stats.csv')
     print('\n'.join(lines))
 
 
