@@ -40,6 +40,12 @@ def parse():
                     help='initialise RCCL and run the all-reduce schedule even with one rank '
                          '(exercises the N>1 code path on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-conv-x3', action='store_true',
+                    help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
+    ap.add_argument('--wino-x3', action='store_true',
+                    help='fp32x3 plan: run the Winograd batched GEMMs in the split too (no gain)')
+    ap.add_argument('--no-conv-streams', action='store_true',
+                    help='one launch per conv layer for all images instead of one stream per image')
     ap.add_argument('--mfma-dtype', default='fp32x3', choices=['fp32x3', 'fp32', 'bf16'],
                     help="fp32x3 (default) and fp32 are both fp32 arithmetic (BASELINE configs[1]/[2]): "
                          "fp32 = v_mfma_f32_32x32x2_f32 everywhere; fp32x3 = fc6/fc7 GEMMs as exact "
@@ -109,6 +115,12 @@ def main():
                       mfma_dtype=args.mfma_dtype)
     if args.force_dist:
         eng.reducer.force = True
+    if args.no_conv_x3:
+        eng.conv_x3 = False
+    if args.wino_x3:
+        eng.wino_x3 = True
+    if args.no_conv_streams:
+        eng.conv_streams = False
     blobs = synthetic.init_blobs(num_fg, seed=11)     # identical on every rank (= broadcast)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)
@@ -125,11 +137,15 @@ def main():
     # the launch stream
     ev = []
 
+    pev = []
+
     def step(timed):
         if timed:
             eng.timing_events = ev
+            eng.phase_events = pev
         else:
             eng.timing_events = None
+            eng.phase_events = None
         out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
         eng.sgd_step()
         return out
@@ -160,6 +176,16 @@ def main():
         fc6_flops = 2.0 * rt * (2 * 4096) * k6
         kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
         achieved = fc6_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
+        # per-stage wall time on the main stream (HIP events), averaged over the timed steps
+        stages, order = {}, []
+        for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]):
+            if n1 == 'start':
+                continue
+            if n1 not in stages:
+                stages[n1] = []
+                order.append(n1)
+            stages[n1].append(e0.elapsed_time(e1))
+        stage_ms = {n: round(sum(v) / len(v), 3) for n, v in stages.items()}
         bf = args.mfma_dtype == 'bf16'
         x3 = args.mfma_dtype == 'fp32x3'
         # fp32x3 executes 6 bf16 MFMA flops per algorithmic fp32 flop: its ceiling in algorithmic
@@ -185,7 +211,7 @@ def main():
                                        'the bf16 MFMA (fp32-accurate), conv/fc8 on the fp32 MFMA'
                                        if x3 else 'fp32 MFMA'),
                        'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
-                       'lr': args.lr, 'final_loss': round(loss, 5)},
+                       'lr': args.lr, 'final_loss': round(loss, 5), 'stage_ms': stage_ms},
             'roofline': {'bound': 'mfma', 'kernel': '%s (fc6 fwd, both branches, M=%d N=8192 K=%d)' % (
                 kname, rt, k6),
                          'achieved': round(achieved, 2) if achieved else None,

@@ -320,6 +320,20 @@ int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t slabA, int64
                        int64_t strideA, int64_t strideB, int64_t strideC, int epilogue,
                        const float* bias, int64_t strideBias, const float* aux, int ldaux,
                        float alpha, float drop_ratio, uint64_t seed, int accumulate, void* stream);
+/* 3x3 / stride 1 / pad = dilation convolution, NHWC fp32 in and out, as an fp32x3 implicit GEMM
+ * (same operator as naws_conv3x3_nhwc_fwd: Caffe2 Conv + Relu, reference
+ * detectron/modeling/VGG16.py:37-130).  W3 = naws_split_bf16x3 (transpose = 0) of the packed
+ * [Cout][3][3][Cin] weight viewed as [Cout][9*Cin].  Cin % 16 == 0. */
+int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const float* bias, int N, int H,
+                                int W, int Cin, int Cout, int dilation, int relu, float* Y,
+                                void* stream);
+/* Winograd F(2x2,3x3) convolution (as naws_conv3x3_winograd_nhwc_fwd) with the 16 batched GEMMs
+ * in the fp32x3 split; U3 = naws_split_bf16x3 (batch 16, transpose 0) of the transformed weight
+ * U[16][Cout][Cin].  Cin % 16 == 0. */
+int64_t naws_winograd_f32x3_workspace_floats(int N, int H, int W, int Cin, int Cout, int dilation);
+int naws_conv3x3_winograd_nhwc_f32x3_fwd(const float* X, const void* U3, const float* bias, int N,
+                                         int H, int W, int Cin, int Cout, int dilation, int relu,
+                                         float* workspace, float* Y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -290,6 +290,199 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X
   }
 }
 
+// ---- 3x3 convolution (NHWC fp32 activations) as an fp32x3 implicit GEMM -------------------------
+// A = activations gathered straight from the fp32 NHWC tensor (branch-free buffer loads, halo ->
+// 0), split into the three bf16 planes in registers (8 VALU ops per element, < 5 % of the MFMA
+// time of a step) and written into the same swizzled LDS image the DMA path uses; B = weight
+// planes [3][9*Cin/16][Cout][16] (naws_split_bf16x3 of the packed [Cout][3][3][Cin] weight) by
+// LDS-DMA.  A K-step is 16 channels of one tap.  Two LDS stages: step t+1's activations are
+// loaded at the top of step t and split/written after its MFMAs.
+struct CArgs {
+  const float* X;            // NHWC
+  const unsigned short* B;   // weight planes
+  const float* bias;
+  float* Y;                  // NHWC
+  int M, Cout, Cin, H, W, dil, relu;
+  long long planeB, slabB;
+  unsigned bytesX;
+  int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void conv_x3_kernel(CArgs g) {
+  constexpr int NT = 64 * WM * WN, NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TI = WTM / 32, TJ = WTN / 32;
+  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;
+  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  constexpr int UA = BM * 2 / NT;                 // (row, 8-channel half) units per thread
+  constexpr int BPIECES = 3 * BN / 32;            // 1 KB DMA pieces of the weight stage
+  static_assert(BM * 2 % NT == 0, "tile vs workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int lid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, rem = ntiles & 7, xcd = lid & 7, within = lid >> 3;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+  }
+  // all Cout tiles of one pixel tile are neighbours: the gathered activations are shared in L2
+  const int tm = lid / g.tiles_n, tn = lid % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  int py[UA], px[UA];
+  unsigned abase[UA];
+  int awr[UA];
+#pragma unroll
+  for (int i = 0; i < UA; ++i) {
+    const int u = tid + i * NT;
+    const int row = u >> 1, half = u & 1;
+    const int gm = m0 + row;
+    if (gm < g.M) {
+      px[i] = gm % g.W; py[i] = (gm / g.W) % g.H;
+      abase[i] = ((unsigned)gm * (unsigned)g.Cin + half * 8) * 4u;
+    } else { px[i] = 0; py[i] = 0; abase[i] = OOB; }
+    awr[i] = row * 32 + ((half ^ ((row >> 3) & 1)) * 16);
+  }
+  const int bslot = ((lane & 1) ^ ((lane >> 4) & 1)) * 8;
+
+  u32x4 ra[UA][2];
+  auto loadA = [&](int t) {
+    const int k0 = t * 16;
+    const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+    const int dy = (tap / 3 - 1) * g.dil, dx = (tap % 3 - 1) * g.dil;
+    const int delta = ((dy * g.W + dx) * g.Cin + c0) * 4;
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = (abase[i] != OOB) && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+      const unsigned off = ok ? (unsigned)((int)abase[i] + delta) : OOB;
+      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
+      ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? (int)(off + 16) : (int)OOB, 0, 0);
+    }
+  };
+  auto storeA = [&](int st) {
+    unsigned char* base = smx + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+      unsigned short q[3][8];
+      const unsigned w[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w,
+                             ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        u32x4 v;
+        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[i]) = v;
+      }
+    }
+  };
+  auto issueB = [&](int t, int st) {
+    unsigned char* base = smx + st * STAGE + 3 * A_PLANE;
+#pragma unroll
+    for (int r = 0; r < (BPIECES + NW - 1) / NW; ++r) {
+      const int piece = wid + r * NW;             // wave-uniform
+      if (piece < BPIECES) {
+        const int pl = piece / (BN / 32), rb = piece % (BN / 32);
+        // weight rows past Cout re-read the last row (their columns are never stored)
+        const int wrow = min(n0 + rb * 32 + (lane >> 1), g.Cout - 1);
+        __builtin_amdgcn_global_load_lds(
+            NAWS_GLB_PTR(g.B + pl * g.planeB + t * g.slabB + (long long)wrow * 16 + bslot),
+            NAWS_LDS_PTR(base + pl * B_PLANE + rb * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int rd_a = (wm * WTM + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+  const int rd_b = 3 * A_PLANE + (wn * WTN + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+
+  const int T = 9 * g.Cin / 16;
+  issueB(0, 0);
+  loadA(0);
+  storeA(0);
+  for (int t = 0; t < T; ++t) {
+    __syncthreads();                     // stage t&1 complete (DMA drained + LDS writes visible)
+    const bool more = t + 1 < T;
+    if (more) { issueB(t + 1, (t + 1) & 1); loadA(t + 1); }
+    const unsigned char* st = smx + (t & 1) * STAGE;
+    bf16x8 a[3][TI], b[3][TJ];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        a[pl][i] = *reinterpret_cast<const bf16x8*>(st + rd_a + pl * A_PLANE + i * 1024);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        b[pl][j] = *reinterpret_cast<const bf16x8*>(st + rd_b + pl * B_PLANE + j * 1024);
+    }
+#define NAWS_X3_TERM(P, Q)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][i], b[Q][j], acc[i][j], 0, 0, 0);
+    NAWS_X3_TERM(0, 0)
+    NAWS_X3_TERM(0, 1)
+    NAWS_X3_TERM(1, 0)
+    NAWS_X3_TERM(1, 1)
+    NAWS_X3_TERM(0, 2)
+    NAWS_X3_TERM(2, 0)
+#undef NAWS_X3_TERM
+    if (more) storeA((t + 1) & 1);
+  }
+
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+    if (col >= g.Cout) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        float v = acc[i][j][e] + bv;
+        if (g.relu) v = fmaxf(v, 0.f);
+        g.Y[(long long)row * g.Cout + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv_x3(CArgs& g, hipStream_t s) {
+  g.tiles_m = (int)naws_cdiv(g.M, BM);
+  g.tiles_n = (int)naws_cdiv(g.Cout, BN);
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
+  auto kern = conv_x3_kernel<BM, BN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * WM * WN), lds, s, g);
+  return naws_check_launch();
+}
+
 }  // namespace
 
 extern "C" int naws_split_bf16x3(const float* X, int batch, int rows, int cols, int ld,
@@ -354,10 +547,42 @@ extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t s
     g_x3_variant = e ? atoi(e) : 0;
   }
   if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2>(g, batch, s);
+  // short K (the Winograd batch GEMMs): prologue and epilogue are a large share of a tile's life,
+  // two 4-wave workgroups per CU overlap one's epilogue with the other's K loop
+  if (K <= 1024 && g_x3_variant != 4) {
+    if (g_x3_variant == 5) return launch_x3<128, 128, 2, 2, 2>(g, batch, s);
+    return launch_x3<256, 128, 2, 2, 2>(g, batch, s);
+  }
   switch (g_x3_variant) {
     case 1: return launch_x3<256, 128, 2, 2, 2>(g, batch, s);
     case 2: return launch_x3<256, 256, 2, 4, 2>(g, batch, s);
     case 3: return launch_x3<256, 128, 2, 2, 3>(g, batch, s);
     default: return launch_x3<256, 256, 2, 4, 3>(g, batch, s);
   }
+}
+
+extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const float* bias,
+                                           int N, int H, int W, int Cin, int Cout, int dilation,
+                                           int relu, float* Y, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (dilation < 1) return NAWS_ERR_ARG;
+  if (Cin % 16 != 0 || Cout % 4 != 0) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W3); NAWS_REQUIRE_PTR(Y);
+  if (!bias && relu) return NAWS_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)W3) & 15) != 0) return NAWS_ERR_ARG;
+  const long long pix = (long long)N * H * W;
+  if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
+  CArgs g{};
+  g.X = X; g.B = (const unsigned short*)W3; g.bias = bias; g.Y = Y;
+  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = dilation; g.relu = relu;
+  g.slabB = (long long)Cout * 16;
+  g.planeB = (long long)9 * Cin * Cout;
+  g.bytesX = (unsigned)(pix * Cin * 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout <= 64) return launch_conv_x3<256, 64, 4, 1>(g, s);
+  if (Cout <= 128 || naws_cdiv(pix, 256) * naws_cdiv(Cout, 256) < 256) {
+    if (naws_cdiv(pix, 256) * naws_cdiv(Cout, 128) < 512) return launch_conv_x3<128, 128, 2, 2>(g, s);
+    return launch_conv_x3<256, 128, 2, 2>(g, s);
+  }
+  return launch_conv_x3<256, 256, 2, 4>(g, s);
 }

@@ -228,3 +228,53 @@ extern "C" int naws_conv3x3_winograd_nhwc_fwd(const float* X, const float* U, co
   }
   return naws_check_launch();
 }
+
+// Same convolution with the 16 batched GEMMs on the bf16 matrix cores in the exact 3xbf16 split
+// (csrc/gemm_x3.hip): V is split into planes after the input transform, U3 is the split of the
+// transformed weight (naws_split_bf16x3 of U viewed [16][Cout][Cin]).
+extern "C" int64_t naws_winograd_f32x3_workspace_floats(int N, int H, int W, int Cin, int Cout,
+                                                        int dilation) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation < 1) return 0;
+  const WinoGeom g = wino_geom(N, H, W, dilation);
+  return naws_winograd_workspace_floats(N, H, W, Cin, Cout, dilation) + 24 * g.P * (int64_t)Cin + 64;
+}
+
+extern "C" int naws_conv3x3_winograd_nhwc_f32x3_fwd(const float* X, const void* U3,
+                                                    const float* bias, int N, int H, int W, int Cin,
+                                                    int Cout, int dilation, int relu,
+                                                    float* workspace, float* Y, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (dilation < 1) return NAWS_ERR_ARG;
+  if (Cin % 16 != 0 || Cout % 4 != 0) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(U3); NAWS_REQUIRE_PTR(workspace); NAWS_REQUIRE_PTR(Y);
+  if ((((uintptr_t)X | (uintptr_t)U3 | (uintptr_t)workspace | (uintptr_t)Y) & 15) != 0)
+    return NAWS_ERR_ARG;
+  const WinoGeom g = wino_geom(N, H, W, dilation);
+  if (g.P > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const long long pad = wino_pad();
+  const long long slabV = g.P * Cin + pad, slabM = g.P * Cout + pad;
+  float* V = workspace;
+  float* Mb = workspace + 16 * slabV;
+  float* Vp = Mb + 16 * slabM;
+  Vp += (16 - ((uintptr_t)Vp & 63) / 4) & 15;            // 64-byte aligned planes
+  {
+    const long long total = g.P * (Cin / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
+                       dim3(256), 0, s, X, g, Cin, slabV, V);
+    int rc = naws_check_launch();
+    if (rc != NAWS_OK) return rc;
+  }
+  int rc = naws_split_bf16x3(V, 16, (int)g.P, Cin, Cin, slabV, 0, Cin, Vp, stream);
+  if (rc != NAWS_OK) return rc;
+  rc = naws_gemm_f32x3_nt((int)g.P, Cout, Cin, Vp, g.P * 16, 16 * g.P * Cin, U3, (int64_t)Cout * 16,
+                          (int64_t)16 * Cout * Cin, Mb, Cout, 16, g.P * Cin, (int64_t)Cout * Cin,
+                          slabM, NAWS_EPI_NONE, nullptr, 0, nullptr, 0, 1.0f, 0.0f, 0, 0, stream);
+  if (rc != NAWS_OK) return rc;
+  {
+    const long long total = g.P * (Cout / 4);
+    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
+                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y);
+  }
+  return naws_check_launch();
+}

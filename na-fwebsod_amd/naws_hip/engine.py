@@ -156,6 +156,14 @@ class WsddnEngine(object):
         # 2.25x fewer MFMA flops, 28-42% less time per layer; the shallow layers stay on the
         # direct implicit GEMM (their transforms would be HBM-bound)
         self.winograd = True
+        # fp32x3: the direct (non-Winograd) layers conv1_2..conv2_2 as fp32x3 implicit GEMMs
+        # (csrc/gemm_x3.hip conv_x3_kernel), 1.8x the fp32-MFMA direct kernel; the deep layers
+        # have too few 256-row tiles to fill 256 CUs and stay on Winograd ('all' forces them too)
+        self.conv_x3 = True
+        # fp32x3: the Winograd layers' 16 batched GEMMs in the split too.  Off: with K = Cin <= 512
+        # those GEMMs are bound by V/M traffic and tile epilogues, not by the MFMA rate
+        # (measured per layer: 0.26-0.62 ms either way, tools/kernel_bench.py --what conv)
+        self.wino_x3 = False
         self.conv_wino = {}
         self._streams = []
         # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
@@ -207,12 +215,20 @@ class WsddnEngine(object):
             name = item[0]
             w = blobs[name + '_w'].to(self.device, torch.float32).contiguous()
             b = blobs[name + '_b'].to(self.device, torch.float32).contiguous()
-            use_wino = (self.winograd and self.mfma_dtype != 'bf16' and w.shape[1] >= 128
-                        and w.shape[0] >= 256)
+            use_wino = (self.winograd and self.mfma_dtype != 'bf16' and
+                        w.shape[1] >= 128 and w.shape[0] >= 256)
+            x3conv = (self.mfma_dtype == 'fp32x3' and self.conv_x3 and name != 'conv1_1' and
+                      (not use_wino or self.conv_x3 == 'all'))
+            use_wino = use_wino and not x3conv
             if name == 'conv1_1':
                 packed = w
+            elif x3conv:
+                # weight planes [3][9*Cin/16][Cout][16] of the packed [Cout][3][3][Cin] weight
+                packed = ops.split_bf16x3(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
             elif use_wino:
                 packed = ops.winograd_weight_transform(w)      # [16][Cout][Cin]
+                if self.mfma_dtype == 'fp32x3' and self.wino_x3:
+                    packed = ops.split_bf16x3(packed)          # planes [3][16][Cin/16][Cout][16]
             else:
                 packed = ops.conv3x3_pack_weight(w)            # [Cout][3][3][Cin]
             self.conv[name] = (packed, b, w)
@@ -251,7 +267,10 @@ class WsddnEngine(object):
                     x = ops.conv3x3_c3_nchw_to_nhwc(data, wp, b, True)
                 else:
                     d = dil if dil is not None else (2 if self.dilation == 2 else 1)
-                    if self.mfma_dtype == 'bf16':
+                    if wp.dtype == torch.bfloat16:
+                        conv = (ops.conv3x3_winograd_nhwc_f32x3 if self.conv_wino[name]
+                                else ops.conv3x3_nhwc_f32x3)
+                    elif self.mfma_dtype == 'bf16':
                         conv = ops.conv3x3_nhwc_bf16
                     else:
                         conv = (ops.conv3x3_winograd_nhwc if self.conv_wino[name]
@@ -369,13 +388,25 @@ class WsddnEngine(object):
         rt = rois.shape[0]
         max_seg = max(seg[i + 1] - seg[i] for i in range(n_img))
         seg_off = torch.tensor(seg, dtype=torch.int32, device=self.device)
+        pev = getattr(self, 'phase_events', None)   # bench.py: per-stage HIP events (main stream)
+
+        def mark(name):
+            if pev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                pev.append((name, e))
+        mark('start')
         conv5 = self.conv_body(data)
+        mark('conv_body')
         roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
                                   boost=obn_scores.reshape(-1), layout='NHWC')
         del conv5
+        mark('roi_pool')
         self.flush()                 # previous iteration's all-reduce + SGD, now overlapped
+        mark('join_update')
         x = roi_feat.view(rt, self.k6)
         h6, h7, lg = self.head_forward(x, train=True)
+        mark('head_fwd')
         lv = [lg[:, i * C:(i + 1) * C] for i in range(4)]    # fc8c, fc8d, noisy_fc8c, noisy_fc8d
         ac, ad, rp, cp = ops.wsddn_outputs(lv[0], lv[1], lv[2], lv[3], seg_off)
         cw, cwn, hs, hsn = ops.entropy_gate(rois, rp[0], cp[0], labels_oh, seg_off, max_seg)
@@ -386,6 +417,7 @@ class WsddnEngine(object):
                    cls_prob_noise=cp[1], class_weight=cw, class_weight_noise=cwn,
                    hatE_sum=hs, hatE_sum_norm=hsn, rois_pred=rp[0])
         self.step_count += 1
+        mark('loss_tail')
         if not compute_grads:
             return out
         # ---- backward (loss gradient seed 1.0 per loss, blob.py:167-173)
@@ -393,6 +425,7 @@ class WsddnEngine(object):
         g = ops.weighted_ce_grad(cp, lab2, wts, ones, self.is_mean, 2 * n_img)
         dl = ops.wsddn_outputs_grad(ac, ad, rp, cp, g, seg_off)          # [Rt, 4C]
         self._head_backward(x, h6, h7, dl)
+        mark('head_bwd')
         out['d_logits'] = dl
         return out
 

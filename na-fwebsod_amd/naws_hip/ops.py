@@ -280,6 +280,36 @@ def split_bf16x3(x, transpose=False, out=None):
     return p
 
 
+def conv3x3_nhwc_f32x3(x, w3, bias, dilation=1, relu=True, out=None):
+    """3x3 conv on NHWC fp32 activations with weight planes w3 = split_bf16x3(packed weight
+    viewed [Cout, 9*Cin]); fp32-accurate, bf16 MFMA."""
+    _chk(x, 'x')
+    n, h, w, cin = x.shape
+    cout = w3.shape[-2]
+    if w3.dtype != torch.bfloat16 or w3.shape[0] != 3 or w3.shape[1] * 16 != 9 * cin:
+        raise TypeError('w3 must be the bf16 planes [3, 9*Cin/16, Cout, 16] of the packed weight')
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    L.call('naws_conv3x3_nhwc_f32x3_fwd', x.data_ptr(), w3.data_ptr(), _ptr(bias), n, h, w, cin,
+           cout, dilation, int(relu), y.data_ptr(), _stream())
+    return y
+
+
+def conv3x3_winograd_nhwc_f32x3(x, u3, bias, dilation=1, relu=True, out=None):
+    """Winograd F(2x2,3x3) with fp32x3 GEMMs; u3 = split_bf16x3(winograd_weight_transform(w))
+    = planes [3, 16, Cin/16, Cout, 16]."""
+    _chk(x, 'x')
+    n, h, w, cin = x.shape
+    cout = u3.shape[-2]
+    if u3.dtype != torch.bfloat16 or tuple(u3.shape[:3]) != (3, 16, cin // 16):
+        raise TypeError('u3 must be the bf16 planes [3, 16, Cin/16, Cout, 16] of U')
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    nws = L.load().naws_winograd_f32x3_workspace_floats(n, h, w, cin, cout, dilation)
+    ws = torch.empty((nws,), device=x.device, dtype=_f32)
+    L.call('naws_conv3x3_winograd_nhwc_f32x3_fwd', x.data_ptr(), u3.data_ptr(), _ptr(bias), n, h,
+           w, cin, cout, dilation, int(relu), ws.data_ptr(), y.data_ptr(), _stream())
+    return y
+
+
 def planes_to_dense(p):
     """[3, (b,) K/16, outer, 16] planes -> float64 [(b,) outer, K] (test / debug helper)."""
     s = p[0].double() + p[1].double() + p[2].double()

@@ -74,6 +74,22 @@ def main():
                       name, m, n, k, batch, ms, fl / ms / 1e9, fl / ms / 1e9 / 416.7 * 100,
                       6 * fl / ms / 1e9))
             del A3, B3, Cc
+        tot = 0.0
+        for cin, cout, h, w, dil, mult in [(64, 64, 600, 1000, 1, 1), (64, 128, 300, 500, 1, 1),
+                                           (128, 128, 300, 500, 1, 1), (128, 256, 150, 250, 1, 1),
+                                           (256, 256, 150, 250, 1, 2), (256, 512, 75, 125, 1, 1),
+                                           (512, 512, 75, 125, 1, 2), (512, 512, 74, 124, 2, 3)]:
+            xx = rnd(a.images, h, w, cin)
+            w3 = torch.empty((3, 9 * cin // 16, cout, 16), device=dev).uniform_(-1, 1).bfloat16()
+            b = rnd(cout)
+            y = torch.empty((a.images, h, w, cout), device=dev)
+            ms = timeit(lambda: ops.conv3x3_nhwc_f32x3(xx, w3, b, dil, True, out=y), a.iters)
+            fl = 2.0 * a.images * h * w * cout * 9 * cin
+            tot += ms * mult
+            print('x3 conv %3d->%3d %4dx%4d d%d  %8.3f ms  %7.1f TFLOP/s fp32-equivalent' % (
+                cin, cout, h, w, dil, ms, fl / ms / 1e9))
+            del xx, w3, b, y
+        print('x3 conv stack conv1_2..conv5_3 (%d images, one launch per layer): %.3f ms' % (a.images, tot))
         x = rnd(R, 25088)
         ms = timeit(lambda: ops.split_bf16x3(x), a.iters)
         print('split_bf16x3      [%d,25088]  %8.3f ms  %6.0f GB/s' % (R, ms, x.numel() * 10 / ms / 1e6))
@@ -138,7 +154,9 @@ def main():
             if cin >= 128:
                 u = rnd(16, cout, cin)
                 msw = timeit(lambda: ops.conv3x3_winograd_nhwc(x, u, b, dil, True, out=y), a.iters)
-                print('   winograd F(2x2,3x3): %8.3f ms (direct %8.3f ms)' % (msw, ms))
+                u3 = ops.split_bf16x3(u)
+                msx = timeit(lambda: ops.conv3x3_winograd_nhwc_f32x3(x, u3, b, dil, True, out=y), a.iters)
+                print('   winograd F(2x2,3x3): %8.3f ms (direct %8.3f ms, winograd fp32x3 %8.3f ms)' % (msw, ms, msx))
             fl = 2.0 * a.images * h * w * cout * 9 * cin
             k = mult.get((cin, cout, h, w, dil), 1)
             tot_ms += ms * k

@@ -159,3 +159,54 @@ def test_gemm_x3_deterministic(dev):
     c1 = ops.gemm_f32x3_nt(a3, b3)
     for _ in range(5):      # the LDS-DMA pipeline has no run-to-run variation (race screen)
         assert torch.equal(ops.gemm_f32x3_nt(a3, b3), c1)
+
+
+@pytest.mark.parametrize('cin,cout,dil,h,w', [(64, 64, 1, 37, 53), (64, 128, 1, 40, 60),
+                                              (128, 256, 1, 19, 23), (512, 512, 2, 20, 31),
+                                              (256, 512, 1, 75, 125)])
+def test_conv3x3_f32x3(dev, cin, cout, dil, h, w):
+    """Held to the tolerance of the fp32-MFMA convolution (tests/test_gpu_ops.py)."""
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(37)
+    n = 2
+    x = rng.uniform(-1, 1, (n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    wp = ops.conv3x3_pack_weight(_t(wt, dev))
+    w3 = ops.split_bf16x3(wp.view(cout, 9 * cin))
+    y = ops.nhwc_to_nchw(ops.conv3x3_nhwc_f32x3(xd, w3, _t(b, dev), dil, True)).cpu().numpy()
+    y32 = ops.nhwc_to_nchw(ops.conv3x3_nhwc(xd, wp, _t(b, dev), dil, True)).cpu().numpy()
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(y - ref).max() < 1e-5 * scale
+    assert np.abs(y - ref).max() <= 2.0 * np.abs(y32 - ref).max() + 1e-6 * scale
+    # no bias / no ReLU
+    y2 = ops.conv3x3_nhwc_f32x3(xd, w3, None, dil, False)
+    r2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, padding=dil,
+                  dilation=dil).numpy()
+    assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 1e-5 * scale
+
+
+@pytest.mark.parametrize('cin,cout,dil,h,w', [(128, 256, 1, 19, 23), (512, 512, 2, 20, 31),
+                                              (256, 256, 1, 38, 63)])
+def test_conv3x3_winograd_f32x3(dev, cin, cout, dil, h, w):
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(38)
+    n = 2
+    x = rng.uniform(-1, 1, (n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    u = ops.winograd_weight_transform(_t(wt, dev))
+    y32 = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc(xd, u, _t(b, dev), dil, True)).cpu().numpy()
+    y = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc_f32x3(xd, ops.split_bf16x3(u), _t(b, dev), dil,
+                                                         True)).cpu().numpy()
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(y - ref).max() < 1e-4 * scale          # the fp32 Winograd test's bound
+    assert np.abs(y - ref).max() <= 2.0 * np.abs(y32 - ref).max() + 1e-6 * scale
