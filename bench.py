@@ -40,6 +40,7 @@ def parse():
                     help='initialise RCCL and run the all-reduce schedule even with one rank '
                          '(exercises the N>1 code path on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--allreduce-chunks', type=int, default=0, help='0 = auto (engine.py)')
     ap.add_argument('--no-conv-x3', action='store_true',
                     help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
     ap.add_argument('--wino-x3', action='store_true',
@@ -111,7 +112,7 @@ def main():
     B = args.images_per_gpu
     eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
                       weight_decay=5e-4, iter_size=1, gpu_num=world * B, seed=11,
-                      process_group=pg, world_size=world, allreduce_chunks=1,
+                      process_group=pg, world_size=world, allreduce_chunks=args.allreduce_chunks,
                       mfma_dtype=args.mfma_dtype)
     if args.force_dist:
         eng.reducer.force = True

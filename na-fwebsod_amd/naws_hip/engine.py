@@ -92,8 +92,8 @@ class ParamArena(object):
 class WsddnEngine(object):
     def __init__(self, num_classes, device, dilation=2, roi_size=7, dropout=0.5, is_mean=True,
                  momentum=0.9, weight_decay=5e-4, iter_size=1, gpu_num=1, seed=11,
-                 process_group=None, world_size=1, allreduce_chunks=1, freeze_conv_body=True,
-                 mfma_dtype='fp32'):
+                 process_group=None, world_size=1, allreduce_chunks=0, freeze_conv_body=True,
+                 mfma_dtype='fp32x3'):
         if not freeze_conv_body:
             raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
                                       '(SURVEY.md fact 2): the conv body has no backward')
@@ -123,7 +123,14 @@ class WsddnEngine(object):
         self.seed = int(seed)
         self.pg, self.world_size = process_group, int(world_size)
         self.reducer = ArenaReducer(process_group, world_size)
-        self.allreduce_chunks = max(1, int(allreduce_chunks))
+        # fc6_w's gradient (822 MB of the 958 MB all-reduce) can be reduced in row chunks while
+        # the rest of its wgrad GEMM still runs.  0 = auto: one message when the collective fits
+        # under the next iteration's parameter-free conv body + RoIPool (~7 ms: 4 and 8 ranks use
+        # 3 / 7 xGMI links per GPU), two chunks at world_size 2, where a single link carries the
+        # whole exchange (~6-13 ms) and the 0.5 ms a chunked GEMM loses to tile quantisation is
+        # the cheaper side
+        ac = int(allreduce_chunks)
+        self.allreduce_chunks = ac if ac >= 1 else (2 if int(world_size) == 2 else 1)
         self.k6 = 512 * roi_size * roi_size
 
         self.arena = ParamArena(head_param_specs(self.C, 512, roi_size), device)
