@@ -334,6 +334,17 @@ int64_t naws_winograd_f32x3_workspace_floats(int N, int H, int W, int Cin, int C
 int naws_conv3x3_winograd_nhwc_f32x3_fwd(const float* X, const void* U3, const float* bias, int N,
                                          int H, int W, int Cin, int Cout, int dilation, int relu,
                                          float* workspace, float* Y, void* stream);
+/* ---- inference post-processing ------------------------------------------------
+ * Greedy NMS for `batch` independent box lists (= the classes of one image) in one call.
+ * replaces: detectron/utils/cython_nms.pyx:36-87 `nms`, called per class from
+ * detectron/core/test_wsl.py:803-863.  boxes[batch][n_max][4] = (x1,y1,x2,y2) of each list's
+ * candidates ALREADY in visiting order (descending score), counts[batch] = candidates per list.
+ * keep[batch][n_max] <- 1 where the box survives (0 beyond counts[b]).  Same fp32 arithmetic and
+ * comparison (suppress when IoU >= thresh, +1 pixel areas) as the reference loop.
+ * workspace: naws_nms_workspace_bytes(batch, n_max) bytes, 8-byte aligned.  n_max <= 16384. */
+int64_t naws_nms_workspace_bytes(int batch, int n_max);
+int naws_nms_sorted_fwd(const float* boxes, const int32_t* counts, int batch, int n_max,
+                        float thresh, void* workspace, int32_t* keep, void* stream);
 
 #ifdef __cplusplus
 }

@@ -112,22 +112,51 @@ def im_detect_bbox_aug(executor, im, boxes, obn_scores):
 
 
 def nms(dets, thresh):
-    """Greedy NMS on [n,5] (x1,y1,x2,y2,score); returns kept indices (cython_nms.pyx `nms`)."""
-    if dets.shape[0] == 0:
+    """Greedy NMS on [n,5] (x1,y1,x2,y2,score); returns the kept indices in ascending order
+    (cython_nms.pyx:36-87: a box is suppressed when IoU >= thresh; `np.where(suppressed == 0)`).
+    Host (numpy) form, used when the detections are not on a GPU."""
+    n = dets.shape[0]
+    if n == 0:
         return []
+    dets = np.asarray(dets, np.float32)
     x1, y1, x2, y2, sc = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3], dets[:, 4]
-    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
-    order = sc.argsort()[::-1]
-    keep = []
-    while order.size > 0:
-        i = order[0]
-        keep.append(int(i))
-        xx1, yy1 = np.maximum(x1[i], x1[order[1:]]), np.maximum(y1[i], y1[order[1:]])
-        xx2, yy2 = np.minimum(x2[i], x2[order[1:]]), np.minimum(y2[i], y2[order[1:]])
-        inter = np.maximum(0.0, xx2 - xx1 + 1) * np.maximum(0.0, yy2 - yy1 + 1)
-        ovr = inter / (areas[i] + areas[order[1:]] - inter)
-        order = order[1:][ovr <= thresh]
-    return keep
+    areas = (x2 - x1 + np.float32(1)) * (y2 - y1 + np.float32(1))
+    order = np.argsort(-sc, kind='stable')
+    suppressed = np.zeros((n,), bool)
+    thresh = np.float32(thresh)
+    for _i in range(n):
+        i = order[_i]
+        if suppressed[i]:
+            continue
+        rest = order[_i + 1:]
+        xx1, yy1 = np.maximum(x1[i], x1[rest]), np.maximum(y1[i], y1[rest])
+        xx2, yy2 = np.minimum(x2[i], x2[rest]), np.minimum(y2[i], y2[rest])
+        inter = (np.maximum(np.float32(0), xx2 - xx1 + np.float32(1)) *
+                 np.maximum(np.float32(0), yy2 - yy1 + np.float32(1)))
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        suppressed[rest[ovr >= thresh]] = True
+    return np.where(~suppressed)[0].tolist()
+
+
+def nms_all_classes(scores, boxes):
+    """cls -> kept row indices (ascending) for every foreground class of one image.  On a GPU box
+    all classes go through one HIP launch pair (naws_nms_sorted_fwd); otherwise the numpy loop."""
+    num_classes = cfg.MODEL.NUM_CLASSES
+    import torch
+    if torch.cuda.is_available():
+        from naws_hip import ops
+        dev = torch.device('cuda', torch.cuda.current_device())
+        sd = torch.as_tensor(np.ascontiguousarray(scores[:, 1:], np.float32), device=dev)
+        bd = torch.as_tensor(np.ascontiguousarray(boxes, np.float32), device=dev)
+        keep = ops.nms_per_class(bd, sd, cfg.TEST.SCORE_THRESH, cfg.TEST.NMS).cpu().numpy()
+        return {j: np.where(keep[j - 1])[0] for j in range(1, num_classes)}
+    out = {}
+    for j in range(1, num_classes):
+        inds = np.where(scores[:, j] > cfg.TEST.SCORE_THRESH)[0]
+        bj = boxes[inds, j * 4:(j + 1) * 4] if boxes.shape[1] > 4 else boxes[inds]
+        dets = np.hstack((bj, scores[inds, j][:, np.newaxis])).astype(np.float32, copy=False)
+        out[j] = inds[nms(dets, cfg.TEST.NMS)]
+    return out
 
 
 def box_results_with_nms_and_limit(scores, boxes):
@@ -135,11 +164,12 @@ def box_results_with_nms_and_limit(scores, boxes):
     -> (scores, boxes, cls_boxes) with cls_boxes[j] = [n_j,5] for class j (0 = background)."""
     num_classes = cfg.MODEL.NUM_CLASSES
     cls_boxes = [np.zeros((0, 5), np.float32) for _ in range(num_classes)]
+    kept = nms_all_classes(scores, boxes)
     for j in range(1, num_classes):
-        inds = np.where(scores[:, j] > cfg.TEST.SCORE_THRESH)[0]
-        dets = np.hstack((boxes[inds, :], scores[inds, j][:, np.newaxis])).astype(np.float32,
-                                                                                  copy=False)
-        cls_boxes[j] = dets[nms(dets, cfg.TEST.NMS), :]
+        inds = kept[j]
+        bj = boxes[inds, j * 4:(j + 1) * 4] if boxes.shape[1] > 4 else boxes[inds, :]
+        cls_boxes[j] = np.hstack((bj, scores[inds, j][:, np.newaxis])).astype(np.float32,
+                                                                              copy=False)
     if cfg.TEST.DETECTIONS_PER_IM > 0:
         all_scores = np.hstack([cls_boxes[j][:, -1] for j in range(1, num_classes)])
         if len(all_scores) > cfg.TEST.DETECTIONS_PER_IM:

@@ -60,6 +60,7 @@ PROTOTYPES = {
     'naws_transpose_to_bf16': [p, i32, i32, i32, i32, i32, p, p],
     'naws_conv3x3_nhwc_f32x3_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
     'naws_conv3x3_winograd_nhwc_f32x3_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p],
+    'naws_nms_sorted_fwd': [p, p, i32, i32, f32, p, p, p],
     'naws_split_bf16x3': [p, i32, i32, i32, i32, i64, i32, i32, p, p],
     'naws_gemm_f32x3_nt': [i32, i32, i32, p, i64, i64, p, i64, i64, p, i32, i32, i64, i64, i64,
                            i32, p, i64, p, i32, f32, f32, u64, i32, p],
@@ -69,6 +70,7 @@ SPECIAL = {
     'naws_last_hip_error': ([], i32),
     'naws_entropy_gate_workspace_floats': ([i32, i32, i32, i32], i64),
     'naws_winograd_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
+    'naws_nms_workspace_bytes': ([i32, i32], i64),
     'naws_winograd_f32x3_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(SPECIAL))

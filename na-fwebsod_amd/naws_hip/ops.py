@@ -310,6 +310,36 @@ def conv3x3_winograd_nhwc_f32x3(x, u3, bias, dilation=1, relu=True, out=None):
     return y
 
 
+def nms_per_class(boxes, scores, score_thresh, nms_thresh):
+    """Per-class greedy NMS of one image on the GPU (cython_nms.pyx `nms` semantics).
+    boxes [R,4] (or [R,4*C] class-tiled, the reference's pred_boxes), scores [R,C] (fg classes).
+    -> keep [C,R] bool: box r survives for class c (score > score_thresh and not suppressed).
+    Visiting order per class = stable descending score."""
+    r, c = scores.shape
+    dev = scores.device
+    if r == 0:
+        return torch.zeros((c, 0), dtype=torch.bool, device=dev)
+    st = scores.t().contiguous()                                  # [C,R]
+    valid = st > score_thresh
+    key = torch.where(valid, st, torch.full_like(st, -float('inf')))
+    order = torch.sort(key, dim=1, descending=True, stable=True).indices     # candidates first
+    counts = valid.sum(dim=1).to(torch.int32).contiguous()
+    if boxes.shape[1] == 4:
+        sb = boxes[order]                                         # [C,R,4]
+    else:
+        b3 = boxes.view(r, -1, 4)
+        off = b3.shape[1] - c                                     # skip the background column(s)
+        sb = b3[order, (torch.arange(c, device=dev) + off)[:, None]]
+    sb = sb.to(_f32).contiguous()
+    ws = torch.empty((L.load().naws_nms_workspace_bytes(c, r) // 8,), dtype=torch.int64, device=dev)
+    keep_sorted = torch.empty((c, r), dtype=torch.int32, device=dev)
+    L.call('naws_nms_sorted_fwd', sb.data_ptr(), counts.data_ptr(), c, r, float(nms_thresh),
+           ws.data_ptr(), keep_sorted.data_ptr(), _stream())
+    keep = torch.zeros((c, r), dtype=torch.bool, device=dev)
+    keep.scatter_(1, order, keep_sorted.bool())
+    return keep
+
+
 def planes_to_dense(p):
     """[3, (b,) K/16, outer, 16] planes -> float64 [(b,) outer, K] (test / debug helper)."""
     s = p[0].double() + p[1].double() + p[2].double()

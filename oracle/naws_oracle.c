@@ -333,3 +333,38 @@ void oracle_entropy_gate(const float* rois, const float* rois_pred, const float*
   }
   free(J); free(E);
 }
+
+/* Greedy NMS.  ref: detectron/utils/cython_nms.pyx:36-87 (`nms`): areas with the +1 pixel
+ * convention, boxes visited in the given score order, box j suppressed when
+ * inter / (area_i + area_j - inter) >= thresh (fp32 arithmetic, in this operation order).
+ * `order` is the visiting order (descending score; the reference takes scores.argsort()[::-1]);
+ * suppressed[n] is written (1 = suppressed); returns the number kept. */
+int oracle_nms(const float* dets /* [n][5] x1 y1 x2 y2 score */, const int64_t* order, int n,
+               float thresh, int32_t* suppressed) {
+  int kept = 0;
+  for (int i = 0; i < n; ++i) suppressed[i] = 0;
+  for (int _i = 0; _i < n; ++_i) {
+    const int i = (int)order[_i];
+    if (suppressed[i]) continue;
+    ++kept;
+    const float ix1 = dets[i * 5 + 0], iy1 = dets[i * 5 + 1];
+    const float ix2 = dets[i * 5 + 2], iy2 = dets[i * 5 + 3];
+    const float iarea = (ix2 - ix1 + 1) * (iy2 - iy1 + 1);
+    for (int _j = _i + 1; _j < n; ++_j) {
+      const int j = (int)order[_j];
+      if (suppressed[j]) continue;
+      const float jarea = (dets[j * 5 + 2] - dets[j * 5 + 0] + 1) * (dets[j * 5 + 3] - dets[j * 5 + 1] + 1);
+      const float xx1 = ix1 >= dets[j * 5 + 0] ? ix1 : dets[j * 5 + 0];
+      const float yy1 = iy1 >= dets[j * 5 + 1] ? iy1 : dets[j * 5 + 1];
+      const float xx2 = ix2 <= dets[j * 5 + 2] ? ix2 : dets[j * 5 + 2];
+      const float yy2 = iy2 <= dets[j * 5 + 3] ? iy2 : dets[j * 5 + 3];
+      float w = xx2 - xx1 + 1, h = yy2 - yy1 + 1;
+      w = 0.0f >= w ? 0.0f : w;
+      h = 0.0f >= h ? 0.0f : h;
+      const float inter = w * h;
+      const float ovr = inter / (iarea + jarea - inter);
+      if (ovr >= thresh) suppressed[j] = 1;
+    }
+  }
+  return kept;
+}

@@ -190,6 +190,20 @@ VGG16_LAYERS = [
 ]
 
 
+def nms(dets, thresh):
+    """Greedy NMS on [n,5] (x1,y1,x2,y2,score) -> kept indices, ascending
+    (ref: detectron/utils/cython_nms.pyx:36-87).  Visiting order = stable descending score."""
+    dets, dp = _f(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return np.zeros((0,), np.int64)
+    order = np.ascontiguousarray(np.argsort(-dets[:, 4], kind='stable').astype(np.int64))
+    sup = np.zeros((n,), np.int32)
+    L().oracle_nms(dp, order.ctypes.data_as(C.c_void_p), n, C.c_float(thresh),
+                   sup.ctypes.data_as(_ip))
+    return np.where(sup == 0)[0]
+
+
 def vgg16_conv5_body(data, blobs):
     """ref: detectron/modeling/VGG16.py:9-48 with WSL.DILATION == 2.
     data: torch CPU [N,3,H,W]; blobs: {name_w: [O,I,3,3], name_b: [O]} -> conv5_3 NCHW."""

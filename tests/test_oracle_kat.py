@@ -150,3 +150,27 @@ def test_golden_python_reference_pairs():
     assert np.array_equal(blob['labels_int32'], z['s_labels_int32'])
     assert np.array_equal(blob['labels_oh'], z['s_labels_oh'])
     c.reset_cfg()
+
+
+def test_nms_known_answers_and_host_mirror():
+    """cython_nms.pyx:36-87: +1 areas, suppress at IoU >= thresh, kept indices ascending."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'na-fwebsod_amd'))
+    from oracle import oracle
+    from detectron.core import test_wsl
+    d = np.array([[0, 0, 9, 9, 0.9], [5, 5, 14, 14, 0.8], [0, 0, 9, 9, 0.7], [20, 20, 29, 29, 0.6]],
+                 np.float32)
+    # inter 25, union 175 -> IoU = 1/7
+    assert oracle.nms(d, 0.3).tolist() == [0, 1, 3]
+    assert oracle.nms(d, np.float32(25.0) / np.float32(175.0)).tolist() == [0, 3]   # >= is inclusive
+    assert oracle.nms(d, 0.15).tolist() == [0, 1, 3]
+    assert oracle.nms(d[::-1].copy(), 0.3).tolist() == [0, 2, 3]                     # ascending index
+    rng = np.random.default_rng(5)
+    for n in (1, 17, 300):
+        xy = rng.integers(0, 60, (n, 2)).astype(np.float32)
+        wh = rng.integers(1, 40, (n, 2)).astype(np.float32)
+        sc = rng.integers(0, 50, (n, 1)).astype(np.float32) / 50.0        # many tied scores
+        dets = np.hstack([xy, xy + wh, sc]).astype(np.float32)
+        for th in (0.3, 0.5, 0.0):
+            assert test_wsl.nms(dets, th) == oracle.nms(dets, th).tolist()
+    assert test_wsl.nms(np.zeros((0, 5), np.float32), 0.5) == []
