@@ -494,3 +494,74 @@ extern "C" int naws_dropout_mask(uint64_t seed, float drop_ratio, int64_t n, flo
                      seed, naws_drop_threshold(drop_ratio), n, mask);
   return naws_check_launch();
 }
+
+// ---- image preparation of the minibatch loader on the GPU ------------------
+// replaces, per image: detectron/roi_data/minibatch_wsl.py:121-157 (flip, crop) and
+// detectron/utils/blob.py:100-131 prep_im_for_blob (float32, - PIXEL_MEANS, / PIXEL_STDS,
+// cv2.resize(fx = fy = im_scale, INTER_LINEAR)) + blob.py:67-97 im_list_to_blob (HWC -> CHW into
+// the zero-padded batch blob).  cv2.resize's float INTER_LINEAR path is restated from OpenCV's
+// published algorithm (imgproc/resize.cpp: pixel-centre mapping fx = (dx+0.5)/im_scale - 0.5 in
+// double -> float, floor, edge taps clamped with weight 1, horizontal pass then vertical pass).
+namespace {
+__global__ __launch_bounds__(256) void prep_image_kernel(
+    const unsigned char* __restrict__ im, int W, int flip, int cy0, int cx0, int ch, int cw,
+    float m0, float m1, float m2, float s0, float s1, float s2, double inv_scale, int oh, int ow,
+    long long plane_stride, int row_stride, float* __restrict__ out) {
+  // Every product and sum is rounded separately, like the numpy / cv2 passes.  (hipcc's
+  // __fmul_rn & co. are inline `x * y` compiled under the header's contract(fast), so plain
+  // operators under this pragma - built with -ffp-contract=fast-honor-pragmas - are used.)
+#pragma clang fp contract(off)
+  const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+  if (dx >= ow) return;
+  const double px = (dx + 0.5) * inv_scale;
+  float fx = (float)(px - 0.5);
+  int sx = (int)floorf(fx);
+  fx = fx - (float)sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= cw - 1) { fx = 0.f; sx = cw - 1; }
+  const double py = (dy + 0.5) * inv_scale;
+  float fy = (float)(py - 0.5);
+  int sy = (int)floorf(fy);
+  fy = fy - (float)sy;
+  if (sy < 0) { fy = 0.f; sy = 0; }
+  if (sy >= ch - 1) { fy = 0.f; sy = ch - 1; }
+  const int sx1 = min(sx + 1, cw - 1), sy1 = min(sy + 1, ch - 1);
+  const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+  const int ys[2] = {cy0 + sy, cy0 + sy1};
+  const int xs[2] = {flip ? (W - 1 - (cx0 + sx)) : (cx0 + sx),       // crop is taken on the
+                     flip ? (W - 1 - (cx0 + sx1)) : (cx0 + sx1)};    // flipped image
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v[2][2];
+#pragma unroll
+    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < 2; ++xx) {
+        const float u = (float)im[((long long)ys[yy] * W + xs[xx]) * 3 + c];
+        const float d = u - mean[c];
+        v[yy][xx] = d / sd[c];
+      }
+    const float t00 = v[0][0] * a0, t01 = v[0][1] * a1, t10 = v[1][0] * a0, t11 = v[1][1] * a1;
+    const float r0 = t00 + t01, r1 = t10 + t11;
+    const float q0 = r0 * b0, q1 = r1 * b1;
+    out[c * plane_stride + (long long)dy * row_stride + dx] = q0 + q1;
+  }
+}
+}  // namespace
+
+extern "C" int naws_prep_image_fwd(const uint8_t* im_bgr_hwc, int H, int W, int flip, int crop_y0,
+                                   int crop_x0, int crop_h, int crop_w, const float* means3,
+                                   const float* stds3, double im_scale, int out_h, int out_w,
+                                   int64_t plane_stride, int row_stride, float* out, void* stream) {
+  if (H <= 0 || W <= 0 || crop_h <= 0 || crop_w <= 0 || out_h <= 0 || out_w <= 0) return NAWS_ERR_SHAPE;
+  if (crop_y0 < 0 || crop_x0 < 0 || crop_y0 + crop_h > H || crop_x0 + crop_w > W) return NAWS_ERR_SHAPE;
+  if (!(im_scale > 0.0) || row_stride < out_w || out_h > 65535) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(im_bgr_hwc); NAWS_REQUIRE_PTR(means3); NAWS_REQUIRE_PTR(stds3); NAWS_REQUIRE_PTR(out);
+  dim3 grid((unsigned)naws_cdiv(out_w, 256), (unsigned)out_h);
+  hipLaunchKernelGGL(prep_image_kernel, grid, dim3(256), 0, (hipStream_t)stream, im_bgr_hwc, W,
+                     flip, crop_y0, crop_x0, crop_h, crop_w, means3[0], means3[1], means3[2],
+                     stds3[0], stds3[1], stds3[2], 1.0 / im_scale, out_h, out_w,
+                     (long long)plane_stride, row_stride, out);
+  return naws_check_launch();
+}

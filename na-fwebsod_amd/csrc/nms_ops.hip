@@ -20,15 +20,20 @@
 namespace {
 
 __device__ __forceinline__ bool nms_suppresses(const float4 a, const float4 b, float thresh) {
-  const float aa = __fmul_rn(__fadd_rn(__fsub_rn(a.z, a.x), 1.f), __fadd_rn(__fsub_rn(a.w, a.y), 1.f));
-  const float ab = __fmul_rn(__fadd_rn(__fsub_rn(b.z, b.x), 1.f), __fadd_rn(__fsub_rn(b.w, b.y), 1.f));
+  // plain operators, each rounded on its own (built with -ffp-contract=fast-honor-pragmas)
+#pragma clang fp contract(off)
+  const float aw = a.z - a.x + 1.f, ah = a.w - a.y + 1.f;
+  const float bw = b.z - b.x + 1.f, bh = b.w - b.y + 1.f;
+  const float aa = aw * ah, ab = bw * bh;
   const float xx1 = a.x >= b.x ? a.x : b.x, yy1 = a.y >= b.y ? a.y : b.y;
   const float xx2 = a.z <= b.z ? a.z : b.z, yy2 = a.w <= b.w ? a.w : b.w;
-  float w = __fadd_rn(__fsub_rn(xx2, xx1), 1.f), h = __fadd_rn(__fsub_rn(yy2, yy1), 1.f);
+  float w = xx2 - xx1 + 1.f, h = yy2 - yy1 + 1.f;
   w = 0.f >= w ? 0.f : w;
   h = 0.f >= h ? 0.f : h;
-  const float inter = __fmul_rn(w, h);
-  const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(aa, ab), inter));
+  const float inter = w * h;
+  const float sum = aa + ab;
+  const float uni = sum - inter;
+  const float ovr = inter / uni;
   return ovr >= thresh;
 }
 

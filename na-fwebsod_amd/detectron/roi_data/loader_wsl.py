@@ -165,11 +165,16 @@ class RoIDataLoader(object):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=device)
         out = {}
+        raws, mixes = host.pop('_raw', None), host.pop('_mix', None)
         counts = np.bincount(host['rois'][:, 0].astype(np.int64), minlength=host['data'].shape[0])
         seg = [0] + np.cumsum(counts).tolist()
         with torch.cuda.stream(self._copy_stream):
             for k, v in host.items():
+                if raws is not None and k == 'data':
+                    continue
                 out[k] = torch.from_numpy(v).pin_memory().to(device, non_blocking=True)
+            if raws is not None:
+                out['data'] = device_prep_images(raws, mixes, device)
         torch.cuda.current_stream(device).wait_stream(self._copy_stream)
         for v in out.values():
             v.record_stream(torch.cuda.current_stream(device))
@@ -177,11 +182,45 @@ class RoIDataLoader(object):
         return out
 
 
+def device_prep_images(raws, mixes, device):
+    """`raws`: per batch image, a list of one raw image dict (or two: a bagging-mixup pair);
+    -> float32 [B,3,Hmax,Wmax] on `device`, each image prepared by naws_prep_image_fwd into its
+    zero-padded slot (blob.py:67-97), pairs blended lam*im0 + (1-lam)*im1 (loader_wsl.py:152)."""
+    import torch
+    from naws_hip import ops, lib as L
+    hmax = max(r['out_hw'][0] for grp in raws for r in grp)
+    wmax = max(r['out_hw'][1] for grp in raws for r in grp)
+    data = torch.zeros((len(raws), 3, hmax, wmax), device=device, dtype=torch.float32)
+    means, stds = cfg.PIXEL_MEANS.reshape(-1)[:3], np.asarray(cfg.PIXEL_STDS).reshape(-1)[:3]
+
+    def prep(r, out):
+        im = torch.from_numpy(r['im']).pin_memory().to(device, non_blocking=True)
+        ops.prep_image(im, out, r['scale'], flip=r['flip'], crop=r['crop'], means=means, stds=stds)
+        im.record_stream(torch.cuda.current_stream(device))
+    for i, grp in enumerate(raws):
+        if len(grp) == 1:
+            prep(grp[0], data[i])
+            continue
+        lam = float(mixes[i])
+        t = torch.zeros((2, 3, hmax, wmax), device=device, dtype=torch.float32)
+        prep(grp[0], t[0])
+        prep(grp[1], t[1])
+        a = ops.unary(L.UN_SCALE, t[0].reshape(-1), np.float32(lam))
+        b = ops.unary(L.UN_SCALE, t[1].reshape(-1), np.float32(1 - lam))
+        ops.binary(L.BIN_ADD, a.view(1, -1), b.view(1, -1), out=data[i].view(1, -1))
+    return data
+
+
 def mixup_blobs(blobs, lam):
     """data = lam*im0 + (1-lam)*im1, labels_oh likewise, all rois on batch index 0
     (loader_wsl.py:149-168)."""
     out = dict(blobs)
-    out['data'] = (lam * blobs['data'][0:1] + (1 - lam) * blobs['data'][1:2]).astype(np.float32)
+    if '_raw' in blobs:          # device-side preparation: blend there
+        out['_raw'] = [list(blobs['_raw'])]
+        out['_mix'] = [lam]
+        out['data'] = blobs['data'][0:1]
+    else:
+        out['data'] = (lam * blobs['data'][0:1] + (1 - lam) * blobs['data'][1:2]).astype(np.float32)
     out['labels_oh'] = (lam * blobs['labels_oh'][0:1] +
                         (1 - lam) * blobs['labels_oh'][1:2]).astype(np.float32)
     rois = blobs['rois'].copy()
@@ -195,6 +234,11 @@ def mixup_blobs(blobs, lam):
 def collate(parts):
     """Stack single-image minibatches into one batch (per-GPU B > 1 is an extension of the
     reference, which asserts IMS_PER_BATCH == 1: wsl_heads.py:214)."""
+    if '_raw' in parts[0]:
+        # each part: '_raw' is [raw] (plain) or [[raw0, raw1]] (mixup, with '_mix' = [lam])
+        for p in parts:
+            if not isinstance(p['_raw'][0], list):
+                p['_raw'], p['_mix'] = [list(p['_raw'])], [None]
     if len(parts) == 1:
         return parts[0]
     hmax = max(p['data'].shape[2] for p in parts)
@@ -209,4 +253,7 @@ def collate(parts):
     out = {'data': data, 'rois': np.concatenate(rois)}
     for k in ('data_ids', 'obn_scores', 'labels_int32', 'labels_oh'):
         out[k] = np.concatenate([p[k] for p in parts])
+    if '_raw' in parts[0]:
+        out['_raw'] = [p['_raw'][0] for p in parts]
+        out['_mix'] = [p['_mix'][0] for p in parts]
     return out

@@ -3,10 +3,14 @@ Mirrors detectron/roi_data/minibatch_wsl.py:25-50 (blob order contract), :53-90
 (get_minibatch), :93-108 (_get_image_id_blob), :111-171 (_get_image_blob) and
 detectron/utils/blob.py:67-131 (im_list_to_blob / prep_im_for_blob).
 
-cv2 is not available on the MI355X image: file images are decoded and resized with PIL
-(bilinear), synthetic roidb entries (detectron.datasets.synthetic) generate their pixels
-from a per-entry seed.  HSV distortion is the one augmentation not restated (it needs the
-OpenCV colour transform); it is rejected loudly rather than skipped silently.
+cv2 is not available on the MI355X image: file images are decoded with PIL, synthetic roidb
+entries (detectron.datasets.synthetic) generate their pixels from a per-entry seed, and
+cv2.resize(INTER_LINEAR) is restated (`resize_linear`, same pixel-centre mapping and edge rule).
+With NAWS.DEVICE_PREP the float conversion, mean/std, flip, crop, resize and HWC->CHW padding run
+on the GPU (naws_prep_image_fwd): the loader threads then only decode, and a minibatch carries
+the raw uint8 images + their parameters (`_raw`) instead of a float `data` blob.
+HSV distortion is the one augmentation not restated (it needs the OpenCV colour transform); it
+is rejected loudly rather than skipped silently.
 """
 import os
 
@@ -22,14 +26,22 @@ def get_minibatch_blob_names(is_training=True):
     return ['data', 'data_ids'] + wsl_roi_data.get_wsl_blob_names(is_training=is_training)
 
 
-def get_minibatch(roidb):
+def get_minibatch(roidb, raw=None):
+    """raw=True (default: cfg.NAWS.DEVICE_PREP): `data` is a placeholder and blobs['_raw'] holds
+    one dict per image (uint8 pixels, flip, crop, scale) for the device-side preparation."""
+    raw = cfg.NAWS.DEVICE_PREP if raw is None else raw
     blobs = {k: [] for k in get_minibatch_blob_names()}
-    im_blob, im_scales, im_crops = _get_image_blob(roidb)
+    im_blob, im_scales, im_crops = _get_image_blob(roidb, raw=raw)
+    raws = im_blob if raw else None
+    if raw:
+        im_blob = np.zeros((len(roidb), 3, 1, 1), np.float32)
     # crops are (y1,x1,y2,x2) -> (x1,y1,x2,y2)
     im_crops = np.array(im_crops, dtype=np.int32)[:, (1, 0, 3, 2)]
     blobs['data'] = im_blob
     blobs['data_ids'] = _get_image_id_blob(roidb)
     valid = wsl_roi_data.add_wsl_blobs(blobs, im_scales, im_crops, roidb)
+    if raw:
+        blobs['_raw'] = raws
     return blobs, valid
 
 
@@ -53,22 +65,46 @@ def _read_image(entry):
     return rgb[:, :, ::-1].copy()
 
 
+def resize_linear(im, im_scale):
+    """cv2.resize(im, None, None, fx=im_scale, fy=im_scale, interpolation=cv2.INTER_LINEAR) on a
+    float32 HxWxC image (blob.py:123-130): destination size cvRound(size*scale); source position
+    float((d+0.5)/scale - 0.5); the two taps floor(pos), +1 with weights (1-frac, frac), clamped
+    to the edge pixel with weight 1; rows first, then columns of rows."""
+    im = np.asarray(im, np.float32)
+    h, w = im.shape[:2]
+    oh, ow = int(np.round(h * im_scale)), int(np.round(w * im_scale))
+
+    def taps(n_dst, n_src):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) / float(im_scale) - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = f - s0.astype(np.float32)
+        f[s0 < 0] = 0.0
+        s0[s0 < 0] = 0
+        f[s0 >= n_src - 1] = 0.0
+        s0[s0 >= n_src - 1] = n_src - 1
+        return s0, np.minimum(s0 + 1, n_src - 1), np.float32(1) - f, f
+    sx, sx1, a0, a1 = taps(ow, w)
+    sy, sy1, b0, b1 = taps(oh, h)
+    rows = im[:, sx, :] * a0[None, :, None] + im[:, sx1, :] * a1[None, :, None]
+    return (rows[sy] * b0[:, None, None] + rows[sy1] * b1[:, None, None]).astype(np.float32)
+
+
+def get_im_scale(shape_hw, target_size, max_size):
+    size_min, size_max = min(shape_hw), max(shape_hw)
+    im_scale = float(target_size) / float(size_min)
+    if np.round(im_scale * size_max) > max_size:      # cap the long side (blob.py:119-122)
+        im_scale = float(max_size) / float(size_max)
+    return im_scale
+
+
 def prep_im_for_blob(im, pixel_means, target_size, max_size):
-    """Mean-subtract, scale the short side to target_size (long side capped at max_size)."""
+    """float32, - PIXEL_MEANS, / PIXEL_STDS, scale the short side to target_size (long side
+    capped at max_size) (blob.py:100-131)."""
     im = im.astype(np.float32, copy=False)
     im = im - np.asarray(pixel_means, np.float32).reshape(1, 1, 3)
-    size_min, size_max = min(im.shape[:2]), max(im.shape[:2])
-    im_scale = float(target_size) / float(size_min)
-    if np.round(im_scale * size_max) > max_size:
-        im_scale = float(max_size) / float(size_max)
-    if im_scale != 1.0:
-        from PIL import Image
-        h = int(round(im.shape[0] * im_scale))
-        w = int(round(im.shape[1] * im_scale))
-        chans = [np.asarray(Image.fromarray(im[:, :, c], mode='F').resize((w, h), Image.BILINEAR))
-                 for c in range(3)]
-        im = np.stack(chans, 2)
-    return im, im_scale
+    im = im / np.asarray(cfg.PIXEL_STDS, np.float32).reshape(1, 1, 3)
+    im_scale = get_im_scale(im.shape[:2], target_size, max_size)
+    return resize_linear(im, im_scale), im_scale
 
 
 def im_list_to_blob(ims):
@@ -82,13 +118,12 @@ def im_list_to_blob(ims):
     return blob.transpose((0, 3, 1, 2)).copy()
 
 
-def _get_image_blob(roidb):
+def _get_image_blob(roidb, raw=False):
     scale_inds = npr.randint(0, high=len(cfg.TRAIN.SCALES), size=len(roidb))
     ims, scales, crops = [], [], []
     for i, entry in enumerate(roidb):
-        im = _read_image(entry)
-        if entry['flipped']:
-            im = im[:, ::-1, :]
+        im0 = _read_image(entry)
+        im = im0[:, ::-1, :] if entry['flipped'] else im0
         if cfg.WSL.USE_DISTORTION:
             raise NotImplementedError('WSL.USE_DISTORTION needs the OpenCV HSV transform, '
                                       'which this image lacks; set WSL.USE_DISTORTION False')
@@ -104,9 +139,15 @@ def _get_image_blob(roidb):
             im = im[crop[0]:crop[2] + 1, crop[1]:crop[3] + 1, :]
         else:
             crop = np.array([0, 0, im.shape[0] - 1, im.shape[1] - 1], dtype=np.int32)
-        im, sc = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TRAIN.SCALES[scale_inds[i]],
-                                  cfg.TRAIN.MAX_SIZE)
-        ims.append(im)
+        if raw:
+            sc = get_im_scale(im.shape[:2], cfg.TRAIN.SCALES[scale_inds[i]], cfg.TRAIN.MAX_SIZE)
+            ims.append(dict(im=np.ascontiguousarray(im0), flip=bool(entry['flipped']),
+                            crop=tuple(int(v) for v in crop), scale=sc,
+                            out_hw=(int(np.round(im.shape[0] * sc)), int(np.round(im.shape[1] * sc)))))
+        else:
+            im, sc = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TRAIN.SCALES[scale_inds[i]],
+                                      cfg.TRAIN.MAX_SIZE)
+            ims.append(im)
         scales.append(sc)
         crops.append(crop)
-    return im_list_to_blob(ims), scales, crops
+    return (ims if raw else im_list_to_blob(ims)), scales, crops

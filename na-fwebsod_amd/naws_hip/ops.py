@@ -4,6 +4,7 @@ torch is plumbing only: it owns device memory and the current HIP stream; every
 computation below is one or more hand-written gfx950 kernels in libnaws_hip.so.
 Inputs must be CUDA(HIP) fp32 tensors; anything else raises (no CPU fallback).
 """
+import numpy as np
 import torch
 
 from . import lib as L
@@ -340,6 +341,29 @@ def nms_per_class(boxes, scores, score_thresh, nms_thresh):
     return keep
 
 
+def prep_image(im_u8, out, im_scale, flip=False, crop=None, means=(0.0, 0.0, 0.0),
+               stds=(1.0, 1.0, 1.0)):
+    """Loader image preparation on the GPU.  im_u8: uint8 [H,W,3] BGR device tensor;
+    crop = (y0, x0, y1, x1) inclusive on the (flipped) image; `out` = this image's [3,Hp,Wp]
+    slice of the NCHW batch blob (zero-filled by the caller).  Returns (out_h, out_w)."""
+    import ctypes
+    if im_u8.dtype != torch.uint8 or im_u8.dim() != 3 or im_u8.shape[2] != 3 or not im_u8.is_contiguous():
+        raise TypeError('im_u8 must be a contiguous uint8 [H,W,3] device tensor')
+    h, w = int(im_u8.shape[0]), int(im_u8.shape[1])
+    y0, x0, y1, x1 = crop if crop is not None else (0, 0, h - 1, w - 1)
+    ch, cw = y1 - y0 + 1, x1 - x0 + 1
+    oh, ow = int(np.round(ch * im_scale)), int(np.round(cw * im_scale))   # cvRound: half to even
+    if out.dim() != 3 or out.shape[0] != 3 or out.shape[1] < oh or out.shape[2] < ow or \
+            out.stride(2) != 1 or out.dtype != _f32:
+        raise TypeError('out must be a [3,Hp,Wp] fp32 view with Hp >= %d, Wp >= %d' % (oh, ow))
+    m = (ctypes.c_float * 3)(*[float(v) for v in means])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in stds])
+    L.call('naws_prep_image_fwd', im_u8.data_ptr(), h, w, int(bool(flip)), int(y0), int(x0), ch, cw,
+           ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), float(im_scale), oh,
+           ow, out.stride(0), out.stride(1), out.data_ptr(), _stream())
+    return oh, ow
+
+
 def planes_to_dense(p):
     """[3, (b,) K/16, outer, 16] planes -> float64 [(b,) outer, K] (test / debug helper)."""
     s = p[0].double() + p[1].double() + p[2].double()
@@ -498,12 +522,12 @@ def unary(op, x, a=0.0, b=0.0, out=None):
     return y
 
 
-def binary(op, a, b):
+def binary(op, a, b, out=None):
     _chk(a, 'A'); _chk(b, 'B')
     a2 = a.reshape(-1, a.shape[-1]) if a.dim() >= 1 else a.reshape(1, 1)
     b2 = b.reshape(-1, b.shape[-1]) if b.dim() >= 1 else b.reshape(1, 1)
     rows, cols = max(a2.shape[0], b2.shape[0]), max(a2.shape[1], b2.shape[1])
-    y = torch.empty((rows, cols), device=a.device, dtype=_f32)
+    y = out if out is not None else torch.empty((rows, cols), device=a.device, dtype=_f32)
     L.call('naws_binary_f32', op, a2.data_ptr(), a2.shape[0], a2.shape[1], b2.data_ptr(),
            b2.shape[0], b2.shape[1], y.data_ptr(), rows, cols, _stream())
     return y

@@ -204,6 +204,49 @@ def nms(dets, thresh):
     return np.where(sup == 0)[0]
 
 
+def resize_bilinear_cv2(im, im_scale):
+    """cv2.resize(im, None, None, fx=im_scale, fy=im_scale, interpolation=cv2.INTER_LINEAR) for a
+    float32 HxWxC image.  OpenCV is an un-vendored dependency of the reference
+    (requirements.txt: opencv-python>=3.2, no pin) and is not installed here: this restates the
+    published algorithm of imgproc/resize.cpp (float path): dsize = cvRound(ssize*f); scale =
+    1/f; per destination index fx = float((dx+0.5)*scale-0.5), sx = floor(fx), fx -= sx, taps
+    clamped at both edges with weight 1; horizontal pass, then vertical pass.  PARITY UNPINNED
+    (no cv2 to check against); used at detectron/utils/blob.py:123-130."""
+    im = np.asarray(im, np.float32)
+    h, w = im.shape[:2]
+    oh, ow = int(np.round(h * im_scale)), int(np.round(w * im_scale))
+    inv = 1.0 / float(im_scale)
+
+    def taps(n_dst, n_src):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * inv - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = (f - s0.astype(np.float32)).astype(np.float32)
+        lo = s0 < 0
+        f[lo], s0[lo] = 0.0, 0
+        hi = s0 >= n_src - 1
+        f[hi], s0[hi] = 0.0, n_src - 1
+        return s0, np.minimum(s0 + 1, n_src - 1), (np.float32(1) - f).astype(np.float32), f
+    sx, sx1, a0, a1 = taps(ow, w)
+    sy, sy1, b0, b1 = taps(oh, h)
+    a0, a1 = a0[None, :, None], a1[None, :, None]
+    rows = (im[:, sx, :] * a0 + im[:, sx1, :] * a1).astype(np.float32)        # horizontal
+    return (rows[sy] * b0[:, None, None] + rows[sy1] * b1[:, None, None]).astype(np.float32)
+
+
+def prep_image(im_u8, im_scale, flip=False, crop=None, means=(0, 0, 0), stds=(1, 1, 1)):
+    """Flip, crop, float32, mean/std, resize: minibatch_wsl.py:121-157 + blob.py:100-131.
+    -> float32 [oh, ow, 3] (HWC, as prep_im_for_blob returns it)."""
+    im = np.asarray(im_u8)
+    if flip:
+        im = im[:, ::-1, :]
+    if crop is not None:
+        im = im[crop[0]:crop[2] + 1, crop[1]:crop[3] + 1, :]
+    im = im.astype(np.float32)
+    im = (im - np.asarray(means, np.float32).reshape(1, 1, 3)).astype(np.float32)
+    im = (im / np.asarray(stds, np.float32).reshape(1, 1, 3)).astype(np.float32)
+    return resize_bilinear_cv2(im, im_scale)
+
+
 def vgg16_conv5_body(data, blobs):
     """ref: detectron/modeling/VGG16.py:9-48 with WSL.DILATION == 2.
     data: torch CPU [N,3,H,W]; blobs: {name_w: [O,I,3,3], name_b: [O]} -> conv5_3 NCHW."""

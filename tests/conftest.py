@@ -19,3 +19,11 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+@pytest.fixture
+def cfgmod():
+    from detectron.core import config as c
+    c.reset_cfg()
+    yield c
+    c.reset_cfg()

@@ -147,6 +147,47 @@ def test_loader_threads(cfgmod):
         ld.shutdown()
 
 
+def test_host_image_prep_matches_oracle_and_raw_mode(cfgmod):
+    """prep_im_for_blob (cv2.resize INTER_LINEAR restated) == the oracle's restatement; the
+    device-prep ("raw") minibatch carries the same parameters the host path applies."""
+    c = cfgmod
+    c.merge_cfg_from_file(YAML)
+    c.merge_cfg_from_list(['WSL.USE_DISTORTION', False, 'TRAIN.SCALES', '(96,)',
+                           'TRAIN.MAX_SIZE', 140])
+    from detectron.datasets import synthetic
+    from detectron.roi_data import minibatch_wsl, loader_wsl
+    from oracle import oracle
+    # known answers of cv2.resize on a ramp (2x up: edge taps clamp; 0.5x down: cvRound(1.5) = 2)
+    ramp = np.arange(12, dtype=np.float32).reshape(3, 4, 1)
+    assert minibatch_wsl.resize_linear(ramp, 2.0)[0, :, 0].tolist() == [0, .25, .75, 1.25, 1.75, 2.25, 2.75, 3]
+    assert minibatch_wsl.resize_linear(ramp, 0.5)[:, :, 0].tolist() == [[2.5, 4.5], [8.5, 10.5]]
+    rng = np.random.default_rng(7)
+    im = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for target, cap in ((96, 140), (20, 1000), (37, 1000)):
+        got, sc = minibatch_wsl.prep_im_for_blob(im, c.cfg.PIXEL_MEANS, target, cap)
+        ref = oracle.prep_image(im, sc, means=c.cfg.PIXEL_MEANS.reshape(-1))
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+    roidb = synthetic.make_roidb(2, 10, 20, 40, 64, seed=5)
+    roidb[1]['flipped'] = True
+    np.random.seed(3)
+    host, _ = minibatch_wsl.get_minibatch(roidb[1:], raw=False)
+    np.random.seed(3)
+    raw, _ = minibatch_wsl.get_minibatch(roidb[1:], raw=True)
+    assert np.array_equal(raw['rois'], host['rois']) and raw['data'].shape == (1, 3, 1, 1)
+    r = raw['_raw'][0]
+    assert r['flip'] and r['out_hw'] == host['data'].shape[2:]
+    ref = oracle.prep_image(r['im'], r['scale'], flip=True, crop=r['crop'],
+                            means=c.cfg.PIXEL_MEANS.reshape(-1))
+    assert np.array_equal(ref.transpose(2, 0, 1), host['data'][0])
+    # collate / mixup keep the raw images and the blend factor for the device side
+    parts = [dict(raw), dict(loader_wsl.mixup_blobs(dict(
+        raw, _raw=[r, r], data=np.zeros((2, 3, 1, 1), np.float32),
+        labels_oh=np.eye(20, dtype=np.float32)[:2], labels_int32=np.zeros((2,), np.int32),
+        data_ids=np.zeros((2, 1), np.int32)), 0.3))]
+    out = loader_wsl.collate(parts)
+    assert [len(g) for g in out['_raw']] == [1, 2] and out['_mix'] == [None, 0.3]
+
+
 def test_graph_trace_fixture_shape():
     ops_ = GOLD['trace_train']['ops']
     assert len(ops_) == 103 and ops_[32][0] == 'RoIPoolF' and ops_[33][0] == 'RoIFeatureBoost'

@@ -1,0 +1,71 @@
+"""GPU parity of the loader's image preparation against the oracle's
+restatement of minibatch_wsl.py:121-157 + blob.py:67-131 (cv2.resize INTER_LINEAR): same
+operations in the same order, correctly rounded -> bit-identical float32."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MEANS = (102.9801, 115.9465, 122.7717)
+
+
+@pytest.mark.parametrize('scale', [1.0, 2.0, 0.5, 600.0 / 37.0, 0.731, 1.0 / 3.0])
+@pytest.mark.parametrize('flip', [False, True])
+def test_prep_image_matches_oracle(dev, scale, flip):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(51)
+    im = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for crop in (None, (3, 5, 30, 47), (0, 0, 0, 52), (36, 52, 36, 52)):
+        ref = oracle.prep_image(im, scale, flip=flip, crop=crop, means=MEANS, stds=(1.0, 2.0, 0.5))
+        oh, ow = ref.shape[:2]
+        if oh == 0 or ow == 0:
+            continue
+        out = torch.full((3, oh + 2, ow + 3), 7.0, device=dev)
+        got = ops.prep_image(torch.from_numpy(im).to(dev), out, scale, flip=flip, crop=crop,
+                             means=MEANS, stds=(1.0, 2.0, 0.5))
+        assert got == (oh, ow)
+        o = out.cpu().numpy()
+        assert np.array_equal(o[:, :oh, :ow], ref.transpose(2, 0, 1))
+        assert (o[:, oh:, :] == 7.0).all() and (o[:, :, ow:] == 7.0).all()   # padding untouched
+
+
+def test_prep_image_errors(dev):
+    from naws_hip import ops, lib
+    im = torch.zeros((8, 8, 3), dtype=torch.uint8, device=dev)
+    with pytest.raises(TypeError):
+        ops.prep_image(im, torch.zeros((3, 4, 4), device=dev), 1.0)          # slot too small
+    with pytest.raises(lib.NawsError):
+        ops.prep_image(im, torch.zeros((3, 32, 32), device=dev), 1.0, crop=(0, 0, 8, 8))
+
+
+def test_loader_device_prep_equals_host_path(dev, cfgmod):
+    """NAWS.DEVICE_PREP: the batch the loader stages on the GPU equals the host-prepared batch
+    (same RNG), including zero padding of B = 2 images of different sizes and a mixup pair."""
+    import os
+    c = cfgmod
+    c.merge_cfg_from_file(os.path.join(os.path.dirname(__file__), '..', 'na-fwebsod_amd', 'configs',
+                                       'flickr_voc', 'na_wsddn_V-16-C5_1x.yaml'))
+    c.merge_cfg_from_list(['WSL.USE_DISTORTION', False, 'TRAIN.SCALES', '(48, 64)',
+                           'TRAIN.MAX_SIZE', 100, 'NAWS.DEVICE_PREP', True])
+    from detectron.datasets import synthetic
+    from detectron.roi_data import minibatch_wsl, loader_wsl
+    roidb = synthetic.make_roidb(3, 10, 20, 40, 64, seed=5)
+    roidb[1]['flipped'] = True
+    roidb[2]['height'], roidb[2]['width'] = 50, 44
+    parts_h, parts_r = [], []
+    for e in roidb[:2]:
+        np.random.seed(9)
+        parts_h.append(minibatch_wsl.get_minibatch([e], raw=False)[0])
+        np.random.seed(9)
+        parts_r.append(minibatch_wsl.get_minibatch([e])[0])
+    np.random.seed(4)
+    mh = loader_wsl.mixup_blobs(minibatch_wsl.get_minibatch(roidb[1:], raw=False)[0], 0.3)
+    np.random.seed(4)
+    mr = loader_wsl.mixup_blobs(minibatch_wsl.get_minibatch(roidb[1:])[0], 0.3)
+    host = loader_wsl.collate(parts_h + [mh])
+    raw = loader_wsl.collate(parts_r + [mr])
+    data = loader_wsl.device_prep_images(raw['_raw'], raw['_mix'], dev)
+    torch.cuda.synchronize()
+    assert data.shape == host['data'].shape
+    assert np.array_equal(data.cpu().numpy(), host['data'])
