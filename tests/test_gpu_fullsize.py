@@ -113,3 +113,46 @@ def test_sgd_identity_properties(dev):
     g.fill_(8.0)
     ops.acm_sgd_update(g, m, lr, p, None, ends, one, zero, 0.0, 0, 1, 8, 1)
     assert torch.allclose(p, p0 - 1e-3, rtol=0, atol=1e-6)       # grad / gpu_num * lr
+
+
+def test_config5_inference_1200x2000_4000_rois(dev):
+    """BASELINE.json configs[4]: the largest TTA scale (1200x2000) with 4000 proposals, forward
+    only.  Size-independent checks: (1) rois_pred is a product of two softmaxes (>= 0, column
+    sums over proposals <= 1, background column = column 0 of the foreground block);
+    (2) the softmax over proposals is permutation-equivariant; (3) the two fp32 plans - two
+    independent kernel families - agree to the fp32 parity tolerance; (4) per-class NMS of the
+    result on the GPU equals the host restatement."""
+    from detectron.datasets import synthetic
+    from detectron.core import test_wsl
+    from naws_hip import ops
+    from naws_hip.engine import WsddnEngine
+    c = 20
+    blobs = synthetic.init_blobs(c, seed=11)
+    mb = synthetic.make_minibatch(synthetic.make_roidb(1, 4000, c, 1200, 2000, seed=13), c,
+                                  max_rois=4000)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    assert t['rois'].shape[0] == 4000
+    res = {}
+    for mode in ('fp32x3', 'fp32'):
+        eng = WsddnEngine(c + 1, dev, gpu_num=1, seed=11, mfma_dtype=mode)
+        eng.set_conv_blobs(blobs)
+        eng.set_head_blobs(blobs)
+        res[mode] = eng.infer(t['data'], t['rois'], t['obn_scores'])
+        if mode == 'fp32x3':
+            perm = torch.randperm(4000, generator=torch.Generator().manual_seed(1)).to(dev)
+            p2 = eng.infer(t['data'], t['rois'][perm], t['obn_scores'][perm])
+        del eng
+    p = res['fp32x3']
+    assert p.shape == (4000, c + 1) and torch.isfinite(p).all() and (p >= 0).all()
+    assert torch.equal(p[:, 0], p[:, 1])
+    assert float(p[:, 1:].sum(0).max()) <= 1.0 + 1e-5
+    scale = float(p.max())
+    assert float((p2 - p[perm]).abs().max()) <= 1e-5 * scale
+    assert float((res['fp32'] - p).abs().max()) <= 1e-4 * scale
+    # NMS on the real score matrix: GPU == host restatement, class by class
+    keep = ops.nms_per_class(t['rois'][:, 1:5].contiguous(), p[:, 1:].contiguous(), 0.0, 0.5)
+    pn, bn = p.cpu().numpy(), mb['rois'][:, 1:5]
+    for j in (1, 7, 20):
+        inds = np.where(pn[:, j] > 0.0)[0]
+        dets = np.hstack([bn[inds], pn[inds, j:j + 1]]).astype(np.float32)
+        assert np.array_equal(np.where(keep[j - 1].cpu().numpy())[0], inds[test_wsl.nms(dets, 0.5)])
