@@ -348,6 +348,8 @@ int naws_nms_sorted_fwd(const float* boxes, const int32_t* counts, int batch, in
 /* ---- loader image preparation --------------------------------------------------
  * One decoded image (uint8 H x W x 3, BGR, on the device) -> its slot of the NCHW batch blob:
  * optional horizontal flip, crop (taken on the flipped image, rows crop_y0.., cols crop_x0..),
+ * optional HSV saturation / exposure jitter (distort != 0: cv2 8-bit BGR2HSV, S = min(saturation*S,
+ * 255), V = min(exposure*V, 255), uint8 truncation, HSV2BGR - minibatch_wsl.py:127-138),
  * float32 (v - means[c]) / stds[c], bilinear resize by im_scale with cv2.resize(INTER_LINEAR)
  * semantics to out_h x out_w (= cvRound(crop_h * im_scale), cvRound(crop_w * im_scale), computed
  * by the caller), written to out[c * plane_stride + y * row_stride + x].
@@ -355,8 +357,9 @@ int naws_nms_sorted_fwd(const float* boxes, const int32_t* counts, int batch, in
  * means3 / stds3 are HOST pointers (3 floats each). */
 int naws_prep_image_fwd(const uint8_t* im_bgr_hwc, int H, int W, int flip, int crop_y0,
                         int crop_x0, int crop_h, int crop_w, const float* means3,
-                        const float* stds3, double im_scale, int out_h, int out_w,
-                        int64_t plane_stride, int row_stride, float* out, void* stream);
+                        const float* stds3, double im_scale, int distort, float saturation,
+                        float exposure, int out_h, int out_w, int64_t plane_stride,
+                        int row_stride, float* out, void* stream);
 
 #ifdef __cplusplus
 }

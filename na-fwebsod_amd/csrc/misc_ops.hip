@@ -503,10 +503,50 @@ extern "C" int naws_dropout_mask(uint64_t seed, float drop_ratio, int64_t n, flo
 // published algorithm (imgproc/resize.cpp: pixel-centre mapping fx = (dx+0.5)/im_scale - 0.5 in
 // double -> float, floor, edge taps clamped with weight 1, horizontal pass then vertical pass).
 namespace {
+// cv2 8-bit BGR->HSV->(S*=sat, V*=expo)->BGR round trip of one pixel (WSL.USE_DISTORTION,
+// minibatch_wsl.py:127-138), restated from OpenCV's RGB2HSV_b (fixed point, hsv_shift 12) and
+// HSV2RGB_b (float sector formula, hscale 6/180, rounded store).
+__device__ __forceinline__ void hsv_jitter(int& b, int& g, int& r, float sat, float expo) {
+#pragma clang fp contract(off)
+  const int v = max(max(b, g), r), vmin = min(min(b, g), r);
+  const int diff = v - vmin;
+  const int sdiv = v ? (int)rint((double)(255 << 12) / (double)v) : 0;
+  const int hdiv = diff ? (int)rint((double)(180 << 12) / (6.0 * (double)diff)) : 0;
+  int s = (diff * sdiv + 2048) >> 12;
+  int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+  h = (h * hdiv + 2048) >> 12;
+  if (h < 0) h += 180;
+  // float32 scaling, cap at 255, truncate to uint8 (np.array(hsv, dtype=np.uint8))
+  const float sf0 = sat * (float)s, vf0 = expo * (float)v;
+  const int s8 = (int)fminf(sf0, 255.f), v8 = (int)fminf(vf0, 255.f);
+  const float sf = (float)s8 * (float)(1.0 / 255.0), vf = (float)v8 * (float)(1.0 / 255.0);
+  float hf = (float)h * (float)(6.0 / 180.0);
+  if (hf >= 6.f) hf = hf - 6.f;
+  int sec = (int)floorf(hf);
+  float fr = hf - (float)sec;
+  if (sec < 0 || sec >= 6) { sec = 0; fr = 0.f; }
+  float tab[4];
+  tab[0] = vf;
+  const float t1 = 1.f - sf;
+  tab[1] = vf * t1;
+  const float sh = sf * fr, t2 = 1.f - sh;
+  tab[2] = vf * t2;
+  const float omf = 1.f - fr, so = sf * omf, t3 = 1.f - so;
+  tab[3] = vf * t3;
+  const int sb[6] = {1, 1, 3, 0, 0, 2}, sg[6] = {3, 0, 0, 2, 1, 1}, sr[6] = {0, 2, 1, 1, 3, 0};
+  float fb = tab[sb[sec]], fg = tab[sg[sec]], frr = tab[sr[sec]];
+  if (s8 == 0) { fb = vf; fg = vf; frr = vf; }
+  const float xb = fb * 255.f, xg = fg * 255.f, xr = frr * 255.f;
+  b = min(max((int)rintf(xb), 0), 255);
+  g = min(max((int)rintf(xg), 0), 255);
+  r = min(max((int)rintf(xr), 0), 255);
+}
+
 __global__ __launch_bounds__(256) void prep_image_kernel(
     const unsigned char* __restrict__ im, int W, int flip, int cy0, int cx0, int ch, int cw,
     float m0, float m1, float m2, float s0, float s1, float s2, double inv_scale, int oh, int ow,
-    long long plane_stride, int row_stride, float* __restrict__ out) {
+    long long plane_stride, int row_stride, int distort, float sat, float expo,
+    float* __restrict__ out) {
   // Every product and sum is rounded separately, like the numpy / cv2 passes.  (hipcc's
   // __fmul_rn & co. are inline `x * y` compiled under the header's contract(fast), so plain
   // operators under this pragma - built with -ffp-contract=fast-honor-pragmas - are used.)
@@ -531,6 +571,16 @@ __global__ __launch_bounds__(256) void prep_image_kernel(
   const int ys[2] = {cy0 + sy, cy0 + sy1};
   const int xs[2] = {flip ? (W - 1 - (cx0 + sx)) : (cx0 + sx),       // crop is taken on the
                      flip ? (W - 1 - (cx0 + sx1)) : (cx0 + sx1)};    // flipped image
+  int pix[2][2][3];
+#pragma unroll
+  for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+    for (int xx = 0; xx < 2; ++xx) {
+      const unsigned char* p = im + ((long long)ys[yy] * W + xs[xx]) * 3;
+      int b = p[0], g = p[1], r = p[2];
+      if (distort) hsv_jitter(b, g, r, sat, expo);
+      pix[yy][xx][0] = b; pix[yy][xx][1] = g; pix[yy][xx][2] = r;
+    }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     float v[2][2];
@@ -538,7 +588,7 @@ __global__ __launch_bounds__(256) void prep_image_kernel(
     for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
       for (int xx = 0; xx < 2; ++xx) {
-        const float u = (float)im[((long long)ys[yy] * W + xs[xx]) * 3 + c];
+        const float u = (float)pix[yy][xx][c];
         const float d = u - mean[c];
         v[yy][xx] = d / sd[c];
       }
@@ -552,7 +602,8 @@ __global__ __launch_bounds__(256) void prep_image_kernel(
 
 extern "C" int naws_prep_image_fwd(const uint8_t* im_bgr_hwc, int H, int W, int flip, int crop_y0,
                                    int crop_x0, int crop_h, int crop_w, const float* means3,
-                                   const float* stds3, double im_scale, int out_h, int out_w,
+                                   const float* stds3, double im_scale, int distort,
+                                   float saturation, float exposure, int out_h, int out_w,
                                    int64_t plane_stride, int row_stride, float* out, void* stream) {
   if (H <= 0 || W <= 0 || crop_h <= 0 || crop_w <= 0 || out_h <= 0 || out_w <= 0) return NAWS_ERR_SHAPE;
   if (crop_y0 < 0 || crop_x0 < 0 || crop_y0 + crop_h > H || crop_x0 + crop_w > W) return NAWS_ERR_SHAPE;
@@ -562,6 +613,6 @@ extern "C" int naws_prep_image_fwd(const uint8_t* im_bgr_hwc, int H, int W, int 
   hipLaunchKernelGGL(prep_image_kernel, grid, dim3(256), 0, (hipStream_t)stream, im_bgr_hwc, W,
                      flip, crop_y0, crop_x0, crop_h, crop_w, means3[0], means3[1], means3[2],
                      stds3[0], stds3[1], stds3[2], 1.0 / im_scale, out_h, out_w,
-                     (long long)plane_stride, row_stride, out);
+                     (long long)plane_stride, row_stride, distort, saturation, exposure, out);
   return naws_check_launch();
 }

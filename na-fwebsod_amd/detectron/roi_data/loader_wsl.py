@@ -195,7 +195,8 @@ def device_prep_images(raws, mixes, device):
 
     def prep(r, out):
         im = torch.from_numpy(r['im']).pin_memory().to(device, non_blocking=True)
-        ops.prep_image(im, out, r['scale'], flip=r['flip'], crop=r['crop'], means=means, stds=stds)
+        ops.prep_image(im, out, r['scale'], flip=r['flip'], crop=r['crop'], means=means, stds=stds,
+                       distort=r.get('distort'))
         im.record_stream(torch.cuda.current_stream(device))
     for i, grp in enumerate(raws):
         if len(grp) == 1:

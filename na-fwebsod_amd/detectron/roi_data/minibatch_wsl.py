@@ -9,8 +9,8 @@ cv2.resize(INTER_LINEAR) is restated (`resize_linear`, same pixel-centre mapping
 With NAWS.DEVICE_PREP the float conversion, mean/std, flip, crop, resize and HWC->CHW padding run
 on the GPU (naws_prep_image_fwd): the loader threads then only decode, and a minibatch carries
 the raw uint8 images + their parameters (`_raw`) instead of a float `data` blob.
-HSV distortion is the one augmentation not restated (it needs the OpenCV colour transform); it
-is rejected loudly rather than skipped silently.
+The HSV distortion (WSL.USE_DISTORTION: cv2.cvtColor BGR2HSV -> scale S, V -> HSV2BGR on uint8)
+is restated from OpenCV's 8-bit algorithm (`distort_hsv`), on the host or inside the device prep.
 """
 import os
 
@@ -63,6 +63,45 @@ def _read_image(entry):
     with Image.open(entry['image']) as im:
         rgb = np.asarray(im.convert('RGB'))
     return rgb[:, :, ::-1].copy()
+
+
+def _hsv_tables():
+    i = np.arange(256, dtype=np.float64)
+    i[0] = 1.0
+    sdiv = np.rint((255 << 12) / i).astype(np.int64)
+    hdiv = np.rint((180 << 12) / (6.0 * i)).astype(np.int64)
+    sdiv[0] = hdiv[0] = 0
+    return sdiv, hdiv
+
+
+def distort_hsv(im, s0, s1):
+    """The saturation / exposure jitter of minibatch_wsl.py:127-138 on a uint8 BGR image:
+    cv2 8-bit BGR->HSV (fixed-point, H in [0,180)), S = min(s0*S, 255), V = min(s1*V, 255) in
+    float32, truncated to uint8, cv2 8-bit HSV->BGR (float sector formula, rounded)."""
+    sdiv, hdiv = _hsv_tables()
+    x = im.astype(np.int64)
+    b, g, r = x[..., 0], x[..., 1], x[..., 2]
+    v = np.maximum(np.maximum(b, g), r)
+    diff = v - np.minimum(np.minimum(b, g), r)
+    s = (diff * sdiv[v] + 2048) >> 12
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * hdiv[diff] + 2048) >> 12
+    h = np.where(h < 0, h + 180, h)
+    f32 = np.float32
+    s = np.minimum(f32(s0) * s.astype(f32), f32(255)).astype(np.uint8).astype(f32) * f32(1.0 / 255.0)
+    v = np.minimum(f32(s1) * v.astype(f32), f32(255)).astype(np.uint8).astype(f32) * f32(1.0 / 255.0)
+    hf = h.astype(f32) * f32(6.0 / 180.0)
+    hf = np.where(hf >= 6, hf - f32(6), hf).astype(f32)
+    sec = np.floor(hf).astype(np.int64)
+    fr = hf - sec.astype(f32)
+    bad = (sec < 0) | (sec >= 6)
+    sec, fr = np.where(bad, 0, sec), np.where(bad, f32(0), fr).astype(f32)
+    one = f32(1)
+    tab = np.stack([v, v * (one - s), v * (one - s * fr), v * (one - s * (one - fr))], -1)
+    slot = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])[sec]
+    bgr = np.take_along_axis(tab, slot, -1)
+    bgr = np.where((s == 0)[..., None], v[..., None], bgr).astype(f32)
+    return np.clip(np.rint(bgr * f32(255)), 0, 255).astype(np.uint8)
 
 
 def resize_linear(im, im_scale):
@@ -124,9 +163,15 @@ def _get_image_blob(roidb, raw=False):
     for i, entry in enumerate(roidb):
         im0 = _read_image(entry)
         im = im0[:, ::-1, :] if entry['flipped'] else im0
+        distort = None
         if cfg.WSL.USE_DISTORTION:
-            raise NotImplementedError('WSL.USE_DISTORTION needs the OpenCV HSV transform, '
-                                      'which this image lacks; set WSL.USE_DISTORTION False')
+            s0 = npr.random() * (cfg.WSL.SATURATION - 1) + 1
+            s1 = npr.random() * (cfg.WSL.EXPOSURE - 1) + 1
+            s0 = s0 if npr.random() > 0.5 else 1.0 / s0
+            s1 = s1 if npr.random() > 0.5 else 1.0 / s1
+            distort = (float(s0), float(s1))
+            if not raw:
+                im = distort_hsv(im, s0, s1)
         if cfg.WSL.USE_CROP:
             shape = np.array(im.shape)
             crop_dims = shape[:2] * cfg.WSL.CROP
@@ -142,7 +187,7 @@ def _get_image_blob(roidb, raw=False):
         if raw:
             sc = get_im_scale(im.shape[:2], cfg.TRAIN.SCALES[scale_inds[i]], cfg.TRAIN.MAX_SIZE)
             ims.append(dict(im=np.ascontiguousarray(im0), flip=bool(entry['flipped']),
-                            crop=tuple(int(v) for v in crop), scale=sc,
+                            crop=tuple(int(v) for v in crop), scale=sc, distort=distort,
                             out_hw=(int(np.round(im.shape[0] * sc)), int(np.round(im.shape[1] * sc)))))
         else:
             im, sc = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TRAIN.SCALES[scale_inds[i]],

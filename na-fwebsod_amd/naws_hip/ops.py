@@ -342,7 +342,7 @@ def nms_per_class(boxes, scores, score_thresh, nms_thresh):
 
 
 def prep_image(im_u8, out, im_scale, flip=False, crop=None, means=(0.0, 0.0, 0.0),
-               stds=(1.0, 1.0, 1.0)):
+               stds=(1.0, 1.0, 1.0), distort=None):
     """Loader image preparation on the GPU.  im_u8: uint8 [H,W,3] BGR device tensor;
     crop = (y0, x0, y1, x1) inclusive on the (flipped) image; `out` = this image's [3,Hp,Wp]
     slice of the NCHW batch blob (zero-filled by the caller).  Returns (out_h, out_w)."""
@@ -359,8 +359,10 @@ def prep_image(im_u8, out, im_scale, flip=False, crop=None, means=(0.0, 0.0, 0.0
     m = (ctypes.c_float * 3)(*[float(v) for v in means])
     sd = (ctypes.c_float * 3)(*[float(v) for v in stds])
     L.call('naws_prep_image_fwd', im_u8.data_ptr(), h, w, int(bool(flip)), int(y0), int(x0), ch, cw,
-           ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), float(im_scale), oh,
-           ow, out.stride(0), out.stride(1), out.data_ptr(), _stream())
+           ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), float(im_scale),
+           int(distort is not None), float(distort[0]) if distort else 1.0,
+           float(distort[1]) if distort else 1.0, oh, ow, out.stride(0), out.stride(1),
+           out.data_ptr(), _stream())
     return oh, ow
 
 

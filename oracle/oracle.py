@@ -233,12 +233,75 @@ def resize_bilinear_cv2(im, im_scale):
     return (rows[sy] * b0[:, None, None] + rows[sy1] * b1[:, None, None]).astype(np.float32)
 
 
-def prep_image(im_u8, im_scale, flip=False, crop=None, means=(0, 0, 0), stds=(1, 1, 1)):
+def _cvround(x):
+    return np.rint(x).astype(np.int64)       # cvRound: round half to even
+
+
+def bgr2hsv_u8(im):
+    """cv2.cvtColor(im, cv2.COLOR_BGR2HSV) for uint8 (H in [0,180), S,V in [0,255]).
+    OpenCV is un-vendored and un-pinned in the reference; this restates the published 8-bit
+    algorithm (imgproc color_hsv: RGB2HSV_b, hsv_shift = 12, division tables
+    sdiv[v] = cvRound((255<<12)/v), hdiv[d] = cvRound((180<<12)/(6 d))).  PARITY UNPINNED.
+    Used at detectron/roi_data/minibatch_wsl.py:128."""
+    im = np.asarray(im, np.uint8).astype(np.int64)
+    b, g, r = im[..., 0], im[..., 1], im[..., 2]
+    v = np.maximum(np.maximum(b, g), r)
+    diff = v - np.minimum(np.minimum(b, g), r)
+    idx = np.arange(256, dtype=np.float64)
+    with np.errstate(divide='ignore'):
+        sdiv = np.where(idx > 0, _cvround((255 << 12) / np.maximum(idx, 1)), 0)
+        hdiv = np.where(idx > 0, _cvround((180 << 12) / (6.0 * np.maximum(idx, 1))), 0)
+    s = (diff * sdiv[v] + (1 << 11)) >> 12
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * hdiv[diff] + (1 << 11)) >> 12            # arithmetic shift (floor) for negatives
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack([np.clip(h, 0, 255), s, v], -1).astype(np.uint8)
+
+
+def hsv2bgr_u8(hsv):
+    """cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR) for uint8: the 8-bit path converts to float
+    (h, s/255, v/255), runs the float HSV2RGB sector formula (hscale = 6/180) and stores
+    saturate_cast<uchar>(x*255) (round half to even).  PARITY UNPINNED (see bgr2hsv_u8).
+    Used at detectron/roi_data/minibatch_wsl.py:138."""
+    hsv = np.asarray(hsv, np.uint8)
+    f32 = np.float32
+    h = hsv[..., 0].astype(f32) * f32(6.0 / 180.0)
+    s = hsv[..., 1].astype(f32) * f32(1.0 / 255.0)
+    v = hsv[..., 2].astype(f32) * f32(1.0 / 255.0)
+    h = np.where(h >= f32(6), h - f32(6), h).astype(f32)     # h < 180*6/180: at most one wrap
+    sector = np.floor(h).astype(np.int64)
+    fr = (h - sector.astype(f32)).astype(f32)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    fr = np.where(bad, f32(0), fr).astype(f32)
+    one = f32(1)
+    tab = np.stack([v, (v * (one - s)).astype(f32), (v * (one - (s * fr).astype(f32))).astype(f32),
+                    (v * (one - (s * (one - fr)).astype(f32))).astype(f32)], -1)
+    sec = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    pick = sec[sector]                                        # [..., 3] -> (b, g, r) table slots
+    bgr = np.take_along_axis(tab, pick, -1)
+    bgr = np.where((hsv[..., 1] == 0)[..., None], v[..., None], bgr).astype(f32)
+    return np.clip(np.rint((bgr * f32(255)).astype(f32)), 0, 255).astype(np.uint8)
+
+
+def distort_hsv(im_u8, s0, s1):
+    """minibatch_wsl.py:127-138: BGR->HSV (uint8), S *= s0, V *= s1 in float32 capped at 255,
+    back to uint8 by truncation, HSV->BGR."""
+    hsv = bgr2hsv_u8(im_u8).astype(np.float32)
+    hsv[..., 1] = np.minimum(np.float32(s0) * hsv[..., 1], 255)
+    hsv[..., 2] = np.minimum(np.float32(s1) * hsv[..., 2], 255)
+    return hsv2bgr_u8(hsv.astype(np.uint8))
+
+
+def prep_image(im_u8, im_scale, flip=False, crop=None, means=(0, 0, 0), stds=(1, 1, 1),
+               distort=None):
     """Flip, crop, float32, mean/std, resize: minibatch_wsl.py:121-157 + blob.py:100-131.
     -> float32 [oh, ow, 3] (HWC, as prep_im_for_blob returns it)."""
     im = np.asarray(im_u8)
     if flip:
         im = im[:, ::-1, :]
+    if distort is not None:
+        im = distort_hsv(im, distort[0], distort[1])
     if crop is not None:
         im = im[crop[0]:crop[2] + 1, crop[1]:crop[3] + 1, :]
     im = im.astype(np.float32)

@@ -98,9 +98,10 @@ def test_blob_order_and_minibatch(cfgmod):
     assert blobs['rois'].shape == (50, 5) and blobs['rois'].dtype == np.float32
     assert blobs['obn_scores'].min() >= 1.0 and blobs['labels_oh'].sum() == 1
     assert blobs['rois'][:, 1:].min() >= 0 and blobs['rois'][:, 3].max() <= 1000
-    c.cfg.WSL.USE_DISTORTION = True
-    with pytest.raises(NotImplementedError):
-        minibatch_wsl.get_minibatch(roidb)
+    c.cfg.WSL.USE_DISTORTION = True                 # the yaml's own setting: HSV jitter applied
+    np.random.seed(3)
+    b2, _ = minibatch_wsl.get_minibatch(roidb)
+    assert b2['data'].shape[1] == 3 and not np.array_equal(b2['data'].shape, ()) 
 
 
 def test_rank_sharding_and_collate(cfgmod):
@@ -152,8 +153,7 @@ def test_host_image_prep_matches_oracle_and_raw_mode(cfgmod):
     device-prep ("raw") minibatch carries the same parameters the host path applies."""
     c = cfgmod
     c.merge_cfg_from_file(YAML)
-    c.merge_cfg_from_list(['WSL.USE_DISTORTION', False, 'TRAIN.SCALES', '(96,)',
-                           'TRAIN.MAX_SIZE', 140])
+    c.merge_cfg_from_list(['TRAIN.SCALES', '(96,)', 'TRAIN.MAX_SIZE', 140])
     from detectron.datasets import synthetic
     from detectron.roi_data import minibatch_wsl, loader_wsl
     from oracle import oracle
@@ -167,6 +167,16 @@ def test_host_image_prep_matches_oracle_and_raw_mode(cfgmod):
         got, sc = minibatch_wsl.prep_im_for_blob(im, c.cfg.PIXEL_MEANS, target, cap)
         ref = oracle.prep_image(im, sc, means=c.cfg.PIXEL_MEANS.reshape(-1))
         assert got.shape == ref.shape and np.array_equal(got, ref)
+    # HSV jitter: known cv2 conversions, and the host restatement == the oracle's
+    px = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0], [255, 255, 255], [128, 128, 128],
+                    [10, 20, 30], [200, 100, 50]]], np.uint8)
+    assert oracle.bgr2hsv_u8(px).reshape(-1, 3).tolist() == [
+        [0, 255, 255], [60, 255, 255], [120, 255, 255], [0, 0, 255], [0, 0, 128], [15, 170, 30],
+        [110, 191, 200]]
+    assert np.array_equal(oracle.hsv2bgr_u8(oracle.bgr2hsv_u8(px)), px)
+    for s0, s1 in ((1.0, 1.0), (1.37, 0.71), (1 / 1.5, 1.5)):
+        assert np.array_equal(minibatch_wsl.distort_hsv(im, s0, s1), oracle.distort_hsv(im, s0, s1))
+    c.cfg.WSL.USE_DISTORTION = True
     roidb = synthetic.make_roidb(2, 10, 20, 40, 64, seed=5)
     roidb[1]['flipped'] = True
     np.random.seed(3)
@@ -176,8 +186,9 @@ def test_host_image_prep_matches_oracle_and_raw_mode(cfgmod):
     assert np.array_equal(raw['rois'], host['rois']) and raw['data'].shape == (1, 3, 1, 1)
     r = raw['_raw'][0]
     assert r['flip'] and r['out_hw'] == host['data'].shape[2:]
+    assert r['distort'] is not None
     ref = oracle.prep_image(r['im'], r['scale'], flip=True, crop=r['crop'],
-                            means=c.cfg.PIXEL_MEANS.reshape(-1))
+                            means=c.cfg.PIXEL_MEANS.reshape(-1), distort=r['distort'])
     assert np.array_equal(ref.transpose(2, 0, 1), host['data'][0])
     # collate / mixup keep the raw images and the blend factor for the device side
     parts = [dict(raw), dict(loader_wsl.mixup_blobs(dict(

@@ -30,6 +30,29 @@ def test_prep_image_matches_oracle(dev, scale, flip):
         assert (o[:, oh:, :] == 7.0).all() and (o[:, :, ow:] == 7.0).all()   # padding untouched
 
 
+@pytest.mark.parametrize('distort', [(1.0, 1.0), (1.37, 0.71), (1 / 1.5, 1.5), (1.5, 1 / 1.5)])
+def test_prep_image_hsv_distortion(dev, distort):
+    """WSL.USE_DISTORTION on the GPU: the uint8 HSV round trip is integer / rounded-float work,
+    held bit-exact against the oracle's restatement of cv2's 8-bit conversions."""
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(52)
+    im = rng.integers(0, 256, (41, 67, 3), dtype=np.uint8)
+    im[0, :7] = [[0, 0, 255], [0, 255, 0], [255, 0, 0], [255, 255, 255], [0, 0, 0], [7, 7, 7],
+                 [255, 254, 255]]
+    # scale 1, no mean: the output IS the distorted uint8 image
+    ref = oracle.distort_hsv(im, *distort)
+    out = torch.zeros((3, 41, 67), device=dev)
+    ops.prep_image(torch.from_numpy(im).to(dev), out, 1.0, distort=distort)
+    assert np.array_equal(out.cpu().numpy().transpose(1, 2, 0), ref.astype(np.float32))
+    # and through flip + crop + resize
+    ref = oracle.prep_image(im, 1.7, flip=True, crop=(2, 3, 38, 60), means=MEANS, distort=distort)
+    out = torch.zeros((3,) + ref.shape[:2], device=dev)
+    ops.prep_image(torch.from_numpy(im).to(dev), out, 1.7, flip=True, crop=(2, 3, 38, 60),
+                   means=MEANS, distort=distort)
+    assert np.array_equal(out.cpu().numpy(), ref.transpose(2, 0, 1))
+
+
 def test_prep_image_errors(dev):
     from naws_hip import ops, lib
     im = torch.zeros((8, 8, 3), dtype=torch.uint8, device=dev)
@@ -46,7 +69,7 @@ def test_loader_device_prep_equals_host_path(dev, cfgmod):
     c = cfgmod
     c.merge_cfg_from_file(os.path.join(os.path.dirname(__file__), '..', 'na-fwebsod_amd', 'configs',
                                        'flickr_voc', 'na_wsddn_V-16-C5_1x.yaml'))
-    c.merge_cfg_from_list(['WSL.USE_DISTORTION', False, 'TRAIN.SCALES', '(48, 64)',
+    c.merge_cfg_from_list(['TRAIN.SCALES', '(48, 64)',
                            'TRAIN.MAX_SIZE', 100, 'NAWS.DEVICE_PREP', True])
     from detectron.datasets import synthetic
     from detectron.roi_data import minibatch_wsl, loader_wsl
