@@ -69,7 +69,8 @@ def _defaults():
             'WEIGHTS': '', 'DATASETS': (), 'PROPOSAL_FILES': (), 'SCALES': (600,),
             'MAX_SIZE': 1000, 'IMS_PER_BATCH': 2, 'BATCH_SIZE_PER_IM': 64,
             'USE_FLIPPED': True, 'SNAPSHOT_ITERS': 80000, 'ASPECT_GROUPING': True,
-            'CROWD_FILTER_THRESH': 0.7, 'GT_MIN_AREA': -1, 'FREEZE_CONV_BODY': False,
+            'CROWD_FILTER_THRESH': 0.7, 'GT_MIN_AREA': -1, 'FG_THRESH': 0.5, 'BG_THRESH_HI': 0.5,
+            'BG_THRESH_LO': 0.0, 'FREEZE_CONV_BODY': False,
             'AUTO_RESUME': True, 'COPY_WEIGHTS': False, 'FREEZE_AT': 2,
         },
         'DATA_LOADER': {'NUM_THREADS': 4, 'MINIBATCH_QUEUE_SIZE': 64, 'BLOBS_QUEUE_CAPACITY': 8},

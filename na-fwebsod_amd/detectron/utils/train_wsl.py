@@ -123,6 +123,22 @@ def create_model():
     return model, weights_file, start_iter, checkpoints, output_dir
 
 
+def training_roidb():
+    """cfg.TRAIN.DATASETS + cfg.TRAIN.PROPOSAL_FILES -> roidb (roidb_wsl.py:21-58), when the
+    named datasets are on disk; otherwise the synthetic roidb of the benchmark (there is no
+    dataset on the MI355X image), loudly."""
+    from detectron.datasets import dataset_catalog
+    names = tuple(cfg.TRAIN.DATASETS)
+    if names and all(dataset_catalog.contains(n) and os.path.exists(dataset_catalog.get_ann_fn(n))
+                     for n in names):
+        from detectron.datasets.roidb_wsl import combined_roidb_for_training
+        return combined_roidb_for_training(names, tuple(cfg.TRAIN.PROPOSAL_FILES))
+    from detectron.datasets import synthetic
+    logger.warning('TRAIN.DATASETS {} not found on disk: using the synthetic roidb'.format(names))
+    return synthetic.make_roidb(64, cfg.TRAIN.BATCH_SIZE_PER_IM, cfg.MODEL.NUM_CLASSES - 1,
+                                seed=cfg.RNG_SEED)
+
+
 def setup_model_for_training(model, weights_file, output_dir, device, pg, world, rank, roidb=None):
     executor = NetExecutor(model, device, process_group=pg, world_size=world, rank=rank,
                            images_per_process=cfg.NAWS.IMS_PER_GPU)
@@ -134,9 +150,7 @@ def setup_model_for_training(model, weights_file, output_dir, device, pg, world,
             logger.warning('weights file {} not found: training from random init'.format(weights_file))
         executor.broadcast_parameters()
     if roidb is None:
-        from detectron.datasets import synthetic
-        roidb = synthetic.make_roidb(64, cfg.TRAIN.BATCH_SIZE_PER_IM, cfg.MODEL.NUM_CLASSES - 1,
-                                     seed=cfg.RNG_SEED)
+        roidb = training_roidb()
     model_builder.add_training_inputs(model, roidb=roidb, rank=rank, world_size=world)
     model.roi_data_loader.start(prefill=False)
     return executor

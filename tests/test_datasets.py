@@ -1,0 +1,154 @@
+"""Dataset / roidb host logic: helper functions against pairs captured
+from the imported reference Python (tests/golden/reference_datasets.npz), and the whole
+json + MCG-pickle -> roidb -> loader chain on a toy dataset written to a temp dir."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+YAML = os.path.join(ROOT, 'na-fwebsod_amd', 'configs', 'flickr_voc', 'na_wsddn_V-16-C5_1x.yaml')
+G = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_datasets.npz'), allow_pickle=True)
+
+
+def test_box_helpers_match_reference():
+    from detectron.utils import boxes as B
+    assert np.array_equal(B.unique_boxes(G['ub_in']), G['ub_out'])
+    assert np.array_equal(B.unique_boxes(G['ub_in_scaled'], 1 / 16.), G['ub_out_scaled'])
+    assert np.array_equal(B.filter_small_boxes(G['ub_in'], 20), G['fs_out'])
+    assert np.array_equal(B.xywh_to_xyxy(G['xywh_in']), G['xywh_out'])
+    assert np.array_equal(np.array(B.xywh_to_xyxy([3.0, 4.0, 0.5, 10.0])), G['xywh_list_out'])
+    assert np.array_equal(B.xyxy_to_xywh(G['xywh_out']), G['xyxy_to_xywh_out'])
+    assert np.array_equal(np.array(B.clip_xyxy_to_image(-3.0, 5.0, 70.0, 41.5, 40, 60)), G['clip_out'])
+    # bbox_overlaps (cython in the reference): +1 areas, known answers
+    ov = B.bbox_overlaps(np.array([[0, 0, 9, 9], [20, 20, 29, 29]], np.float32),
+                         np.array([[5, 5, 14, 14], [0, 0, 9, 9]], np.float32))
+    assert np.allclose(ov, [[25 / 175., 1.0], [0.0, 0.0]])
+    # crowd rule: intersection over the proposal's own area
+    assert np.allclose(B.crowd_iou(np.array([[0, 0, 10, 10.]]), np.array([[5, 0, 10, 10.]])), 0.5)
+
+
+def test_roidb_helpers_match_reference(cfgmod):
+    cfgmod.merge_cfg_from_file(YAML)
+    from detectron.datasets import json_dataset_wsl as jd, roidb_wsl
+    roidb = [{'gt_overlaps': scipy.sparse.csr_matrix(G['ca_in'])},
+             {'gt_overlaps': scipy.sparse.csr_matrix(np.zeros((3, 5), np.float32))}]
+    jd._add_class_assignments(roidb)
+    assert np.array_equal(roidb[0]['max_classes'], G['ca_max_classes'])
+    assert np.array_equal(roidb[0]['max_overlaps'], G['ca_max_overlaps'])
+    assert [len(jd._filter_no_class('flickr_voc', list(roidb))),
+            len(jd._filter_no_class('voc_2007_test', list(roidb)))] == G['fnc_kept'].tolist()
+    props = {'indexes': [30, 10, 20],
+             'boxes': [np.full((1, 4), 3.0), np.full((1, 4), 1.0), np.full((1, 4), 2.0)],
+             'scores': [np.array([[.3]]), np.array([[.1]]), np.array([[.2]])]}
+    jd._sort_proposals(props, 'indexes')
+    assert props['indexes'] == G['sp_ids'].tolist()
+    assert np.array_equal(np.concatenate(props['boxes']), G['sp_boxes'])
+    db = [dict(width=60, height=40, boxes=G['flip_in'].copy(), segms=[], flipped=False)]
+    roidb_wsl.extend_with_flipped_entries(db, None)
+    assert np.array_equal(db[1]['boxes'], G['flip_out'])
+    assert [db[0]['flipped'], db[1]['flipped']] == G['flip_flags'].tolist()
+    got = [len(roidb_wsl.filter_for_training([{'max_overlaps': c}])) for c in G['fft_cases']]
+    assert got == G['fft_valid'].tolist()
+
+
+def _toy_dataset(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    imdir = tmp_path / 'images'
+    imdir.mkdir()
+    images, anns = [], []
+    sizes = {11: (48, 64), 5: (40, 50), 8: (64, 48)}      # id -> (h, w); ids deliberately unsorted
+    for iid, (h, w) in sizes.items():
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(
+            str(imdir / ('im_%06d.png' % iid)))
+        images.append(dict(id=iid, file_name='im_%06d.png' % iid, height=h, width=w, license=1))
+    cats = [dict(id=7, name='cat'), dict(id=3, name='bird')]   # contiguous ids by sorted json id
+    aid = 0
+
+    def ann(iid, cid, bbox, **kw):
+        nonlocal aid
+        aid += 1
+        a = dict(id=aid, image_id=iid, category_id=cid, bbox=bbox, area=bbox[2] * bbox[3],
+                 iscrowd=0, segmentation=[])
+        a.update(kw)
+        anns.append(a)
+    ann(11, 7, [10, 10, 30, 20])
+    ann(11, 3, [-5, 30, 20, 30])               # clipped to the image
+    ann(11, 3, [0, 0, 5, 5], ignore=1)         # skipped
+    ann(5, 3, [5, 5, 20, 20])
+    ann(5, 7, [25, 5, 20, 30], iscrowd=1)      # crowd region
+    ann(8, 7, [3, 3, 10, 10], area=0)          # invalid: zero area -> image 8 has no class
+    annf = tmp_path / 'toy.json'
+    annf.write_text(json.dumps(dict(images=images, annotations=anns, categories=cats)))
+    # MCG-style proposals (tools/convert_mcg.py): uint16 boxes, float32 scores, image ids
+    def boxes_for(h, w, n):
+        xy = np.stack([rng.integers(0, w - 30, n), rng.integers(0, h - 30, n)], 1)
+        wh = rng.integers(5, 30, (n, 2))
+        return np.hstack([xy, xy + wh]).astype(np.uint16)
+    pb, ps, pi = [], [], []
+    for iid, (h, w) in sizes.items():
+        b = boxes_for(h, w, 12)
+        b[3] = b[1]                             # duplicate
+        b[4] = [1, 1, 15, 40 if h > 41 else 30]  # too small a side for min size 20 (w = 15)
+        pb.append(b)
+        ps.append(rng.uniform(0, 1, (12, 1)).astype(np.float32))
+        pi.append(iid)
+    pf = tmp_path / 'mcg.pkl'
+    with open(str(pf), 'wb') as f:
+        pickle.dump(dict(boxes=pb, scores=ps, indexes=pi), f, 2)
+    return str(imdir), str(annf), str(pf), sizes, pb, ps
+
+
+def test_toy_dataset_to_roidb_to_loader(tmp_path, cfgmod):
+    c = cfgmod
+    c.merge_cfg_from_file(YAML)
+    c.merge_cfg_from_list(['TRAIN.SCALES', '(48,)', 'TRAIN.MAX_SIZE', 80, 'MODEL.NUM_CLASSES', 3,
+                           'TRAIN.CROWD_FILTER_THRESH', 0.7])
+    from detectron.datasets import dataset_catalog, roidb_wsl
+    from detectron.datasets.json_dataset_wsl import JsonDataset
+    from detectron.roi_data import minibatch_wsl
+    imdir, annf, pf, sizes, pb, ps = _toy_dataset(tmp_path)
+    dataset_catalog.register('toy_train', imdir, annf)
+    ds = JsonDataset('toy_train')
+    assert ds.classes == ['__background__', 'bird', 'cat']              # by sorted json id 3, 7
+    assert ds.json_category_id_to_contiguous_id == {3: 1, 7: 2}
+    roidb = ds.get_roidb(gt=True, proposal_file=pf, crowd_filter_thresh=0.7)
+    assert [e['id'] for e in roidb] == [5, 11]                          # sorted ids; image 8 has no class
+    e11 = roidb[1]
+    # two valid gt boxes (xywh -> xyxy with -1, clipped), then the filtered proposals
+    assert e11['boxes'][0].tolist() == [10, 10, 39, 29] and e11['boxes'][1].tolist() == [0, 30, 14, 47]
+    assert e11['gt_classes'][:2].tolist() == [2, 1] and (e11['gt_classes'][2:] == 0).all()
+    assert e11['image'].endswith('im_000011.png') and 'file_name' not in e11 and not e11['flipped']
+    # proposals: unique (first occurrence), both sides > 20 px, sorted by score, appended after gt
+    b, s = pb[0].astype(np.float32), ps[0]
+    keep = [i for i in range(12) if i != 3 and (b[i, 2] - b[i, 0] + 1 > 20) and (b[i, 3] - b[i, 1] + 1 > 20)]
+    keep = sorted(keep, key=lambda i: -s[i, 0])
+    assert np.array_equal(e11['boxes'][2:], b[keep]) and np.array_equal(e11['obn_scores'][2:], s[keep])
+    assert e11['obn_scores'][:2].tolist() == [[0.0], [0.0]]
+    ov = e11['gt_overlaps'].toarray()
+    assert ov[0, 2] == 1.0 and ov[1, 1] == 1.0 and ov.shape == (2 + len(keep), 3)
+    assert np.array_equal(e11['max_classes'], ov.argmax(1)) and e11['box_to_gt_ind_map'][1] == 1
+    # crowd: the crowd gt row is -1 everywhere; proposals mostly inside it are excluded too
+    e5 = roidb[0]
+    assert (e5['gt_overlaps'].toarray()[1] == -1).all() and e5['is_crowd'][1]
+    # training roidb: + flipped copies (x mirrored), entries without fg/bg rois dropped
+    c.cfg.TRAIN.DATASETS, c.cfg.TRAIN.PROPOSAL_FILES = ('toy_train',), (pf,)
+    tr = roidb_wsl.combined_roidb_for_training(('toy_train',), (pf,))
+    def usable(e):
+        o = e['max_overlaps']
+        return (o >= 0.5).any() and ((o < 0.5) & (o >= 0.0)).any()
+    want = [e['id'] for e in roidb if usable(e)]
+    assert 11 in want and [e['id'] for e in tr] == want + want
+    assert [e['flipped'] for e in tr] == [False] * len(want) + [True] * len(want)
+    f11 = [e for e in tr if e['id'] == 11 and e['flipped']][0]
+    assert f11['boxes'][0].tolist() == [64 - 39 - 1, 10, 64 - 10 - 1, 29]
+    # and the loader consumes it (image decoded from the PNG, flipped, cropped, scaled)
+    np.random.seed(1)
+    blobs, valid = minibatch_wsl.get_minibatch([f11], raw=False)
+    assert valid and blobs['data'].shape[:2] == (1, 3) and blobs['labels_oh'].tolist() == [[1.0, 1.0]]
+    assert blobs['rois'].shape[1] == 5 and blobs['rois'].shape[0] == f11['boxes'].shape[0]
+    assert blobs['data_ids'].tolist() == [[11]]
