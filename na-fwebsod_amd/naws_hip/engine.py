@@ -66,9 +66,6 @@ class ParamArena(object):
         off = 0
         for name, shape in specs:
             n = int(np.prod(shape))
-            if n % 4 != 0:
-                raise NotImplementedError('blob %s has %d elements; arena segments must be a '
-                                          'multiple of 4 floats' % (name, n))
             self.offsets[name] = (off, n, shape)
             off += n
         self.total = off
@@ -132,6 +129,7 @@ class WsddnEngine(object):
         ac = int(allreduce_chunks)
         self.allreduce_chunks = ac if ac >= 1 else (2 if int(world_size) == 2 else 1)
         self.k6 = 512 * roi_size * roi_size
+        self.ld8 = (2 * self.C + 3) // 4 * 4       # per-branch column block of the logit matrices
 
         self.arena = ParamArena(head_param_specs(self.C, 512, roi_size), device)
         self.params = self.arena.alloc()
@@ -141,14 +139,23 @@ class WsddnEngine(object):
         ends, lr_mult, wd = [], [], []
         for name, _ in self.arena.specs:
             off, n, _s = self.arena.offsets[name]
-            ends.append(off + n)
             is_bias = name.endswith('_b')
             # biases: no weight decay, 2x lr (optimizer_wsl.py:106-123); '_lrm10_' -> x10 (:125)
             lm = 2.0 if is_bias else 1.0
             if '_lrm10_' in name:
                 lm *= 10.0
+            w = 0.0 if is_bias else float(weight_decay)
+            ends.append(off + n)
+            if len(lr_mult) and lr_mult[-1] == lm and wd[-1] == w:
+                ends.pop()
+                ends[-1] = off + n          # same hyper-parameters as the previous blob: one run
+                continue
             lr_mult.append(lm)
-            wd.append(0.0 if is_bias else float(weight_decay))
+            wd.append(w)
+        # the fused SGD kernel works on float4s: run boundaries must not split one (they are
+        # 4096-multiples or the four fc8 biases = 4C floats, for any class count)
+        if any(e % 4 for e in ends):
+            raise NotImplementedError('SGD hyper-parameter runs must end on multiples of 4 floats')
         self.seg_end = torch.tensor(ends, dtype=torch.int64, device=device)
         self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=device)
         self.seg_wd = torch.tensor(wd, dtype=torch.float32, device=device)
@@ -378,10 +385,25 @@ class WsddnEngine(object):
         else:
             ops.gemm(h6v, w7[:nb], False, True, out=h7v, epilogue=epi, bias=b7,
                      drop_ratio=self.dropout if drop else 0.0, seed=self._seed(7))
-        lg = torch.empty((rt, nb * 2 * C), device=self.device, dtype=torch.float32)
-        lgv = lg.view(rt, nb, 2 * C).permute(1, 0, 2)
-        ops.gemm(h7v, w8[:nb], False, True, out=lgv, epilogue=L.EPI_BIAS, bias=b8)
+        # logits [Rt, nb * ld8]: branch b holds fc8c | fc8d in columns b*ld8 .. b*ld8 + 2C.  ld8 = 2C
+        # rounded up to 4 floats so the batch-2 GEMM operands stay 16-byte aligned for any class
+        # count (odd C: the weights / bias are copied into zero-padded [ld8, 4096] operands)
+        ld8 = self.ld8
+        w8g, b8g = self._fc8_operands(w8, b8)
+        lg = torch.empty((rt, nb * ld8), device=self.device, dtype=torch.float32)
+        lgv = lg.view(rt, nb, ld8).permute(1, 0, 2)
+        ops.gemm(h7v, w8g[:nb], False, True, out=lgv, epilogue=L.EPI_BIAS, bias=b8g)
         return h6, h7, lg
+
+    def _fc8_operands(self, w8, b8):
+        C, ld8 = self.C, self.ld8
+        if ld8 == 2 * C:
+            return w8, b8
+        w8p = torch.zeros((2, ld8, HIDDEN), device=self.device, dtype=torch.float32)
+        b8p = torch.zeros((2, ld8), device=self.device, dtype=torch.float32)
+        w8p[:, :2 * C].copy_(w8)
+        b8p[:, :2 * C].copy_(b8)
+        return w8p, b8p
 
     def forward_backward(self, data, rois, obn_scores, labels_oh, compute_grads=True, seg=None):
         """One training pass over this GPU's images.  Returns dict of loss tensors
@@ -414,7 +436,9 @@ class WsddnEngine(object):
         x = roi_feat.view(rt, self.k6)
         h6, h7, lg = self.head_forward(x, train=True)
         mark('head_fwd')
-        lv = [lg[:, i * C:(i + 1) * C] for i in range(4)]    # fc8c, fc8d, noisy_fc8c, noisy_fc8d
+        ld8 = self.ld8
+        cols = [0, C, ld8, ld8 + C]                          # fc8c, fc8d, noisy_fc8c, noisy_fc8d
+        lv = [lg[:, o:o + C] for o in cols]
         ac, ad, rp, cp = ops.wsddn_outputs(lv[0], lv[1], lv[2], lv[3], seg_off)
         cw, cwn, hs, hsn = ops.entropy_gate(rois, rp[0], cp[0], labels_oh, seg_off, max_seg)
         wts = torch.stack([cw, cwn])                           # [2, nseg, C]
@@ -430,10 +454,12 @@ class WsddnEngine(object):
         # ---- backward (loss gradient seed 1.0 per loss, blob.py:167-173)
         ones = torch.ones((2 * n_img,), device=self.device, dtype=torch.float32)
         g = ops.weighted_ce_grad(cp, lab2, wts, ones, self.is_mean, 2 * n_img)
-        dl = ops.wsddn_outputs_grad(ac, ad, rp, cp, g, seg_off)          # [Rt, 4C]
+        dl = (torch.zeros if ld8 != 2 * C else torch.empty)((rt, 2 * ld8), device=self.device,
+                                                            dtype=torch.float32)
+        ops.wsddn_outputs_grad(ac, ad, rp, cp, g, seg_off, out=dl, col_offsets=cols)
         self._head_backward(x, h6, h7, dl)
         mark('head_bwd')
-        out['d_logits'] = dl
+        out['d_logits'] = dl if ld8 == 2 * C else torch.cat([dl[:, o:o + C] for o in cols], 1)
         return out
 
     def _head_backward(self, x, h6, h7, dl):
@@ -448,12 +474,22 @@ class WsddnEngine(object):
         gb7 = self.arena.span(G, 'fc7_b', '_[noisy]_fc7_b')
         gw8 = self.arena.span(G, 'fc8c_w', 'noisy_fc8d_w').view(2, 2 * C, HIDDEN)
         gb8 = self.arena.span(G, 'fc8c_b', 'noisy_fc8d_b')
-        dlv = dl.view(rt, 2, 2 * C).permute(1, 0, 2)           # [2, Rt, 2C]
+        ld8 = self.ld8
+        pad = ld8 != 2 * C
+        dlv = dl.view(rt, 2, ld8).permute(1, 0, 2)             # [2, Rt, ld8]
         h7v = h7.view(rt, 2, HIDDEN).permute(1, 0, 2)
         h6v = h6.view(rt, 2, HIDDEN).permute(1, 0, 2)
         # fc8: dW = dL^T H7, db = colsum(dL), dH7 = dL W8 gated by ReLU/Dropout of fc7
-        ops.gemm(dlv, h7v, True, False, out=gw8)
-        ops.colsum(dl, out=gb8)
+        if pad:
+            gw8p = torch.empty((2, ld8, HIDDEN), device=self.device, dtype=torch.float32)
+            ops.gemm(dlv, h7v, True, False, out=gw8p)
+            gw8.copy_(gw8p[:, :2 * C])
+            gb8.view(2, 2 * C).copy_(ops.colsum(dl).view(2, ld8)[:, :2 * C])
+            w8 = self._fc8_operands(w8, self.arena.span(self.params, 'fc8c_b', 'noisy_fc8d_b')
+                                    .view(2, 2 * C))[0]
+        else:
+            ops.gemm(dlv, h7v, True, False, out=gw8)
+            ops.colsum(dl, out=gb8)
         dz7 = torch.empty_like(h7)
         dz7v = dz7.view(rt, 2, HIDDEN).permute(1, 0, 2)
         ops.gemm(dlv, w8, False, False, out=dz7v, epilogue=L.EPI_GATE_POS, aux=h7v, alpha=scale)
@@ -559,6 +595,8 @@ class WsddnEngine(object):
 
     # -------------------------------------------------------------- inference
     def infer(self, data, rois, obn_scores, seg=None):
+        if rois.shape[0] == 0:
+            raise ValueError('infer: no proposals (rois is empty)')
         self.flush()
         """Test-mode forward: cls_prob [R, C+1] = Concat(rois_pred[:, :1], rois_pred)
         (wsl_heads.py:58-67); no dropout; only the clean branch is fetched (test_wsl.py:151)."""

@@ -441,16 +441,19 @@ def wsddn_outputs(fc8c, fc8d, noisy_fc8c, noisy_fc8d, seg_off):
     return ac, ad, rp, cp
 
 
-def wsddn_outputs_grad(alpha_cls, alpha_det, rois_pred, cls_prob, d_cls_prob, seg_off, out=None):
+def wsddn_outputs_grad(alpha_cls, alpha_det, rois_pred, cls_prob, d_cls_prob, seg_off, out=None,
+                       col_offsets=None):
     """-> d_fc8c, d_fc8d, d_noisy_fc8c, d_noisy_fc8d as column slices of `out`
-    ([Rt, 4C]; allocated when None)."""
+    ([Rt, 4C] at columns 0, C, 2C, 3C; allocated when None - or at `col_offsets` of a wider
+    row-major `out`)."""
     nb, rt, c = alpha_cls.shape
     nseg = seg_off.numel() - 1
     if out is None:
         out = torch.empty((rt, 4 * c), device=alpha_cls.device, dtype=_f32)
     ld = out.stride(0)
     base = out.data_ptr()
-    ptrs = [base + 4 * c * i for i in range(4)]
+    offs = col_offsets if col_offsets is not None else [c * i for i in range(4)]
+    ptrs = [base + 4 * o for o in offs]
     L.call('naws_wsddn_outputs_bwd', alpha_cls.data_ptr(), alpha_det.data_ptr(),
            rois_pred.data_ptr(), cls_prob.data_ptr(), d_cls_prob.data_ptr(), seg_off.data_ptr(),
            nseg, rt, c, nb, ptrs[0], ptrs[1], ptrs[2] if nb == 2 else 0,

@@ -46,15 +46,52 @@ def main(argv=None):
     ex.init_params()
     if cfg.TEST.WEIGHTS and os.path.exists(cfg.TEST.WEIGHTS):
         nu.initialize_from_weights_file(model, cfg.TEST.WEIGHTS, ex, broadcast=False)
-    roidb = synthetic.make_roidb(args.num_images, min(cfg.TEST.PROPOSAL_LIMIT, 2000),
-                                 cfg.MODEL.NUM_CLASSES - 1, seed=cfg.RNG_SEED)
+    # test roidb: the named dataset + proposal file when on disk (test_engine.py:324-352:
+    # JsonDataset.get_roidb(proposal_file, proposal_limit)), else synthetic entries
+    from detectron.datasets import dataset_catalog
+    names = tuple(cfg.TEST.DATASETS)
+    real = bool(names) and dataset_catalog.contains(names[0]) and \
+        os.path.exists(dataset_catalog.get_ann_fn(names[0]))
+    if real:
+        from detectron.datasets.json_dataset_wsl import JsonDataset
+        from detectron.roi_data.minibatch_wsl import _read_image
+        pf = cfg.TEST.PROPOSAL_FILES[0] if len(cfg.TEST.PROPOSAL_FILES) else None
+        roidb = JsonDataset(names[0]).get_roidb(proposal_file=pf,
+                                                proposal_limit=cfg.TEST.PROPOSAL_LIMIT)
+    else:
+        roidb = synthetic.make_roidb(args.num_images, min(cfg.TEST.PROPOSAL_LIMIT, 2000),
+                                     cfg.MODEL.NUM_CLASSES - 1, seed=cfg.RNG_SEED)
     lo, hi = args.range if args.range else (0, len(roidb))
+    num_classes = cfg.MODEL.NUM_CLASSES
+    # all_boxes[cls][image] = N x 5 (x1, y1, x2, y2, score), test_engine.py:236-300
+    all_boxes = [[[] for _ in range(len(roidb))] for _ in range(num_classes)]
     for i in range(lo, hi):
         e = roidb[i]
-        im = synthetic.make_image(e).transpose(1, 2, 0) + synthetic.PIXEL_MEANS_BGR
-        scores, boxes = test_wsl.im_detect_bbox(ex, im.astype(np.float32), cfg.TEST.SCALE,
-                                                cfg.TEST.MAX_SIZE, e['boxes'], e['obn_scores'])
-        print('image %d: %d proposals, top class score %.4g' % (i, boxes.shape[0], scores[:, 1:].max()))
+        if real:
+            im = _read_image(e).astype(np.float32)
+        else:
+            im = synthetic.make_image(e).transpose(1, 2, 0) + synthetic.PIXEL_MEANS_BGR
+        sel = (e['gt_classes'] == 0) if real else slice(None)    # proposals only (test_engine.py:256)
+        if e['boxes'][sel].shape[0] == 0:                        # test_engine.py:257-258: skip
+            for j in range(1, num_classes):
+                all_boxes[j][i] = np.zeros((0, 5), np.float32)
+            print('image %d: no proposals' % i)
+            continue
+        cls_boxes = test_wsl.im_detect_all(ex, im.astype(np.float32), e['boxes'][sel],
+                                           e['obn_scores'][sel])
+        for j in range(1, num_classes):
+            all_boxes[j][i] = cls_boxes[j]
+        n_det = sum(len(cls_boxes[j]) for j in range(1, num_classes))
+        top = max([cls_boxes[j][:, 4].max() for j in range(1, num_classes) if len(cls_boxes[j])] or [0.0])
+        print('image %d: %d proposals -> %d detections, top score %.4g' % (
+            i, int(np.sum(sel)) if real else e['boxes'].shape[0], n_det, top))
+    from detectron.core.config import get_output_dir
+    out_dir = get_output_dir(names if names else ('synthetic',), training=False)
+    det_file = os.path.join(out_dir, 'detections.pkl' if not args.range else
+                            'detection_range_%s_%s.pkl' % (lo, hi))
+    nu.save_object(dict(all_boxes=all_boxes, cfg=str(cfg)), det_file)
+    print('Wrote detections to: {}'.format(os.path.abspath(det_file)))
+    return all_boxes
 
 
 if __name__ == '__main__':

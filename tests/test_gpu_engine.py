@@ -42,7 +42,7 @@ def _masks(eng, rt, dev):
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
-@pytest.mark.parametrize('dropout,c', [(0.5, 20), (0.0, 20), (0.5, 80)])
+@pytest.mark.parametrize('dropout,c', [(0.5, 20), (0.0, 20), (0.5, 80), (0.5, 2), (0.5, 21)])
 def test_engine_matches_oracle(dev, dropout, c, mode):
     """Both fp32 plans (fp32 MFMA everywhere / fc6+fc7 as exact 3xbf16 splits on the bf16 MFMA)
     are held to the same fp32 tolerances."""

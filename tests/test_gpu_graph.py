@@ -166,3 +166,59 @@ def test_tta_inference_and_nms(dev, cfgmod):
     assert u.shape[0] <= 39 and np.array_equal(np.round(u[inv] * 0.125), np.round(rois * 0.125))
     assert test_wsl.nms(np.array([[0, 0, 10, 10, .9], [1, 1, 10, 10, .8], [20, 20, 30, 30, .7]],
                                  np.float32), 0.5) == [0, 2]
+
+
+def _load_tool(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        name, os.path.join(ROOT, 'na-fwebsod_amd', 'tools', name + '.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    return tool
+
+
+def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys):
+    """The whole caller chain on real files: COCO json + MCG pickle -> roidb -> loader threads
+    (PNG decode) -> device-side image prep with the yaml's HSV distortion / crop / flip ->
+    training iterations -> checkpoint;  then test_net_wsl: dataset -> multi-scale + flip TTA ->
+    GPU NMS -> detections.pkl in the reference's all_boxes[cls][image] layout."""
+    from test_datasets import _toy_dataset
+    from detectron.datasets import dataset_catalog
+    from detectron.utils.net_wsl import load_object
+    cfgmod.reset_cfg()
+    imdir, annf, pf, sizes, _pb, _ps = _toy_dataset(tmp_path)
+    dataset_catalog.register('toy_train', imdir, annf)
+    dataset_catalog.register('toy_test', imdir, annf)
+    common = ['OUTPUT_DIR', str(tmp_path), 'MODEL.NUM_CLASSES', '3', 'DATA_LOADER.NUM_THREADS', '1',
+              'TRAIN.CROWD_FILTER_THRESH', '0.0']
+    _load_tool('train_net_wsl').main(
+        ['--cfg', YAML, '--skip-test', '--max-iter', '3'] + common +
+        ['TRAIN.DATASETS', "('toy_train',)", 'TRAIN.PROPOSAL_FILES', "('%s',)" % pf,
+         'TRAIN.SCALES', '(64, 80)', 'TRAIN.MAX_SIZE', '120', 'SOLVER.BASE_LR', '1e-5',
+         'NAWS.DEVICE_PREP', 'True'])
+    out = capsys.readouterr().out
+    import json as _json
+    stats = [_json.loads(l.split('json_stats: ', 1)[1]) for l in out.splitlines() if 'json_stats: {' in l]
+    assert stats and all(np.isfinite(float(st['loss'])) for st in stats)
+    # (the Stat lines print nan for "bg" when an image carries every class: AI/AL = 0/0, as the
+    # reference's stat_op.cu:68-74 does)
+    wts = os.path.join(str(tmp_path), 'train', 'toy_train', 'generalized_wsl', 'model_final.pkl')
+    assert os.path.exists(wts)
+    cfgmod.reset_cfg()
+    all_boxes = _load_tool('test_net_wsl').main(
+        ['--cfg', YAML] + common +
+        ['TEST.DATASETS', "('toy_test',)", 'TEST.PROPOSAL_FILES', "('%s',)" % pf, 'TEST.WEIGHTS', wts,
+         'TEST.SCALE', '64', 'TEST.MAX_SIZE', '120', 'TEST.BBOX_AUG.ENABLED', 'True',
+         'TEST.BBOX_AUG.SCALES', '(48, 64)', 'TEST.BBOX_AUG.MAX_SIZE', '120',
+         'TEST.BBOX_AUG.H_FLIP', 'True', 'TEST.BBOX_AUG.SCALE_H_FLIP', 'True'])
+    det = load_object(os.path.join(str(tmp_path), 'test', 'toy_test', 'generalized_wsl',
+                                   'detections.pkl'))
+    assert len(det['all_boxes']) == 3 and len(det['all_boxes'][1]) == len(sizes)
+    n = 0
+    for j in (1, 2):
+        for i in range(len(sizes)):
+            d = np.asarray(det['all_boxes'][j][i])
+            assert d.ndim == 2 and d.shape[1] == 5 and np.isfinite(d).all()
+            assert np.array_equal(d, np.asarray(all_boxes[j][i]))
+            n += d.shape[0]
+    assert n > 0
