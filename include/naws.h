@@ -360,6 +360,14 @@ int naws_prep_image_fwd(const uint8_t* im_bgr_hwc, int H, int W, int flip, int c
                         const float* stds3, double im_scale, int distort, float saturation,
                         float exposure, int out_h, int out_w, int64_t plane_stride,
                         int row_stride, float* out, void* stream);
+/* ---- adjacent loss op -----------------------------------------------------------
+ * MinEntropyLoss / MinEntropyLossGradient (cfg.WSL.MIN_ENTROPY_LOSS), detectron/ops/
+ * min_entropy_loss_op.cc:7-98: X [N,C] probabilities, L [1,C] labels (B must be 1, :30),
+ * Y[0] = -sum_{n, L[c]>=0.5} p log p / count with p = max(X, 1e-20);
+ * dX = min(dY[0]/count * (-1 - log p), 1e4) on those entries, 0 elsewhere. */
+int naws_min_entropy_loss_fwd(const float* X, const float* L, int N, int C, float* Y, void* stream);
+int naws_min_entropy_loss_bwd(const float* X, const float* L, const float* dY, int N, int C,
+                              float* dX, void* stream);
 
 #ifdef __cplusplus
 }

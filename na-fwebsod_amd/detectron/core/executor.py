@@ -279,6 +279,8 @@ class NetExecutor(object):
             ws[out[0]] = O.CrossEntropyWithLogits(x[0], x[1], is_mean=a.get('is_mean', False))
         elif t == 'AveragedLoss':
             ws[out[0]] = O.AveragedLoss(x[0])
+        elif t == 'MinEntropyLoss':
+            ws[out[0]] = O.MinEntropyLoss(x[0], x[1])
         elif t == 'Accuracy':
             ws[out[0]] = O.Accuracy(x[0], x[1])
         elif t == 'Split':
@@ -324,6 +326,8 @@ class NetExecutor(object):
                                                     is_mean=a.get('is_mean', False))]
         elif t == 'RoIFeatureBoost':
             res = [O.RoIFeatureBoostGradient(gout[0], ws[ins[1]])]
+        elif t == 'MinEntropyLoss':
+            res = [O.MinEntropyLossGradient(ws[ins[0]], ws[ins[1]], gout[0])]
         else:
             raise NotImplementedError('gradient of ' + t)
         for i, g in enumerate(a['_gin']):

@@ -42,6 +42,10 @@ def add_webly_losses(model, prefix=''):
                        prefix + 'accuracy_cls' + suffix)
         model.AddLosses([prefix + 'loss_cls' + suffix])
         model.AddMetrics(prefix + 'accuracy_cls' + suffix)
+    if cfg.WSL.MIN_ENTROPY_LOSS:       # webly_heads.py:208-214
+        from detectron.modeling.wsl_heads import add_min_entropy_loss
+        loss_gradients.update(add_min_entropy_loss(model, prefix + 'rois_pred', 'labels_oh',
+                                                   prefix + 'loss_entropy', cpg=None))
     return loss_gradients
 
 

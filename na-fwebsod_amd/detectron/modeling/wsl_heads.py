@@ -76,3 +76,23 @@ def add_VGG16_roi_2fc_head(model, blob_in, dim_in, spatial_scale, prefix=''):
     out = _two_fc(model, feat, prefix + 'fc6', prefix + 'drop6', prefix + 'fc7', prefix + 'drop7',
                   dim_in * roi_size * roi_size)
     return out, 4096
+
+
+def add_min_entropy_loss(model, pred, label, loss, cpg=None):
+    """wsl_heads.py:279-289: MinEntropyLoss on rois_pred with the loss gradient weighted 0.1."""
+    in_blobs = [pred, label]
+    if cpg:
+        in_blobs.append(cpg)
+    loss_entropy = model.net.MinEntropyLoss(in_blobs, [loss])
+    loss_gradients = get_loss_gradients_weighted(model, [loss_entropy], 0.1)
+    model.AddLosses([loss])
+    return loss_gradients
+
+
+def get_loss_gradients_weighted(model, loss_blobs, loss_weight):
+    """wsl_heads.py:610-617: a gradient seed of loss_weight per loss blob."""
+    loss_gradients = {}
+    for b in loss_blobs:
+        loss_grad = model.net.ConstantFill(b, [str(b) + '_grad'], value=1.0 * loss_weight)
+        loss_gradients[str(b)] = str(loss_grad)
+    return loss_gradients

@@ -58,6 +58,16 @@ def WeightedCrossEntropyWithLogitsGradient(X, L, W, dY, is_mean=False):
     return _k.weighted_ce_grad(X, L, W, dY.reshape(1), is_mean)
 
 
+def MinEntropyLoss(X, L, cpg=None):
+    """detectron/ops/min_entropy_loss_op.cc:7-45 (schema :105-113): Y[] scalar."""
+    return _k.min_entropy_loss(X.contiguous(), L.contiguous())[0]
+
+
+def MinEntropyLossGradient(X, L, dY):
+    """detectron/ops/min_entropy_loss_op.cc:47-98."""
+    return _k.min_entropy_loss_grad(X.contiguous(), L.contiguous(), dY.reshape(1))
+
+
 def CrossEntropyWithLogits(X, L, cpg=None, is_mean=False):
     if X.dim() != 2:
         raise NawsError('CrossEntropyWithLogits', _L.ERR_SHAPE)

@@ -366,6 +366,24 @@ def prep_image(im_u8, out, im_scale, flip=False, crop=None, means=(0.0, 0.0, 0.0
     return oh, ow
 
 
+def min_entropy_loss(x, l):
+    _chk(x, 'X'); _chk(l, 'L')
+    if x.dim() != 2 or l.dim() != 2 or l.shape[0] != 1 or l.shape[1] != x.shape[1]:
+        raise L.NawsError('naws_min_entropy_loss_fwd', L.ERR_SHAPE)    # CAFFE_ENFORCE sites :11-13,30
+    y = torch.empty((1,), device=x.device, dtype=_f32)
+    L.call('naws_min_entropy_loss_fwd', x.data_ptr(), l.data_ptr(), x.shape[0], x.shape[1],
+           y.data_ptr(), _stream())
+    return y
+
+
+def min_entropy_loss_grad(x, l, dy):
+    _chk(x, 'X'); _chk(l, 'L'); _chk(dy, 'dY')
+    dx = torch.empty_like(x)
+    L.call('naws_min_entropy_loss_bwd', x.data_ptr(), l.data_ptr(), dy.data_ptr(), x.shape[0],
+           x.shape[1], dx.data_ptr(), _stream())
+    return dx
+
+
 def planes_to_dense(p):
     """[3, (b,) K/16, outer, 16] planes -> float64 [(b,) outer, K] (test / debug helper)."""
     s = p[0].double() + p[1].double() + p[2].double()

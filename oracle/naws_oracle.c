@@ -368,3 +368,36 @@ int oracle_nms(const float* dets /* [n][5] x1 y1 x2 y2 score */, const int64_t* 
   }
   return kept;
 }
+
+/* MinEntropyLoss.  ref: detectron/ops/min_entropy_loss_op.cc:7-45 (forward), :47-98 (gradient).
+ * X [N,C] probabilities, L [1,C] image labels: over rows n and the classes with L[c] >= 0.5,
+ * loss = -sum p log p / norm, p = max(X, 1e-20), norm = number of terms (fp32 serial sum in
+ * (n, c) order).  dX = min(dY/norm * (-1 - log p), 1e4) on those entries, 0 elsewhere. */
+float oracle_min_entropy_fwd(const float* X, const float* L, int N, int C) {
+  float loss = 0;
+  int norm = 0;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      if (L[c] < 0.5) continue;
+      float prob = X[n * C + c] > 1e-20f ? X[n * C + c] : 1e-20f;
+      loss -= (prob * logf(prob));
+      norm += 1;
+    }
+  return loss / norm;
+}
+
+void oracle_min_entropy_bwd(const float* X, const float* L, float dY, int N, int C, float* dX) {
+  int norm = 0;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c)
+      if (!(L[c] < 0.5)) norm += 1;
+  const float scale = dY / norm;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      dX[n * C + c] = 0.f;
+      if (L[c] < 0.5) continue;
+      float prob = X[n * C + c] > 1e-20f ? X[n * C + c] : 1e-20f;
+      float g = scale * (-1 + (-1) * (float)logf(prob));
+      dX[n * C + c] = g < 1e4f ? g : 1e4f;
+    }
+}

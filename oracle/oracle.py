@@ -190,6 +190,24 @@ VGG16_LAYERS = [
 ]
 
 
+def min_entropy_loss(x, l):
+    """ref: detectron/ops/min_entropy_loss_op.cc:7-45."""
+    x, xp = _f(x)
+    l, lp = _f(l)
+    L().oracle_min_entropy_fwd.restype = C.c_float
+    return np.float32(L().oracle_min_entropy_fwd(xp, lp, x.shape[0], x.shape[1]))
+
+
+def min_entropy_loss_grad(x, l, dy):
+    """ref: detectron/ops/min_entropy_loss_op.cc:47-98."""
+    x, xp = _f(x)
+    l, lp = _f(l)
+    dx = np.zeros_like(x)
+    L().oracle_min_entropy_bwd(xp, lp, C.c_float(float(dy)), x.shape[0], x.shape[1],
+                               dx.ctypes.data_as(_fp))
+    return dx
+
+
 def nms(dets, thresh):
     """Greedy NMS on [n,5] (x1,y1,x2,y2,score) -> kept indices, ascending
     (ref: detectron/utils/cython_nms.pyx:36-87).  Visiting order = stable descending score."""

@@ -162,6 +162,14 @@ def main():
 
     out['trace_train'] = trace(True)
     out['trace_test'] = trace(False)
+    # the same head with cfg.WSL.MIN_ENTROPY_LOSS (webly_heads.py:208-214): only the tail differs
+    cfg.immutable(False) if hasattr(cfg, 'immutable') else None
+    cfg.WSL.MIN_ENTROPY_LOSS = True
+    t2 = trace(True)
+    cfg.WSL.MIN_ENTROPY_LOSS = False
+    n0 = len(out['trace_train']['ops'])
+    assert t2['ops'][:n0] == out['trace_train']['ops']
+    out['trace_train_min_entropy_tail'] = dict(ops=t2['ops'][n0:], losses=t2['losses'])
     with open(os.path.join(HERE, 'reference_python.json'), 'w') as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print('train ops', len(out['trace_train']['ops']), 'test ops', len(out['trace_test']['ops']))

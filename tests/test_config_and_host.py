@@ -204,3 +204,35 @@ def test_graph_trace_fixture_shape():
     assert len(ops_) == 103 and ops_[32][0] == 'RoIPoolF' and ops_[33][0] == 'RoIFeatureBoost'
     assert GOLD['trace_train']['losses'] == ['loss_cls', 'loss_cls_noise']
     assert len(GOLD['trace_test']['ops']) == 61
+
+
+def test_graph_builders_reproduce_reference_trace(cfgmod):
+    """The op lists the builders emit == the trace recorded from the reference builders
+    (Conv / FC are recorded by the reference helper without their parameter blobs), in train and
+    test mode, and with cfg.WSL.MIN_ENTROPY_LOSS (the f-4 adjacent loss)."""
+    c = cfgmod
+    c.merge_cfg_from_file(YAML)
+    c.merge_cfg_from_list(['NUM_GPUS', 1])
+    import detectron.modeling.model_builder_wsl as mb
+
+    def norm(m):
+        out = []
+        for o in m.net.ops:
+            ins = list(o.inputs)
+            outs = list(o.outputs)
+            if o.type in ('Conv', 'FC'):
+                ins = ins[:1]
+            if o.type == 'Dropout':          # the Caffe2 op's mask output is implicit in the helper call
+                outs = outs[:1]
+            out.append([o.type, ins, outs])
+        return out
+    for train, key in ((True, 'trace_train'), (False, 'trace_test')):
+        m = mb.create(c.cfg.MODEL.TYPE, train=train)
+        assert norm(m) == [[o[0], o[1], o[2]] for o in GOLD[key]['ops']]
+    c.cfg.WSL.MIN_ENTROPY_LOSS = True
+    m = mb.create(c.cfg.MODEL.TYPE, train=True)
+    tail = GOLD['trace_train_min_entropy_tail']
+    got = [[o.type, list(o.inputs), list(o.outputs), dict(o.args)] for o in m.net.ops[103:]]
+    assert got == tail['ops'] and m.losses == tail['losses']
+    assert m.grad_ops[0].type == 'MinEntropyLossGradient'      # its gradient joins rois_pred_grad
+    assert 'rois_pred_grad' in m.grad_ops[0].outputs

@@ -222,3 +222,55 @@ def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys):
             assert np.array_equal(d, np.asarray(all_boxes[j][i]))
             n += d.shape[0]
     assert n > 0
+
+
+def test_min_entropy_loss_op_and_graph(dev, cfgmod):
+    """cfg.WSL.MIN_ENTROPY_LOSS: the HIP op against the oracle's
+    restatement of min_entropy_loss_op.cc, and inside the graph (op-by-op plan): loss_entropy of
+    the run equals the oracle on the fetched rois_pred, and the extra gradient that reaches the
+    fc8c / fc8d logits equals autograd of 0.1 * loss_entropy through the two softmaxes."""
+    from naws_hip import ops
+    from oracle import oracle
+    from detectron.datasets import synthetic
+    rng = np.random.default_rng(61)
+    x = rng.uniform(0, 1, (300, 20)).astype(np.float32) ** 6
+    x[0, :3] = [0.0, 1.0, 1e-30]
+    lab = np.zeros((1, 20), np.float32)
+    lab[0, [0, 1, 2, 7]] = [1.0, 0.7, 0.5, 0.49]               # mixup-style fractional labels
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+    y = float(ops.min_entropy_loss(xd, ld))
+    assert abs(y - float(oracle.min_entropy_loss(x, lab))) <= 1e-5 * abs(y)
+    g = ops.min_entropy_loss_grad(xd, ld, torch.tensor([0.1], device=dev)).cpu().numpy()
+    np.testing.assert_allclose(g, oracle.min_entropy_loss_grad(x, lab, 0.1), rtol=1e-5, atol=1e-9)
+    # ---- in the graph
+    blobs = synthetic.init_blobs(20, seed=3)
+    t = _inputs(dev)
+    res = {}
+    for flag in (False, True):
+        cfgmod.cfg.WSL.MIN_ENTROPY_LOSS = flag
+        m, ex = _build(dev, True, True, blobs)
+        assert ex.plan == 'interpreted' and (('loss_entropy' in m.losses) == flag)
+        m.UpdateWorkspaceLr(0, 1e-3)
+        ex.feed(t)
+        ex.run()
+        res[flag] = {k: ex.fetch(k).clone() for k in ('fc8c_grad', 'fc8d_grad', 'rois_pred',
+                                                        'fc8c', 'fc8d', 'noisy_fc8c_grad')}
+        if flag:
+            le = float(ex.fetch('loss_entropy').reshape(-1)[0])
+    cfgmod.cfg.WSL.MIN_ENTROPY_LOSS = False
+    rp = res[True]['rois_pred'].cpu().numpy()
+    lab_oh = t['labels_oh'].cpu().numpy()
+    assert abs(le - float(oracle.min_entropy_loss(rp, lab_oh))) <= 1e-5 * abs(le)
+    # autograd (float64, CPU) of 0.1 * H(rois_pred) w.r.t. the clean logits
+    a = res[True]['fc8c'].double().cpu().requires_grad_(True)
+    b = res[True]['fc8d'].double().cpu().requires_grad_(True)
+    p = torch.softmax(a, 1) * torch.softmax(b, 0)
+    sel = torch.from_numpy(lab_oh[0] >= 0.5)
+    pe = p[:, sel].clamp_min(1e-20)
+    loss = 0.1 * (-(pe * pe.log()).sum() / pe.numel())
+    da, db = torch.autograd.grad(loss, [a, b])
+    for k, d in (('fc8c_grad', da), ('fc8d_grad', db)):
+        extra = (res[True][k] - res[False][k]).double().cpu()
+        assert float((extra - d).abs().max()) <= 1e-4 * float(d.abs().max()) + 1e-9, k
+    # the noisy branch's own logits do not see the entropy term
+    assert torch.equal(res[True]['noisy_fc8c_grad'], res[False]['noisy_fc8c_grad'])

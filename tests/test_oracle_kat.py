@@ -174,3 +174,18 @@ def test_nms_known_answers_and_host_mirror():
         for th in (0.3, 0.5, 0.0):
             assert test_wsl.nms(dets, th) == oracle.nms(dets, th).tolist()
     assert test_wsl.nms(np.zeros((0, 5), np.float32), 0.5) == []
+
+
+def test_min_entropy_loss_known_answer():
+    """min_entropy_loss_op.cc:7-98 by hand: X=[[.5,.25],[.1,.9]], L=[1,0] -> two terms."""
+    from oracle import oracle
+    x = np.array([[.5, .25], [.1, .9]], np.float32)
+    l = np.array([[1, 0]], np.float32)
+    want = -(.5 * np.log(.5) + .1 * np.log(.1)) / 2
+    assert abs(float(oracle.min_entropy_loss(x, l)) - want) < 1e-6
+    g = oracle.min_entropy_loss_grad(x, l, 0.1)
+    assert np.allclose(g, [[0.05 * (-1 - np.log(.5)), 0], [0.05 * (-1 - np.log(.1)), 0]], atol=1e-7)
+    # p = 0 is clamped to 1e-20; the gradient is capped at 1e4
+    g0 = oracle.min_entropy_loss_grad(np.zeros((1, 2), np.float32), l, 1e6)
+    assert g0[0, 0] == np.float32(1e4) and g0[0, 1] == 0
+    assert oracle.min_entropy_loss(np.zeros((3, 2), np.float32), l) == np.float32(1e-20 * -np.log(np.float32(1e-20)))
