@@ -193,7 +193,7 @@ def main():
         # TFLOP/s is the bf16 dense peak / 6 (frac = executed MFMA flops / bf16 peak)
         peak = (BF16_MFMA_PEAK_TFLOPS if bf else
                 round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if x3 else FP32_MFMA_PEAK_TFLOPS)
-        kname = ('gemm_bf16_kernel<256,128,4x2 waves,fp32 sources>' if bf else
+        kname = ('gemm_x3_kernel<256,256,2x4 waves,2 stages,1 plane x 4 K-slabs> (bf16 slab operands)' if bf else
                  'gemm_x3_kernel<256,256,2x4 waves,3 stages> = 6 x v_mfma_f32_32x32x16_bf16 per '
                  'fp32 product' if x3 else 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
         res = {
@@ -204,7 +204,7 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if bf else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'flickr_voc na_wsddn_V-16-C5_1x (C=%d): %d images %dx%d per '
+            'config': {'workload': 'flickr_voc na_wsddn_V-16-C5_1x (= BASELINE.json webly_wsddn_V-16-C5_1x; C=%d): %d images %dx%d per '
                                    'GPU x %d proposals, fwd+bwd+allreduce+SGD, %s' % (
                                        num_fg, B, args.height, args.width, args.rois,
                                        'bf16 MFMA conv/fc6/fc7, fp32 storage/fc8/loss/SGD'

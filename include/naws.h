@@ -320,6 +320,17 @@ int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t slabA, int64
                        int64_t strideA, int64_t strideB, int64_t strideC, int epilogue,
                        const float* bias, int64_t strideBias, const float* aux, int ldaux,
                        float alpha, float drop_ratio, uint64_t seed, int accumulate, void* stream);
+/* bf16 plan on the same pipeline: one plane (operands rounded to bf16), 64-deep K-steps.
+ * naws_to_bf16_slab: as naws_split_bf16x3 with a single plane, P[batch][kpad/16][outer][16],
+ * kpad = K rounded up to 64.  naws_gemm_bf16_slab_nt: C (+)= A B^T on such operands, K % 64 == 0;
+ * replaces naws_gemm_bf16_nt for fc6 / fc7 of the bf16 plan (same reference operators). */
+int naws_to_bf16_slab(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
+                      int transpose, int kpad, void* P, void* stream);
+int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_t slabA, const void* B,
+                           int64_t slabB, float* C, int ldc, int batch, int64_t strideA,
+                           int64_t strideB, int64_t strideC, int epilogue, const float* bias,
+                           int64_t strideBias, const float* aux, int ldaux, float alpha,
+                           float drop_ratio, uint64_t seed, int accumulate, void* stream);
 /* 3x3 / stride 1 / pad = dilation convolution, NHWC fp32 in and out, as an fp32x3 implicit GEMM
  * (same operator as naws_conv3x3_nhwc_fwd: Caffe2 Conv + Relu, reference
  * detectron/modeling/VGG16.py:37-130).  W3 = naws_split_bf16x3 (transpose = 0) of the packed

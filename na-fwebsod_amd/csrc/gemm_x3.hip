@@ -70,16 +70,21 @@ __device__ __forceinline__ void wait_vmcnt() {
 // s_waitcnt vmcnt (retires this wave's pieces of step t, leaves the younger steps in flight),
 // one raw s_barrier (everybody's pieces landed; everybody is done reading the stage about to be
 // refilled), issue step t+STAGES-1, then 6 x TI x TJ MFMAs on step t.
-template <int BM, int BN, int WM, int WN, int STAGES>
+//
+// NPL = 3, KS = 1: the fp32x3 GEMM (6 MFMA terms per 16-deep K slab).  NPL = 1, KS = 4: the same
+// pipeline as a plain bf16 GEMM for the bf16 plan (one plane, 64-deep K-steps of 4 slabs, so a
+// step still carries 32 MFMAs per wave between barriers).
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_kernel(XArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TI = WTM / 32, TJ = WTN / 32;
-  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;       // bytes per plane per stage
-  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;       // bytes per plane-slab per stage
+  constexpr int NQ = NPL * KS;                              // plane-slabs per operand per stage
+  constexpr int STAGE = NQ * (A_PLANE + B_PLANE);
   constexpr int PIECE_ROWS = NT / 2;                        // rows one DMA round covers
   constexpr int PA = BM / PIECE_ROWS, PB = BN / PIECE_ROWS;
-  constexpr int G = 3 * (PA + PB);                          // DMA instructions per thread per step
+  constexpr int G = NQ * (PA + PB);                         // DMA instructions per thread per step
   static_assert(BM % PIECE_ROWS == 0 && BN % PIECE_ROWS == 0, "tile vs workgroup");
   static_assert((STAGES - 2) * G <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
@@ -125,15 +130,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   auto issue = [&](int t, int st) {
     unsigned char* base = smx + st * STAGE + wid * 1024;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int q = 0; q < NQ; ++q) {
+      const int pl = q / KS, ks = q % KS;
+      const long long ka = (long long)(t * KS + ks) * g.slabA, kb = (long long)(t * KS + ks) * g.slabB;
 #pragma unroll
       for (int p = 0; p < PA; ++p)
-        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcA[p] + pl * g.planeA + t * g.slabA),
-                                         NAWS_LDS_PTR(base + pl * A_PLANE + p * (NT * 16)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcA[p] + pl * g.planeA + ka),
+                                         NAWS_LDS_PTR(base + q * A_PLANE + p * (NT * 16)), 16, 0, 0);
 #pragma unroll
       for (int p = 0; p < PB; ++p)
-        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcB[p] + pl * g.planeB + t * g.slabB),
-                                         NAWS_LDS_PTR(base + 3 * A_PLANE + pl * B_PLANE + p * (NT * 16)),
+        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcB[p] + pl * g.planeB + kb),
+                                         NAWS_LDS_PTR(base + NQ * A_PLANE + q * B_PLANE + p * (NT * 16)),
                                          16, 0, 0);
     }
   };
@@ -147,9 +154,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int rd_a = (wm * WTM + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
-  const int rd_b = 3 * A_PLANE + (wn * WTN + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+  const int rd_b = NQ * A_PLANE + (wn * WTN + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
 
-  const int T = g.K / 16;
+  const int T = g.K / (16 * KS);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < T) issue(s, s);
@@ -160,26 +167,31 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
     __builtin_amdgcn_s_barrier();
     if (t + STAGES - 1 < T) issue(t + STAGES - 1, st_fill);
     const unsigned char* st = smx + st_cur * STAGE;
-    bf16x8 a[3][TI], b[3][TJ];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-        a[pl][i] = *reinterpret_cast<const bf16x8*>(st + rd_a + pl * A_PLANE + i * 1024);
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-        b[pl][j] = *reinterpret_cast<const bf16x8*>(st + rd_b + pl * B_PLANE + j * 1024);
-    }
-    // consecutive MFMAs go to different accumulators
 #define NAWS_X3_TERM(P, Q)                                                                      \
   _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][i], b[Q][j], acc[i][j], 0, 0, 0);
-    NAWS_X3_TERM(0, 0)
-    NAWS_X3_TERM(0, 1)
-    NAWS_X3_TERM(1, 0)
-    NAWS_X3_TERM(1, 1)
-    NAWS_X3_TERM(0, 2)
-    NAWS_X3_TERM(2, 0)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 a[NPL][TI], b[NPL][TJ];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          a[pl][i] = *reinterpret_cast<const bf16x8*>(st + rd_a + (pl * KS + ks) * A_PLANE + i * 1024);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          b[pl][j] = *reinterpret_cast<const bf16x8*>(st + rd_b + (pl * KS + ks) * B_PLANE + j * 1024);
+      }
+      // consecutive MFMAs go to different accumulators
+      NAWS_X3_TERM(0, 0)
+      if constexpr (NPL == 3) {
+        NAWS_X3_TERM(0, 1)
+        NAWS_X3_TERM(1, 0)
+        NAWS_X3_TERM(1, 1)
+        NAWS_X3_TERM(0, 2)
+        NAWS_X3_TERM(2, 0)
+      }
+    }
 #undef NAWS_X3_TERM
     st_cur = (st_cur + 1 == STAGES) ? 0 : st_cur + 1;
     st_fill = (st_fill + 1 == STAGES) ? 0 : st_fill + 1;
@@ -216,12 +228,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1>
 int launch_x3(XArgs& g, int batch, hipStream_t s) {
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
-  const size_t lds = (size_t)STAGES * 3 * (BM + BN) * 32;
-  auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES>;
+  const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;
+  auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES, NPL, KS>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -248,7 +260,7 @@ __device__ __forceinline__ void split3(float a, unsigned short& p1, unsigned sho
 // X fp32 [rows][ld] -> P[3][slabs][outer][16] through 64 x 64 LDS tiles.
 //   TRANS == false: outer = rows, K = cols;  TRANS == true: outer = cols, K = rows.
 // Each workgroup writes, per plane, 4 runs of 64 * 32 contiguous bytes.
-template <bool TRANS>
+template <bool TRANS, int NPL = 3>
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X, int rows, int cols,
                                                      int ld, int outer, int slabs, long long sx,
                                                      long long plane, long long sp,
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X
     }
     const long long dst = ((long long)(k0 / 16 + s) * outer + (o0 + o)) * 16 + hh * 8;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl) {
       u32x4 w;
       w.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
       w.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
@@ -485,29 +497,40 @@ int launch_conv_x3(CArgs& g, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int naws_split_bf16x3(const float* X, int batch, int rows, int cols, int ld,
-                                 int64_t strideX, int transpose, int kpad, void* P, void* stream) {
+template <int NPL>
+static int split_planes(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
+                        int transpose, int kpad, int kmult, void* P, void* stream) {
   if (batch <= 0 || rows <= 0 || cols <= 0 || ld < cols) return NAWS_ERR_SHAPE;
   NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(P);
   const int kdim = transpose ? rows : cols;
-  if (kpad != (kdim + 15) / 16 * 16) return NAWS_ERR_ARG;
+  if (kpad != (kdim + kmult - 1) / kmult * kmult) return NAWS_ERR_ARG;
   if (((uintptr_t)P & 15) != 0) return NAWS_ERR_ARG;
   const int outer = transpose ? cols : rows;
   const long long sp = (long long)kpad * outer;              // one batch item of one plane
-  const long long plane = (long long)batch * sp;             // P[3][batch][kpad/16][outer][16]
+  const long long plane = (long long)batch * sp;             // P[NPL][batch][kpad/16][outer][16]
   const long long gy = naws_cdiv(transpose ? kpad : rows, 64);
   if (batch > 65535 || gy > 65535) return NAWS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (!transpose) {
     dim3 grid((unsigned)naws_cdiv(kpad, 64), (unsigned)gy, batch);
-    hipLaunchKernelGGL(split3_kernel<false>, grid, dim3(256), 0, s, X, rows, cols, ld, outer,
+    hipLaunchKernelGGL((split3_kernel<false, NPL>), grid, dim3(256), 0, s, X, rows, cols, ld, outer,
                        kpad / 16, (long long)strideX, plane, sp, (unsigned short*)P);
   } else {
     dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, batch);
-    hipLaunchKernelGGL(split3_kernel<true>, grid, dim3(256), 0, s, X, rows, cols, ld, outer,
+    hipLaunchKernelGGL((split3_kernel<true, NPL>), grid, dim3(256), 0, s, X, rows, cols, ld, outer,
                        kpad / 16, (long long)strideX, plane, sp, (unsigned short*)P);
   }
   return naws_check_launch();
+}
+
+extern "C" int naws_split_bf16x3(const float* X, int batch, int rows, int cols, int ld,
+                                 int64_t strideX, int transpose, int kpad, void* P, void* stream) {
+  return split_planes<3>(X, batch, rows, cols, ld, strideX, transpose, kpad, 16, P, stream);
+}
+
+extern "C" int naws_to_bf16_slab(const float* X, int batch, int rows, int cols, int ld,
+                                 int64_t strideX, int transpose, int kpad, void* P, void* stream) {
+  return split_planes<1>(X, batch, rows, cols, ld, strideX, transpose, kpad, 64, P, stream);
 }
 
 static int g_x3_variant = -1;
@@ -585,4 +608,37 @@ extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const
     return launch_conv_x3<256, 128, 2, 2>(g, s);
   }
   return launch_conv_x3<256, 256, 2, 4>(g, s);
+}
+
+extern "C" int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_t slabA,
+                                      const void* B, int64_t slabB, float* C, int ldc, int batch,
+                                      int64_t strideA, int64_t strideB, int64_t strideC,
+                                      int epilogue, const float* bias, int64_t strideBias,
+                                      const float* aux, int ldaux, float alpha, float drop_ratio,
+                                      uint64_t seed, int accumulate, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(A); NAWS_REQUIRE_PTR(B); NAWS_REQUIRE_PTR(C);
+  if (epilogue < NAWS_EPI_NONE || epilogue > NAWS_EPI_GATE_POS) return NAWS_ERR_ARG;
+  if (epilogue == NAWS_EPI_GATE_POS && aux == nullptr) return NAWS_ERR_NULL;
+  if (epilogue == NAWS_EPI_BIAS_RELU_DROP && !(drop_ratio >= 0.f && drop_ratio < 1.f)) return NAWS_ERR_ARG;
+  if (slabA < (int64_t)M * 16 || slabB < (int64_t)N * 16 || ldc < N) return NAWS_ERR_SHAPE;
+  if (K % 64 != 0 || slabA % 8 != 0 || slabB % 8 != 0 || strideA % 8 != 0 || strideB % 8 != 0)
+    return NAWS_ERR_ARG;
+  if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return NAWS_ERR_ARG;
+  if (batch > 65535) return NAWS_ERR_UNSUPPORTED;
+  if ((long long)(M - 1) * ldc + N > 0x7fffffffLL ||
+      (aux && (long long)(M - 1) * ldaux + N > 0x7fffffffLL))
+    return NAWS_ERR_UNSUPPORTED;
+  XArgs g{};
+  g.A = (const unsigned short*)A; g.B = (const unsigned short*)B; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+  g.slabA = slabA; g.slabB = slabB;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sBias = strideBias;
+  g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.alpha = alpha;
+  g.drop_thr = naws_drop_threshold(drop_ratio);
+  g.drop_scale = (float)(1.0 / (1.0 - (double)drop_ratio));
+  g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 1, 4>(g, batch, s);
+  return launch_x3<256, 256, 2, 4, 2, 1, 4>(g, batch, s);
 }

@@ -205,13 +205,13 @@ class WsddnEngine(object):
     def _refresh_weight_planes(self):
         """fp32x3: re-split fc6_w / fc7_w (and fc7_w^T for the dgrad) into bf16 planes."""
         w6, w7 = self._weight_views()
+        cv = ops.split_bf16x3 if self.mfma_dtype == 'fp32x3' else ops.to_bf16_slab
         if self._wplanes is None:
-            self._wplanes = dict(w6=ops.split_bf16x3(w6), w7=ops.split_bf16x3(w7),
-                                 w7t=ops.split_bf16x3(w7, transpose=True))
+            self._wplanes = dict(w6=cv(w6), w7=cv(w7), w7t=cv(w7, transpose=True))
         else:
-            ops.split_bf16x3(w6, out=self._wplanes['w6'])
-            ops.split_bf16x3(w7, out=self._wplanes['w7'])
-            ops.split_bf16x3(w7, transpose=True, out=self._wplanes['w7t'])
+            cv(w6, out=self._wplanes['w6'])
+            cv(w7, out=self._wplanes['w7'])
+            cv(w7, transpose=True, out=self._wplanes['w7t'])
         self._planes_dirty = False
 
     def grad_blob(self, name):
@@ -364,8 +364,11 @@ class WsddnEngine(object):
                                    seed=self._seed(6))
             del xp
         elif bf:
-            h6 = ops.gemm_bf16_nt(roi_feat, w6[:nb * HIDDEN], epilogue=epi, bias=b6,
-                                  drop_ratio=self.dropout if drop else 0.0, seed=self._seed(6))
+            if self._planes_dirty:
+                self._refresh_weight_planes()
+            h6 = ops.gemm_bf16_slab_nt(ops.to_bf16_slab(roi_feat),
+                                       self._wplanes['w6'][:, :nb * HIDDEN], epilogue=epi, bias=b6,
+                                       drop_ratio=self.dropout if drop else 0.0, seed=self._seed(6))
         else:
             h6 = ops.gemm(roi_feat, w6[:nb * HIDDEN], False, True, epilogue=epi, bias=b6,
                           drop_ratio=self.dropout if drop else 0.0, seed=self._seed(6))
@@ -380,8 +383,9 @@ class WsddnEngine(object):
                               epilogue=epi, bias=b7, drop_ratio=self.dropout if drop else 0.0,
                               seed=self._seed(7))
         elif bf:
-            ops.gemm_bf16_nt(h6v, w7[:nb], out=h7v, epilogue=epi, bias=b7,
-                             drop_ratio=self.dropout if drop else 0.0, seed=self._seed(7))
+            ops.gemm_bf16_slab_nt(ops.to_bf16_slab(h6v), self._wplanes['w7'][:nb], out=h7v,
+                                  epilogue=epi, bias=b7, drop_ratio=self.dropout if drop else 0.0,
+                                  seed=self._seed(7))
         else:
             ops.gemm(h6v, w7[:nb], False, True, out=h7v, epilogue=epi, bias=b7,
                      drop_ratio=self.dropout if drop else 0.0, seed=self._seed(7))
@@ -507,17 +511,11 @@ class WsddnEngine(object):
             ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v), self._wplanes['w7t'], out=dz6v,
                               epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
         elif bf:
-            # the bf16 kernel takes K-contiguous operands: dW = dZ^T H needs dZ^T and H^T
-            # ([2*4096, Rt] bf16, the zero-padded Rt is the K dim), dX = dZ W needs W^T
-            rp8 = (rt + 7) // 8 * 8
-            dz7t = ops.transpose_to_bf16(dz7, rp8).view(2, HIDDEN, rp8)
-            h6t = ops.transpose_to_bf16(h6, rp8).view(2, HIDDEN, rp8)
-            ops.gemm_bf16_nt(dz7t, h6t, out=gw7)
-            del h6t
+            ops.gemm_bf16_slab_nt(ops.to_bf16_slab(dz7v, transpose=True),
+                                  ops.to_bf16_slab(h6v, transpose=True), out=gw7)
             ops.colsum(dz7, out=gb7)
-            w7t = ops.transpose_to_bf16(w7)                    # [2, in, out]
-            ops.gemm_bf16_nt(dz7v, w7t, out=dz6v, epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
-            del w7t, dz7t
+            ops.gemm_bf16_slab_nt(ops.to_bf16_slab(dz7v), self._wplanes['w7t'], out=dz6v,
+                                  epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
         else:
             ops.gemm(dz7v, h6v, True, False, out=gw7)
             ops.colsum(dz7, out=gb7)
@@ -531,13 +529,13 @@ class WsddnEngine(object):
             dz6t = ops.split_bf16x3(dz6, transpose=True)       # [3, Rt/16, 8192, 16]
             xt = ops.split_bf16x3(x, transpose=True)           # [3, Rt/16, 25088, 16]
         elif bf:
-            dz6t = ops.transpose_to_bf16(dz6, rp8)             # [8192, Rt]
-            xt = ops.transpose_to_bf16(x, rp8)                 # [25088, Rt]
+            dz6t = ops.to_bf16_slab(dz6, transpose=True)       # [Rt/16, 8192, 16]
+            xt = ops.to_bf16_slab(x, transpose=True)           # [Rt/16, 25088, 16]
         for r0, r1 in row_chunks(2 * HIDDEN, self.allreduce_chunks if red.active else 1):
             if x3:
                 ops.gemm_f32x3_nt(dz6t[:, :, r0:r1], xt, out=gw6[r0:r1])
             elif bf:
-                ops.gemm_bf16_nt(dz6t[r0:r1], xt, out=gw6[r0:r1])
+                ops.gemm_bf16_slab_nt(dz6t[:, r0:r1], xt, out=gw6[r0:r1])
             else:
                 ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
             red.reduce_async(gw6[r0:r1].reshape(-1))
@@ -590,7 +588,7 @@ class WsddnEngine(object):
                            self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
                            self.iter_size, self.gpu_num, self.sgd_iter_count)
         self.sgd_iter_count += 1
-        if self.mfma_dtype == 'fp32x3' and self._wplanes is not None:
+        if self.mfma_dtype != 'fp32' and self._wplanes is not None:
             self._refresh_weight_planes()      # same stream as the update: hidden with it
 
     # -------------------------------------------------------------- inference

@@ -384,6 +384,50 @@ def min_entropy_loss_grad(x, l, dy):
     return dx
 
 
+def to_bf16_slab(x, transpose=False, out=None):
+    """fp32 [rows, cols] or [b, rows, cols] -> bf16 [(b,) K/16, outer, 16] (K-slab-major, K
+    rounded up to 64 and zero-filled): the operand layout of gemm_bf16_slab_nt."""
+    batched = x.dim() == 3
+    x2 = x[0] if batched else x
+    if not x.is_cuda or x.dtype != _f32 or x2.stride(1) != 1:
+        raise TypeError('x must be a HIP fp32 tensor with a contiguous last dim')
+    batch = x.shape[0] if batched else 1
+    rows, cols = x2.shape
+    outer, k = (cols, rows) if transpose else (rows, cols)
+    kpad = (k + 63) // 64 * 64
+    shape = (batch, kpad // 16, outer, 16) if batched else (kpad // 16, outer, 16)
+    p = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.bfloat16)
+    L.call('naws_to_bf16_slab', x.data_ptr(), batch, rows, cols, x2.stride(0),
+           (x.stride(0) if batched else 0), int(transpose), kpad, p.data_ptr(), _stream())
+    return p
+
+
+def gemm_bf16_slab_nt(a, b, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, alpha=1.0,
+                      drop_ratio=0.0, seed=0, accumulate=False):
+    """C[M,N] (+)= A B^T for bf16 slab operands a [(b,)K/16,M,16], b [(b,)K/16,N,16]
+    (to_bf16_slab); bf16 MFMA, fp32 accumulate.  Row-sliced views (a[..., r0:r1, :]) are fine."""
+    batched = a.dim() == 4
+    for t in (a, b):
+        if (not t.is_cuda or t.dtype != torch.bfloat16 or t.shape[-1] != 16 or t.stride(-1) != 1
+                or t.stride(-2) != 16):
+            raise TypeError('operands must be bf16 slab tensors [..., K/16, rows, 16]')
+    batch = a.shape[0] if batched else 1
+    mm, k = a.shape[-2], a.shape[-3] * 16
+    nn, kb = b.shape[-2], b.shape[-3] * 16
+    if k != kb:
+        raise L.NawsError('naws_gemm_bf16_slab_nt', L.ERR_SHAPE)
+    if out is None:
+        out = torch.empty(((batch, mm, nn) if batched else (mm, nn)), device=a.device, dtype=_f32)
+    c2 = out[0] if batched else out
+    sbias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    L.call('naws_gemm_bf16_slab_nt', mm, nn, k, a.data_ptr(), a.stride(-3), b.data_ptr(),
+           b.stride(-3), out.data_ptr(), c2.stride(0), batch, (a.stride(0) if batched else 0),
+           (b.stride(0) if batched else 0), (out.stride(0) if batched else 0), epilogue,
+           _ptr(bias), sbias, _ptr(aux), (aux.stride(-2) if aux is not None else 0), float(alpha),
+           float(drop_ratio), int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate), _stream())
+    return out
+
+
 def planes_to_dense(p):
     """[3, (b,) K/16, outer, 16] planes -> float64 [(b,) outer, K] (test / debug helper)."""
     s = p[0].double() + p[1].double() + p[2].double()

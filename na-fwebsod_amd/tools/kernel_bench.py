@@ -123,6 +123,17 @@ def main():
                   '%6.0f GB/s min-traffic' % (name, m, n, k, batch, a16, b16, ms, fl / ms / 1e9,
                                               fl / ms / 1e9 / PEAK * 100, by / ms / 1e6))
             del A, B, Cc
+        for name, m, n, k, batch in [('fc6 fwd ', R, 8192, 25088, 1), ('fc7 fwd ', R, 4096, 4096, 2),
+                                     ('fc6 wgrad', 8192, 25088, (R + 63) // 64 * 64, 1)]:
+            bs = (batch,) if batch > 1 else ()
+            A1 = torch.empty((*bs, k // 16, m, 16), device=dev).uniform_(-1, 1).bfloat16()
+            B1 = torch.empty((*bs, k // 16, n, 16), device=dev).uniform_(-1, 1).bfloat16()
+            Cc = torch.empty((*bs, m, n), device=dev)
+            ms = timeit(lambda: ops.gemm_bf16_slab_nt(A1, B1, out=Cc), a.iters)
+            fl = 2.0 * m * n * k * batch
+            print('bf16 slab %-10s M=%6d N=%6d K=%6d b=%d %8.3f ms %7.1f TFLOP/s (%.1f%% of 2500)' % (
+                name, m, n, k, batch, ms, fl / ms / 1e9, fl / ms / 1e9 / PEAK * 100))
+            del A1, B1, Cc
         x = rnd(2, R, 4096)
         ms = timeit(lambda: ops.transpose_to_bf16(x, rows_pad=(R + 7) // 8 * 8), a.iters)
         print('transpose_to_bf16 [2,%d,4096]  %8.3f ms  %6.0f GB/s' % (R, ms, x.numel() * 6 / ms / 1e6))

@@ -115,3 +115,52 @@ def test_conv3x3_bf16(dev, cin, cout, dil, h, w):
     wp = ops.conv3x3_pack_weight(_t(wt, dev))
     y = ops.nhwc_to_nchw(ops.conv3x3_nhwc_bf16(xd, wp, _t(b, dev), dil, True)).cpu().numpy()
     assert np.abs(y - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('m,n,k', [(256, 256, 64), (130, 72, 64), (517, 260, 1000), (64, 4000, 264),
+                                   (2100, 140, 96)])
+def test_gemm_bf16_slab(dev, m, n, k):
+    """The bf16 plan's FC GEMM on the LDS-DMA pipeline (one-plane form of gemm_x3_kernel)."""
+    from naws_hip import ops
+    rng = np.random.default_rng(25)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    ref = _bf(a) @ _bf(b).T
+    a1, b1 = ops.to_bf16_slab(_t(a, dev)), ops.to_bf16_slab(_t(b, dev))
+    kp = (k + 63) // 64 * 64
+    assert a1.shape == (kp // 16, m, 16) and a1.dtype == torch.bfloat16
+    # layout: [k/16][row][k%16], zero-filled K pad
+    dense = a1.float().permute(1, 0, 2).reshape(m, kp).cpu().numpy()
+    assert np.array_equal(dense[:, :k], _bf(a).astype(np.float32)) and not dense[:, k:].any()
+    c = ops.gemm_bf16_slab_nt(a1, b1).cpu().numpy()
+    assert np.abs(c - ref).max() / np.abs(ref).max() < 5e-6
+    # transposing conversion: dW = dY^T X with K = rows
+    r = 203
+    dy = rng.uniform(-1, 1, (r, 96)).astype(np.float32)
+    x = rng.uniform(-1, 1, (r, n)).astype(np.float32)
+    c2 = ops.gemm_bf16_slab_nt(ops.to_bf16_slab(_t(dy, dev), transpose=True),
+                               ops.to_bf16_slab(_t(x, dev), transpose=True)).cpu().numpy()
+    ref2 = _bf(dy).T @ _bf(x)
+    assert np.abs(c2 - ref2).max() / np.abs(ref2).max() < 5e-6
+
+
+def test_gemm_bf16_slab_epilogues_batched(dev):
+    from naws_hip import ops, lib
+    rng = np.random.default_rng(26)
+    m, n, k = 260, 384, 160
+    a = rng.uniform(-1, 1, (2, m, k)).astype(np.float32)
+    w = rng.uniform(-1, 1, (2, n, k)).astype(np.float32)
+    bias = rng.uniform(-1, 1, (2, n)).astype(np.float32)
+    zz = np.stack([_bf(a[i]) @ _bf(w[i]).T for i in range(2)])
+    z = zz + bias[:, None, :]
+    a1, w1, bd = ops.to_bf16_slab(_t(a, dev)), ops.to_bf16_slab(_t(w, dev)), _t(bias, dev)
+    y = ops.gemm_bf16_slab_nt(a1, w1, epilogue=lib.EPI_BIAS_RELU_DROP, bias=bd, drop_ratio=0.5,
+                              seed=77).cpu().numpy()
+    mask = ops.dropout_mask(77, 0.5, 2 * m * n, dev).reshape(2, m, n).cpu().numpy()
+    np.testing.assert_allclose(y, np.maximum(z, 0) * mask * 2.0, rtol=1e-5, atol=2e-4)
+    aux = rng.standard_normal((2, m, n)).astype(np.float32)
+    g = ops.gemm_bf16_slab_nt(a1, w1, epilogue=lib.EPI_GATE_POS, aux=_t(aux, dev), alpha=2.0)
+    np.testing.assert_allclose(g.cpu().numpy(), np.where(aux > 0, zz * 2.0, 0.0), rtol=1e-5, atol=2e-4)
+    out = torch.zeros((2, m, n), device=dev)
+    ops.gemm_bf16_slab_nt(a1[:, :, :100], w1, out=out[:, :100])          # row-sliced operand
+    np.testing.assert_allclose(out[:, :100].cpu().numpy(), zz[:, :100], rtol=1e-5, atol=2e-4)
