@@ -156,3 +156,45 @@ def test_config5_inference_1200x2000_4000_rois(dev):
         inds = np.where(pn[:, j] > 0.0)[0]
         dets = np.hstack([bn[inds], pn[inds, j:j + 1]]).astype(np.float32)
         assert np.array_equal(np.where(keep[j - 1].cpu().numpy())[0], inds[test_wsl.nms(dets, 0.5)])
+
+
+@pytest.mark.parametrize('h,w,rois', [(203, 317, (517, 301)), (480, 640, (999,)), (97, 131, (5, 1, 64))])
+def test_ragged_shapes_plans_agree(dev, h, w, rois):
+    """Odd image sizes, ragged proposal counts (not multiples of any tile / K-slab), 1-3 images
+    per process: the fp32x3 and fp32 plans - disjoint GEMM / conv kernels - agree on losses,
+    probabilities and parameter gradients to the fp32 parity tolerance, and the bf16 plan to
+    its own."""
+    from detectron.datasets import synthetic
+    from naws_hip.engine import WsddnEngine
+    c = 20
+    b = len(rois)
+    blobs = synthetic.init_blobs(c, seed=5)
+    roidb = synthetic.make_roidb(b, max(rois), c, h, w, seed=9)
+    for e, r in zip(roidb, rois):
+        for k in ('boxes', 'obn_scores', 'gt_classes'):
+            e[k] = e[k][:r]
+        e['gt_classes'][0] = max(int(e['gt_classes'][0]), 1)
+    mb = synthetic.make_minibatch(roidb, c, max_rois=4000)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    assert t['rois'].shape[0] == sum(rois)
+    res = {}
+    for mode in ('fp32', 'fp32x3', 'bf16'):
+        eng = WsddnEngine(c + 1, dev, dropout=0.5, gpu_num=b, seed=3, mfma_dtype=mode)
+        eng.set_conv_blobs(blobs)
+        eng.set_head_blobs(blobs)
+        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+        torch.cuda.synchronize()
+        res[mode] = (out, eng.grads.clone())
+        del eng
+    o32, g32 = res['fp32']
+    for mode, tol, gtol in (('fp32x3', 1e-4, 2e-3), ('bf16', 5e-2, 0.2)):
+        o, g = res[mode]
+        lscale = float(o32['loss_cls'].abs().max())       # (the noise loss is ~100x smaller)
+        for k in ('loss_cls', 'loss_cls_noise'):
+            a, r = o[k].cpu().numpy(), o32[k].cpu().numpy()
+            bound = tol * (np.abs(r).max() if mode == 'fp32x3' else lscale)
+            assert np.isfinite(a).all() and np.abs(a - r).max() <= bound, (mode, k)
+        pa, pr = o['cls_prob'].cpu().numpy(), o32['cls_prob'].cpu().numpy()
+        assert np.abs(pa - pr).max() <= tol * pr.max(), mode
+        ga, gr = g.double(), g32.double()
+        assert float((ga - gr).norm()) <= gtol * float(gr.norm()), mode
