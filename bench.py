@@ -40,6 +40,8 @@ def parse():
                     help='initialise RCCL and run the all-reduce schedule even with one rank '
                          '(exercises the N>1 code path on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt-plan', action='store_true',
+                    help='skip the extra fp32-MFMA-only measurement of the same workload')
     ap.add_argument('--allreduce-chunks', type=int, default=0, help='0 = auto (engine.py)')
     ap.add_argument('--no-conv-x3', action='store_true',
                     help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
@@ -88,6 +90,36 @@ def cpu_baseline(args, num_fg):
             'sample': '1 iteration (fwd+bwd+SGD) of 2 images %dx%d x %d proposals, fp32, '
                       'torch-CPU conv/fc + C oracle ops, %.1f s' % (args.height, args.width,
                                                                     args.cpu_rois, dt)}
+
+
+def alt_plan(args, dev, num_fg, B, t, seg, mode):
+    import torch
+    from detectron.datasets import synthetic
+    from naws_hip.engine import WsddnEngine
+    eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
+                      weight_decay=5e-4, iter_size=1, gpu_num=B, seed=11, mfma_dtype=mode)
+    blobs = synthetic.init_blobs(num_fg, seed=11)
+    eng.set_conv_blobs(blobs)
+    eng.set_head_blobs(blobs)
+    del blobs
+    eng.set_lr(args.lr)
+    steps = max(1, min(args.steps, 5))
+
+    def run(n):
+        for _ in range(n):
+            out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            eng.sgd_step()
+        eng.flush()
+        torch.cuda.synchronize()
+        return out
+    run(2)
+    t0 = time.perf_counter()
+    out = run(steps)
+    dt = time.perf_counter() - t0
+    return {'mfma_dtype': mode, 'value': round(B * steps / dt, 3), 'unit': 'images/sec',
+            'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': 2,
+            'final_loss': round(float(out['loss_cls'].sum().item() +
+                                      out['loss_cls_noise'].sum().item()), 5)}
 
 
 def main():
@@ -228,6 +260,12 @@ def main():
         if tj and args.rois == 2000 and B == 2:
             res['roofline']['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
             res['roofline']['traffic_source'] = os.path.relpath(tj[-1], ROOT)
+        if world == 1 and args.mfma_dtype == 'fp32x3' and not args.no_alt_plan:
+            # the same workload with every GEMM on v_mfma_f32_32x32x2_f32, measured in this run,
+            # for readers who want the number without the 3xbf16 operand split
+            del eng
+            torch.cuda.empty_cache()
+            res['fp32_mfma_plan'] = alt_plan(args, dev, num_fg, B, t, seg, 'fp32')
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, num_fg)
         print(json.dumps(res))
