@@ -252,6 +252,13 @@ def main():
                          'frac': round(achieved / peak, 4) if achieved else None,
                          'traffic': None, 'kernel_ms': round(kern_ms, 4)},
         }
+        if x3 and achieved:
+            # 6 executed bf16-MFMA flops per algorithmic flop: the same fraction against the
+            # instruction's own peak
+            res['roofline'].update(executed_tflops=round(6 * achieved, 1),
+                                   executed_peak=BF16_MFMA_PEAK_TFLOPS,
+                                   note='achieved/peak are algorithmic fp32 TFLOP/s against '
+                                        'bf16 dense peak / 6 passes')
         # HBM traffic of that kernel comes from the rocprofv3 PMC passes of this same command
         # (profiles/rNN_bench_traffic.json, written by tools/summarize_profile.py)
         import glob
