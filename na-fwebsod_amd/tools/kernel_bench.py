@@ -184,6 +184,35 @@ def main():
         tot_fl += 2.0 * a.images * 600 * 1000 * 64 * 27
         print('conv stack (MFMA layers + conv1_1, no pools): %.3f ms, %.1f TFLOP/s (%.1f%%)' % (
             tot_ms, tot_fl / tot_ms / 1e9, tot_fl / tot_ms / 1e9 / 157.3 * 100))
+    if 'infer' in what:
+        # BASELINE configs[4]: multi-scale TTA inference, 4000 proposals per image, forward only
+        import numpy as np
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+        from detectron.datasets import synthetic
+        from naws_hip.engine import WsddnEngine
+        c = 20
+        blobs = synthetic.init_blobs(c, seed=11)
+        eng = WsddnEngine(c + 1, dev, gpu_num=1, seed=11)
+        eng.set_conv_blobs(blobs)
+        eng.set_head_blobs(blobs)
+        tot = 0.0
+        for short in (480, 576, 688, 864, 1200):
+            hh, ww = short, int(round(short * 1000 / 600))
+            mb = synthetic.make_minibatch(synthetic.make_roidb(1, 4000, c, hh, ww, seed=13), c,
+                                          max_rois=4000)
+            t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+            seg = [0, t['rois'].shape[0]]
+            ms_all = timeit(lambda: eng.infer(t['data'], t['rois'], t['obn_scores'], seg=seg), a.iters)
+            ms_conv = timeit(lambda: eng.conv_body(t['data']), a.iters)
+            conv5 = eng.conv_body(t['data'])
+            ms_roi = timeit(lambda: ops.roi_pool_f(conv5, t['rois'], 7, 7, 0.125,
+                                                   boost=t['obn_scores'].reshape(-1), layout='NHWC'),
+                            a.iters)
+            tot += 2 * ms_all      # + horizontal flip
+            print('infer %4dx%4d R=%d: total %7.3f ms (conv %6.3f, RoIPool %6.3f, head %6.3f)' % (
+                hh, ww, t['rois'].shape[0], ms_all, ms_conv, ms_roi, ms_all - ms_conv - ms_roi))
+            del conv5, t
+        print('10-pass TTA (5 scales x flip): %.1f ms per image forward' % tot)
     if 'roi' in what:
         import numpy as np
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..',

@@ -1,3 +1,5 @@
+# Round profile of bench.py on the GPU box (run from the repo root): kernel stats + the two PMC
+# passes (FETCH_SIZE, WRITE_SIZE); summarise with tools/summarize_profile.py into profiles/.
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_x3_stats -o st -- python bench.py --no-cpu-baseline > gpurun_out/bench_x3_prof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_x3_fetch -o pf -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/pmc_x3_fetch.log 2>&1
