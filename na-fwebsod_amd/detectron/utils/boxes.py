@@ -46,19 +46,26 @@ def clip_xyxy_to_image(x1, y1, x2, y2, height, width):
 
 
 def bbox_overlaps(boxes, query_boxes):
-    """[N,K] IoU with +1 pixel areas (cython_bbox.pyx:27-63)."""
+    """[N,K] IoU with +1 pixel areas (cython_bbox.pyx:27-63), bit-identical to the compiled
+    reference (tests/test_datasets.py against oracle/_ref): coordinate differences are float32,
+    the `+ 1` and the area products are evaluated in double (Cython emits the literal as 1.0),
+    box_area / iw / ih are stored as float32, the union `float(...)` is a double expression
+    stored as float32, and iw*ih/ua is float32."""
     b = np.asarray(boxes, np.float32)
     q = np.asarray(query_boxes, np.float32)
     out = np.zeros((b.shape[0], q.shape[0]), np.float32)
     if b.shape[0] == 0 or q.shape[0] == 0:
         return out
-    qa = (q[:, 2] - q[:, 0] + 1) * (q[:, 3] - q[:, 1] + 1)
-    ba = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
-    iw = np.minimum(b[:, None, 2], q[None, :, 2]) - np.maximum(b[:, None, 0], q[None, :, 0]) + 1
-    ih = np.minimum(b[:, None, 3], q[None, :, 3]) - np.maximum(b[:, None, 1], q[None, :, 1]) + 1
+    f64 = np.float64
+    qa = (((q[:, 2] - q[:, 0]).astype(f64) + 1.0) * ((q[:, 3] - q[:, 1]).astype(f64) + 1.0)).astype(np.float32)
+    barea = ((b[:, 2] - b[:, 0]).astype(f64) + 1.0) * ((b[:, 3] - b[:, 1]).astype(f64) + 1.0)
+    iw = ((np.minimum(b[:, None, 2], q[None, :, 2]) - np.maximum(b[:, None, 0], q[None, :, 0])).astype(f64)
+          + 1.0).astype(np.float32)
+    ih = ((np.minimum(b[:, None, 3], q[None, :, 3]) - np.maximum(b[:, None, 1], q[None, :, 1])).astype(f64)
+          + 1.0).astype(np.float32)
     ok = (iw > 0) & (ih > 0)
-    inter = np.where(ok, iw * ih, 0).astype(np.float32)
-    ua = ba[:, None] + qa[None, :] - inter
+    inter = (np.where(ok, iw, 0).astype(np.float32) * np.where(ok, ih, 0).astype(np.float32))
+    ua = (barea[:, None] + qa.astype(f64)[None, :] - inter.astype(f64)).astype(np.float32)
     out[ok] = (inter / ua)[ok]
     return out
 

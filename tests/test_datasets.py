@@ -31,6 +31,50 @@ def test_box_helpers_match_reference():
     assert np.allclose(B.crowd_iou(np.array([[0, 0, 10, 10.]]), np.array([[5, 0, 10, 10.]])), 0.5)
 
 
+def _ref_cython_bbox():
+    """The reference's own cython_bbox.pyx, compiled where it lies by `make -C oracle ref`
+    (oracle/_ref/, git-ignored, travels with gpurun); None when it has not been built."""
+    import glob
+    import importlib.util
+    so = glob.glob(os.path.join(ROOT, 'oracle', '_ref', 'cython_bbox*.so'))
+    if not so:
+        return None
+    spec = importlib.util.spec_from_file_location('cython_bbox', so[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bbox_overlaps_and_proposal_merge_match_reference(cfgmod):
+    """bbox_overlaps (numpy restatement) against the golden produced by the COMPILED reference
+    cython_bbox, and - when oracle/_ref is built - against that module live on fresh boxes;
+    _merge_proposal_boxes_into_roidb against the reference function run on top of it."""
+    cfgmod.merge_cfg_from_file(YAML)
+    from detectron.utils import boxes as B
+    from detectron.datasets import json_dataset_wsl as jd
+    assert np.array_equal(B.bbox_overlaps(G['bo_boxes'], G['bo_query']), G['bo_out'])
+    ref = _ref_cython_bbox()
+    if ref is not None:
+        rng = np.random.default_rng(23)
+        for n, k in ((1, 1), (57, 9), (300, 40)):
+            b = rng.uniform(0, 500, (n, 4)).astype(np.float32)
+            b[:, 2:] += b[:, :2]
+            q = rng.uniform(0, 500, (k, 4)).astype(np.float32)
+            q[:, 2:] += q[:, :2]
+            assert np.array_equal(B.bbox_overlaps(b, q), ref.bbox_overlaps(b, q))
+    rng = np.random.default_rng(17)   # unused draws keep nothing in sync: inputs come from the golden
+    gtb = G['mg_boxes'][:6]
+    e = dict(boxes=gtb.copy(), obn_scores=np.zeros((6, 1), np.float32),
+             gt_classes=np.array([2, 4, 1, 3, 3, 2], np.int32), seg_areas=np.ones((6,), np.float32),
+             is_crowd=np.zeros((6,), bool), box_to_gt_ind_map=np.arange(6, dtype=np.int32),
+             gt_overlaps=scipy.sparse.csr_matrix(np.eye(5, dtype=np.float32)[[2, 4, 1, 3, 3, 2]]))
+    jd._merge_proposal_boxes_into_roidb([e], [G['mg_boxes'][6:]], [G['mg_obn'][6:]])
+    assert np.array_equal(e['boxes'], G['mg_boxes']) and np.array_equal(e['obn_scores'], G['mg_obn'])
+    assert np.array_equal(e['gt_overlaps'].toarray(), G['mg_overlaps'])
+    assert np.array_equal(e['box_to_gt_ind_map'], G['mg_map'])
+    assert np.array_equal(e['gt_classes'], G['mg_classes'])
+
+
 def test_roidb_helpers_match_reference(cfgmod):
     cfgmod.merge_cfg_from_file(YAML)
     from detectron.datasets import json_dataset_wsl as jd, roidb_wsl
