@@ -49,3 +49,44 @@ def test_product_never_imports_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_argument_validation_happens_before_any_launch():
+    """The ENFORCE-style checks (shape / arg / null / unsupported codes, include/naws.h) return
+    before a kernel is launched, so they can be exercised without a GPU."""
+    from naws_hip import lib
+    L = lib.load()
+    p = ctypes.c_void_p
+    buf = (ctypes.c_float * 64)()
+    a = ctypes.cast(buf, p)
+    none = p(0)
+    # fp32x3 GEMM: K % 16, null operand, bad epilogue
+    args = lambda k, A: (32, 32, k, A, 32 * 16, 0, a, 32 * 16, 0, a, 32, 1, 0, 0, 0,
+                         lib.EPI_NONE, none, 0, none, 0, 1.0, 0.0, 0, 0, none)
+    assert L.naws_gemm_f32x3_nt(*args(24, a)) == lib.ERR_ARG
+    assert L.naws_gemm_f32x3_nt(*args(32, none)) == lib.ERR_NULL
+    bad = list(args(32, a)); bad[15] = 99
+    assert L.naws_gemm_f32x3_nt(*bad) == lib.ERR_ARG
+    assert L.naws_gemm_bf16_slab_nt(32, 32, 48, a, 512, a, 512, a, 32, 1, 0, 0, 0, lib.EPI_NONE,
+                                    none, 0, none, 0, 1.0, 0.0, 0, 0, none) == lib.ERR_ARG
+    # split: kpad must be K rounded up to 16 (64 for the one-plane form)
+    assert L.naws_split_bf16x3(a, 1, 4, 20, 20, 0, 0, 20, a, none) == lib.ERR_ARG
+    assert L.naws_to_bf16_slab(a, 1, 4, 20, 20, 0, 0, 32, a, none) == lib.ERR_ARG
+    assert L.naws_split_bf16x3(a, 1, 0, 20, 20, 0, 0, 32, a, none) == lib.ERR_SHAPE
+    # conv: Cin % 16, relu without bias
+    assert L.naws_conv3x3_nhwc_f32x3_fwd(a, a, a, 1, 8, 8, 24, 64, 1, 1, a, none) == lib.ERR_UNSUPPORTED
+    assert L.naws_conv3x3_nhwc_f32x3_fwd(a, a, none, 1, 8, 8, 32, 64, 1, 1, a, none) == lib.ERR_ARG
+    # NMS: too many boxes for the scan kernel, null keep
+    assert L.naws_nms_sorted_fwd(a, a, 1, 20000, 0.5, a, a, none) == lib.ERR_UNSUPPORTED
+    assert L.naws_nms_sorted_fwd(a, a, 1, 64, 0.5, a, none, none) == lib.ERR_NULL
+    assert L.naws_nms_workspace_bytes(3, 4000) == 3 * 4000 * 63 * 8
+    # image prep: crop outside the image, non-positive scale
+    m3 = (ctypes.c_float * 3)(0, 0, 0)
+    mp = ctypes.cast(m3, p)
+    assert L.naws_prep_image_fwd(a, 8, 8, 0, 0, 0, 9, 8, mp, mp, 1.0, 0, 1.0, 1.0, 9, 8, 72, 8, a,
+                                 none) == lib.ERR_SHAPE
+    assert L.naws_prep_image_fwd(a, 8, 8, 0, 0, 0, 8, 8, mp, mp, 0.0, 0, 1.0, 1.0, 8, 8, 64, 8, a,
+                                 none) == lib.ERR_ARG
+    # MinEntropyLoss
+    assert L.naws_min_entropy_loss_fwd(a, a, 0, 4, a, none) == lib.ERR_SHAPE
+    assert L.naws_min_entropy_loss_bwd(a, a, none, 2, 4, a, none) == lib.ERR_NULL
