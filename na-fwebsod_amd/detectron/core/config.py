@@ -136,7 +136,7 @@ def _defaults():
             'ALLREDUCE_CHUNKS': 0,   # 0 = auto (2 at world_size 2, else 1); >1: cut fc6 wgrad into row chunks, each all-reduced while
                                      # the next chunk's GEMM runs (default: one launch; the
                                      # collective hides under the next iteration's conv body)
-            'DEVICE_PREP': False,    # loader: float conversion / mean / flip / crop / resize / CHW padding
+            'DEVICE_PREP': True,     # loader + inference: float conversion / mean / flip / crop / resize / CHW padding
                                      # of the images on the GPU (naws_prep_image_fwd); threads only decode
             'MFMA_DTYPE': 'fp32x3',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact
                                      # 3-way bf16 splits on the bf16 MFMA (fp32-accurate, faster);

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from detectron.core.config import cfg
-from detectron.roi_data.minibatch_wsl import im_list_to_blob, prep_im_for_blob
+from detectron.roi_data.minibatch_wsl import get_im_scale, im_list_to_blob, prep_im_for_blob
 
 
 def dedup_rois(rois, dedup_boxes):
@@ -17,18 +17,40 @@ def dedup_rois(rois, dedup_boxes):
     return rois[index, :], index, inv_index
 
 
-def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_scores):
-    """im: HxWx3 BGR float/uint8; boxes [n,4] in image pixels -> (scores [n, C+1], boxes)."""
-    blob_im, im_scale = prep_im_for_blob(im, cfg.PIXEL_MEANS, target_scale, target_max_size)
-    data = im_list_to_blob([blob_im])
+def _device_image_blob(dev, im, im_scale, flip):
+    """The [1,3,H',W'] input blob prepared on the GPU (naws_prep_image_fwd: mean/std, optional
+    flip, cv2-semantics bilinear resize) when the image holds 8-bit pixel values; None otherwise."""
+    if not cfg.NAWS.DEVICE_PREP:
+        return None
+    u8 = im if im.dtype == np.uint8 else im.astype(np.uint8)
+    if im.dtype != np.uint8 and not np.array_equal(u8, im):
+        return None
+    from naws_hip import ops
+    h, w = im.shape[:2]
+    oh, ow = int(np.round(h * im_scale)), int(np.round(w * im_scale))
+    data = torch.zeros((1, 3, oh, ow), device=dev, dtype=torch.float32)
+    ops.prep_image(torch.from_numpy(np.ascontiguousarray(u8)).to(dev), data[0], im_scale, flip=flip,
+                   means=cfg.PIXEL_MEANS.reshape(-1)[:3], stds=np.asarray(cfg.PIXEL_STDS).reshape(-1)[:3])
+    return data
+
+
+def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_scores, flip=False):
+    """im: HxWx3 BGR float/uint8; boxes [n,4] in image pixels (already mirrored when `flip`)
+    -> (scores [n, C+1], boxes).  `flip` mirrors the image horizontally."""
+    dev = executor.device
+    im_scale = get_im_scale(im.shape[:2], target_scale, target_max_size)
+    data = _device_image_blob(dev, im, im_scale, flip)
+    if data is None:
+        imh = np.ascontiguousarray(im[:, ::-1, :]) if flip else im
+        blob_im, im_scale = prep_im_for_blob(imh, cfg.PIXEL_MEANS, target_scale, target_max_size)
+        data = torch.from_numpy(im_list_to_blob([blob_im])).to(dev)
     rois = np.hstack((np.zeros((boxes.shape[0], 1), np.float32), boxes * im_scale)).astype(np.float32)
     obn = (obn_scores + 1.0).astype(np.float32)
     inv_index = None
     if cfg.DEDUP_BOXES > 0:
         rois, index, inv_index = dedup_rois(rois, cfg.DEDUP_BOXES)
         obn = obn[index, :]
-    dev = executor.device
-    executor.feed(dict(data=torch.from_numpy(data).to(dev), rois=torch.from_numpy(rois).to(dev),
+    executor.feed(dict(data=data, rois=torch.from_numpy(rois).to(dev),
                        obn_scores=torch.from_numpy(obn).to(dev), _seg=[0, rois.shape[0]]))
     executor.run()
     scores = executor.fetch('cls_prob').cpu().numpy()
@@ -53,9 +75,8 @@ def flip_boxes(boxes, im_width):
 
 
 def im_detect_bbox_hflip(executor, im, target_scale, target_max_size, boxes, obn_scores):
-    im_hf = np.ascontiguousarray(im[:, ::-1, :])
-    scores_hf, _ = im_detect_bbox(executor, im_hf, target_scale, target_max_size,
-                                  flip_boxes(boxes, im.shape[1]), obn_scores)
+    scores_hf, _ = im_detect_bbox(executor, im, target_scale, target_max_size,
+                                  flip_boxes(boxes, im.shape[1]), obn_scores, flip=True)
     return scores_hf, boxes        # scores refer to the un-flipped proposals, in order
 
 

@@ -91,7 +91,7 @@ def test_blob_order_and_minibatch(cfgmod):
         'data', 'data_ids', 'rois', 'obn_scores', 'labels_int32', 'labels_oh']
     roidb = synthetic.make_roidb(1, 50, 20, 120, 200, seed=5)
     np.random.seed(3)
-    blobs, valid = minibatch_wsl.get_minibatch(roidb)
+    blobs, valid = minibatch_wsl.get_minibatch(roidb, raw=False)
     assert valid and blobs['data'].dtype == np.float32 and blobs['data'].shape[1] == 3
     # short side scaled to 600 (cap 1000): 120x200 crop 0.9 -> 108x180 -> scale 5.555 -> 600x1000
     assert blobs['data'].shape[2:] == (600, 1000)
@@ -100,7 +100,7 @@ def test_blob_order_and_minibatch(cfgmod):
     assert blobs['rois'][:, 1:].min() >= 0 and blobs['rois'][:, 3].max() <= 1000
     c.cfg.WSL.USE_DISTORTION = True                 # the yaml's own setting: HSV jitter applied
     np.random.seed(3)
-    b2, _ = minibatch_wsl.get_minibatch(roidb)
+    b2, _ = minibatch_wsl.get_minibatch(roidb, raw=False)
     assert b2['data'].shape[1] == 3 and not np.array_equal(b2['data'].shape, ()) 
 
 

@@ -159,6 +159,14 @@ def test_tta_inference_and_nms(dev, cfgmod):
     assert np.array_equal(boxes, e['boxes']) and not np.allclose(scores, s1)   # 6 passes averaged
     cls_boxes = test_wsl.im_detect_all(ex, im, e['boxes'], e['obn_scores'])
     assert len(cls_boxes) == 21 and sum(len(b) for b in cls_boxes[1:]) <= 20
+    # the image blob prepared on the GPU (default) == prepared on the host, plain and mirrored
+    assert c.cfg.NAWS.DEVICE_PREP
+    c.cfg.NAWS.DEVICE_PREP = False
+    s_host, _ = test_wsl.im_detect_bbox(ex, im, 64, 200, e['boxes'], e['obn_scores'])
+    f_host, _ = test_wsl.im_detect_bbox_hflip(ex, im, 80, 200, e['boxes'], e['obn_scores'])
+    c.cfg.NAWS.DEVICE_PREP = True
+    f_dev, _ = test_wsl.im_detect_bbox_hflip(ex, im, 80, 200, e['boxes'], e['obn_scores'])
+    assert np.array_equal(s1, s_host) and np.array_equal(f_dev, f_host)
     # dedup hash: rows 0 and 1 collapse to one roi in the forward pass
     rois = np.hstack((np.zeros((40, 1), np.float32), e['boxes'])).astype(np.float32)
     u, idx, inv = test_wsl.dedup_rois(rois, 0.125)
