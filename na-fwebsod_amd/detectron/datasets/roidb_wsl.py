@@ -1,7 +1,13 @@
-"""roidb assembly for training (reference: detectron/datasets/roidb_wsl.py:21-58
-combined_roidb_for_training, :61-93 extend_with_flipped_entries, :96-121 filter_for_training).
-Bounding-box regression targets (:124-161) belong to the Fast R-CNN box head, which the WSL
-path does not have (no bbox_pred blob): not restated."""
+"""Training roidb assembly.
+
+Behaviour follows the reference's detectron/datasets/roidb_wsl.py: one roidb per
+(dataset, proposal file) pair with ground truth and crowd filtering (:26-37), horizontally
+mirrored duplicates when TRAIN.USE_FLIPPED (:61-93: x1' = W - x2 - 1, x2' = W - x1 - 1),
+concatenation, and removal of images without at least one foreground (overlap >= FG_THRESH)
+and one background (BG_THRESH_LO <= overlap < BG_THRESH_HI) box (:96-121).  Box-regression
+targets (:124-161) are not produced: the WSL heads have no bbox_pred.
+Checked against pairs captured from the reference functions (tests/test_datasets.py).
+"""
 import logging
 
 import numpy as np
@@ -11,61 +17,56 @@ from detectron.datasets.json_dataset_wsl import JsonDataset
 
 logger = logging.getLogger(__name__)
 
-
-def combined_roidb_for_training(dataset_names, proposal_files):
-    def get_roidb(dataset_name, proposal_file):
-        ds = JsonDataset(dataset_name)
-        roidb = ds.get_roidb(gt=True, proposal_file=proposal_file,
-                             crowd_filter_thresh=cfg.TRAIN.CROWD_FILTER_THRESH)
-        if cfg.TRAIN.USE_FLIPPED:
-            logger.info('Appending horizontally-flipped training examples...')
-            extend_with_flipped_entries(roidb, ds)
-        logger.info('Loaded dataset: {:s}'.format(ds.name))
-        return roidb
-
-    if isinstance(dataset_names, str):
-        dataset_names = (dataset_names, )
-    if isinstance(proposal_files, str):
-        proposal_files = (proposal_files, )
-    if len(proposal_files) == 0:
-        proposal_files = (None, ) * len(dataset_names)
-    assert len(dataset_names) == len(proposal_files)
-    roidbs = [get_roidb(*args) for args in zip(dataset_names, proposal_files)]
-    roidb = roidbs[0]
-    for r in roidbs[1:]:
-        roidb.extend(r)
-    return filter_for_training(roidb)
+_NOT_SHARED_WITH_MIRROR = frozenset(('boxes', 'segms', 'gt_keypoints', 'flipped'))
 
 
-def extend_with_flipped_entries(roidb, dataset):
-    flipped_roidb = []
-    for entry in roidb:
-        width = entry['width']
-        boxes = entry['boxes'].copy()
-        oldx1 = boxes[:, 0].copy()
-        oldx2 = boxes[:, 2].copy()
-        boxes[:, 0] = width - oldx2 - 1
-        boxes[:, 2] = width - oldx1 - 1
-        assert (boxes[:, 2] >= boxes[:, 0]).all()
-        flipped_entry = {k: v for k, v in entry.items()
-                         if k not in ('boxes', 'segms', 'gt_keypoints', 'flipped')}
-        flipped_entry['boxes'] = boxes
-        flipped_entry['segms'] = []
-        flipped_entry['flipped'] = True
-        flipped_roidb.append(flipped_entry)
-    roidb.extend(flipped_roidb)
+def _as_tuple(v):
+    return (v,) if isinstance(v, str) else tuple(v)
+
+
+def _mirrored(entry):
+    """A shallow copy of `entry` describing the horizontally flipped image."""
+    w = entry['width']
+    src = entry['boxes']
+    flipped = src.copy()
+    flipped[:, 0], flipped[:, 2] = w - src[:, 2] - 1, w - src[:, 0] - 1
+    assert (flipped[:, 2] >= flipped[:, 0]).all()
+    twin = {k: v for k, v in entry.items() if k not in _NOT_SHARED_WITH_MIRROR}
+    twin.update(boxes=flipped, segms=[], flipped=True)
+    return twin
+
+
+def extend_with_flipped_entries(roidb, dataset=None):
+    """Append the mirrored twin of every entry, in order, after the originals."""
+    roidb.extend([_mirrored(e) for e in list(roidb)])
+
+
+def _usable_for_training(entry):
+    ov = entry['max_overlaps']
+    has_fg = bool(np.any(ov >= cfg.TRAIN.FG_THRESH))
+    has_bg = bool(np.any((ov >= cfg.TRAIN.BG_THRESH_LO) & (ov < cfg.TRAIN.BG_THRESH_HI)))
+    return has_fg and has_bg
 
 
 def filter_for_training(roidb):
-    def is_valid(entry):
-        overlaps = entry['max_overlaps']
-        fg_inds = np.where(overlaps >= cfg.TRAIN.FG_THRESH)[0]
-        bg_inds = np.where((overlaps < cfg.TRAIN.BG_THRESH_HI) &
-                           (overlaps >= cfg.TRAIN.BG_THRESH_LO))[0]
-        return len(fg_inds) > 0 and len(bg_inds) > 0
+    kept = list(filter(_usable_for_training, roidb))
+    logger.info('Filtered %d roidb entries: %d -> %d', len(roidb) - len(kept), len(roidb), len(kept))
+    return kept
 
-    num = len(roidb)
-    filtered = [entry for entry in roidb if is_valid(entry)]
-    logger.info('Filtered {} roidb entries: {} -> {}'.format(num - len(filtered), num,
-                                                             len(filtered)))
-    return filtered
+
+def combined_roidb_for_training(dataset_names, proposal_files):
+    names, files = _as_tuple(dataset_names), _as_tuple(proposal_files)
+    if not files:
+        files = (None,) * len(names)
+    assert len(names) == len(files)
+    merged = []
+    for name, pfile in zip(names, files):
+        ds = JsonDataset(name)
+        part = ds.get_roidb(gt=True, proposal_file=pfile,
+                            crowd_filter_thresh=cfg.TRAIN.CROWD_FILTER_THRESH)
+        if cfg.TRAIN.USE_FLIPPED:
+            logger.info('Appending horizontally-flipped training examples...')
+            extend_with_flipped_entries(part, ds)
+        logger.info('Loaded dataset: %s', ds.name)
+        merged += part
+    return filter_for_training(merged)
