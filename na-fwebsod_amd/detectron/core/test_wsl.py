@@ -63,8 +63,9 @@ def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_score
 # ---------------------------------------------------------------------------------------
 # Test-time augmentation and post-processing (reference: core/test_wsl.py:29-99 im_detect_all,
 # :181-281 im_detect_bbox_aug, :284-352 hflip / scale variants, :803-863
-# box_results_with_nms_and_limit).  Host logic over the same forward pass; NMS is the plain
-# greedy CPU algorithm (the reference uses a cython CPU NMS; a GPU NMS is SURVEY.md §8f-2).
+# box_results_with_nms_and_limit).  Host logic over the same forward pass; the per-class NMS of
+# an image runs on the GPU in one launch pair (naws_nms_sorted_fwd, same arithmetic as the
+# reference's cython loop), with the numpy `nms` below as the host form.
 # ---------------------------------------------------------------------------------------
 def flip_boxes(boxes, im_width):
     """Horizontal flip of [n,4] boxes (utils/boxes.py `flip_boxes`)."""
