@@ -87,6 +87,42 @@ def im_detect_bbox_scale(executor, im, target_scale, target_max_size, boxes, obn
     return fn(executor, im, target_scale, target_max_size, boxes, obn_scores)
 
 
+def im_detect_bbox_pair(executor, im, target_scale, target_max_size, boxes, obn_scores):
+    """The plain and the horizontally mirrored pass of one scale as ONE forward pass over a batch
+    of two images (proposal softmax and ReduceSum are per image: engine segments), so the two conv
+    bodies overlap on their streams and the head GEMMs run once with 2R rows.  Returns
+    (scores, scores_hflip), each [n, C+1] in the order of `boxes`; the same values as two
+    separate im_detect_bbox calls."""
+    dev = executor.device
+    im_scale = get_im_scale(im.shape[:2], target_scale, target_max_size)
+    blobs = [_device_image_blob(dev, im, im_scale, f) for f in (False, True)]
+    if blobs[0] is None or getattr(executor, 'engine', None) is None:
+        s0, _ = im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_scores)
+        s1, _ = im_detect_bbox_hflip(executor, im, target_scale, target_max_size, boxes, obn_scores)
+        return s0, s1
+    rois, obns, invs, seg = [], [], [], [0]
+    for b, bx in enumerate((boxes, flip_boxes(boxes, im.shape[1]))):
+        r = np.hstack((np.zeros((bx.shape[0], 1), np.float32), bx * im_scale)).astype(np.float32)
+        o = (obn_scores + 1.0).astype(np.float32)
+        inv = None
+        if cfg.DEDUP_BOXES > 0:
+            r, index, inv = dedup_rois(r, cfg.DEDUP_BOXES)
+            o = o[index, :]
+        r[:, 0] = b
+        rois.append(r); obns.append(o); invs.append(inv)
+        seg.append(seg[-1] + r.shape[0])
+    executor.feed(dict(data=torch.cat(blobs, 0), rois=torch.from_numpy(np.vstack(rois)).to(dev),
+                       obn_scores=torch.from_numpy(np.vstack(obns)).to(dev), _seg=seg))
+    executor.run()
+    scores = executor.fetch('cls_prob').cpu().numpy()
+    scores = scores.reshape([-1, scores.shape[-1]])
+    out = []
+    for b in range(2):
+        sb = scores[seg[b]:seg[b + 1]]
+        out.append(sb[invs[b], :] if invs[b] is not None else sb)
+    return out[0], out[1]
+
+
 def im_detect_bbox_aug(executor, im, boxes, obn_scores):
     """hflip at TEST.SCALE, each BBOX_AUG.SCALES (+flip), identity last; scores combined by
     BBOX_AUG.SCORE_HEUR ('ID' | 'AVG' | 'UNION'), boxes by COORD_HEUR."""
@@ -104,15 +140,33 @@ def im_detect_bbox_aug(executor, im, boxes, obn_scores):
         if aug.COORD_HEUR == 'ID':
             assert np.array_equal(boxes_ts[0], b), 'boxes at each scale should be the same'
 
+    # a scale's plain + mirrored passes go through the network as one batch of two images
+    # (cfg.NAWS.TTA_PAIR_FLIPS; same values, see im_detect_bbox_pair); results are added in the
+    # reference's order: hflip at TEST.SCALE, each aug scale (+ its flip), identity last
+    pair = bool(cfg.NAWS.TTA_PAIR_FLIPS)
+    scores_i = None
     if aug.H_FLIP:
-        add(*im_detect_bbox_hflip(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes, obn_scores))
+        if pair:
+            scores_i, s_hf = im_detect_bbox_pair(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE,
+                                                 boxes, obn_scores)
+            add(s_hf, boxes)
+        else:
+            add(*im_detect_bbox_hflip(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes,
+                                      obn_scores))
     for scale in aug.SCALES:
+        if pair and aug.SCALE_H_FLIP:
+            s0, s1 = im_detect_bbox_pair(executor, im, scale, aug.MAX_SIZE, boxes, obn_scores)
+            add(s0, boxes)
+            add(s1, boxes)
+            continue
         add(*im_detect_bbox_scale(executor, im, scale, aug.MAX_SIZE, boxes, obn_scores))
         if aug.SCALE_H_FLIP:
             add(*im_detect_bbox_scale(executor, im, scale, aug.MAX_SIZE, boxes, obn_scores,
                                       hflip=True))
-    scores_i, boxes_i = im_detect_bbox(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes,
-                                       obn_scores)
+    boxes_i = boxes
+    if scores_i is None:
+        scores_i, boxes_i = im_detect_bbox(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes,
+                                           obn_scores)
     add(scores_i, boxes_i)
     if aug.SCORE_HEUR == 'ID':
         scores_c = scores_i

@@ -195,7 +195,7 @@ def main():
         eng = WsddnEngine(c + 1, dev, gpu_num=1, seed=11)
         eng.set_conv_blobs(blobs)
         eng.set_head_blobs(blobs)
-        tot = 0.0
+        tot = tot_pair = 0.0
         for short in (480, 576, 688, 864, 1200):
             hh, ww = short, int(round(short * 1000 / 600))
             mb = synthetic.make_minibatch(synthetic.make_roidb(1, 4000, c, hh, ww, seed=13), c,
@@ -208,11 +208,23 @@ def main():
             ms_roi = timeit(lambda: ops.roi_pool_f(conv5, t['rois'], 7, 7, 0.125,
                                                    boost=t['obn_scores'].reshape(-1), layout='NHWC'),
                             a.iters)
+            # plain + mirrored pass as one batch of two images (core/test_wsl.im_detect_bbox_pair)
+            d2 = torch.cat([t['data'], t['data'].flip(-1)], 0)
+            r2 = torch.cat([t['rois'], t['rois']], 0)
+            r2[t['rois'].shape[0]:, 0] = 1
+            o2 = torch.cat([t['obn_scores'], t['obn_scores']], 0)
+            seg2 = [0, seg[1], 2 * seg[1]]
+            ms_pair = timeit(lambda: eng.infer(d2, r2, o2, seg=seg2), a.iters)
             tot += 2 * ms_all      # + horizontal flip
-            print('infer %4dx%4d R=%d: total %7.3f ms (conv %6.3f, RoIPool %6.3f, head %6.3f)' % (
-                hh, ww, t['rois'].shape[0], ms_all, ms_conv, ms_roi, ms_all - ms_conv - ms_roi))
+            tot_pair += ms_pair
+            print('infer %4dx%4d R=%d: total %7.3f ms (conv %6.3f, RoIPool %6.3f, head %6.3f); '
+                  'plain+flip as one batch of 2: %7.3f ms' % (
+                      hh, ww, t['rois'].shape[0], ms_all, ms_conv, ms_roi,
+                      ms_all - ms_conv - ms_roi, ms_pair))
+            del d2, r2, o2
             del conv5, t
-        print('10-pass TTA (5 scales x flip): %.1f ms per image forward' % tot)
+        print('10-pass TTA (5 scales x flip): %.1f ms per image forward, %.1f ms with paired flips' % (
+            tot, tot_pair))
     if 'roi' in what:
         import numpy as np
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..',

@@ -167,6 +167,17 @@ def test_tta_inference_and_nms(dev, cfgmod):
     c.cfg.NAWS.DEVICE_PREP = True
     f_dev, _ = test_wsl.im_detect_bbox_hflip(ex, im, 80, 200, e['boxes'], e['obn_scores'])
     assert np.array_equal(s1, s_host) and np.array_equal(f_dev, f_host)
+    # a scale's plain + mirrored pass as one batch of two images == the two separate passes,
+    # and the whole TTA result is unchanged by the pairing
+    p0, p1 = test_wsl.im_detect_bbox_pair(ex, im, 80, 200, e['boxes'], e['obn_scores'])
+    q0, _ = test_wsl.im_detect_bbox(ex, im, 80, 200, e['boxes'], e['obn_scores'])
+    np.testing.assert_allclose(p0, q0, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(p1, f_dev, rtol=1e-5, atol=1e-9)
+    assert c.cfg.NAWS.TTA_PAIR_FLIPS
+    c.cfg.NAWS.TTA_PAIR_FLIPS = False
+    scores_seq, _ = test_wsl.im_detect_bbox_aug(ex, im, e['boxes'], e['obn_scores'])
+    c.cfg.NAWS.TTA_PAIR_FLIPS = True
+    np.testing.assert_allclose(scores, scores_seq, rtol=1e-5, atol=1e-9)
     # dedup hash: rows 0 and 1 collapse to one roi in the forward pass
     rois = np.hstack((np.zeros((40, 1), np.float32), e['boxes'])).astype(np.float32)
     u, idx, inv = test_wsl.dedup_rois(rois, 0.125)
