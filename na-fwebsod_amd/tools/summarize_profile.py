@@ -90,6 +90,23 @@ def main():
         lines += ['', 'fc6 fwd GEMM: FETCH %.0f KiB, WRITE %.0f KiB per launch -> %.2f GB fabric '
                   'traffic per launch (algorithmic %.3f GB)' % (dom['FETCH_SIZE'], dom['WRITE_SIZE'],
                                                                tb / 1e9, alg_gb)]
+    # per-shape durations of the dominant kernel's template from the kernel trace (the stats table
+    # above averages every launch of the template: fc6 fwd, fc6 wgrad and the three fc7 GEMMs)
+    tr = _find(stats_dir, '*_kernel_trace.csv')
+    if tr:
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr[0])):
+            if dom_sub in r['Kernel_Name']:
+                key = (r['Grid_Size_X'], r['Grid_Size_Z'])
+                by[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
+        lines += ['', '| %s launches by grid (x, z) | launches | avg ms | min ms | max ms |' % short(dom_sub),
+                  '|---|---|---|---|---|']
+        for key, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+            lines.append('| grid %s x %s | %d | %.3f | %.3f | %.3f |' % (key[0], key[1], len(v),
+                                                                       sum(v) / len(v), min(v), max(v)))
+        lines += ['', 'bench.py times the fc6-forward launch (M=4000 N=8192 K=25088: grid 262144 x 1 for '
+                  'the fp32x3 plan) live with HIP events on the launch stream; its `roofline.kernel_ms` '
+                  'is that row.']
     open(out + '.md', 'w').write('\n'.join(lines) + '\n')
     import shutil
     shutil.copy(_find(stats_dir, '*_kernel_stats.csv')[0], out + '_kernel_stats.csv')
