@@ -13,6 +13,10 @@
 // fp32 MFMA peak.  tests/test_gpu_x3.py pins the claim: against a float64 product the error of
 // this kernel is not larger than that of the fp32-MFMA kernel (gemm_f32.hip) on the same data.
 //
+// Non-finite operands: NaN propagates as in fp32; an infinite operand gives NaN instead of inf
+// whenever the other factor has an exactly-zero low plane (inf * 0 in a cross term) - a state
+// the fp32 path has also left the realm of useful numbers in.
+//
 // Operands arrive pre-split ("planes": P[3][rows][K] bf16, K-contiguous, K % 16 == 0, made by
 // naws_split_bf16x3, which also transposes for the dW = dY^T X form).  With 48 MFMAs (1536
 // cycles) per wave per 16-deep K-step the staging pipeline can be the simplest correct one:
