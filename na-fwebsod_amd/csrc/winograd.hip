@@ -9,17 +9,14 @@
 // Dilation 2 (conv5_x) = four independent dense convolutions on the (y%2, x%2) sub-grids.
 //
 // Workspace layout: V [16][P*Cin + PAD] | M [16][P*Cout + PAD], P = N * d*d * ceil(Hs/2) *
-// ceil(Ws/2); PAD floats keep the 16 slabs a lane touches off one HBM channel.
+// ceil(Ws/2); PAD = 0 (spacing the 16 slabs apart was tried against HBM-channel aliasing: no effect).
 #include <stdlib.h>
 #include "naws_common.h"
 
 namespace {
 
-int wino_pad() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NAWS_WINO_PAD"); v = e ? atoi(e) : 0; }
-  return v;
-}
+// (padding the 16 V / M slabs apart was tried against channel aliasing: no effect)
+constexpr long long wino_pad() { return 0; }
 
 struct WinoGeom {
   int N, H, W, d, Hs, Ws, th, tw;
