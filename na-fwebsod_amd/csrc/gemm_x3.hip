@@ -29,6 +29,8 @@
 #include <stdlib.h>
 #include "naws_common.h"
 
+static int g_x3_variant = -1;
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -499,6 +501,197 @@ int launch_conv_x3(CArgs& g, hipStream_t s) {
   return naws_check_launch();
 }
 
+
+// ---- 3x3 conv, fp32x3, with the input halo tile staged once per channel slab -------------------
+// The linear-pixel kernel above gathers every tap's activations again: 9 x 64 B per output pixel
+// per 16-channel slab.  For the wide shallow layers (Cout <= 128: conv1_2, conv2_1, conv2_2) that
+// gather, not the MFMA, sets the pace.  Here a workgroup owns an 8-row x 32-column pixel tile:
+// for each 16-channel slab the (8+2) x (32+2) halo is gathered, split and written to LDS ONCE
+// (340 pixels instead of 9 x 256), and the nine taps read their A fragments from it at shifted
+// rows - a wave's 32-lane fragment is one image row of the tile, so a tap is just a row offset
+// (dy * 34 + dx) into the halo image.  Same LDS row format and bank swizzle as everywhere else;
+// weights per (tap, slab) by LDS-DMA, double buffered.  dilation 1, stride 1.
+template <int BN>
+__global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(CArgs g) {
+  // BN = 64: one halo stage (refilled behind an extra barrier every 9th step) keeps the
+  // workgroup at 45 KB of LDS, so three of them share a CU; BN = 128: two halo stages
+  constexpr int ASTAGES = BN <= 64 ? 1 : 2;
+  constexpr int TH = 8, TW = 32, HWD = TW + 2, HPIX = (TH + 2) * HWD;     // 340 halo pixels
+  constexpr int A_ROWS = (HPIX + 7) / 8 * 8;
+  constexpr int A_PLANE = A_ROWS * 32, A_STAGE = 3 * A_PLANE;
+  constexpr int B_PLANE = BN * 32, B_STAGE = 3 * B_PLANE;
+  constexpr int TJ = BN / 32, TI = 2;
+  constexpr int UR = (HPIX * 2 + 255) / 256;                                // staging rounds (3)
+  constexpr int BPIECES = 3 * BN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  unsigned char* smA = smx;
+  unsigned char* smB = smx + ASTAGES * A_STAGE;
+
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  int lid = blockIdx.x;
+  const int tn = lid % g.tiles_n;
+  lid /= g.tiles_n;
+  const int tx0 = (lid % tiles_x) * TW;
+  const int ty0 = ((lid / tiles_x) % tiles_y) * TH;
+  const int img = lid / (tiles_x * tiles_y);
+  const int n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  unsigned abase[UR];
+  int awr[UR];
+#pragma unroll
+  for (int r = 0; r < UR; ++r) {
+    const int u = tid + r * 256;
+    const int hp = u >> 1, half = u & 1;
+    const int y = ty0 - 1 + hp / HWD, x = tx0 - 1 + hp % HWD;
+    const bool ok = hp < HPIX && y >= 0 && y < g.H && x >= 0 && x < g.W;
+    abase[r] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)g.Cin + half * 8) * 4u : OOB;
+    awr[r] = hp < HPIX ? hp * 32 + ((half ^ ((hp >> 3) & 1)) * 16) : -1;
+  }
+  u32x4 ra[UR][2];
+  auto loadA = [&](int slab) {
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      const unsigned off = abase[r] != OOB ? abase[r] + (unsigned)slab * 64u : OOB;
+      ra[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
+      ra[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, abase[r] != OOB ? (int)(off + 16) : (int)OOB, 0, 0);
+    }
+  };
+  auto storeA = [&](int st) {
+    unsigned char* base = smA + st * A_STAGE;
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      if (awr[r] < 0) continue;
+      unsigned short q[3][8];
+      const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
+                             ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        u32x4 v;
+        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[r]) = v;
+      }
+    }
+  };
+  const int bslot = ((lane & 1) ^ ((lane >> 4) & 1)) * 8;
+  auto issueB = [&](int kslab, int st) {
+    unsigned char* base = smB + st * B_STAGE;
+#pragma unroll
+    for (int r = 0; r < (BPIECES + 3) / 4; ++r) {
+      const int piece = wid + r * 4;
+      if (piece < BPIECES) {
+        const int pl = piece / (BN / 32), rb = piece % (BN / 32);
+        const int wrow = min(n0 + rb * 32 + (lane >> 1), g.Cout - 1);
+        __builtin_amdgcn_global_load_lds(
+            NAWS_GLB_PTR(g.B + pl * g.planeB + (long long)kslab * g.slabB + (long long)wrow * 16 + bslot),
+            NAWS_LDS_PTR(base + pl * B_PLANE + rb * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int S = g.Cin / 16, T = 9 * S;
+  const int rd_b = l31 * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+  issueB(0, 0);                  // (tap 0, slab 0)
+  loadA(0);
+  storeA(0);
+  for (int kk = 0; kk < T; ++kk) {
+    const int slab = kk / 9, tap = kk - slab * 9;
+    __syncthreads();             // halo stage + weight stage of this step are complete
+    if (kk + 1 < T) {
+      const int s1 = (kk + 1) / 9, t1 = (kk + 1) - s1 * 9;
+      issueB(t1 * S + s1, (kk + 1) & 1);
+    }
+    if (tap == 0 && slab + 1 < S) loadA(slab + 1);
+    const unsigned char* sa = smA + (slab & (ASTAGES - 1)) * A_STAGE;
+    const unsigned char* sb = smB + (kk & 1) * B_STAGE;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    bf16x8 a[3][TI], b[3][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int hp = (2 * wid + i + 1 + dy) * HWD + (l31 + 1 + dx);
+      const int off = hp * 32 + ((h ^ ((hp >> 3) & 1)) * 16);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[pl][i] = *reinterpret_cast<const bf16x8*>(sa + pl * A_PLANE + off);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        b[pl][j] = *reinterpret_cast<const bf16x8*>(sb + pl * B_PLANE + rd_b + j * 1024);
+#define NAWS_X3_TERM(P, Q)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][i], b[Q][j], acc[i][j], 0, 0, 0);
+    NAWS_X3_TERM(0, 0)
+    NAWS_X3_TERM(0, 1)
+    NAWS_X3_TERM(1, 0)
+    NAWS_X3_TERM(1, 1)
+    NAWS_X3_TERM(0, 2)
+    NAWS_X3_TERM(2, 0)
+#undef NAWS_X3_TERM
+    if (tap == 8 && slab + 1 < S) {
+      if (ASTAGES == 1) __syncthreads();   // every wave is done with the only halo stage
+      storeA((slab + 1) & (ASTAGES - 1));
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + j * 32 + l31;
+    if (col >= g.Cout) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int y = ty0 + 2 * wid + i;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int x = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (y >= g.H || x >= g.W) continue;
+        float v = acc[i][j][e] + bv;
+        if (g.relu) v = fmaxf(v, 0.f);
+        g.Y[((long long)(img * g.H + y) * g.W + x) * g.Cout + col] = v;
+      }
+    }
+  }
+}
+
+template <int BN>
+int launch_conv_x3_halo(CArgs& g, int N, hipStream_t s) {
+  g.tiles_n = (int)naws_cdiv(g.Cout, BN);
+  const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
+  if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  constexpr int A_ROWS = (10 * 34 + 7) / 8 * 8;
+  const size_t lds = (size_t)(BN <= 64 ? 1 : 2) * 3 * A_ROWS * 32 + (size_t)2 * 3 * BN * 32;
+  auto kern = conv_x3_halo_kernel<BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
+  return naws_check_launch();
+}
+
 }  // namespace
 
 template <int NPL>
@@ -537,7 +730,6 @@ extern "C" int naws_to_bf16_slab(const float* X, int batch, int rows, int cols, 
   return split_planes<1>(X, batch, rows, cols, ld, strideX, transpose, kpad, 64, P, stream);
 }
 
-static int g_x3_variant = -1;
 
 extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t slabA,
                                   int64_t planeA, const void* B3, int64_t slabB, int64_t planeB,
@@ -606,6 +798,15 @@ extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const
   g.planeB = (long long)9 * Cin * Cout;
   g.bytesX = (unsigned)(pix * Cin * 4);
   hipStream_t s = (hipStream_t)stream;
+  if (g_x3_variant < 0) {
+    const char* e = getenv("NAWS_X3_VARIANT");
+    g_x3_variant = e ? atoi(e) : 0;
+  }
+  // wide shallow layers: the halo-tile kernel (input gathered once per channel slab, not per tap)
+  if (dilation == 1 && Cout <= 128 && Cout % 32 == 0 && g_x3_variant != 6) {
+    if (Cout <= 64) return launch_conv_x3_halo<64>(g, N, s);
+    return launch_conv_x3_halo<128>(g, N, s);
+  }
   if (Cout <= 64) return launch_conv_x3<256, 64, 4, 1>(g, s);
   if (Cout <= 128 || naws_cdiv(pix, 256) * naws_cdiv(Cout, 256) < 256) {
     if (naws_cdiv(pix, 256) * naws_cdiv(Cout, 128) < 512) return launch_conv_x3<128, 128, 2, 2>(g, s);

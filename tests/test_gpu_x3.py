@@ -162,8 +162,9 @@ def test_gemm_x3_deterministic(dev):
 
 
 @pytest.mark.parametrize('cin,cout,dil,h,w', [(64, 64, 1, 37, 53), (64, 128, 1, 40, 60),
-                                              (128, 256, 1, 19, 23), (512, 512, 2, 20, 31),
-                                              (256, 512, 1, 75, 125)])
+                                              (128, 128, 1, 8, 32), (128, 128, 1, 67, 97),
+                                              (64, 64, 2, 21, 40), (128, 256, 1, 19, 23),
+                                              (512, 512, 2, 20, 31), (256, 512, 1, 75, 125)])
 def test_conv3x3_f32x3(dev, cin, cout, dil, h, w):
     """Held to the tolerance of the fp32-MFMA convolution (tests/test_gpu_ops.py)."""
     from naws_hip import ops
