@@ -33,7 +33,7 @@ def main():
     dom_sub, dom_name, alg_gb, dom_grid = {
         'fp32': ('gemm_f32_kernel<256, 256, 16, true, true, false, 4, 4>',
                  'gemm_f32_kernel<256,256,16,KC,KC,4x4> fc6 fwd', 1.354, None),
-        'fp32x3': ('gemm_x3_kernel<256, 256, 2, 4, 3>', 'gemm_x3_kernel<256,256,2x4,3 stages> fc6 fwd',
+        'fp32x3': ('gemm_x3_kernel<256, 256, 2, 4, 3, 3, 1>', 'gemm_x3_kernel<256,256,2x4,3 stages> fc6 fwd',
                    1.966, '262144'),
         'bf16': ('gemm_bf16_kernel<256, 128, 4, 2, false, false, false>',
                  'gemm_bf16_kernel<256,128,4x2,fp32 sources> fc6 fwd', 1.354, None),
