@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void roi_pool_nhwc_xcd_kernel(
     const float* __restrict__ boost, int PH, int PW, float spatial_scale, int nslices,
     float* __restrict__ Y) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* tile = reinterpret_cast<float*>(smem_raw);  // [4][16][PW]
+  float* tile = reinterpret_cast<float*>(smem_raw);  // [64 channels][PH*PW]: the output order
   const int slice = blockIdx.x % nslices;
   const int r = blockIdx.x / nslices;
   const int lane = threadIdx.x;
@@ -215,7 +215,35 @@ __global__ __launch_bounds__(64) void roi_pool_nhwc_xcd_kernel(
       const bool empty = (he <= hs) || (we <= ws);
       const float init = empty ? 0.0f : -FLT_MAX;
       float4 best = make_float4(init, init, init, init);
-      for (int h = hs; h < he; ++h) {
+#define NAWS_UPD(v) \
+  best.x = (v.x > best.x) ? v.x : best.x; best.y = (v.y > best.y) ? v.y : best.y; \
+  best.z = (v.z > best.z) ? v.z : best.z; best.w = (v.w > best.w) ? v.w : best.w;
+      // max is order-independent: window rows are taken in pairs so that up to eight
+      // independent 16-byte loads are in flight per step
+      int h = hs;
+      for (; h + 2 <= he; h += 2) {
+        const float* r0 = Xn + (int64_t)h * W * C;
+        const float* r1 = r0 + (int64_t)W * C;
+        int w = ws;
+        for (; w + 4 <= we; w += 4) {
+          const float4 a0 = *reinterpret_cast<const float4*>(r0 + (int64_t)(w + 0) * C);
+          const float4 a1 = *reinterpret_cast<const float4*>(r0 + (int64_t)(w + 1) * C);
+          const float4 a2 = *reinterpret_cast<const float4*>(r0 + (int64_t)(w + 2) * C);
+          const float4 a3 = *reinterpret_cast<const float4*>(r0 + (int64_t)(w + 3) * C);
+          const float4 b0 = *reinterpret_cast<const float4*>(r1 + (int64_t)(w + 0) * C);
+          const float4 b1 = *reinterpret_cast<const float4*>(r1 + (int64_t)(w + 1) * C);
+          const float4 b2 = *reinterpret_cast<const float4*>(r1 + (int64_t)(w + 2) * C);
+          const float4 b3 = *reinterpret_cast<const float4*>(r1 + (int64_t)(w + 3) * C);
+          NAWS_UPD(a0) NAWS_UPD(a1) NAWS_UPD(a2) NAWS_UPD(a3)
+          NAWS_UPD(b0) NAWS_UPD(b1) NAWS_UPD(b2) NAWS_UPD(b3)
+        }
+        for (; w < we; ++w) {
+          const float4 a = *reinterpret_cast<const float4*>(r0 + (int64_t)w * C);
+          const float4 b = *reinterpret_cast<const float4*>(r1 + (int64_t)w * C);
+          NAWS_UPD(a) NAWS_UPD(b)
+        }
+      }
+      for (; h < he; ++h) {
         const float* row = Xn + (int64_t)h * W * C;
         int w = ws;
         for (; w + 4 <= we; w += 4) {
@@ -223,9 +251,6 @@ __global__ __launch_bounds__(64) void roi_pool_nhwc_xcd_kernel(
           const float4 v1 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 1) * C);
           const float4 v2 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 2) * C);
           const float4 v3 = *reinterpret_cast<const float4*>(row + (int64_t)(w + 3) * C);
-#define NAWS_UPD(v) \
-  best.x = (v.x > best.x) ? v.x : best.x; best.y = (v.y > best.y) ? v.y : best.y; \
-  best.z = (v.z > best.z) ? v.z : best.z; best.w = (v.w > best.w) ? v.w : best.w;
           NAWS_UPD(v0) NAWS_UPD(v1) NAWS_UPD(v2) NAWS_UPD(v3)
         }
         for (; w < we; ++w) {
@@ -235,20 +260,19 @@ __global__ __launch_bounds__(64) void roi_pool_nhwc_xcd_kernel(
 #undef NAWS_UPD
       }
       if (lane_on) {
-        tile[(0 * 16 + cg) * PW + pw] = best.x * scale;
-        tile[(1 * 16 + cg) * PW + pw] = best.y * scale;
-        tile[(2 * 16 + cg) * PW + pw] = best.z * scale;
-        tile[(3 * 16 + cg) * PW + pw] = best.w * scale;
+        const int bin = ph * PW + pw;
+        tile[(cg * 4 + 0) * nb + bin] = best.x * scale;
+        tile[(cg * 4 + 1) * nb + bin] = best.y * scale;
+        tile[(cg * 4 + 2) * nb + bin] = best.z * scale;
+        tile[(cg * 4 + 3) * nb + bin] = best.w * scale;
       }
     }
-    __syncthreads();
-    const int count = 64 * PW;
-    for (int i = lane; i < count; i += 64) {
-      const int cl = i / PW, pw = i - cl * PW;
-      Y[obase + (int64_t)cl * nb + ph * PW + pw] = tile[((cl & 3) * 16 + (cl >> 2)) * PW + pw];
-    }
-    __syncthreads();
   }
+  // the (roi, 64-channel slice) block of the output is one contiguous run of 64*PH*PW floats:
+  // written once, fully coalesced, from the LDS tile
+  __syncthreads();
+  const int count = 64 * nb;
+  for (int i = lane; i < count; i += 64) Y[obase + i] = tile[i];
 }
 
 // ---- NCHW: one lane = one output element (op-level API on reference layout)
@@ -345,11 +369,11 @@ extern "C" int naws_roi_pool_f_fwd(const float* X, int layout, int N, int C, int
     if (argmax)
       hipLaunchKernelGGL(roi_pool_nhwc_kernel<true>, grid, dim3(CT), lds, s, X, C, H, W, rois,
                          boost, pooled_h, pooled_w, spatial_scale, Y, argmax);
-    else if (C % 64 == 0 && ((uintptr_t)X % 16) == 0 && pooled_w <= 64 &&
+    else if (C % 64 == 0 && ((uintptr_t)X % 16) == 0 && pooled_h * pooled_w <= 256 &&
              (int64_t)R * (C / 64) < 0x7fffffffLL)
       hipLaunchKernelGGL(roi_pool_nhwc_xcd_kernel, dim3((unsigned)(R * (C / 64))), dim3(64),
-                         (size_t)64 * pooled_w * sizeof(float), s, X, C, H, W, rois, boost,
-                         pooled_h, pooled_w, spatial_scale, C / 64, Y);
+                         (size_t)64 * pooled_h * pooled_w * sizeof(float), s, X, C, H, W, rois,
+                         boost, pooled_h, pooled_w, spatial_scale, C / 64, Y);
     else if (C % 4 == 0 && ((uintptr_t)X % 16) == 0 && pooled_w <= 64)
       hipLaunchKernelGGL(roi_pool_nhwc_v4_kernel, dim3(R, (unsigned)naws_cdiv(C, 256)), dim3(64),
                          (size_t)4 * 64 * pooled_w * sizeof(float), s, X, C, H, W, rois, boost,
