@@ -138,6 +138,7 @@ def _defaults():
                                      # collective hides under the next iteration's conv body)
             'DEVICE_PREP': True,     # loader + inference: float conversion / mean / flip / crop / resize / CHW padding
                                      # of the images on the GPU (naws_prep_image_fwd); threads only decode
+            'HOST_NMS': False,       # True: per-class NMS with the numpy loop instead of the HIP kernel
             'TTA_PAIR_FLIPS': True,  # inference TTA: a scale's plain + mirrored pass as one batch of 2
             'MFMA_DTYPE': 'fp32x3',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact
                                      # 3-way bf16 splits on the bf16 MFMA (fp32-accurate, faster);

@@ -215,11 +215,13 @@ def nms(dets, thresh):
 
 
 def nms_all_classes(scores, boxes):
-    """cls -> kept row indices (ascending) for every foreground class of one image.  On a GPU box
-    all classes go through one HIP launch pair (naws_nms_sorted_fwd); otherwise the numpy loop."""
+    """cls -> kept row indices (ascending) for every foreground class of one image: all classes
+    go through one HIP launch pair (naws_nms_sorted_fwd).  The numpy loop below is the reference's
+    own host form (its NMS is a CPU cython routine) and runs only when cfg.NAWS.HOST_NMS asks for
+    it - there is no silent fallback."""
     num_classes = cfg.MODEL.NUM_CLASSES
     import torch
-    if torch.cuda.is_available():
+    if not cfg.NAWS.HOST_NMS:
         from naws_hip import ops
         dev = torch.device('cuda', torch.cuda.current_device())
         sd = torch.as_tensor(np.ascontiguousarray(scores[:, 1:], np.float32), device=dev)
