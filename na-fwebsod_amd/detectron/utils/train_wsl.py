@@ -44,13 +44,19 @@ def train_model(roidb=None, max_iter=None, printer=print):
     period = max(1, int(cfg.TRAIN.SNAPSHOT_ITERS / max(cfg.NUM_GPUS, 1)))
     last = cfg.SOLVER.MAX_ITER if max_iter is None else min(cfg.SOLVER.MAX_ITER, max_iter)
     loader = model.roi_data_loader
+    # Software pipeline: the batch of iteration i+1 is staged (one pinned copy + the device-side
+    # image preparation, on the loader's copy stream) right after iteration i has been enqueued
+    # and before its losses are fetched, so the host-side staging hides behind the GPU's work.
+    batch = loader.next_device_batch(device, cfg.NAWS.IMS_PER_GPU) if start_iter < last else None
     for cur_iter in range(start_iter, last):
         if loader.has_stopped():
             handle_critical_error(model, 'roi_data_loader failed')
         stats.IterTic()
         lr = model.UpdateWorkspaceLr(cur_iter, lr_policy.get_lr_at_iter(cur_iter))
-        executor.feed(loader.next_device_batch(device, cfg.NAWS.IMS_PER_GPU))
+        executor.feed(batch)
         executor.run()
+        batch = (loader.next_device_batch(device, cfg.NAWS.IMS_PER_GPU)
+                 if cur_iter + 1 < last else None)
         vals = iteration_values(executor, model, pg, world)
         stats.IterToc()
         stats.UpdateIterStats(vals)

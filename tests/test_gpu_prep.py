@@ -92,3 +92,26 @@ def test_loader_device_prep_equals_host_path(dev, cfgmod):
     torch.cuda.synchronize()
     assert data.shape == host['data'].shape
     assert np.array_equal(data.cpu().numpy(), host['data'])
+
+
+def test_pinned_ring_round_trip(dev):
+    """The loader's staging ring: mixed dtypes / odd sizes through one copy, slots reused and
+    regrown, views typed and shaped like their sources."""
+    import sys
+    from detectron.roi_data.loader_wsl import PinnedRing
+    ring = PinnedRing(dev, slots=2)
+    rng = np.random.default_rng(5)
+    for it in range(7):
+        n = 3 + it * 1000
+        arrays = {'rois': rng.uniform(0, 500, (n, 5)).astype(np.float32),
+                  'labels_int32': rng.integers(0, 20, (1, 1)).astype(np.int32),
+                  ('_im', 0, 0): rng.integers(0, 256, (37 + it, 53, 3)).astype(np.uint8),
+                  'ids': rng.integers(0, 1 << 40, (2,)).astype(np.int64),
+                  'strided': rng.standard_normal((8, 6)).astype(np.float32)[:, ::2]}
+        if it == 5:
+            arrays['big'] = rng.standard_normal((600, 1000)).astype(np.float32)   # grows the slot
+        out = ring.upload(arrays)
+        for k, v in arrays.items():
+            t = out[k]
+            assert tuple(t.shape) == v.shape and str(t.dtype).split('.')[-1] == v.dtype.name
+            assert np.array_equal(t.cpu().numpy(), v), k
