@@ -49,12 +49,14 @@ def parse():
                     help='fp32x3 plan: run the Winograd batched GEMMs in the split too (no gain)')
     ap.add_argument('--no-conv-streams', action='store_true',
                     help='one launch per conv layer for all images instead of one stream per image')
-    ap.add_argument('--mfma-dtype', default='fp32x3', choices=['fp32x3', 'fp32', 'bf16'],
-                    help="fp32x3 (default) and fp32 are both fp32 arithmetic (BASELINE configs[1]/[2]): "
-                         "fp32 = v_mfma_f32_32x32x2_f32 everywhere; fp32x3 = fc6/fc7 GEMMs as exact "
-                         "3-way bf16 splits, 6 bf16-MFMA passes, fp32 accumulate (fp32-accurate, "
-                         "tests/test_gpu_x3.py).  bf16 = the configs[3] option (operands rounded to "
-                         "bf16, fp32 storage + loss)")
+    ap.add_argument('--mfma-dtype', default='fp16x2', choices=['fp16x2', 'fp32x3', 'fp32', 'bf16'],
+                    help="fp16x2 (default), fp32x3 and fp32 are all fp32 arithmetic (BASELINE "
+                         "configs[1]/[2]): fp32 = v_mfma_f32_32x32x2_f32 everywhere; fp32x3 = fc6/fc7 "
+                         "GEMMs as exact 3-way bf16 splits, 6 bf16-MFMA passes; fp16x2 = the same "
+                         "GEMMs as row-scaled 2-way f16 splits, 3 f16-MFMA passes; both accumulate "
+                         "in fp32 and are as accurate as the fp32 MFMA (tests/test_gpu_x3.py, "
+                         "test_gpu_h2.py).  bf16 = the configs[3] option (operands rounded to bf16, "
+                         "fp32 storage + loss)")
     ap.add_argument('--cpu-rois', type=int, default=500)
     return ap.parse_args()
 
@@ -221,13 +223,18 @@ def main():
         stage_ms = {n: round(sum(v) / len(v), 3) for n, v in stages.items()}
         bf = args.mfma_dtype == 'bf16'
         x3 = args.mfma_dtype == 'fp32x3'
+        h2 = args.mfma_dtype == 'fp16x2'
         # fp32x3 executes 6 bf16 MFMA flops per algorithmic fp32 flop: its ceiling in algorithmic
         # TFLOP/s is the bf16 dense peak / 6 (frac = executed MFMA flops / bf16 peak)
         peak = (BF16_MFMA_PEAK_TFLOPS if bf else
-                round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if x3 else FP32_MFMA_PEAK_TFLOPS)
+                round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if x3 else
+                round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1) if h2 else FP32_MFMA_PEAK_TFLOPS)
         kname = ('gemm_x3_kernel<256,256,2x4 waves,2 stages,1 plane x 4 K-slabs> (bf16 slab operands)' if bf else
                  'gemm_x3_kernel<256,256,2x4 waves,3 stages> = 6 x v_mfma_f32_32x32x16_bf16 per '
-                 'fp32 product' if x3 else 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
+                 'fp32 product' if x3 else
+                 'gemm_x3_kernel<256,256,2x4 waves,2 stages,2 planes x 2 K-slabs,f16> = 3 x '
+                 'v_mfma_f32_32x32x16_f16 per fp32 product' if h2 else
+                 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
         res = {
             'metric': 'images/sec (600px, 2000 proposals) VGG16-C5 WSDDN fwd+bwd',
             'value': round(world * B * args.steps / dt, 3),
@@ -242,7 +249,10 @@ def main():
                                        'bf16 MFMA conv/fc6/fc7, fp32 storage/fc8/loss/SGD'
                                        if bf else 'fp32; fc6/fc7 GEMMs as exact 3xbf16 splits on '
                                        'the bf16 MFMA (fp32-accurate), conv/fc8 on the fp32 MFMA'
-                                       if x3 else 'fp32 MFMA'),
+                                       if x3 else 'fp32; fc6/fc7 GEMMs as row-scaled 2xf16 splits on '
+                                       'the f16 MFMA (fp32 accumulate, operand error 2^-22), '
+                                       'conv1_2..2_2 as 3xbf16 splits, rest on the fp32 MFMA'
+                                       if h2 else 'fp32 MFMA'),
                        'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
                        'lr': args.lr, 'final_loss': round(loss, 5), 'stage_ms': stage_ms},
             'roofline': {'bound': 'mfma', 'kernel': '%s (fc6 fwd, both branches, M=%d N=8192 K=%d)' % (
@@ -252,13 +262,14 @@ def main():
                          'frac': round(achieved / peak, 4) if achieved else None,
                          'traffic': None, 'kernel_ms': round(kern_ms, 4)},
         }
-        if x3 and achieved:
-            # 6 executed bf16-MFMA flops per algorithmic flop: the same fraction against the
-            # instruction's own peak
-            res['roofline'].update(executed_tflops=round(6 * achieved, 1),
+        if (x3 or h2) and achieved:
+            # 6 (3) executed 16-bit MFMA flops per algorithmic flop: the same fraction against
+            # the instruction's own peak
+            npass = 6 if x3 else 3
+            res['roofline'].update(executed_tflops=round(npass * achieved, 1),
                                    executed_peak=BF16_MFMA_PEAK_TFLOPS,
                                    note='achieved/peak are algorithmic fp32 TFLOP/s against '
-                                        'bf16 dense peak / 6 passes')
+                                        '16-bit dense MFMA peak / %d passes' % npass)
         # HBM traffic of that kernel comes from the rocprofv3 PMC passes of this same command
         # (profiles/rNN_bench_traffic.json, written by tools/summarize_profile.py)
         import glob
@@ -267,7 +278,7 @@ def main():
         if tj and args.rois == 2000 and B == 2:
             res['roofline']['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
             res['roofline']['traffic_source'] = os.path.relpath(tj[-1], ROOT)
-        if world == 1 and args.mfma_dtype == 'fp32x3' and not args.no_alt_plan:
+        if world == 1 and args.mfma_dtype in ('fp16x2', 'fp32x3') and not args.no_alt_plan:
             # the same workload with every GEMM on v_mfma_f32_32x32x2_f32, measured in this run,
             # for readers who want the number without the 3xbf16 operand split
             del eng

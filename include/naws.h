@@ -320,6 +320,31 @@ int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t slabA, int64
                        int64_t strideA, int64_t strideB, int64_t strideC, int epilogue,
                        const float* bias, int64_t strideBias, const float* aux, int ldaux,
                        float alpha, float drop_ratio, uint64_t seed, int accumulate, void* stream);
+/* ---- fp32 GEMM on the f16 matrix cores ("2 x f16" split with per-row scaling) -------------------
+ * Same operators again (Caffe2 FC / FCGradient of fc6 / fc7; wsl_heads.py:674-679,
+ * webly_heads.py:490-498), half the MFMA work of the bf16 split.  Every row of an NT operand
+ * (= one output row or column) is scaled by s = 2^(14 - floor(log2 max|x|)) and written as
+ * hi = f16(x s), lo = f16(x s - hi):  |x s - hi - lo| <= max(2^-22 |x s|, 2^-25), i.e. >= 22
+ * significand bits for every element within 2^-18 of its row's maximum and an absolute floor of
+ * 2^-39 of the row maximum below that.  The GEMM keeps hi*hi + hi*lo + lo*hi (dropped: lo*lo
+ * < 2^-22 |ab|), accumulates in fp32 inside v_mfma_f32_32x32x16_f16 and multiplies the
+ * accumulator by 1/(s_row s_col) (exact).  s is capped at 2^101: rows whose maximum is below
+ * 2^-87 keep an absolute floor of 2^-126.  NaN / inf propagate as NaN.
+ *
+ * naws_split_f16x2: X fp32 [batch][rows][ld] -> P f16 [2][batch][kpad/16][outer][16] (layout and
+ * transpose as naws_split_bf16x3, kpad = K rounded up to 32) and scales fp32 [2][batch][outer]:
+ * [1] = 1/s per outer index (the GEMM's scaleA / scaleB), [0] = scratch.
+ * naws_gemm_f32_f16x2_nt: C[M,N] (+)= A B^T; scaleA[M], scaleB[N] (strideScale* between batch
+ * items), K % 32 == 0, everything else as naws_gemm_f32x3_nt. */
+int naws_split_f16x2(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
+                     int transpose, int kpad, void* P, float* scales, void* stream);
+int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA, int64_t planeA,
+                           const float* scaleA, const void* B2, int64_t slabB, int64_t planeB,
+                           const float* scaleB, float* C, int ldc, int batch, int64_t strideA,
+                           int64_t strideB, int64_t strideC, int64_t strideScaleA,
+                           int64_t strideScaleB, int epilogue, const float* bias,
+                           int64_t strideBias, const float* aux, int ldaux, float alpha,
+                           float drop_ratio, uint64_t seed, int accumulate, void* stream);
 /* bf16 plan on the same pipeline: one plane (operands rounded to bf16), 64-deep K-steps.
  * naws_to_bf16_slab: as naws_split_bf16x3 with a single plane, P[batch][kpad/16][outer][16],
  * kpad = K rounded up to 64.  naws_gemm_bf16_slab_nt: C (+)= A B^T on such operands, K % 64 == 0;

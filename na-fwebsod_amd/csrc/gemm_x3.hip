@@ -35,6 +35,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct XArgs {
@@ -55,7 +56,19 @@ struct XArgs {
   unsigned long long seed;
   int epilogue, accumulate;
   int tiles_m, tiles_n;
+  const float* rs;           // fp16x2: per-row / per-column power-of-two factors undoing the
+  const float* cs;           //         operand scaling (null otherwise)
+  long long sRs, sCs;
 };
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <bool F16> struct OperandVec { typedef bf16x8 type; };
+template <> struct OperandVec<true> { typedef f16x8 type; };
 
 #define NAWS_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define NAWS_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -79,9 +92,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 //
 // NPL = 3, KS = 1: the fp32x3 GEMM (6 MFMA terms per 16-deep K slab).  NPL = 1, KS = 4: the same
 // pipeline as a plain bf16 GEMM for the bf16 plan (one plane, 64-deep K-steps of 4 slabs, so a
-// step still carries 32 MFMAs per wave between barriers).
-template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1>
+// step still carries 32 MFMAs per wave between barriers).  F16 (NPL = 2): the fp16x2 GEMM, see
+// the note above naws_split_f16x2 - two f16 planes per operand, 3 MFMA terms per slab.
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_kernel(XArgs g) {
+  static_assert(!F16 || NPL == 2, "fp16x2 uses two planes");
+  typedef typename OperandVec<F16>::type vec_t;
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TI = WTM / 32, TJ = WTN / 32;
@@ -175,24 +191,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
     const unsigned char* st = smx + st_cur * STAGE;
 #define NAWS_X3_TERM(P, Q)                                                                      \
   _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][i], b[Q][j], acc[i][j], 0, 0, 0);
+      acc[i][j] = mfma16(a[P][i], b[Q][j], acc[i][j]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 a[NPL][TI], b[NPL][TJ];
+      vec_t a[NPL][TI], b[NPL][TJ];
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
-          a[pl][i] = *reinterpret_cast<const bf16x8*>(st + rd_a + (pl * KS + ks) * A_PLANE + i * 1024);
+          a[pl][i] = *reinterpret_cast<const vec_t*>(st + rd_a + (pl * KS + ks) * A_PLANE + i * 1024);
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
-          b[pl][j] = *reinterpret_cast<const bf16x8*>(st + rd_b + (pl * KS + ks) * B_PLANE + j * 1024);
+          b[pl][j] = *reinterpret_cast<const vec_t*>(st + rd_b + (pl * KS + ks) * B_PLANE + j * 1024);
       }
       // consecutive MFMAs go to different accumulators
       NAWS_X3_TERM(0, 0)
-      if constexpr (NPL == 3) {
+      if constexpr (NPL >= 2) {
         NAWS_X3_TERM(0, 1)
         NAWS_X3_TERM(1, 0)
+      }
+      if constexpr (NPL == 3) {
         NAWS_X3_TERM(1, 1)
         NAWS_X3_TERM(0, 2)
         NAWS_X3_TERM(2, 0)
@@ -206,18 +224,41 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
   const int epi = g.epilogue;
+  if constexpr (F16) {
+    // undo the row scaling first (powers of two: exact).  Accumulator register e of a lane in
+    // half h is row (e&3) + 8(e>>2) + 4h of the 32x32 block: lane l fetches the factor of row l,
+    // v_readlane hands each register its row's factor (one load per block instead of 16).
+    const float* rs = g.rs + bz * g.sRs;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int mine = __float_as_int(rs[min(m0 + wm * WTM + i * 32 + l31, g.M - 1)]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int l0 = (e & 3) + 8 * (e >> 2);
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(mine, l0));
+        const float r1 = __int_as_float(__builtin_amdgcn_readlane(mine, l0 + 4));
+        const float r = h ? r1 : r0;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j][e] *= r;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int col = n0 + wn * WTN + j * 32 + l31;
     if (col >= g.N) continue;
     const float bv = (bias && epi >= NAWS_EPI_BIAS && epi <= NAWS_EPI_BIAS_RELU_DROP) ? bias[col] : 0.f;
+    float cscale = 1.f;
+    if constexpr (F16) cscale = g.cs[bz * g.sCs + col];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (row >= g.M) continue;
-        float v = acc[i][j][e] + bv;
+        float v = acc[i][j][e];
+        if constexpr (F16) v *= cscale;                 // power of two: exact
+        v += bv;
         if (epi == NAWS_EPI_BIAS_RELU || epi == NAWS_EPI_BIAS_RELU_DROP) v = fmaxf(v, 0.f);
         if (epi == NAWS_EPI_BIAS_RELU_DROP) {
           const unsigned long long idx =
@@ -234,12 +275,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1>
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1, bool F16 = false>
 int launch_x3(XArgs& g, int batch, hipStream_t s) {
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;
-  auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES, NPL, KS>;
+  auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -298,6 +339,131 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X
     const long long dst = ((long long)(k0 / 16 + s) * outer + (o0 + o)) * 16 + hh * 8;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
+      u32x4 w;
+      w.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+      w.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+      w.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+      w.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+      *reinterpret_cast<u32x4*>(Pb + pl * plane + dst) = w;
+    }
+  }
+}
+
+// ---- fp16x2: fp32 operands as two scaled f16 planes ---------------------------------------------
+// Per outer index o (a row of the NT operand = one output row / column of the GEMM):
+//      s_o  = 2^(14 - floor(log2 amax_o))              (amax_o * s_o in [2^14, 2^15))
+//      hi   = f16(x * s_o),   lo = f16(x * s_o - hi)   (the residue is exact in fp32)
+// |x*s - hi - lo| <= max(2^-22 |x*s|, 2^-25): 22+ significand bits for every element within
+// 2^-18 of its row's maximum, an absolute floor of 2^-39 of the row maximum below that.  The GEMM
+// keeps hi*hi + hi*lo + lo*hi (the dropped lo*lo is < 2^-22 |ab|), accumulates in fp32 and
+// multiplies the accumulator by 1/(s_row * s_col) - exact.  Three MFMA passes instead of the six
+// of the bf16 split, at an operand error far below the fp32 accumulation error of a K >= 1000
+// dot product (profiles/r01_x3_accuracy.md has the measured comparison).
+// amax_kernel: |x| maxima per outer index (non-negative floats order like their bit patterns).
+constexpr int AMAX_CT = 16;
+template <bool TRANS>
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, int rows, int cols,
+                                                   int ld, int outer, long long sx,
+                                                   unsigned* __restrict__ amax) {
+  __shared__ unsigned red[4][64];
+  const float* Xb = X + blockIdx.z * sx;
+  unsigned* out = amax + (long long)blockIdx.z * outer;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  if (TRANS) {            // outer = columns: each thread folds 16 rows of its column
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + i * 4 + tr, c = c0 + tc;
+      if (r < rows && c < cols) m = fmaxf(m, fabsf(Xb[(long long)r * ld + c]));
+    }
+    red[tr][tc] = __float_as_uint(m);
+    __syncthreads();
+    if (tr == 0 && c0 + tc < cols) {
+      const unsigned v = max(max(red[0][tc], red[1][tc]), max(red[2][tc], red[3][tc]));
+      if (v) atomicMax(out + c0 + tc, v);
+    }
+  } else {                // outer = rows: blockIdx.x covers AMAX_CT column tiles; a thread folds its
+                          // column of each, then the wave folds the 64 lanes (16 rows per wave)
+    float m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = 0.f;
+    for (int ct = 0; ct < AMAX_CT; ++ct) {
+      const int c = (blockIdx.x * AMAX_CT + ct) * 64 + tc;
+      if (c >= cols) break;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = r0 + i * 4 + tr;
+        if (r < rows) m[i] = fmaxf(m[i], fabsf(Xb[(long long)r * ld + c]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = m[i];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+      const int r = r0 + i * 4 + tr;
+      if (tc == 0 && r < rows && v > 0.f) atomicMax(out + r, __float_as_uint(v));
+    }
+  }
+}
+
+// amax bits -> (scale, 1/scale); NaN / inf maxima keep scale 1 (the NaN then propagates through
+// the f16 conversion); the scale is capped at 2^101, so rows whose maximum is below 2^-87 sit
+// lower in the f16 range (absolute floor 2^-126, the edge of fp32's own normal range).
+__device__ __forceinline__ void f16x2_scales(unsigned amax_bits, float& s, float& inv) {
+  int e = (int)((amax_bits >> 23) & 0xff);
+  if (amax_bits == 0 || e == 0xff) e = 127 + 14;
+  e = min(max(e, 40), 250);
+  s = __uint_as_float((unsigned)(268 - e) << 23);
+  inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ X, int rows, int cols,
+                                                      int ld, int outer, int slabs, long long sx,
+                                                      long long plane, long long sp,
+                                                      const unsigned* __restrict__ amax,
+                                                      float* __restrict__ inv_scale,
+                                                      unsigned short* __restrict__ P) {
+  __shared__ float tile[64][65];
+  const float* Xb = X + blockIdx.z * sx;
+  unsigned short* Pb = P + blockIdx.z * sp;
+  const unsigned* am = amax + (long long)blockIdx.z * outer;
+  float* inv = inv_scale + (long long)blockIdx.z * outer;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + i * 4 + tr, c = c0 + tc;
+    tile[i * 4 + tr][tc] = (r < rows && c < cols) ? Xb[(long long)r * ld + c] : 0.f;
+  }
+  __syncthreads();
+  const int o0 = TRANS ? c0 : r0;
+  const int k0 = TRANS ? r0 : c0;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int u = threadIdx.x + it * 256;
+    const int hh = u & 1, o = (u >> 1) & 63, s = u >> 7;
+    if (o0 + o >= outer || k0 / 16 + s >= slabs) continue;
+    float sc, isc;
+    f16x2_scales(am[o0 + o], sc, isc);
+    if (k0 == 0 && s == 0 && hh == 0) inv[o0 + o] = isc;
+    unsigned short q[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = s * 16 + hh * 8 + e;
+      const float t = (TRANS ? tile[kk][o] : tile[o][kk]) * sc;
+      const _Float16 hi = (_Float16)t;
+      float r = t - (float)hi;
+      if (!(fabsf(t) <= 65504.f)) r = 0.f;             // NaN / overflow live in the hi plane only
+      const _Float16 lo = (_Float16)r;
+      q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+      q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+    }
+    const long long dst = ((long long)(k0 / 16 + s) * outer + (o0 + o)) * 16 + hh * 8;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
       u32x4 w;
       w.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
       w.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
@@ -777,6 +943,97 @@ extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t s
     case 2: return launch_x3<256, 256, 2, 4, 2>(g, batch, s);
     case 3: return launch_x3<256, 128, 2, 2, 3>(g, batch, s);
     default: return launch_x3<256, 256, 2, 4, 3>(g, batch, s);
+  }
+}
+
+// P[2][batch][kpad/16][outer][16] f16 + scales[2][batch][outer]: [0] = |x| maxima (bit patterns,
+// scratch), [1] = 1/scale per outer index, handed to naws_gemm_f32_f16x2_nt.
+extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, int ld,
+                                int64_t strideX, int transpose, int kpad, void* P, float* scales,
+                                void* stream) {
+  if (batch <= 0 || rows <= 0 || cols <= 0 || ld < cols) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(P); NAWS_REQUIRE_PTR(scales);
+  const int kdim = transpose ? rows : cols;
+  if (kpad != (kdim + 31) / 32 * 32) return NAWS_ERR_ARG;
+  if (((uintptr_t)P & 15) != 0) return NAWS_ERR_ARG;
+  const int outer = transpose ? cols : rows;
+  const long long sp = (long long)kpad * outer;
+  const long long plane = (long long)batch * sp;
+  const long long gy = naws_cdiv(transpose ? kpad : rows, 64);
+  const long long gy_src = naws_cdiv(rows, 64);
+  if (batch > 65535 || gy > 65535 || gy_src > 65535) return NAWS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* amax = (unsigned*)scales;
+  float* inv = scales + (long long)batch * outer;
+  if (hipMemsetAsync(amax, 0, sizeof(unsigned) * (size_t)batch * outer, s) != hipSuccess)
+    return NAWS_ERR_LAUNCH;
+  dim3 gsrc((unsigned)naws_cdiv(cols, 64), (unsigned)gy_src, batch);
+  if (!transpose) {
+    dim3 grow((unsigned)naws_cdiv(cols, 64 * AMAX_CT), (unsigned)gy_src, batch);
+    hipLaunchKernelGGL((amax_kernel<false>), grow, dim3(256), 0, s, X, rows, cols, ld, outer,
+                       (long long)strideX, amax);
+    dim3 grid((unsigned)naws_cdiv(kpad, 64), (unsigned)gy, batch);
+    hipLaunchKernelGGL((split2h_kernel<false>), grid, dim3(256), 0, s, X, rows, cols, ld, outer,
+                       kpad / 16, (long long)strideX, plane, sp, (const unsigned*)amax, inv,
+                       (unsigned short*)P);
+  } else {
+    hipLaunchKernelGGL((amax_kernel<true>), gsrc, dim3(256), 0, s, X, rows, cols, ld, outer,
+                       (long long)strideX, amax);
+    dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, batch);
+    hipLaunchKernelGGL((split2h_kernel<true>), grid, dim3(256), 0, s, X, rows, cols, ld, outer,
+                       kpad / 16, (long long)strideX, plane, sp, (const unsigned*)amax, inv,
+                       (unsigned short*)P);
+  }
+  return naws_check_launch();
+}
+
+static int g_h2_variant = -1;
+
+extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA,
+                                      int64_t planeA, const float* scaleA, const void* B2,
+                                      int64_t slabB, int64_t planeB, const float* scaleB, float* C,
+                                      int ldc, int batch, int64_t strideA, int64_t strideB,
+                                      int64_t strideC, int64_t strideScaleA, int64_t strideScaleB,
+                                      int epilogue, const float* bias, int64_t strideBias,
+                                      const float* aux, int ldaux, float alpha, float drop_ratio,
+                                      uint64_t seed, int accumulate, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(A2); NAWS_REQUIRE_PTR(B2); NAWS_REQUIRE_PTR(C);
+  NAWS_REQUIRE_PTR(scaleA); NAWS_REQUIRE_PTR(scaleB);
+  if (epilogue < NAWS_EPI_NONE || epilogue > NAWS_EPI_GATE_POS) return NAWS_ERR_ARG;
+  if (epilogue == NAWS_EPI_GATE_POS && aux == nullptr) return NAWS_ERR_NULL;
+  if (epilogue == NAWS_EPI_BIAS_RELU_DROP && !(drop_ratio >= 0.f && drop_ratio < 1.f)) return NAWS_ERR_ARG;
+  if (slabA < (int64_t)M * 16 || slabB < (int64_t)N * 16 || ldc < N) return NAWS_ERR_SHAPE;
+  if (K % 32 != 0 || slabA % 8 != 0 || slabB % 8 != 0 || planeA % 8 != 0 || planeB % 8 != 0 ||
+      strideA % 8 != 0 || strideB % 8 != 0)
+    return NAWS_ERR_ARG;
+  if ((((uintptr_t)A2 | (uintptr_t)B2) & 15) != 0) return NAWS_ERR_ARG;
+  if (batch > 65535) return NAWS_ERR_UNSUPPORTED;
+  if ((long long)(M - 1) * ldc + N > 0x7fffffffLL ||
+      (aux && (long long)(M - 1) * ldaux + N > 0x7fffffffLL))
+    return NAWS_ERR_UNSUPPORTED;
+  XArgs g{};
+  g.A = (const unsigned short*)A2; g.B = (const unsigned short*)B2; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+  g.planeA = planeA; g.planeB = planeB; g.slabA = slabA; g.slabB = slabB;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sBias = strideBias;
+  g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.alpha = alpha;
+  g.drop_thr = naws_drop_threshold(drop_ratio);
+  g.drop_scale = (float)(1.0 / (1.0 - (double)drop_ratio));
+  g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
+  g.rs = scaleA; g.cs = scaleB; g.sRs = strideScaleA; g.sCs = strideScaleB;
+  hipStream_t s = (hipStream_t)stream;
+  if (g_h2_variant < 0) {
+    const char* e = getenv("NAWS_H2_VARIANT");
+    g_h2_variant = e ? atoi(e) : 0;
+  }
+  if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+  switch (g_h2_variant) {
+    case 1: return launch_x3<256, 256, 2, 4, 3, 2, 1, true>(g, batch, s);
+    case 2: return launch_x3<256, 256, 2, 4, 4, 2, 1, true>(g, batch, s);
+    case 3: return launch_x3<256, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+    case 4: return launch_x3<256, 128, 2, 2, 3, 2, 2, true>(g, batch, s);
+    default: return launch_x3<256, 256, 2, 4, 2, 2, 2, true>(g, batch, s);
   }
 }
 

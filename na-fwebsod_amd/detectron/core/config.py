@@ -140,8 +140,10 @@ def _defaults():
                                      # of the images on the GPU (naws_prep_image_fwd); threads only decode
             'HOST_NMS': False,       # True: per-class NMS with the numpy loop instead of the HIP kernel
             'TTA_PAIR_FLIPS': True,  # inference TTA: a scale's plain + mirrored pass as one batch of 2
-            'MFMA_DTYPE': 'fp32x3',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact
+            'MFMA_DTYPE': 'fp16x2',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact
                                      # 3-way bf16 splits on the bf16 MFMA (fp32-accurate, faster);
+                                     # 'fp16x2': the same GEMMs as row-scaled 2-way f16 splits on
+                                     # the f16 MFMA (same measured accuracy, faster still);
                                      # 'bf16': conv2..conv5 + fc6/fc7 operands rounded to bf16,
                                      # fp32 accumulation; storage, fc8, loss and SGD stay fp32
         },

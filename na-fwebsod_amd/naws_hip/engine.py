@@ -90,14 +90,18 @@ class WsddnEngine(object):
     def __init__(self, num_classes, device, dilation=2, roi_size=7, dropout=0.5, is_mean=True,
                  momentum=0.9, weight_decay=5e-4, iter_size=1, gpu_num=1, seed=11,
                  process_group=None, world_size=1, allreduce_chunks=0, freeze_conv_body=True,
-                 mfma_dtype='fp32x3'):
+                 mfma_dtype='fp16x2'):
         if not freeze_conv_body:
             raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
                                       '(SURVEY.md fact 2): the conv body has no backward')
-        if mfma_dtype not in ('fp32', 'fp32x3', 'bf16'):
-            raise ValueError("mfma_dtype must be 'fp32', 'fp32x3' or 'bf16'")
+        if mfma_dtype not in ('fp32', 'fp32x3', 'fp16x2', 'bf16'):
+            raise ValueError("mfma_dtype must be 'fp32', 'fp32x3', 'fp16x2' or 'bf16'")
         L.load()
         # 'fp32'  : every GEMM on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
+        # 'fp16x2' (default): fc6/fc7 forward, dgrad and wgrad on the f16 matrix cores, each fp32
+        #           operand a row-scaled hi + lo pair of f16 planes, 3 MFMA passes, fp32 accumulate
+        #           (csrc/gemm_x3.hip, naws_split_f16x2): as accurate as fp32x3 on every case of
+        #           tests/test_gpu_h2.py / profiles/r01_x3_accuracy.md, 1.6x faster.
         # 'fp32x3': fc6/fc7 forward, dgrad and wgrad on the bf16 matrix cores with each fp32
         #           operand split exactly into three bf16 planes and six MFMA passes
         #           (csrc/gemm_x3.hip): fp32-accurate (tests/test_gpu_x3.py), ~1.65x faster.
@@ -188,7 +192,7 @@ class WsddnEngine(object):
         self._update_pending = False
         self._upd_stream = None
         self._upd_event = None
-        self._wplanes = None         # fp32x3: split planes of fc6_w / fc7_w / fc7_w^T
+        self._wplanes = None         # split planes of fc6_w / fc7_w / fc7_w^T (16-bit MFMA plans)
         self._planes_dirty = True
 
     # ------------------------------------------------------------------ params
@@ -203,9 +207,11 @@ class WsddnEngine(object):
         return w6, w7
 
     def _refresh_weight_planes(self):
-        """fp32x3: re-split fc6_w / fc7_w (and fc7_w^T for the dgrad) into bf16 planes."""
+        """fp16x2 / fp32x3 / bf16: re-split fc6_w / fc7_w (and fc7_w^T for the dgrad) into their
+        16-bit operand planes."""
         w6, w7 = self._weight_views()
-        cv = ops.split_bf16x3 if self.mfma_dtype == 'fp32x3' else ops.to_bf16_slab
+        cv = {'fp32x3': ops.split_bf16x3, 'fp16x2': ops.split_f16x2}.get(self.mfma_dtype,
+                                                                         ops.to_bf16_slab)
         if self._wplanes is None:
             self._wplanes = dict(w6=cv(w6), w7=cv(w7), w7t=cv(w7, transpose=True))
         else:
@@ -231,7 +237,7 @@ class WsddnEngine(object):
             b = blobs[name + '_b'].to(self.device, torch.float32).contiguous()
             use_wino = (self.winograd and self.mfma_dtype != 'bf16' and
                         w.shape[1] >= 128 and w.shape[0] >= 256)
-            x3conv = (self.mfma_dtype == 'fp32x3' and self.conv_x3 and name != 'conv1_1' and
+            x3conv = (self.mfma_dtype in ('fp32x3', 'fp16x2') and self.conv_x3 and name != 'conv1_1' and
                       (not use_wino or self.conv_x3 == 'all'))
             use_wino = use_wino and not x3conv
             if name == 'conv1_1':
@@ -241,7 +247,7 @@ class WsddnEngine(object):
                 packed = ops.split_bf16x3(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
             elif use_wino:
                 packed = ops.winograd_weight_transform(w)      # [16][Cout][Cin]
-                if self.mfma_dtype == 'fp32x3' and self.wino_x3:
+                if self.mfma_dtype in ('fp32x3', 'fp16x2') and self.wino_x3:
                     packed = ops.split_bf16x3(packed)          # planes [3][16][Cin/16][Cout][16]
             else:
                 packed = ops.conv3x3_pack_weight(w)            # [Cout][3][3][Cin]
@@ -355,7 +361,15 @@ class WsddnEngine(object):
             e0.record()
         bf = self.mfma_dtype == 'bf16'
         x3 = self.mfma_dtype == 'fp32x3'
-        if x3:
+        h2 = self.mfma_dtype == 'fp16x2'
+        if h2:
+            if self._planes_dirty:
+                self._refresh_weight_planes()
+            h6 = ops.gemm_f32_f16x2_nt(ops.split_f16x2(roi_feat),
+                                       self._wplanes['w6'].rows(0, nb * HIDDEN), epilogue=epi,
+                                       bias=b6, drop_ratio=self.dropout if drop else 0.0,
+                                       seed=self._seed(6))
+        elif x3:
             if self._planes_dirty:
                 self._refresh_weight_planes()
             xp = roi_feat if roi_feat.dtype == torch.bfloat16 else ops.split_bf16x3(roi_feat)
@@ -378,7 +392,11 @@ class WsddnEngine(object):
         h6v = h6.view(rt, nb, HIDDEN).permute(1, 0, 2)       # [nb, Rt, 4096] strided views
         h7 = torch.empty((rt, nb * HIDDEN), device=self.device, dtype=torch.float32)
         h7v = h7.view(rt, nb, HIDDEN).permute(1, 0, 2)
-        if x3:
+        if h2:
+            ops.gemm_f32_f16x2_nt(ops.split_f16x2(h6v), self._wplanes['w7'].batches(nb), out=h7v,
+                                  epilogue=epi, bias=b7, drop_ratio=self.dropout if drop else 0.0,
+                                  seed=self._seed(7))
+        elif x3:
             ops.gemm_f32x3_nt(ops.split_bf16x3(h6v), self._wplanes['w7'][:, :nb], out=h7v,
                               epilogue=epi, bias=b7, drop_ratio=self.dropout if drop else 0.0,
                               seed=self._seed(7))
@@ -500,9 +518,16 @@ class WsddnEngine(object):
         # fc7
         bf = self.mfma_dtype == 'bf16'
         x3 = self.mfma_dtype == 'fp32x3'
+        h2 = self.mfma_dtype == 'fp16x2'
         dz6 = torch.empty_like(h6)
         dz6v = dz6.view(rt, 2, HIDDEN).permute(1, 0, 2)
-        if x3:
+        if h2:
+            ops.gemm_f32_f16x2_nt(ops.split_f16x2(dz7v, transpose=True),
+                                  ops.split_f16x2(h6v, transpose=True), out=gw7)
+            ops.colsum(dz7, out=gb7)
+            ops.gemm_f32_f16x2_nt(ops.split_f16x2(dz7v), self._wplanes['w7t'], out=dz6v,
+                                  epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
+        elif x3:
             # dW = dZ^T H: both operands K(=rows)-contiguous through the transposing split;
             # dX = dZ W: W^T planes are kept beside the W planes
             ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v, transpose=True),
@@ -525,14 +550,19 @@ class WsddnEngine(object):
         # everything except fc6_w is ready: start its all-reduce, then stream fc6 wgrad chunks
         red = self.reducer
         red.reduce_async(self.arena.span(G, 'fc6_b', 'noisy_fc8d_b'))
-        if x3:
+        if h2:
+            dz6t = ops.split_f16x2(dz6, transpose=True)        # planes [2, Rt/16, 8192, 16]
+            xt = ops.split_f16x2(x, transpose=True)            # planes [2, Rt/16, 25088, 16]
+        elif x3:
             dz6t = ops.split_bf16x3(dz6, transpose=True)       # [3, Rt/16, 8192, 16]
             xt = ops.split_bf16x3(x, transpose=True)           # [3, Rt/16, 25088, 16]
         elif bf:
             dz6t = ops.to_bf16_slab(dz6, transpose=True)       # [Rt/16, 8192, 16]
             xt = ops.to_bf16_slab(x, transpose=True)           # [Rt/16, 25088, 16]
         for r0, r1 in row_chunks(2 * HIDDEN, self.allreduce_chunks if red.active else 1):
-            if x3:
+            if h2:
+                ops.gemm_f32_f16x2_nt(dz6t.rows(r0, r1), xt, out=gw6[r0:r1])
+            elif x3:
                 ops.gemm_f32x3_nt(dz6t[:, :, r0:r1], xt, out=gw6[r0:r1])
             elif bf:
                 ops.gemm_bf16_slab_nt(dz6t[:, r0:r1], xt, out=gw6[r0:r1])

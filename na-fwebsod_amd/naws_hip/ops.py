@@ -463,6 +463,82 @@ def gemm_f32x3_nt(a3, b3, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, al
     return out
 
 
+class F16x2(object):
+    """An fp32 matrix split for the fp16x2 GEMM: `planes` [2, (b,) K/32*2, outer, 16] f16
+    (hi, lo of x * scale_row) and `scales` [2, (b,) outer] fp32 ([1] = 1/scale_row, [0] scratch)."""
+    __slots__ = ('planes', 'scales')
+
+    def __init__(self, planes, scales):
+        self.planes, self.scales = planes, scales
+
+    def rows(self, r0, r1):
+        """The operand restricted to outer indices r0..r1 (views, no copy)."""
+        return F16x2(self.planes[..., r0:r1, :], self.scales[..., r0:r1])
+
+    def batches(self, nb):
+        return F16x2(self.planes[:, :nb], self.scales[:, :nb])
+
+    @property
+    def inv_scale(self):
+        return self.scales[1]
+
+
+def split_f16x2(x, transpose=False, out=None):
+    """fp32 [rows, cols] or [b, rows, cols] (last dim contiguous) -> F16x2 with planes
+    [2, (b,) K/16, outer, 16] (K rounded up to 32, zero-filled) scaled per outer index by a
+    power of two that puts the row maximum in [2^14, 2^15):  x * s = hi + lo to 22+ bits."""
+    batched = x.dim() == 3
+    x2 = x[0] if batched else x
+    if not x.is_cuda or x.dtype != _f32 or x2.stride(1) != 1:
+        raise TypeError('x must be a HIP fp32 tensor with a contiguous last dim')
+    batch = x.shape[0] if batched else 1
+    rows, cols = x2.shape
+    outer, k = (cols, rows) if transpose else (rows, cols)
+    kpad = (k + 31) // 32 * 32
+    if out is None:
+        shape = (2, batch, kpad // 16, outer, 16) if batched else (2, kpad // 16, outer, 16)
+        out = F16x2(torch.empty(shape, device=x.device, dtype=torch.float16),
+                    torch.empty((2, batch, outer) if batched else (2, outer), device=x.device,
+                                dtype=_f32))
+    L.call('naws_split_f16x2', x.data_ptr(), batch, rows, cols, x2.stride(0),
+           (x.stride(0) if batched else 0), int(transpose), kpad, out.planes.data_ptr(),
+           out.scales.data_ptr(), _stream())
+    return out
+
+
+def gemm_f32_f16x2_nt(a, b, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, alpha=1.0,
+                      drop_ratio=0.0, seed=0, accumulate=False):
+    """C[M,N] (+)= A B^T from F16x2 operands (split_f16x2); fp32 in / fp32 accumulate / fp32 out
+    on the f16 MFMA with three products per K-slab.  Row-sliced operands (`.rows`) are fine."""
+    a3, b3 = a.planes, b.planes
+    batched = a3.dim() == 5
+    for t in (a3, b3):
+        if (not t.is_cuda or t.dtype != torch.float16 or t.shape[0] != 2 or t.shape[-1] != 16
+                or t.stride(-1) != 1 or t.stride(-2) != 16):
+            raise TypeError('operands must be f16 split planes [2, ..., K/16, rows, 16]')
+    sa, sb = a.inv_scale, b.inv_scale
+    if sa.stride(-1) != 1 or sb.stride(-1) != 1:
+        raise TypeError('scale vectors must be contiguous')
+    batch = a3.shape[1] if batched else 1
+    mm, k = a3.shape[-2], a3.shape[-3] * 16
+    nn, kb = b3.shape[-2], b3.shape[-3] * 16
+    if k != kb:
+        raise L.NawsError('naws_gemm_f32_f16x2_nt', L.ERR_SHAPE)
+    if out is None:
+        out = torch.empty(((batch, mm, nn) if batched else (mm, nn)), device=a3.device, dtype=_f32)
+    c2 = out[0] if batched else out
+    sbias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    L.call('naws_gemm_f32_f16x2_nt', mm, nn, k, a3.data_ptr(), a3.stride(-3), a3.stride(0),
+           sa.data_ptr(), b3.data_ptr(), b3.stride(-3), b3.stride(0), sb.data_ptr(),
+           out.data_ptr(), c2.stride(0), batch,
+           (a3.stride(1) if batched else 0), (b3.stride(1) if batched else 0),
+           (out.stride(0) if batched else 0), (sa.stride(0) if batched else 0),
+           (sb.stride(0) if batched else 0), epilogue, _ptr(bias), sbias, _ptr(aux),
+           (aux.stride(-2) if aux is not None else 0), float(alpha), float(drop_ratio),
+           int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate), _stream())
+    return out
+
+
 def dropout_mask(seed, ratio, n, device):
     m = torch.empty((n,), device=device, dtype=_f32)
     L.call('naws_dropout_mask', int(seed) & 0xFFFFFFFFFFFFFFFF, float(ratio), n, m.data_ptr(),

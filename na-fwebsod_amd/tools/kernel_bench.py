@@ -100,6 +100,33 @@ def main():
         ms = timeit(lambda: ops.split_bf16x3(w), a.iters)
         print('split_bf16x3   [8192,25088]  %8.3f ms  %6.0f GB/s' % (ms, w.numel() * 10 / ms / 1e6))
         del w
+    if 'h2' in what:
+        # fp16x2: fp32 GEMM as 3 f16 MFMA products per K-slab (ceiling 2500/3 = 833 TFLOP/s)
+        shapes = [('fc6 fwd ', R, 8192, 25088, 1), ('fc7 fwd ', R, 4096, 4096, 2),
+                  ('fc7 wgrad', 4096, 4096, (R + 31) // 32 * 32, 2),
+                  ('fc6 wgrad', 8192, 25088, (R + 31) // 32 * 32, 1)]
+        for name, m, n, k, batch in shapes:
+            bs = (batch,) if batch > 1 else ()
+            A2 = ops.split_f16x2(torch.empty((*bs, m, k), device=dev).normal_())
+            B2 = ops.split_f16x2(torch.empty((*bs, n, k), device=dev).normal_())
+            Cc = torch.empty((*bs, m, n), device=dev)
+            ms = timeit(lambda: ops.gemm_f32_f16x2_nt(A2, B2, out=Cc), a.iters)
+            fl = 2.0 * m * n * k * batch
+            print('h2 %-10s M=%6d N=%6d K=%6d b=%d %8.3f ms %7.1f TFLOP/s fp32-equivalent '
+                  '(%.1f%% of 833.3 = 2500/3; f16 MFMA %.0f TFLOP/s)' % (
+                      name, m, n, k, batch, ms, fl / ms / 1e9, fl / ms / 1e9 / 833.3 * 100,
+                      3 * fl / ms / 1e9))
+            del A2, B2, Cc
+        x = rnd(R, 25088)
+        ms = timeit(lambda: ops.split_f16x2(x), a.iters)
+        print('split_f16x2      [%d,25088]  %8.3f ms  %6.0f GB/s' % (R, ms, x.numel() * 12 / ms / 1e6))
+        ms = timeit(lambda: ops.split_f16x2(x, transpose=True), a.iters)
+        print('split_f16x2 (T)  [%d,25088]  %8.3f ms  %6.0f GB/s' % (R, ms, x.numel() * 12 / ms / 1e6))
+        del x
+        w = rnd(8192, 25088)
+        ms = timeit(lambda: ops.split_f16x2(w), a.iters)
+        print('split_f16x2   [8192,25088]  %8.3f ms  %6.0f GB/s' % (ms, w.numel() * 12 / ms / 1e6))
+        del w
     if 'bf16' in what:
         PEAK = 2500.0
         shapes = [('fc6 fwd ', R, 8192, 25088, 1, False, False),

@@ -4,7 +4,7 @@ passes) into the small summaries kept under profiles/.
 
   summarize_profile.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <out_prefix> [mfma_dtype]
 
-mfma_dtype (fp32x3 default | fp32 | bf16) selects which kernel is bench.py's dominant one.
+mfma_dtype (fp16x2 default | fp32x3 | fp32 | bf16) selects which kernel is bench.py's dominant one.
 
 HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, so
@@ -27,13 +27,15 @@ def _find(d, pat):
 
 def main():
     stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
-    mode = sys.argv[5] if len(sys.argv) > 5 else 'fp32x3'
+    mode = sys.argv[5] if len(sys.argv) > 5 else 'fp16x2'
     # (kernel-name substring, label, algorithmic GB per launch, Grid_Size of the fc6-fwd launch:
     #  other launches of the same template - fc6 wgrad - have another grid)
     dom_sub, dom_name, alg_gb, dom_grid = {
         'fp32': ('gemm_f32_kernel<256, 256, 16, true, true, false, 4, 4>',
                  'gemm_f32_kernel<256,256,16,KC,KC,4x4> fc6 fwd', 1.354, None),
-        'fp32x3': ('gemm_x3_kernel<256, 256, 2, 4, 3, 3, 1>', 'gemm_x3_kernel<256,256,2x4,3 stages> fc6 fwd',
+        'fp16x2': ('gemm_x3_kernel<256, 256, 2, 4, 2, 2, 2, true>',
+                   'gemm_x3_kernel<256,256,2x4,2 stages,2 planes x 2 slabs,f16> fc6 fwd', 1.354, '262144'),
+        'fp32x3': ('gemm_x3_kernel<256, 256, 2, 4, 3, 3, 1', 'gemm_x3_kernel<256,256,2x4,3 stages> fc6 fwd',
                    1.966, '262144'),
         'bf16': ('gemm_bf16_kernel<256, 128, 4, 2, false, false, false>',
                  'gemm_bf16_kernel<256,128,4x2,fp32 sources> fc6 fwd', 1.354, None),
@@ -105,7 +107,7 @@ def main():
             lines.append('| grid %s x %s | %d | %.3f | %.3f | %.3f |' % (key[0], key[1], len(v),
                                                                        sum(v) / len(v), min(v), max(v)))
         lines += ['', 'bench.py times the fc6-forward launch (M=4000 N=8192 K=25088: grid 262144 x 1 for '
-                  'the fp32x3 plan) live with HIP events on the launch stream; its `roofline.kernel_ms` '
+                  'the fp16x2 / fp32x3 plans) live with HIP events on the launch stream; its `roofline.kernel_ms` '
                   'is that row.']
     open(out + '.md', 'w').write('\n'.join(lines) + '\n')
     import shutil

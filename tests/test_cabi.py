@@ -69,6 +69,13 @@ def test_argument_validation_happens_before_any_launch():
     assert L.naws_gemm_f32x3_nt(*bad) == lib.ERR_ARG
     assert L.naws_gemm_bf16_slab_nt(32, 32, 48, a, 512, a, 512, a, 32, 1, 0, 0, 0, lib.EPI_NONE,
                                     none, 0, none, 0, 1.0, 0.0, 0, 0, none) == lib.ERR_ARG
+    # fp16x2 GEMM: K % 32, missing scale vector; split: kpad = K rounded up to 32
+    h2 = lambda k, sa: (32, 32, k, a, 32 * 16, 0, sa, a, 32 * 16, 0, a, a, 32, 1, 0, 0, 0, 0, 0,
+                        lib.EPI_NONE, none, 0, none, 0, 1.0, 0.0, 0, 0, none)
+    assert L.naws_gemm_f32_f16x2_nt(*h2(48, a)) == lib.ERR_ARG
+    assert L.naws_gemm_f32_f16x2_nt(*h2(64, none)) == lib.ERR_NULL
+    assert L.naws_split_f16x2(a, 1, 4, 20, 20, 0, 0, 48, a, a, none) == lib.ERR_ARG
+    assert L.naws_split_f16x2(a, 1, 4, 20, 20, 0, 0, 32, a, none, none) == lib.ERR_NULL
     # split: kpad must be K rounded up to 16 (64 for the one-plane form)
     assert L.naws_split_bf16x3(a, 1, 4, 20, 20, 0, 0, 20, a, none) == lib.ERR_ARG
     assert L.naws_to_bf16_slab(a, 1, 4, 20, 20, 0, 0, 32, a, none) == lib.ERR_ARG

@@ -41,7 +41,7 @@ def _masks(eng, rt, dev):
             'drop7': m7[0], '_[noisy]_drop7': m7[1]}
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'fp16x2'])
 @pytest.mark.parametrize('dropout,c', [(0.5, 20), (0.0, 20), (0.5, 80), (0.5, 2), (0.5, 21)])
 def test_engine_matches_oracle(dev, dropout, c, mode):
     """Both fp32 plans (fp32 MFMA everywhere / fc6+fc7 as exact 3xbf16 splits on the bf16 MFMA)
@@ -122,7 +122,7 @@ def test_engine_bf16_mode(dev, c):
     assert torch.equal(out['loss_cls'], out2['loss_cls'])
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'fp16x2'])
 def test_engine_sgd_steps(dev, mode):
     """3 iterations of fwd+bwd+SGD vs the oracle (dropout masks replayed)."""
     from oracle import oracle
@@ -154,7 +154,7 @@ def test_engine_sgd_steps(dev, mode):
         assert np.abs(m_got - m_ref).max() <= 2e-3 * np.abs(m_ref).max() + 1e-9, name
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'fp16x2'])
 def test_engine_infer(dev, mode):
     from oracle import oracle
     eng, mb, blobs = _setup(dev, dropout=0.5, mfma_dtype=mode)
@@ -169,7 +169,7 @@ def test_engine_infer(dev, mode):
                                rtol=1e-4, atol=1e-8)
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'fp32x3'])
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'fp16x2'])
 def test_deferred_update_is_equivalent(dev, mode):
     """The N>1 schedule (all-reduce launched after backward, SGD applied after the NEXT
     iteration's conv body) gives bit-identical parameters to the immediate update (fp32x3: the

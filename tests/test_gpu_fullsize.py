@@ -133,22 +133,23 @@ def test_config5_inference_1200x2000_4000_rois(dev):
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
     assert t['rois'].shape[0] == 4000
     res = {}
-    for mode in ('fp32x3', 'fp32'):
+    for mode in ('fp16x2', 'fp32x3', 'fp32'):
         eng = WsddnEngine(c + 1, dev, gpu_num=1, seed=11, mfma_dtype=mode)
         eng.set_conv_blobs(blobs)
         eng.set_head_blobs(blobs)
         res[mode] = eng.infer(t['data'], t['rois'], t['obn_scores'])
-        if mode == 'fp32x3':
+        if mode == 'fp16x2':
             perm = torch.randperm(4000, generator=torch.Generator().manual_seed(1)).to(dev)
             p2 = eng.infer(t['data'], t['rois'][perm], t['obn_scores'][perm])
         del eng
-    p = res['fp32x3']
+    p = res['fp16x2']
     assert p.shape == (4000, c + 1) and torch.isfinite(p).all() and (p >= 0).all()
     assert torch.equal(p[:, 0], p[:, 1])
     assert float(p[:, 1:].sum(0).max()) <= 1.0 + 1e-5
     scale = float(p.max())
     assert float((p2 - p[perm]).abs().max()) <= 1e-5 * scale
     assert float((res['fp32'] - p).abs().max()) <= 1e-4 * scale
+    assert float((res['fp32x3'] - p).abs().max()) <= 1e-4 * scale
     # NMS on the real score matrix: GPU == host restatement, class by class
     keep = ops.nms_per_class(t['rois'][:, 1:5].contiguous(), p[:, 1:].contiguous(), 0.0, 0.5)
     pn, bn = p.cpu().numpy(), mb['rois'][:, 1:5]
@@ -161,7 +162,7 @@ def test_config5_inference_1200x2000_4000_rois(dev):
 @pytest.mark.parametrize('h,w,rois', [(203, 317, (517, 301)), (480, 640, (999,)), (97, 131, (5, 1, 64))])
 def test_ragged_shapes_plans_agree(dev, h, w, rois):
     """Odd image sizes, ragged proposal counts (not multiples of any tile / K-slab), 1-3 images
-    per process: the fp32x3 and fp32 plans - disjoint GEMM / conv kernels - agree on losses,
+    per process: the fp16x2, fp32x3 and fp32 plans - disjoint GEMM / conv kernels - agree on losses,
     probabilities and parameter gradients to the fp32 parity tolerance, and the bf16 plan to
     its own."""
     from detectron.datasets import synthetic
@@ -178,7 +179,7 @@ def test_ragged_shapes_plans_agree(dev, h, w, rois):
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
     assert t['rois'].shape[0] == sum(rois)
     res = {}
-    for mode in ('fp32', 'fp32x3', 'bf16'):
+    for mode in ('fp32', 'fp32x3', 'fp16x2', 'bf16'):
         eng = WsddnEngine(c + 1, dev, dropout=0.5, gpu_num=b, seed=3, mfma_dtype=mode)
         eng.set_conv_blobs(blobs)
         eng.set_head_blobs(blobs)
@@ -187,12 +188,12 @@ def test_ragged_shapes_plans_agree(dev, h, w, rois):
         res[mode] = (out, eng.grads.clone())
         del eng
     o32, g32 = res['fp32']
-    for mode, tol, gtol in (('fp32x3', 1e-4, 2e-3), ('bf16', 5e-2, 0.2)):
+    for mode, tol, gtol in (('fp32x3', 1e-4, 2e-3), ('fp16x2', 1e-4, 2e-3), ('bf16', 5e-2, 0.2)):
         o, g = res[mode]
         lscale = float(o32['loss_cls'].abs().max())       # (the noise loss is ~100x smaller)
         for k in ('loss_cls', 'loss_cls_noise'):
             a, r = o[k].cpu().numpy(), o32[k].cpu().numpy()
-            bound = tol * (np.abs(r).max() if mode == 'fp32x3' else lscale)
+            bound = tol * (np.abs(r).max() if mode != 'bf16' else lscale)
             assert np.isfinite(a).all() and np.abs(a - r).max() <= bound, (mode, k)
         pa, pr = o['cls_prob'].cpu().numpy(), o32['cls_prob'].cpu().numpy()
         assert np.abs(pa - pr).max() <= tol * pr.max(), mode

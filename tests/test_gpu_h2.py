@@ -1,0 +1,201 @@
+"""GPU parity of the fp32 GEMM on the f16 matrix cores ("2 x f16" split with per-row power-of-two
+scaling, csrc/gemm_x3.hip: naws_split_f16x2 / naws_gemm_f32_f16x2_nt).
+
+Pinned here: (1) the split's stated representation bound, |x s - hi - lo| <= max(2^-22 |x s|,
+2^-25), the scale a power of two with the row maximum in [2^14, 2^15); (2) against a float64
+product the kernel's error is at the level of the fp32-MFMA kernel's own on the same data,
+max and rms, including operands whose rows span 12 orders of magnitude; (3) same epilogues and
+dropout stream as the other GEMMs; (4) run-to-run determinism.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _dense(op, k):
+    """F16x2 -> (hi + lo) / scale as float64 [.., outer, k], and the inverse scales."""
+    p = op.planes.double()                      # [2, (b,) K/16, outer, 16]
+    s = p[0] + p[1]
+    s = s.movedim(-3, -2).reshape(*s.shape[:-3], s.shape[-2], -1)   # [(b,) outer, Kpad]
+    inv = op.inv_scale.double()
+    return (s * inv.unsqueeze(-1)).cpu().numpy(), inv.cpu().numpy(), s.cpu().numpy()
+
+
+@pytest.mark.parametrize('transpose', [False, True])
+def test_split_representation_bound(dev, transpose):
+    from naws_hip import ops
+    rng = np.random.default_rng(41)
+    x = (rng.standard_normal((2, 77, 52)) * np.exp(rng.uniform(-6, 6, (2, 77, 52)))).astype(np.float32)
+    x[0, 0, :4] = [0.0, -0.0, 1.0, -1.0]
+    x[1, 5, :] = 0.0                            # an all-zero row / column entry
+    op = ops.split_f16x2(_t(x, dev), transpose=transpose)
+    k = 77 if transpose else 52
+    kp = (k + 31) // 32 * 32
+    assert op.planes.shape == ((2, 2, kp // 16, 52, 16) if transpose else (2, 2, kp // 16, 77, 16))
+    assert op.planes.dtype == torch.float16 and op.scales.shape == (2, 2, 52 if transpose else 77)
+    ref = (x.transpose(0, 2, 1) if transpose else x).astype(np.float64)
+    dense, inv, scaled = _dense(op, k)
+    assert not scaled[..., k:].any()            # zero-filled K pad
+    amax = np.abs(ref).max(axis=-1)
+    nz = amax > 0
+    # scale: a power of two, row maximum lands in [2^14, 2^15)
+    assert np.array_equal(np.log2(inv), np.round(np.log2(inv)))
+    top = amax[nz] / inv[nz]
+    assert (top >= 2.0 ** 14).all() and (top < 2.0 ** 15).all()
+    err = np.abs(dense[..., :k] - ref)
+    bound = np.maximum(2.0 ** -22 * np.abs(ref), 2.0 ** -25 * inv[..., None])
+    assert (err <= bound).all()
+    # strided 2-D source (column slice of a wider matrix)
+    xs = _t(x, dev)[1][:, 8:40]
+    rs = x[1][:, 8:40]
+    rs = (rs.T if transpose else rs).astype(np.float64)
+    d2, inv2, _ = _dense(ops.split_f16x2(xs, transpose=transpose), rs.shape[1])
+    assert (np.abs(d2[..., :rs.shape[1]] - rs) <=
+            np.maximum(2.0 ** -22 * np.abs(rs), 2.0 ** -25 * inv2[..., None])).all()
+
+
+def test_split_nonfinite_and_tiny(dev):
+    from naws_hip import ops
+    x = np.ones((32, 32), np.float32)
+    x[0, 0], x[1, 1], x[2, :] = np.nan, np.inf, 1e-30
+    op = ops.split_f16x2(_t(x, dev))
+    d, inv, _ = _dense(op, 32)
+    assert np.isnan(d[0, 0]) and not np.isnan(d[0, 1:]).any()
+    assert not np.isfinite(d[1, 1])
+    assert np.isfinite(inv).all()
+    assert (np.abs(d[2] - np.float64(np.float32(1e-30))) <= 2.0 ** -22 * 1e-30).all()   # scale cap 2^101
+    assert np.array_equal(d[3:], x[3:].astype(np.float64))
+
+
+@pytest.mark.parametrize('m,n,k', [(256, 128, 32), (130, 72, 64), (517, 260, 1000), (64, 4000, 264),
+                                   (2100, 140, 96), (300, 200, 25088)])
+def test_gemm_h2_fp32_accurate(dev, m, n, k):
+    from naws_hip import ops
+    rng = np.random.default_rng(42)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64).T
+    ad, bd = _t(a, dev), _t(b, dev)
+    c = ops.gemm_f32_f16x2_nt(ops.split_f16x2(ad), ops.split_f16x2(bd)).cpu().numpy()
+    c32 = ops.gemm(ad, bd, False, True).cpu().numpy()
+    scale = np.abs(ref).max()
+    err = np.abs(c - ref).max() / scale
+    err32 = np.abs(c32 - ref).max() / scale
+    assert err < 5e-6 * max(1.0, np.sqrt(k / 4096.0)), (err, err32)
+    assert err <= 2.0 * err32 + 2e-7, (err, err32)
+    rms, rms32 = np.sqrt(np.mean((c - ref) ** 2)), np.sqrt(np.mean((c32 - ref) ** 2))
+    assert rms <= 2.0 * rms32 + 1e-7 * scale, (rms, rms32)
+
+
+def test_gemm_h2_activation_like(dev):
+    """Post-ReLU activations (half zeros, heavy tail) against small-variance weights, the fc6
+    shape's statistics: same-sign partial sums, where operand error would show as bias."""
+    from naws_hip import ops
+    rng = np.random.default_rng(47)
+    m, n, k = 384, 320, 8192
+    a = np.maximum(rng.standard_normal((m, k)) * np.exp(rng.uniform(-2, 2, (m, k))), 0).astype(np.float32)
+    b = (np.abs(rng.standard_normal((n, k))) * 0.01).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64).T
+    ad, bd = _t(a, dev), _t(b, dev)
+    c = ops.gemm_f32_f16x2_nt(ops.split_f16x2(ad), ops.split_f16x2(bd)).cpu().numpy()
+    c32 = ops.gemm(ad, bd, False, True).cpu().numpy()
+    c3 = ops.gemm_f32x3_nt(ops.split_bf16x3(ad), ops.split_bf16x3(bd)).cpu().numpy()
+    rel, rel32, rel3 = (c - ref) / ref, (c32 - ref) / ref, (c3 - ref) / ref
+    assert np.abs(rel).max() <= 1.5 * np.abs(rel32).max() + 2e-7, (np.abs(rel).max(), np.abs(rel32).max())
+    assert np.sqrt(np.mean(rel ** 2)) <= 1.5 * np.sqrt(np.mean(rel32 ** 2)) + 1e-7
+    # the mean signed error is the MFMA's own accumulation bias (the bf16 split shows the same);
+    # the operand split adds nothing to it: exact product of the split operands vs float64
+    assert abs(rel.mean()) <= 1.5 * abs(rel3.mean()) + 5e-8, (rel.mean(), rel3.mean())
+    assert abs(rel.mean()) < 1e-6
+
+
+def test_gemm_h2_wide_dynamic_range(dev):
+    """Rows spanning 12 orders of magnitude: per-row scaling keeps every row at full precision."""
+    from naws_hip import ops
+    rng = np.random.default_rng(43)
+    m, n, k = 192, 160, 512
+    a = (rng.standard_normal((m, k)) * np.exp(rng.uniform(-14, 14, (m, 1)))).astype(np.float32)
+    b = (rng.standard_normal((n, k)) * np.exp(rng.uniform(-14, 14, (n, 1)))).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64).T
+    c = ops.gemm_f32_f16x2_nt(ops.split_f16x2(_t(a, dev)), ops.split_f16x2(_t(b, dev))).cpu().numpy()
+    bound = (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T)
+    assert (np.abs(c - ref) <= 2e-6 * bound).all()
+    # and elements far below their row's maximum: absolute floor 2^-39 of the row maximum
+    a2 = a.copy()
+    a2[:, ::2] *= np.float32(1e-7)
+    ref2 = a2.astype(np.float64) @ b.astype(np.float64).T
+    c2 = ops.gemm_f32_f16x2_nt(ops.split_f16x2(_t(a2, dev)), ops.split_f16x2(_t(b, dev))).cpu().numpy()
+    bound2 = (np.abs(a2).astype(np.float64) @ np.abs(b).astype(np.float64).T)
+    assert (np.abs(c2 - ref2) <= 2e-6 * bound2).all()
+
+
+def test_gemm_h2_identity(dev):
+    from naws_hip import ops
+    n = 256
+    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) * 1.0009765625) % 1013.0
+    c = ops.gemm_f32_f16x2_nt(ops.split_f16x2(_t(np.eye(n, dtype=np.float32), dev)),
+                              ops.split_f16x2(_t(b.T.copy(), dev))).cpu().numpy()
+    assert np.abs(c - b).max() <= 2.0 ** -22 * 1013.0
+
+
+def test_gemm_h2_transposed_operands(dev):
+    from naws_hip import ops
+    rng = np.random.default_rng(44)
+    r, m, n = 203, 96, 300
+    dy = rng.uniform(-1, 1, (r, m)).astype(np.float32)
+    x = rng.uniform(-1, 1, (r, n)).astype(np.float32)
+    ref = dy.astype(np.float64).T @ x.astype(np.float64)
+    a2 = ops.split_f16x2(_t(dy, dev), transpose=True)
+    b2 = ops.split_f16x2(_t(x, dev), transpose=True)
+    c = ops.gemm_f32_f16x2_nt(a2, b2)
+    assert np.abs(c.cpu().numpy() - ref).max() < 5e-6 * np.abs(ref).max()
+    out = torch.zeros((m, n), device=dev)
+    for r0, r1 in ((0, 40), (40, 96)):          # row-chunked output (all-reduce overlap)
+        ops.gemm_f32_f16x2_nt(a2.rows(r0, r1), b2, out=out[r0:r1])
+    assert torch.equal(out, c)
+
+
+def test_gemm_h2_epilogues_batched(dev):
+    from naws_hip import ops, lib
+    rng = np.random.default_rng(45)
+    m, n, k = 260, 384, 160
+    a = rng.uniform(-1, 1, (2, m, k)).astype(np.float32)
+    w = rng.uniform(-1, 1, (2, n, k)).astype(np.float32)
+    w[1] *= 37.0                                 # batch items with different scales
+    bias = rng.uniform(-1, 1, (2, n)).astype(np.float32)
+    zz = np.stack([a[i].astype(np.float64) @ w[i].astype(np.float64).T for i in range(2)])
+    z = zz + bias[:, None, :]
+    a2, w2, bd = ops.split_f16x2(_t(a, dev)), ops.split_f16x2(_t(w, dev)), _t(bias, dev)
+    y = ops.gemm_f32_f16x2_nt(a2, w2, epilogue=lib.EPI_BIAS, bias=bd).cpu().numpy()
+    np.testing.assert_allclose(y, z, rtol=1e-5, atol=1e-4)
+    y = ops.gemm_f32_f16x2_nt(a2, w2, epilogue=lib.EPI_BIAS_RELU_DROP, bias=bd, drop_ratio=0.5,
+                              seed=77).cpu().numpy()
+    mask = ops.dropout_mask(77, 0.5, 2 * m * n, dev).reshape(2, m, n).cpu().numpy()
+    np.testing.assert_allclose(y, np.maximum(z, 0) * mask * 2.0, rtol=1e-5, atol=2e-4)
+    aux = rng.standard_normal((2, m, n)).astype(np.float32)
+    gt = ops.gemm_f32_f16x2_nt(a2, w2, epilogue=lib.EPI_GATE_POS, aux=_t(aux, dev), alpha=2.0)
+    np.testing.assert_allclose(gt.cpu().numpy(), np.where(aux > 0, zz * 2.0, 0.0), rtol=1e-5, atol=4e-4)
+    c0 = rng.standard_normal((2, m, n)).astype(np.float32)
+    cd = _t(c0, dev)
+    ops.gemm_f32_f16x2_nt(a2, w2, out=cd, accumulate=True)
+    np.testing.assert_allclose(cd.cpu().numpy(), c0 + zz, rtol=1e-5, atol=4e-4)
+    y1 = ops.gemm_f32_f16x2_nt(a2.batches(1), w2.batches(1)).cpu().numpy()
+    np.testing.assert_allclose(y1[0], zz[0], rtol=1e-5, atol=1e-4)
+    with pytest.raises(lib.NawsError):      # K mismatch
+        ops.gemm_f32_f16x2_nt(a2, ops.split_f16x2(_t(w[:, :, :96].copy(), dev)))
+
+
+def test_gemm_h2_deterministic(dev):
+    from naws_hip import ops
+    rng = np.random.default_rng(46)
+    a2 = ops.split_f16x2(_t(rng.standard_normal((700, 1024)).astype(np.float32), dev))
+    b2 = ops.split_f16x2(_t(rng.standard_normal((900, 1024)).astype(np.float32), dev))
+    c1 = ops.gemm_f32_f16x2_nt(a2, b2)
+    for _ in range(5):
+        assert torch.equal(ops.gemm_f32_f16x2_nt(a2, b2), c1)
