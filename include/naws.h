@@ -345,6 +345,16 @@ int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA, i
                            int64_t strideScaleB, int epilogue, const float* bias,
                            int64_t strideBias, const float* aux, int ldaux, float alpha,
                            float drop_ratio, uint64_t seed, int accumulate, void* stream);
+/* Winograd F(2x2,3x3) convolution (as naws_conv3x3_winograd_nhwc_fwd: reference
+ * detectron/modeling/VGG16.py:24-46, conv3_x .. conv5_x) with the 16 batched GEMMs in the 2 x f16
+ * split: the input transform scales by one power of two per tensor (|B^T d B| <= 4 max|x|) and
+ * writes the f16 hi / lo planes itself.  U2 / scaleU: naws_split_f16x2 of the transformed weight
+ * viewed as batch 16 of [Cout][Cin] (scaleU = its scales[1], [16][Cout]).  Cin % 32 == 0. */
+int64_t naws_winograd_f16x2_workspace_floats(int N, int H, int W, int Cin, int Cout, int dilation);
+int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const float* scaleU,
+                                         const float* bias, int N, int H, int W, int Cin, int Cout,
+                                         int dilation, int relu, float* workspace, float* Y,
+                                         void* stream);
 /* bf16 plan on the same pipeline: one plane (operands rounded to bf16), 64-deep K-steps.
  * naws_to_bf16_slab: as naws_split_bf16x3 with a single plane, P[batch][kpad/16][outer][16],
  * kpad = K rounded up to 64.  naws_gemm_bf16_slab_nt: C (+)= A B^T on such operands, K % 64 == 0;

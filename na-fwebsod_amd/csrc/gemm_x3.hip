@@ -1028,6 +1028,12 @@ extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64
     g_h2_variant = e ? atoi(e) : 0;
   }
   if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+  // short K (the Winograd batch GEMMs): two 4-wave workgroups per CU overlap one's prologue /
+  // epilogue with the other's K loop
+  if (K <= 1024 && g_h2_variant != 5) {
+    if (g_h2_variant == 6) return launch_x3<256, 128, 2, 2, 2, 2, 1, true>(g, batch, s);
+    return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+  }
   switch (g_h2_variant) {
     case 1: return launch_x3<256, 256, 2, 4, 3, 2, 1, true>(g, batch, s);
     case 2: return launch_x3<256, 256, 2, 4, 4, 2, 1, true>(g, batch, s);

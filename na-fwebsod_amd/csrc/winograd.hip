@@ -92,6 +92,108 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
 }
 
+// ---- fp16x2 form: the input transform emits the GEMM's f16 operand planes directly ---------------
+// |x| maximum of a whole tensor (non-negative floats order like their bit patterns).
+__global__ __launch_bounds__(256) void amax_all_kernel(const float* __restrict__ X, long long n4,
+                                                       unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(X)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(m));
+  }
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void put_h2(float4 v, float sc, unsigned short* __restrict__ hi,
+                                       unsigned short* __restrict__ lo) {
+  const float t[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+  unsigned short h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 a = (_Float16)t[e];
+    float r = t[e] - (float)a;
+    if (!(fabsf(t[e]) <= 65504.f)) r = 0.f;
+    const _Float16 b = (_Float16)r;
+    h[e] = *reinterpret_cast<const unsigned short*>(&a);
+    l[e] = *reinterpret_cast<const unsigned short*>(&b);
+  }
+  u32x2 wh, wl;
+  wh.x = h[0] | ((unsigned)h[1] << 16); wh.y = h[2] | ((unsigned)h[3] << 16);
+  wl.x = l[0] | ((unsigned)l[1] << 16); wl.y = l[2] | ((unsigned)l[3] << 16);
+  *reinterpret_cast<u32x2*>(hi) = wh;
+  *reinterpret_cast<u32x2*>(lo) = wl;
+}
+
+// V planes P[2][16][Cin/16][tiles][16] f16 = split of (B^T d B) * s, s = one power of two for the
+// whole tensor: |B^T d B| <= 4 max|x|, so s = 2^(12 - floor(log2 max|x|)) keeps it below 2^15.
+// One lane = one tile x 4 channels; lane order (4 channel groups of a 16-channel slab, then tiles):
+// a wave writes 16 tiles x 32 B = 512 contiguous bytes per (xi, plane).
+__global__ __launch_bounds__(256) void wino_input_h2_kernel(const float* __restrict__ X, WinoGeom g,
+                                                            int Cin, const unsigned* __restrict__ amax,
+                                                            float* __restrict__ inv_scale,
+                                                            unsigned short* __restrict__ Vp) {
+  int e = (int)((*amax >> 23) & 0xff);
+  if (*amax == 0 || e == 0xff) e = 127 + 12;
+  e = min(max(e, 40), 250);
+  const float sc = __uint_as_float((unsigned)(266 - e) << 23);      // 2^(12 - (e - 127))
+  const float isc = __uint_as_float((unsigned)(e - 12) << 23);
+  const long long total = g.P * (Cin / 4);
+  const long long xi_stride = (long long)Cin * g.P;                 // elements between the 16 xi
+  const long long plane = 16 * xi_stride;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (long long)gridDim.x * 256) {
+    const int cq = (int)(t & 3);
+    const long long p = (t >> 2) % g.P;
+    const int s = (int)((t >> 2) / g.P);
+    const int c = s * 16 + cq * 4;
+    if (s == 0 && cq == 0) inv_scale[p] = isc;
+    int n, py, px, ty, tx;
+    tile_coords(g, p, n, py, px, ty, tx);
+    float4 dd[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ys = 2 * ty - 1 + i;
+      const int y = ys * g.d + py;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xs = 2 * tx - 1 + j;
+        const int x = xs * g.d + px;
+        const bool ok = ys >= 0 && xs >= 0 && y < g.H && x < g.W;
+        dd[i][j] = ok ? *reinterpret_cast<const float4*>(
+                            X + (((long long)n * g.H + y) * g.W + x) * Cin + c)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 tt[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // B^T d
+      tt[0][j] = f4sub(dd[0][j], dd[2][j]);
+      tt[1][j] = f4add(dd[1][j], dd[2][j]);
+      tt[2][j] = f4sub(dd[2][j], dd[1][j]);
+      tt[3][j] = f4sub(dd[1][j], dd[3][j]);
+    }
+    unsigned short* hi = Vp + ((long long)s * g.P + p) * 16 + cq * 4;
+    unsigned short* lo = hi + plane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // (.) B
+      put_h2(f4sub(tt[i][0], tt[i][2]), sc, hi + (i * 4 + 0) * xi_stride, lo + (i * 4 + 0) * xi_stride);
+      put_h2(f4add(tt[i][1], tt[i][2]), sc, hi + (i * 4 + 1) * xi_stride, lo + (i * 4 + 1) * xi_stride);
+      put_h2(f4sub(tt[i][2], tt[i][1]), sc, hi + (i * 4 + 2) * xi_stride, lo + (i * 4 + 2) * xi_stride);
+      put_h2(f4sub(tt[i][1], tt[i][3]), sc, hi + (i * 4 + 3) * xi_stride, lo + (i * 4 + 3) * xi_stride);
+    }
+  }
+}
+
 // Y tile = A^T m A (+ bias, ReLU);  one lane = one tile x 4 output channels
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, WinoGeom g,
                                                           int Cout, long long slab,
@@ -267,6 +369,61 @@ extern "C" int naws_conv3x3_winograd_nhwc_f32x3_fwd(const float* X, const void* 
   rc = naws_gemm_f32x3_nt((int)g.P, Cout, Cin, Vp, g.P * 16, 16 * g.P * Cin, U3, (int64_t)Cout * 16,
                           (int64_t)16 * Cout * Cin, Mb, Cout, 16, g.P * Cin, (int64_t)Cout * Cin,
                           slabM, NAWS_EPI_NONE, nullptr, 0, nullptr, 0, 1.0f, 0.0f, 0, 0, stream);
+  if (rc != NAWS_OK) return rc;
+  {
+    const long long total = g.P * (Cout / 4);
+    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
+                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y);
+  }
+  return naws_check_launch();
+}
+
+// Same convolution with the 16 batched GEMMs on the f16 matrix cores in the row-scaled 2 x f16
+// split (csrc/gemm_x3.hip, naws_gemm_f32_f16x2_nt): the input transform writes the scaled hi / lo
+// planes itself (no fp32 V round trip); U2 / scaleU = naws_split_f16x2 of the transformed weight
+// viewed [16][Cout][Cin] (planes [2][16][Cin/16][Cout][16], scales [2][16][Cout], scaleU = [1]).
+extern "C" int64_t naws_winograd_f16x2_workspace_floats(int N, int H, int W, int Cin, int Cout,
+                                                        int dilation) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation < 1) return 0;
+  const WinoGeom g = wino_geom(N, H, W, dilation);
+  return 16 * g.P * ((int64_t)Cin + Cout) + g.P + 64;
+}
+
+extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2,
+                                                    const float* scaleU, const float* bias, int N,
+                                                    int H, int W, int Cin, int Cout, int dilation,
+                                                    int relu, float* workspace, float* Y,
+                                                    void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (dilation < 1) return NAWS_ERR_ARG;
+  if (Cin % 32 != 0 || Cout % 4 != 0) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(U2); NAWS_REQUIRE_PTR(scaleU);
+  NAWS_REQUIRE_PTR(workspace); NAWS_REQUIRE_PTR(Y);
+  if ((((uintptr_t)X | (uintptr_t)U2 | (uintptr_t)workspace | (uintptr_t)Y) & 15) != 0)
+    return NAWS_ERR_ARG;
+  const WinoGeom g = wino_geom(N, H, W, dilation);
+  if (g.P > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const long long slabM = g.P * Cout;
+  unsigned short* Vp = (unsigned short*)workspace;                   // 16 * P * Cin floats
+  float* Mb = workspace + 16 * g.P * Cin;
+  float* invA = Mb + 16 * slabM;                                     // P floats
+  unsigned* amax = (unsigned*)(invA + g.P);
+  if (hipMemsetAsync(amax, 0, sizeof(unsigned), s) != hipSuccess) return NAWS_ERR_LAUNCH;
+  {
+    const long long n4 = (long long)N * H * W * Cin / 4;
+    hipLaunchKernelGGL(amax_all_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(n4, 256 * 8), 2048)),
+                       dim3(256), 0, s, X, n4, amax);
+    const long long total = g.P * (Cin / 4);
+    hipLaunchKernelGGL(wino_input_h2_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
+                       dim3(256), 0, s, X, g, Cin, (const unsigned*)amax, invA, Vp);
+    int rc = naws_check_launch();
+    if (rc != NAWS_OK) return rc;
+  }
+  int rc = naws_gemm_f32_f16x2_nt((int)g.P, Cout, Cin, Vp, g.P * 16, 16 * g.P * Cin, invA, U2,
+                                  (int64_t)Cout * 16, (int64_t)16 * Cout * Cin, scaleU, Mb, Cout, 16,
+                                  g.P * Cin, (int64_t)Cout * Cin, slabM, 0, Cout, NAWS_EPI_NONE,
+                                  nullptr, 0, nullptr, 0, 1.0f, 0.0f, 0, 0, stream);
   if (rc != NAWS_OK) return rc;
   {
     const long long total = g.P * (Cout / 4);

@@ -126,12 +126,12 @@ class WsddnEngine(object):
         self.reducer = ArenaReducer(process_group, world_size)
         # fc6_w's gradient (822 MB of the 958 MB all-reduce) can be reduced in row chunks while
         # the rest of its wgrad GEMM still runs.  0 = auto: one message when the collective fits
-        # under the next iteration's parameter-free conv body + RoIPool (~7 ms: 4 and 8 ranks use
-        # 3 / 7 xGMI links per GPU), two chunks at world_size 2, where a single link carries the
-        # whole exchange (~6-13 ms) and the 0.5 ms a chunked GEMM loses to tile quantisation is
-        # the cheaper side
+        # under the tail of the backward pass + the next iteration's parameter-free conv body +
+        # RoIPool (~6.5 ms: 4 and 8 ranks use 3 / 7 xGMI links per GPU, ~7 / ~4 ms), four chunks
+        # at world_size 2, where a single link carries the whole exchange (~11-13 ms) and the
+        # ~1 ms the chunked GEMMs lose to tile quantisation is the cheaper side
         ac = int(allreduce_chunks)
-        self.allreduce_chunks = ac if ac >= 1 else (2 if int(world_size) == 2 else 1)
+        self.allreduce_chunks = ac if ac >= 1 else (4 if int(world_size) == 2 else 1)
         self.k6 = 512 * roi_size * roi_size
         self.ld8 = (2 * self.C + 3) // 4 * 4       # per-branch column block of the logit matrices
 
@@ -182,6 +182,9 @@ class WsddnEngine(object):
         # those GEMMs are bound by V/M traffic and tile epilogues, not by the MFMA rate
         # (measured per layer: 0.26-0.62 ms either way, tools/kernel_bench.py --what conv)
         self.wino_x3 = False
+        # fp16x2: the Winograd layers' 16 batched GEMMs on the f16 MFMA, operand planes written
+        # by the input transform itself (csrc/winograd.hip, naws_conv3x3_winograd_nhwc_f16x2_fwd)
+        self.wino_h2 = True
         self.conv_wino = {}
         self._streams = []
         # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
@@ -247,7 +250,9 @@ class WsddnEngine(object):
                 packed = ops.split_bf16x3(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
             elif use_wino:
                 packed = ops.winograd_weight_transform(w)      # [16][Cout][Cin]
-                if self.mfma_dtype in ('fp32x3', 'fp16x2') and self.wino_x3:
+                if self.mfma_dtype == 'fp16x2' and self.wino_h2:
+                    packed = ops.split_f16x2(packed)           # F16x2, planes [2][16][Cin/16][Cout][16]
+                elif self.mfma_dtype in ('fp32x3', 'fp16x2') and self.wino_x3:
                     packed = ops.split_bf16x3(packed)          # planes [3][16][Cin/16][Cout][16]
             else:
                 packed = ops.conv3x3_pack_weight(w)            # [Cout][3][3][Cin]
@@ -287,7 +292,9 @@ class WsddnEngine(object):
                     x = ops.conv3x3_c3_nchw_to_nhwc(data, wp, b, True)
                 else:
                     d = dil if dil is not None else (2 if self.dilation == 2 else 1)
-                    if wp.dtype == torch.bfloat16:
+                    if isinstance(wp, ops.F16x2):
+                        conv = ops.conv3x3_winograd_nhwc_f16x2
+                    elif wp.dtype == torch.bfloat16:
                         conv = (ops.conv3x3_winograd_nhwc_f32x3 if self.conv_wino[name]
                                 else ops.conv3x3_nhwc_f32x3)
                     elif self.mfma_dtype == 'bf16':
@@ -501,55 +508,36 @@ class WsddnEngine(object):
         dlv = dl.view(rt, 2, ld8).permute(1, 0, 2)             # [2, Rt, ld8]
         h7v = h7.view(rt, 2, HIDDEN).permute(1, 0, 2)
         h6v = h6.view(rt, 2, HIDDEN).permute(1, 0, 2)
-        # fc8: dW = dL^T H7, db = colsum(dL), dH7 = dL W8 gated by ReLU/Dropout of fc7
-        if pad:
-            gw8p = torch.empty((2, ld8, HIDDEN), device=self.device, dtype=torch.float32)
-            ops.gemm(dlv, h7v, True, False, out=gw8p)
-            gw8.copy_(gw8p[:, :2 * C])
-            gb8.view(2, 2 * C).copy_(ops.colsum(dl).view(2, ld8)[:, :2 * C])
-            w8 = self._fc8_operands(w8, self.arena.span(self.params, 'fc8c_b', 'noisy_fc8d_b')
-                                    .view(2, 2 * C))[0]
-        else:
-            ops.gemm(dlv, h7v, True, False, out=gw8)
-            ops.colsum(dl, out=gb8)
-        dz7 = torch.empty_like(h7)
-        dz7v = dz7.view(rt, 2, HIDDEN).permute(1, 0, 2)
-        ops.gemm(dlv, w8, False, False, out=dz7v, epilogue=L.EPI_GATE_POS, aux=h7v, alpha=scale)
-        # fc7
         bf = self.mfma_dtype == 'bf16'
         x3 = self.mfma_dtype == 'fp32x3'
         h2 = self.mfma_dtype == 'fp16x2'
+        red = self.reducer
+        # Order: the data-gradient chain first, then fc6_w's gradient (86 % of the all-reduce
+        # bytes) so that its exchange starts as early as possible, the small gradients last.
+        # 1. dZ7 = dL W8 and dZ6 = dZ7 W7, each gated by the ReLU / Dropout of its layer
+        w8g = w8
+        if pad:
+            w8g = self._fc8_operands(w8, self.arena.span(self.params, 'fc8c_b', 'noisy_fc8d_b')
+                                     .view(2, 2 * C))[0]
+        dz7 = torch.empty_like(h7)
+        dz7v = dz7.view(rt, 2, HIDDEN).permute(1, 0, 2)
+        ops.gemm(dlv, w8g, False, False, out=dz7v, epilogue=L.EPI_GATE_POS, aux=h7v, alpha=scale)
         dz6 = torch.empty_like(h6)
         dz6v = dz6.view(rt, 2, HIDDEN).permute(1, 0, 2)
-        if h2:
-            ops.gemm_f32_f16x2_nt(ops.split_f16x2(dz7v, transpose=True),
-                                  ops.split_f16x2(h6v, transpose=True), out=gw7)
-            ops.colsum(dz7, out=gb7)
+        if h2:      # dX = dZ W: W^T planes are kept beside the W planes
             ops.gemm_f32_f16x2_nt(ops.split_f16x2(dz7v), self._wplanes['w7t'], out=dz6v,
                                   epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
         elif x3:
-            # dW = dZ^T H: both operands K(=rows)-contiguous through the transposing split;
-            # dX = dZ W: W^T planes are kept beside the W planes
-            ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v, transpose=True),
-                              ops.split_bf16x3(h6v, transpose=True), out=gw7)
-            ops.colsum(dz7, out=gb7)
             ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v), self._wplanes['w7t'], out=dz6v,
                               epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
         elif bf:
-            ops.gemm_bf16_slab_nt(ops.to_bf16_slab(dz7v, transpose=True),
-                                  ops.to_bf16_slab(h6v, transpose=True), out=gw7)
-            ops.colsum(dz7, out=gb7)
             ops.gemm_bf16_slab_nt(ops.to_bf16_slab(dz7v), self._wplanes['w7t'], out=dz6v,
                                   epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
         else:
-            ops.gemm(dz7v, h6v, True, False, out=gw7)
-            ops.colsum(dz7, out=gb7)
             ops.gemm(dz7v, w7, False, False, out=dz6v, epilogue=L.EPI_GATE_POS, aux=h6v,
                      alpha=scale)
-        ops.colsum(dz6, out=gb6)
-        # everything except fc6_w is ready: start its all-reduce, then stream fc6 wgrad chunks
-        red = self.reducer
-        red.reduce_async(self.arena.span(G, 'fc6_b', 'noisy_fc8d_b'))
+        # 2. fc6: dW = dZ6^T X in row chunks (both operands K(=rows)-contiguous through the
+        # transposing split); each chunk's all-reduce starts while the next one is computed
         if h2:
             dz6t = ops.split_f16x2(dz6, transpose=True)        # planes [2, Rt/16, 8192, 16]
             xt = ops.split_f16x2(x, transpose=True)            # planes [2, Rt/16, 25088, 16]
@@ -569,6 +557,30 @@ class WsddnEngine(object):
             else:
                 ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
             red.reduce_async(gw6[r0:r1].reshape(-1))
+        # 3. the small gradients (under the fc6_w exchange): fc6 db; fc7 dW = dZ7^T H6, db;
+        # fc8 dW = dL^T H7, db
+        ops.colsum(dz6, out=gb6)
+        if h2:
+            ops.gemm_f32_f16x2_nt(ops.split_f16x2(dz7v, transpose=True),
+                                  ops.split_f16x2(h6v, transpose=True), out=gw7)
+        elif x3:
+            ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v, transpose=True),
+                              ops.split_bf16x3(h6v, transpose=True), out=gw7)
+        elif bf:
+            ops.gemm_bf16_slab_nt(ops.to_bf16_slab(dz7v, transpose=True),
+                                  ops.to_bf16_slab(h6v, transpose=True), out=gw7)
+        else:
+            ops.gemm(dz7v, h6v, True, False, out=gw7)
+        ops.colsum(dz7, out=gb7)
+        if pad:
+            gw8p = torch.empty((2, ld8, HIDDEN), device=self.device, dtype=torch.float32)
+            ops.gemm(dlv, h7v, True, False, out=gw8p)
+            gw8.copy_(gw8p[:, :2 * C])
+            gb8.view(2, 2 * C).copy_(ops.colsum(dl).view(2, ld8)[:, :2 * C])
+        else:
+            ops.gemm(dlv, h7v, True, False, out=gw8)
+            ops.colsum(dl, out=gb8)
+        red.reduce_async(self.arena.span(G, 'fc6_b', 'noisy_fc8d_b'))
 
     def wait_allreduce(self):
         self.reducer.wait()

@@ -311,6 +311,23 @@ def conv3x3_winograd_nhwc_f32x3(x, u3, bias, dilation=1, relu=True, out=None):
     return y
 
 
+def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None):
+    """Winograd F(2x2,3x3) with fp16x2 GEMMs; u2 = split_f16x2(winograd_weight_transform(w))
+    (F16x2: planes [2, 16, Cin/16, Cout, 16], scales [2, 16, Cout])."""
+    _chk(x, 'x')
+    n, h, w, cin = x.shape
+    cout = u2.planes.shape[-2]
+    if u2.planes.dtype != torch.float16 or tuple(u2.planes.shape[:3]) != (2, 16, cin // 16):
+        raise TypeError('u2 must hold the f16 planes [2, 16, Cin/16, Cout, 16] of U')
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    nws = L.load().naws_winograd_f16x2_workspace_floats(n, h, w, cin, cout, dilation)
+    ws = torch.empty((nws,), device=x.device, dtype=_f32)
+    L.call('naws_conv3x3_winograd_nhwc_f16x2_fwd', x.data_ptr(), u2.planes.data_ptr(),
+           u2.inv_scale.data_ptr(), _ptr(bias), n, h, w, cin, cout, dilation, int(relu),
+           ws.data_ptr(), y.data_ptr(), _stream())
+    return y
+
+
 def nms_per_class(boxes, scores, score_thresh, nms_thresh):
     """Per-class greedy NMS of one image on the GPU (cython_nms.pyx `nms` semantics).
     boxes [R,4] (or [R,4*C] class-tiled, the reference's pred_boxes), scores [R,C] (fg classes).

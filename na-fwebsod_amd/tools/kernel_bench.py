@@ -194,7 +194,10 @@ def main():
                 msw = timeit(lambda: ops.conv3x3_winograd_nhwc(x, u, b, dil, True, out=y), a.iters)
                 u3 = ops.split_bf16x3(u)
                 msx = timeit(lambda: ops.conv3x3_winograd_nhwc_f32x3(x, u3, b, dil, True, out=y), a.iters)
-                print('   winograd F(2x2,3x3): %8.3f ms (direct %8.3f ms, winograd fp32x3 %8.3f ms)' % (msw, ms, msx))
+                u2 = ops.split_f16x2(u)
+                msh = timeit(lambda: ops.conv3x3_winograd_nhwc_f16x2(x, u2, b, dil, True, out=y), a.iters)
+                print('   winograd F(2x2,3x3): %8.3f ms (direct %8.3f ms, winograd fp32x3 %8.3f ms, '
+                      'winograd fp16x2 %8.3f ms)' % (msw, ms, msx, msh))
             fl = 2.0 * a.images * h * w * cout * 9 * cin
             k = mult.get((cin, cout, h, w, dil), 1)
             tot_ms += ms * k

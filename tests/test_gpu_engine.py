@@ -188,3 +188,45 @@ def test_deferred_update_is_equivalent(dev, mode):
         eng.flush()
         res.append((eng.params.clone(), eng.momentum_buf.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_rccl_chunked_allreduce_single_rank(dev):
+    """The distributed schedule on one GPU: a 1-rank RCCL group forced active, fc6_w's gradient
+    exchanged in four row chunks behind the wgrad GEMMs, the small gradients last - identical
+    gradients and parameters to the plain single-process run."""
+    import os
+    import torch.distributed as dist
+    from detectron.datasets import synthetic
+    from naws_hip.engine import WsddnEngine
+    c = 20
+    blobs = synthetic.init_blobs(c, seed=5)
+    mb = synthetic.make_minibatch(synthetic.make_roidb(2, 300, c, 160, 224, seed=9), c, max_rois=300)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29541')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        res = []
+        for forced in (False, True):
+            eng = WsddnEngine(c + 1, dev, dropout=0.5, gpu_num=2, seed=3,
+                              process_group=dist.group.WORLD if forced else None, world_size=1,
+                              allreduce_chunks=4)
+            eng.reducer.force = forced
+            eng.set_conv_blobs(blobs)
+            eng.set_head_blobs(blobs)
+            eng.set_lr(1e-4)
+            for _ in range(2):
+                eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+                eng.sgd_step()
+            eng.flush()
+            torch.cuda.synchronize()
+            res.append((eng.grads.clone(), eng.params.clone()))
+            assert eng.reducer.active == forced
+            del eng
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    finally:
+        if created:
+            dist.destroy_process_group()

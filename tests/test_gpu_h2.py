@@ -199,3 +199,35 @@ def test_gemm_h2_deterministic(dev):
     c1 = ops.gemm_f32_f16x2_nt(a2, b2)
     for _ in range(5):
         assert torch.equal(ops.gemm_f32_f16x2_nt(a2, b2), c1)
+
+
+@pytest.mark.parametrize('cin,cout,dil,h,w,amp', [(128, 256, 1, 19, 23, 1.0), (512, 512, 2, 20, 31, 1.0),
+                                                  (256, 256, 1, 38, 63, 300.0), (256, 512, 1, 75, 125, 1e-3)])
+def test_conv3x3_winograd_f16x2(dev, cin, cout, dil, h, w, amp):
+    """Winograd F(2x2,3x3) with the batch-16 GEMMs on the f16 MFMA, operand planes written by the
+    input transform: held to the fp32 Winograd path's own error against a float64 convolution,
+    at activation magnitudes from 1e-3 to 300 (the per-tensor power-of-two scale)."""
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(48)
+    n = 2
+    x = (np.maximum(rng.standard_normal((n, cin, h, w)), 0) * amp).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.uniform(-0.5, 0.5, cout) * amp).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    u = ops.winograd_weight_transform(_t(wt, dev))
+    y32 = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc(xd, u, _t(b, dev), dil, True)).cpu().numpy()
+    y = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc_f16x2(xd, ops.split_f16x2(u), _t(b, dev), dil,
+                                                         True)).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(y - ref).max() < 1e-5 * scale
+    assert np.abs(y - ref).max() <= 2.0 * np.abs(y32 - ref).max() + 1e-6 * scale
+    # no bias / no ReLU, and an all-zero input
+    y2 = ops.conv3x3_winograd_nhwc_f16x2(xd, ops.split_f16x2(u), None, dil, False)
+    r2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, padding=dil,
+                  dilation=dil).numpy()
+    assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 1e-5 * np.abs(r2).max()
+    y0 = ops.conv3x3_winograd_nhwc_f16x2(torch.zeros_like(xd), ops.split_f16x2(u), None, dil, False)
+    assert not y0.any()
