@@ -349,12 +349,16 @@ int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA, i
  * detectron/modeling/VGG16.py:24-46, conv3_x .. conv5_x) with the 16 batched GEMMs in the 2 x f16
  * split: the input transform scales by one power of two per tensor (|B^T d B| <= 4 max|x|) and
  * writes the f16 hi / lo planes itself.  U2 / scaleU: naws_split_f16x2 of the transformed weight
- * viewed as batch 16 of [Cout][Cin] (scaleU = its scales[1], [16][Cout]).  Cin % 32 == 0. */
+ * viewed as batch 16 of [Cout][Cin] (scaleU = its scales[1], [16][Cout]).  Cin % 32 == 0.
+ * amax_in (nullable): device word holding the bit pattern of an upper bound of max|X| (e.g. the
+ * amax_out of the layer that produced X, also valid across a max-pool); null = measured here.
+ * amax_out (nullable): device word, atomically maxed with the bit pattern of max|Y|; the caller
+ * zeroes it before the launch. */
 int64_t naws_winograd_f16x2_workspace_floats(int N, int H, int W, int Cin, int Cout, int dilation);
 int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const float* scaleU,
                                          const float* bias, int N, int H, int W, int Cin, int Cout,
                                          int dilation, int relu, float* workspace, float* Y,
-                                         void* stream);
+                                         const uint32_t* amax_in, uint32_t* amax_out, void* stream);
 /* bf16 plan on the same pipeline: one plane (operands rounded to bf16), 64-deep K-steps.
  * naws_to_bf16_slab: as naws_split_bf16x3 with a single plane, P[batch][kpad/16][outer][16],
  * kpad = K rounded up to 64.  naws_gemm_bf16_slab_nt: C (+)= A B^T on such operands, K % 64 == 0;

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void amax_all_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (v > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, v);
   }
 }
 
@@ -198,9 +198,11 @@ __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float* __restr
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, WinoGeom g,
                                                           int Cout, long long slab,
                                                           const float* __restrict__ bias,
-                                                          int relu, float* __restrict__ Y) {
+                                                          int relu, float* __restrict__ Y,
+                                                          unsigned* __restrict__ amax_out) {
   const int c4n = Cout / 4;
   const long long total = g.P * c4n;
+  float vmax = 0.f;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
        t += (long long)gridDim.x * 256) {
     const int c4 = (int)(t % c4n);
@@ -235,7 +237,21 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         float4 v = f4add(o[j], b);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4*>(Y + (((long long)n * g.H + y) * g.W + x) * Cout + c4 * 4) = v;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
       }
+    }
+  }
+  if (amax_out) {          // |y| maximum of the layer's output, for the next layer's operand scale
+    __shared__ float red[4];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+      // one word for the whole grid: only blocks that would raise it touch it atomically
+      if (v > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(amax_out, v);
     }
   }
 }
@@ -323,7 +339,7 @@ extern "C" int naws_conv3x3_winograd_nhwc_fwd(const float* X, const float* U, co
   {
     const long long total = g.P * (Cout / 4);
     hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y);
+                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y, (unsigned*)nullptr);
   }
   return naws_check_launch();
 }
@@ -373,7 +389,7 @@ extern "C" int naws_conv3x3_winograd_nhwc_f32x3_fwd(const float* X, const void* 
   {
     const long long total = g.P * (Cout / 4);
     hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y);
+                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y, (unsigned*)nullptr);
   }
   return naws_check_launch();
 }
@@ -393,6 +409,7 @@ extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* 
                                                     const float* scaleU, const float* bias, int N,
                                                     int H, int W, int Cin, int Cout, int dilation,
                                                     int relu, float* workspace, float* Y,
+                                                    const uint32_t* amax_in, uint32_t* amax_out,
                                                     void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
   if (dilation < 1) return NAWS_ERR_ARG;
@@ -408,15 +425,19 @@ extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* 
   unsigned short* Vp = (unsigned short*)workspace;                   // 16 * P * Cin floats
   float* Mb = workspace + 16 * g.P * Cin;
   float* invA = Mb + 16 * slabM;                                     // P floats
-  unsigned* amax = (unsigned*)(invA + g.P);
-  if (hipMemsetAsync(amax, 0, sizeof(unsigned), s) != hipSuccess) return NAWS_ERR_LAUNCH;
+  const unsigned* amax = (const unsigned*)amax_in;
   {
-    const long long n4 = (long long)N * H * W * Cin / 4;
-    hipLaunchKernelGGL(amax_all_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(n4, 256 * 8), 2048)),
-                       dim3(256), 0, s, X, n4, amax);
+    if (!amax) {           // no bound handed over by the producer of X: take the maximum here
+      unsigned* own = (unsigned*)(invA + g.P);
+      if (hipMemsetAsync(own, 0, sizeof(unsigned), s) != hipSuccess) return NAWS_ERR_LAUNCH;
+      const long long n4 = (long long)N * H * W * Cin / 4;
+      hipLaunchKernelGGL(amax_all_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(n4, 256 * 8), 2048)),
+                         dim3(256), 0, s, X, n4, own);
+      amax = own;
+    }
     const long long total = g.P * (Cin / 4);
     hipLaunchKernelGGL(wino_input_h2_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, X, g, Cin, (const unsigned*)amax, invA, Vp);
+                       dim3(256), 0, s, X, g, Cin, amax, invA, Vp);
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
   }
@@ -428,7 +449,7 @@ extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* 
   {
     const long long total = g.P * (Cout / 4);
     hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y);
+                       dim3(256), 0, s, Mb, g, Cout, slabM, bias, relu, Y, (unsigned*)amax_out);
   }
   return naws_check_launch();
 }

@@ -280,7 +280,11 @@ class WsddnEngine(object):
         """data NCHW [b,3,H,W] -> conv5_3 NHWC, on the current stream."""
         x = None
         last = VGG16_CONVS[-1][0]
-        for item in VGG16_CONVS:
+        # fp16x2 Winograd layers hand max|y| to the next layer (its operand scale needs an upper
+        # bound of max|x|; a max-pool in between only lowers it), saving that layer's own pass
+        amax = torch.zeros((len(VGG16_CONVS),), device=self.device, dtype=torch.int32)
+        prev = None                      # slot holding the bound for the current x, if any
+        for li, item in enumerate(VGG16_CONVS):
             if item[0] == 'pool':
                 x = ops.maxpool2x2_nhwc(x, 2)
             elif item[0] == 'pool4':
@@ -290,11 +294,18 @@ class WsddnEngine(object):
                 wp, b, _w = self.conv[name]
                 if name == 'conv1_1':
                     x = ops.conv3x3_c3_nchw_to_nhwc(data, wp, b, True)
+                    prev = None
                 else:
                     d = dil if dil is not None else (2 if self.dilation == 2 else 1)
+                    dst = out if name == last else None
                     if isinstance(wp, ops.F16x2):
-                        conv = ops.conv3x3_winograd_nhwc_f16x2
-                    elif wp.dtype == torch.bfloat16:
+                        x = ops.conv3x3_winograd_nhwc_f16x2(
+                            x, wp, b, d, True, out=dst,
+                            amax_in=None if prev is None else amax[prev:prev + 1],
+                            amax_out=amax[li:li + 1])
+                        prev = li
+                        continue
+                    if wp.dtype == torch.bfloat16:
                         conv = (ops.conv3x3_winograd_nhwc_f32x3 if self.conv_wino[name]
                                 else ops.conv3x3_nhwc_f32x3)
                     elif self.mfma_dtype == 'bf16':
@@ -302,7 +313,8 @@ class WsddnEngine(object):
                     else:
                         conv = (ops.conv3x3_winograd_nhwc if self.conv_wino[name]
                                 else ops.conv3x3_nhwc)
-                    x = conv(x, wp, b, d, True, out=out if name == last else None)
+                    x = conv(x, wp, b, d, True, out=dst)
+                    prev = None
         return x
 
     def conv_body(self, data):

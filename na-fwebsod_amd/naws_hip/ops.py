@@ -311,9 +311,12 @@ def conv3x3_winograd_nhwc_f32x3(x, u3, bias, dilation=1, relu=True, out=None):
     return y
 
 
-def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None):
+def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None, amax_in=None,
+                                amax_out=None):
     """Winograd F(2x2,3x3) with fp16x2 GEMMs; u2 = split_f16x2(winograd_weight_transform(w))
-    (F16x2: planes [2, 16, Cin/16, Cout, 16], scales [2, 16, Cout])."""
+    (F16x2: planes [2, 16, Cin/16, Cout, 16], scales [2, 16, Cout]).  amax_in / amax_out: optional
+    one-element int32 tensors (bit pattern of an upper bound of max|x| / receives max|y|, zeroed
+    by the caller)."""
     _chk(x, 'x')
     n, h, w, cin = x.shape
     cout = u2.planes.shape[-2]
@@ -324,7 +327,7 @@ def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None):
     ws = torch.empty((nws,), device=x.device, dtype=_f32)
     L.call('naws_conv3x3_winograd_nhwc_f16x2_fwd', x.data_ptr(), u2.planes.data_ptr(),
            u2.inv_scale.data_ptr(), _ptr(bias), n, h, w, cin, cout, dilation, int(relu),
-           ws.data_ptr(), y.data_ptr(), _stream())
+           ws.data_ptr(), y.data_ptr(), _ptr(amax_in), _ptr(amax_out), _stream())
     return y
 
 

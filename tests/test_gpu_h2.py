@@ -231,3 +231,14 @@ def test_conv3x3_winograd_f16x2(dev, cin, cout, dil, h, w, amp):
     assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 1e-5 * np.abs(r2).max()
     y0 = ops.conv3x3_winograd_nhwc_f16x2(torch.zeros_like(xd), ops.split_f16x2(u), None, dil, False)
     assert not y0.any()
+    # operand-scale bound handed over instead of measured: exact max -> identical result and the
+    # layer reports max|y|; a bound 3x too high (as after a max-pool) -> same accuracy class
+    am = torch.zeros((2,), device=dev, dtype=torch.int32)
+    am[0] = int(np.float32(np.abs(x).max()).view(np.int32))
+    y3 = ops.conv3x3_winograd_nhwc_f16x2(xd, ops.split_f16x2(u), _t(b, dev), dil, True,
+                                         amax_in=am[0:1], amax_out=am[1:2])
+    assert np.array_equal(ops.nhwc_to_nchw(y3).cpu().numpy(), y)
+    assert np.int32(am[1].item()).view(np.float32) == np.float32(y.max())
+    am[0] = int(np.float32(3.0 * np.abs(x).max()).view(np.int32))
+    y4 = ops.conv3x3_winograd_nhwc_f16x2(xd, ops.split_f16x2(u), _t(b, dev), dil, True, amax_in=am[0:1])
+    assert np.abs(ops.nhwc_to_nchw(y4).cpu().numpy() - ref).max() < 1e-5 * scale
