@@ -352,8 +352,7 @@ int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA, i
  * viewed as batch 16 of [Cout][Cin] (scaleU = its scales[1], [16][Cout]).  Cin % 32 == 0.
  * amax_in (nullable): device word holding the bit pattern of an upper bound of max|X| (e.g. the
  * amax_out of the layer that produced X, also valid across a max-pool); null = measured here.
- * amax_out (nullable): device word, atomically maxed with the bit pattern of max|Y|; the caller
- * zeroes it before the launch. */
+ * amax_out (nullable, != amax_in): device word that receives the bit pattern of max|Y|. */
 int64_t naws_winograd_f16x2_workspace_floats(int N, int H, int W, int Cin, int Cout, int dilation);
 int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const float* scaleU,
                                          const float* bias, int N, int H, int W, int Cin, int Cout,

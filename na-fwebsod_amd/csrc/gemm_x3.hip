@@ -1028,6 +1028,9 @@ extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64
     g_h2_variant = e ? atoi(e) : 0;
   }
   if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+  // fewer 256x256 tiles than CUs (the column remainder of a wgrad split into whole waves)
+  if (naws_cdiv(M, 256) * naws_cdiv(N, 256) * batch < 256 && g_h2_variant != 5)
+    return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
   // short K (the Winograd batch GEMMs): two 4-wave workgroups per CU overlap one's prologue /
   // epilogue with the other's K loop
   if (K <= 1024 && g_h2_variant != 5) {

@@ -141,7 +141,10 @@ __device__ __forceinline__ void put_h2(float4 v, float sc, unsigned short* __res
 __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float* __restrict__ X, WinoGeom g,
                                                             int Cin, const unsigned* __restrict__ amax,
                                                             float* __restrict__ inv_scale,
-                                                            unsigned short* __restrict__ Vp) {
+                                                            unsigned short* __restrict__ Vp,
+                                                            unsigned* __restrict__ amax_out) {
+  // this layer's output maximum is accumulated by wino_output_kernel, stream-ordered after this
+  if (amax_out && blockIdx.x == 0 && threadIdx.x == 0) *amax_out = 0u;
   int e = (int)((*amax >> 23) & 0xff);
   if (*amax == 0 || e == 0xff) e = 127 + 12;
   e = min(max(e, 40), 250);
@@ -437,7 +440,7 @@ extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* 
     }
     const long long total = g.P * (Cin / 4);
     hipLaunchKernelGGL(wino_input_h2_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, X, g, Cin, amax, invA, Vp);
+                       dim3(256), 0, s, X, g, Cin, amax, invA, Vp, (unsigned*)amax_out);
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
   }

@@ -282,7 +282,7 @@ class WsddnEngine(object):
         last = VGG16_CONVS[-1][0]
         # fp16x2 Winograd layers hand max|y| to the next layer (its operand scale needs an upper
         # bound of max|x|; a max-pool in between only lowers it), saving that layer's own pass
-        amax = torch.zeros((len(VGG16_CONVS),), device=self.device, dtype=torch.int32)
+        amax = torch.empty((len(VGG16_CONVS),), device=self.device, dtype=torch.int32)
         prev = None                      # slot holding the bound for the current x, if any
         for li, item in enumerate(VGG16_CONVS):
             if item[0] == 'pool':
@@ -561,7 +561,15 @@ class WsddnEngine(object):
             xt = ops.to_bf16_slab(x, transpose=True)           # [Rt/16, 25088, 16]
         for r0, r1 in row_chunks(2 * HIDDEN, self.allreduce_chunks if red.active else 1):
             if h2:
-                ops.gemm_f32_f16x2_nt(dz6t.rows(r0, r1), xt, out=gw6[r0:r1])
+                # 25088 = 98 column tiles of 256: 32 x 98 = 12.25 waves of 256 CUs.  96 column
+                # tiles make 12 full waves; the last 512 columns go out as one wave of 128x128 tiles
+                ncut = self._wgrad_column_cut(r1 - r0)
+                if ncut:
+                    ops.gemm_f32_f16x2_nt(dz6t.rows(r0, r1), xt.rows(0, ncut), out=gw6[r0:r1, :ncut])
+                    ops.gemm_f32_f16x2_nt(dz6t.rows(r0, r1), xt.rows(ncut, self.k6),
+                                          out=gw6[r0:r1, ncut:])
+                else:
+                    ops.gemm_f32_f16x2_nt(dz6t.rows(r0, r1), xt, out=gw6[r0:r1])
             elif x3:
                 ops.gemm_f32x3_nt(dz6t[:, :, r0:r1], xt, out=gw6[r0:r1])
             elif bf:
@@ -593,6 +601,17 @@ class WsddnEngine(object):
             ops.gemm(dlv, h7v, True, False, out=gw8)
             ops.colsum(dl, out=gb8)
         red.reduce_async(self.arena.span(G, 'fc6_b', 'noisy_fc8d_b'))
+
+    def _wgrad_column_cut(self, rows, cus=256):
+        """fc6 wgrad tile quantisation: with 256x256 tiles the [rows, k6] output is tm x tn tiles;
+        if the last partial wave of `cus` tiles is less than half full, return the column where
+        to cut so that the first launch is whole waves (the rest runs as small tiles), else 0."""
+        tm, tn = (rows + 255) // 256, (self.k6 + 255) // 256
+        tail = (tm * tn) % cus
+        if tail == 0 or tail * 2 > cus or tail % tm != 0:
+            return 0
+        ncut = (tn - tail // tm) * 256
+        return ncut if 0 < ncut < self.k6 else 0
 
     def wait_allreduce(self):
         self.reducer.wait()

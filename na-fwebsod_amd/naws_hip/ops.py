@@ -315,8 +315,7 @@ def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None, am
                                 amax_out=None):
     """Winograd F(2x2,3x3) with fp16x2 GEMMs; u2 = split_f16x2(winograd_weight_transform(w))
     (F16x2: planes [2, 16, Cin/16, Cout, 16], scales [2, 16, Cout]).  amax_in / amax_out: optional
-    one-element int32 tensors (bit pattern of an upper bound of max|x| / receives max|y|, zeroed
-    by the caller)."""
+    one-element int32 tensors (bit pattern of an upper bound of max|x| / receives that of max|y|)."""
     _chk(x, 'x')
     n, h, w, cin = x.shape
     cout = u2.planes.shape[-2]
