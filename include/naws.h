@@ -358,6 +358,21 @@ int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const f
                                          const float* bias, int N, int H, int W, int Cin, int Cout,
                                          int dilation, int relu, float* workspace, float* Y,
                                          const uint32_t* amax_in, uint32_t* amax_out, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution of the shallow VGG layers (conv1_2 .. conv2_2; reference
+ * detectron/modeling/VGG16.py:12-22) in the 2 x f16 split: as naws_conv3x3_nhwc_f32x3_fwd's
+ * halo-tile kernel with 3 MFMA terms.  W2 / scaleW: naws_split_f16x2 of the packed weight
+ * (naws_conv3x3_pack_weight) viewed [Cout][9*Cin].  The activations are scaled by the power of
+ * two derived from the bound (*amax_in) * in_mul + in_add >= max|X| (amax_in: bit pattern of a
+ * float on the device, e.g. the amax_out of the producing layer with in_mul = 1, in_add = 0, or
+ * naws_amax_f32 of the network input with the producing layer's weight L1 norm / bias maximum).
+ * amax_out (nullable, != amax_in) receives the bit pattern of max|Y|.
+ * Cin % 16 == 0, Cout % 32 == 0, Cout <= 128. */
+int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,
+                                const float* bias, int N, int H, int W, int Cin, int Cout, int relu,
+                                float* Y, const uint32_t* amax_in, float in_mul, float in_add,
+                                uint32_t* amax_out, void* stream);
+/* out[0] = bit pattern of max|X[0..n)| (non-negative floats order like unsigned words). */
+int naws_amax_f32(const float* X, int64_t n, uint32_t* out, void* stream);
 /* bf16 plan on the same pipeline: one plane (operands rounded to bf16), 64-deep K-steps.
  * naws_to_bf16_slab: as naws_split_bf16x3 with a single plane, P[batch][kpad/16][outer][16],
  * kpad = K rounded up to 64.  naws_gemm_bf16_slab_nt: C (+)= A B^T on such operands, K % 64 == 0;

@@ -490,6 +490,11 @@ struct CArgs {
   long long planeB, slabB;
   unsigned bytesX;
   int tiles_m, tiles_n;
+  // fp16x2 form of the halo kernel
+  const float* scaleB;       // 1/scale per output channel (naws_split_f16x2 of the weight)
+  const unsigned* amax_in;   // bit pattern of an upper bound b of max|X| ...
+  float in_mul, in_add;      // ... the bound used is b * in_mul + in_add
+  unsigned* amax_out;        // receives the bit pattern of max|Y| (nullable)
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -677,18 +682,24 @@ int launch_conv_x3(CArgs& g, hipStream_t s) {
 // rows - a wave's 32-lane fragment is one image row of the tile, so a tap is just a row offset
 // (dy * 34 + dx) into the halo image.  Same LDS row format and bank swizzle as everywhere else;
 // weights per (tap, slab) by LDS-DMA, double buffered.  dilation 1, stride 1.
-template <int BN>
+// F16: the fp16x2 form - activations scaled by one power of two per tensor (from an upper bound
+// of max|X| handed in by the producer of X), split into f16 hi / lo planes in registers; weight
+// planes from naws_split_f16x2 (per-output-channel scales); 3 MFMA terms instead of 6; the
+// accumulator is un-scaled in the epilogue, which also reports max|Y| for the next layer.
+template <int BN, bool F16 = false>
 __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(CArgs g) {
+  constexpr int NPL = F16 ? 2 : 3;
+  typedef typename OperandVec<F16>::type vec_t;
   // BN = 64: one halo stage (refilled behind an extra barrier every 9th step) keeps the
   // workgroup at 45 KB of LDS, so three of them share a CU; BN = 128: two halo stages
   constexpr int ASTAGES = BN <= 64 ? 1 : 2;
   constexpr int TH = 8, TW = 32, HWD = TW + 2, HPIX = (TH + 2) * HWD;     // 340 halo pixels
   constexpr int A_ROWS = (HPIX + 7) / 8 * 8;
-  constexpr int A_PLANE = A_ROWS * 32, A_STAGE = 3 * A_PLANE;
-  constexpr int B_PLANE = BN * 32, B_STAGE = 3 * B_PLANE;
+  constexpr int A_PLANE = A_ROWS * 32, A_STAGE = NPL * A_PLANE;
+  constexpr int B_PLANE = BN * 32, B_STAGE = NPL * B_PLANE;
   constexpr int TJ = BN / 32, TI = 2;
   constexpr int UR = (HPIX * 2 + 255) / 256;                                // staging rounds (3)
-  constexpr int BPIECES = 3 * BN / 32;
+  constexpr int BPIECES = NPL * BN / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
   unsigned char* smA = smx;
   unsigned char* smB = smx + ASTAGES * A_STAGE;
@@ -708,6 +719,11 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
   const __amdgpu_buffer_rsrc_t rsX =
       __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
+  float scA = 1.f, iscA = 1.f;
+  if constexpr (F16) {
+    const float bound = __uint_as_float(*g.amax_in) * g.in_mul + g.in_add;
+    f16x2_scales(__float_as_uint(bound), scA, iscA);
+  }
 
   unsigned abase[UR];
   int awr[UR];
@@ -738,9 +754,21 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
       const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
                              ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+      for (int e = 0; e < 8; ++e) {
+        if constexpr (F16) {
+          const float t = __uint_as_float(w[e]) * scA;
+          const _Float16 hi = (_Float16)t;
+          float rr = t - (float)hi;
+          if (!(fabsf(t) <= 65504.f)) rr = 0.f;
+          const _Float16 lo = (_Float16)rr;
+          q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+          q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+        } else {
+          split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+        }
+      }
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) {
         u32x4 v;
         v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
         v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
@@ -790,29 +818,31 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
     const unsigned char* sa = smA + (slab & (ASTAGES - 1)) * A_STAGE;
     const unsigned char* sb = smB + (kk & 1) * B_STAGE;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    bf16x8 a[3][TI], b[3][TJ];
+    vec_t a[NPL][TI], b[NPL][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int hp = (2 * wid + i + 1 + dy) * HWD + (l31 + 1 + dx);
       const int off = hp * 32 + ((h ^ ((hp >> 3) & 1)) * 16);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        a[pl][i] = *reinterpret_cast<const bf16x8*>(sa + pl * A_PLANE + off);
+      for (int pl = 0; pl < NPL; ++pl)
+        a[pl][i] = *reinterpret_cast<const vec_t*>(sa + pl * A_PLANE + off);
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
-        b[pl][j] = *reinterpret_cast<const bf16x8*>(sb + pl * B_PLANE + rd_b + j * 1024);
+        b[pl][j] = *reinterpret_cast<const vec_t*>(sb + pl * B_PLANE + rd_b + j * 1024);
 #define NAWS_X3_TERM(P, Q)                                                                      \
   _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][i], b[Q][j], acc[i][j], 0, 0, 0);
+      acc[i][j] = mfma16(a[P][i], b[Q][j], acc[i][j]);
     NAWS_X3_TERM(0, 0)
     NAWS_X3_TERM(0, 1)
     NAWS_X3_TERM(1, 0)
-    NAWS_X3_TERM(1, 1)
-    NAWS_X3_TERM(0, 2)
-    NAWS_X3_TERM(2, 0)
+    if constexpr (!F16) {
+      NAWS_X3_TERM(1, 1)
+      NAWS_X3_TERM(0, 2)
+      NAWS_X3_TERM(2, 0)
+    }
 #undef NAWS_X3_TERM
     if (tap == 8 && slab + 1 < S) {
       if (ASTAGES == 1) __syncthreads();   // every wave is done with the only halo stage
@@ -820,11 +850,14 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
     }
   }
 
+  float vmax = 0.f;
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int col = n0 + j * 32 + l31;
     if (col >= g.Cout) continue;
     const float bv = g.bias ? g.bias[col] : 0.f;
+    float un = 1.f;
+    if constexpr (F16) un = iscA * g.scaleB[col];        // powers of two: exact
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int y = ty0 + 2 * wid + i;
@@ -832,22 +865,41 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
       for (int e = 0; e < 16; ++e) {
         const int x = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (y >= g.H || x >= g.W) continue;
-        float v = acc[i][j][e] + bv;
+        float v = acc[i][j][e];
+        if constexpr (F16) v *= un;
+        v += bv;
         if (g.relu) v = fmaxf(v, 0.f);
         g.Y[((long long)(img * g.H + y) * g.W + x) * g.Cout + col] = v;
+        if constexpr (F16) vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  }
+  if constexpr (F16) {
+    if (g.amax_out) {
+      float* red = reinterpret_cast<float*>(smx);     // the operand stages are no longer read
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+      __syncthreads();
+      if (lane == 0) red[wid] = vmax;
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        if (v > __hip_atomic_load(g.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicMax(g.amax_out, v);
       }
     }
   }
 }
 
-template <int BN>
+template <int BN, bool F16 = false>
 int launch_conv_x3_halo(CArgs& g, int N, hipStream_t s) {
   g.tiles_n = (int)naws_cdiv(g.Cout, BN);
   const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
   if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
   constexpr int A_ROWS = (10 * 34 + 7) / 8 * 8;
-  const size_t lds = (size_t)(BN <= 64 ? 1 : 2) * 3 * A_ROWS * 32 + (size_t)2 * 3 * BN * 32;
-  auto kern = conv_x3_halo_kernel<BN>;
+  constexpr int NPL = F16 ? 2 : 3;
+  const size_t lds = (size_t)(BN <= 64 ? 1 : 2) * NPL * A_ROWS * 32 + (size_t)2 * NPL * BN * 32;
+  auto kern = conv_x3_halo_kernel<BN, F16>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1079,6 +1131,78 @@ extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const
     return launch_conv_x3<256, 128, 2, 2>(g, s);
   }
   return launch_conv_x3<256, 256, 2, 4>(g, s);
+}
+
+// |x| maximum of a tensor, as a bit pattern (non-negative floats order like unsigned words).
+namespace {
+__global__ __launch_bounds__(256) void amax_word_kernel(const float* __restrict__ X, long long n,
+                                                        unsigned* __restrict__ out) {
+  float m = 0.f;
+  // scalar head up to the first 16-byte boundary, float4 body, scalar tail
+  const long long head = min((long long)(((16 - ((uintptr_t)X & 15)) & 15) / 4), n);
+  const long long n4 = (n - head) / 4;
+  const float* Xb = X + head;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(Xb)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < head) m = fmaxf(m, fabsf(X[threadIdx.x]));
+    const long long t0 = head + n4 * 4;
+    if (t0 + threadIdx.x < n && threadIdx.x < 4) m = fmaxf(m, fabsf(X[t0 + threadIdx.x]));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (v > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, v);
+  }
+}
+}  // namespace
+
+extern "C" int naws_amax_f32(const float* X, int64_t n, uint32_t* out, void* stream) {
+  if (n <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(out);
+  if (((uintptr_t)X & 3) != 0) return NAWS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(uint32_t), s) != hipSuccess) return NAWS_ERR_LAUNCH;
+  hipLaunchKernelGGL(amax_word_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(n / 4 + 1, 256 * 8), 2048)),
+                     dim3(256), 0, s, X, (long long)n, (unsigned*)out);
+  return naws_check_launch();
+}
+
+// fp16x2 form of the shallow-layer convolution (the halo-tile kernel): W2 / scaleW =
+// naws_split_f16x2 of the packed weight viewed [Cout][9*Cin]; the activation scale comes from
+// *amax_in * in_mul + in_add (an upper bound of max|X|); dilation 1, Cout <= 128, Cout % 32 == 0.
+extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,
+                                           const float* bias, int N, int H, int W, int Cin,
+                                           int Cout, int relu, float* Y, const uint32_t* amax_in,
+                                           float in_mul, float in_add, uint32_t* amax_out,
+                                           void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (Cin % 16 != 0 || (9 * Cin) % 32 != 0 || Cout % 32 != 0 || Cout > 128) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W2); NAWS_REQUIRE_PTR(scaleW); NAWS_REQUIRE_PTR(Y);
+  NAWS_REQUIRE_PTR(amax_in);
+  if (!bias && relu) return NAWS_ERR_ARG;
+  if (!(in_mul > 0.f) || !(in_add >= 0.f) || amax_in == amax_out) return NAWS_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)W2) & 15) != 0) return NAWS_ERR_ARG;
+  const long long pix = (long long)N * H * W;
+  if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
+  CArgs g{};
+  g.X = X; g.B = (const unsigned short*)W2; g.bias = bias; g.Y = Y;
+  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = 1; g.relu = relu;
+  g.slabB = (long long)Cout * 16;
+  g.planeB = (long long)9 * Cin * Cout;
+  g.bytesX = (unsigned)(pix * Cin * 4);
+  g.scaleB = scaleW; g.amax_in = (const unsigned*)amax_in; g.in_mul = in_mul; g.in_add = in_add;
+  g.amax_out = (unsigned*)amax_out;
+  hipStream_t s = (hipStream_t)stream;
+  if (amax_out && hipMemsetAsync(amax_out, 0, sizeof(uint32_t), s) != hipSuccess) return NAWS_ERR_LAUNCH;
+  if (Cout <= 64) return launch_conv_x3_halo<64, true>(g, N, s);
+  return launch_conv_x3_halo<128, true>(g, N, s);
 }
 
 extern "C" int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_t slabA,

@@ -185,6 +185,8 @@ class WsddnEngine(object):
         # fp16x2: the Winograd layers' 16 batched GEMMs on the f16 MFMA, operand planes written
         # by the input transform itself (csrc/winograd.hip, naws_conv3x3_winograd_nhwc_f16x2_fwd)
         self.wino_h2 = True
+        # fp16x2: conv1_2..conv2_2 (the halo-tile kernel) in the 2 x f16 split as well
+        self.conv_h2 = True
         self.conv_wino = {}
         self._streams = []
         # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
@@ -235,7 +237,7 @@ class WsddnEngine(object):
         for item in VGG16_CONVS:
             if item[0].startswith('pool'):
                 continue
-            name = item[0]
+            name, dil = item[0], item[3]
             w = blobs[name + '_w'].to(self.device, torch.float32).contiguous()
             b = blobs[name + '_b'].to(self.device, torch.float32).contiguous()
             use_wino = (self.winograd and self.mfma_dtype != 'bf16' and
@@ -245,6 +247,14 @@ class WsddnEngine(object):
             use_wino = use_wino and not x3conv
             if name == 'conv1_1':
                 packed = w
+                # |conv1_1(x)| <= max|x| * max_c sum|w_c| + max|b|: the operand-scale bound of
+                # the layer that consumes it, without a pass over its 154 MB output
+                self._c11_bound = (float(w.abs().sum(dim=(1, 2, 3)).max().item()),
+                                   float(b.abs().max().item()))
+            elif (x3conv and self.mfma_dtype == 'fp16x2' and self.conv_h2 and dil in (None, 1)
+                  and w.shape[0] <= 128 and w.shape[0] % 32 == 0 and w.shape[1] % 16 == 0):
+                # f16 hi / lo planes [2][9*Cin/16][Cout][16] + per-channel scales
+                packed = ops.split_f16x2(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
             elif x3conv:
                 # weight planes [3][9*Cin/16][Cout][16] of the packed [Cout][3][3][Cin] weight
                 packed = ops.split_bf16x3(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
@@ -283,7 +293,7 @@ class WsddnEngine(object):
         # fp16x2 Winograd layers hand max|y| to the next layer (its operand scale needs an upper
         # bound of max|x|; a max-pool in between only lowers it), saving that layer's own pass
         amax = torch.empty((len(VGG16_CONVS),), device=self.device, dtype=torch.int32)
-        prev = None                      # slot holding the bound for the current x, if any
+        prev, affine = None, (1.0, 0.0)  # slot holding the bound for the current x, if any
         for li, item in enumerate(VGG16_CONVS):
             if item[0] == 'pool':
                 x = ops.maxpool2x2_nhwc(x, 2)
@@ -295,9 +305,20 @@ class WsddnEngine(object):
                 if name == 'conv1_1':
                     x = ops.conv3x3_c3_nchw_to_nhwc(data, wp, b, True)
                     prev = None
+                    if self.mfma_dtype == 'fp16x2' and self.conv_h2:
+                        ops.amax_word(data, out=amax[li:li + 1])     # 7 MB: the network input
+                        prev, affine = li, self._c11_bound
                 else:
                     d = dil if dil is not None else (2 if self.dilation == 2 else 1)
                     dst = out if name == last else None
+                    if isinstance(wp, ops.F16x2) and wp.planes.dim() == 4:
+                        mul, add = affine if prev == 0 else (1.0, 0.0)
+                        x = ops.conv3x3_nhwc_f16x2(
+                            x, wp, b, True, out=dst,
+                            amax_in=None if prev is None else amax[prev:prev + 1],
+                            in_mul=mul, in_add=add, amax_out=amax[li:li + 1])
+                        prev = li
+                        continue
                     if isinstance(wp, ops.F16x2):
                         x = ops.conv3x3_winograd_nhwc_f16x2(
                             x, wp, b, d, True, out=dst,

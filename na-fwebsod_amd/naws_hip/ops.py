@@ -311,6 +311,33 @@ def conv3x3_winograd_nhwc_f32x3(x, u3, bias, dilation=1, relu=True, out=None):
     return y
 
 
+def amax_word(x, out=None):
+    """Bit pattern (int32 [1]) of max|x| over a contiguous fp32 tensor."""
+    _chk(x, 'x')
+    o = out if out is not None else torch.empty((1,), device=x.device, dtype=torch.int32)
+    L.call('naws_amax_f32', x.data_ptr(), x.numel(), o.data_ptr(), _stream())
+    return o
+
+
+def conv3x3_nhwc_f16x2(x, w2, bias, relu=True, out=None, amax_in=None, in_mul=1.0, in_add=0.0,
+                       amax_out=None):
+    """3x3 / pad 1 conv (shallow layers) with w2 = split_f16x2(packed weight viewed
+    [Cout, 9*Cin]); amax_in: int32 [1] bit pattern of a bound b, max|x| <= b * in_mul + in_add
+    (measured here when None); amax_out: int32 [1] receiving the bit pattern of max|y|."""
+    _chk(x, 'x')
+    n, h, w, cin = x.shape
+    cout = w2.planes.shape[-2]
+    if w2.planes.dtype != torch.float16 or tuple(w2.planes.shape[:2]) != (2, 9 * cin // 16):
+        raise TypeError('w2 must hold the f16 planes [2, 9*Cin/16, Cout, 16] of the packed weight')
+    if amax_in is None:
+        amax_in, in_mul, in_add = amax_word(x), 1.0, 0.0
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    L.call('naws_conv3x3_nhwc_f16x2_fwd', x.data_ptr(), w2.planes.data_ptr(),
+           w2.inv_scale.data_ptr(), _ptr(bias), n, h, w, cin, cout, int(relu), y.data_ptr(),
+           amax_in.data_ptr(), float(in_mul), float(in_add), _ptr(amax_out), _stream())
+    return y
+
+
 def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None, amax_in=None,
                                 amax_out=None):
     """Winograd F(2x2,3x3) with fp16x2 GEMMs; u2 = split_f16x2(winograd_weight_transform(w))

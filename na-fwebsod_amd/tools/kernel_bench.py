@@ -86,8 +86,14 @@ def main():
             ms = timeit(lambda: ops.conv3x3_nhwc_f32x3(xx, w3, b, dil, True, out=y), a.iters)
             fl = 2.0 * a.images * h * w * cout * 9 * cin
             tot += ms * mult
-            print('x3 conv %3d->%3d %4dx%4d d%d  %8.3f ms  %7.1f TFLOP/s fp32-equivalent' % (
-                cin, cout, h, w, dil, ms, fl / ms / 1e9))
+            extra = ''
+            if dil == 1 and cout <= 128:
+                w2 = ops.split_f16x2(torch.empty((cout, 9 * cin), device=dev).uniform_(-1, 1))
+                am = ops.amax_word(xx)
+                msh = timeit(lambda: ops.conv3x3_nhwc_f16x2(xx, w2, b, True, out=y, amax_in=am), a.iters)
+                extra = '   fp16x2 halo: %8.3f ms %7.1f TFLOP/s' % (msh, fl / msh / 1e9)
+            print('x3 conv %3d->%3d %4dx%4d d%d  %8.3f ms  %7.1f TFLOP/s fp32-equivalent%s' % (
+                cin, cout, h, w, dil, ms, fl / ms / 1e9, extra))
             del xx, w3, b, y
         print('x3 conv stack conv1_2..conv5_3 (%d images, one launch per layer): %.3f ms' % (a.images, tot))
         x = rnd(R, 25088)

@@ -242,3 +242,52 @@ def test_conv3x3_winograd_f16x2(dev, cin, cout, dil, h, w, amp):
     am[0] = int(np.float32(3.0 * np.abs(x).max()).view(np.int32))
     y4 = ops.conv3x3_winograd_nhwc_f16x2(xd, ops.split_f16x2(u), _t(b, dev), dil, True, amax_in=am[0:1])
     assert np.abs(ops.nhwc_to_nchw(y4).cpu().numpy() - ref).max() < 1e-5 * scale
+
+
+def test_amax_word(dev):
+    from naws_hip import ops
+    rng = np.random.default_rng(49)
+    for n, off in ((1, 0), (3, 1), (1000, 0), (4099, 3), (772212, 1), (5_000_001, 2)):
+        x = rng.standard_normal(n + off).astype(np.float32)
+        x[rng.integers(off, n + off)] = -37.5 if n > 2 else x[off]
+        xd = _t(x, dev)[off:]
+        got = np.int32(ops.amax_word(xd).item()).view(np.float32)
+        assert got == np.abs(x[off:]).max(), (n, off)
+
+
+@pytest.mark.parametrize('cin,cout,h,w,amp', [(64, 64, 37, 53, 1.0), (64, 128, 40, 60, 50.0),
+                                              (128, 128, 8, 32, 1e-2), (128, 128, 67, 97, 1.0)])
+def test_conv3x3_f16x2_halo(dev, cin, cout, h, w, amp):
+    """The shallow-layer convolution in the 2 x f16 split, held to the tolerance of the fp32-MFMA
+    convolution (tests/test_gpu_ops.py) and to the 3 x bf16 form's error; bound handed in exactly,
+    loosely (x 37 + 5, as from a weight-norm bound) or measured by the op itself."""
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(50)
+    n = 2
+    x = (np.maximum(rng.standard_normal((n, cin, h, w)), 0) * amp).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    wt[3] *= 1e-3                                  # per-output-channel weight scales differ
+    b = (rng.uniform(-0.5, 0.5, cout) * amp).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=1)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    wp = ops.conv3x3_pack_weight(_t(wt, dev))
+    w2 = ops.split_f16x2(wp.view(cout, 9 * cin))
+    w3 = ops.split_bf16x3(wp.view(cout, 9 * cin))
+    y3 = ops.nhwc_to_nchw(ops.conv3x3_nhwc_f32x3(xd, w3, _t(b, dev), 1, True)).cpu().numpy()
+    scale = max(amp, np.abs(ref).max())
+    am = torch.zeros((2,), device=dev, dtype=torch.int32)
+    ops.amax_word(xd, out=am[0:1])
+    outs = [ops.conv3x3_nhwc_f16x2(xd, w2, _t(b, dev), True),
+            ops.conv3x3_nhwc_f16x2(xd, w2, _t(b, dev), True, amax_in=am[0:1], amax_out=am[1:2]),
+            ops.conv3x3_nhwc_f16x2(xd, w2, _t(b, dev), True, amax_in=am[0:1], in_mul=37.0, in_add=5.0)]
+    ys = [ops.nhwc_to_nchw(o).cpu().numpy() for o in outs]
+    assert np.array_equal(ys[0], ys[1])
+    assert np.int32(am[1].item()).view(np.float32) == np.float32(ys[1].max())
+    for y in ys:
+        assert np.abs(y - ref).max() < 1e-5 * scale
+        assert np.abs(y - ref).max() <= 2.0 * np.abs(y3 - ref).max() + 1e-6 * scale
+    y2 = ops.conv3x3_nhwc_f16x2(xd, w2, None, False)          # no bias / no ReLU
+    r2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, padding=1).numpy()
+    assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 1e-5 * scale
