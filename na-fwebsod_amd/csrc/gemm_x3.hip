@@ -1183,7 +1183,8 @@ extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const
                                            float in_mul, float in_add, uint32_t* amax_out,
                                            void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
-  if (Cin % 16 != 0 || (9 * Cin) % 32 != 0 || Cout % 32 != 0 || Cout > 128) return NAWS_ERR_UNSUPPORTED;
+  if (Cin % 16 != 0 || (9 * Cin) % 32 != 0 || Cout % 32 != 0 || (Cout > 128 && Cout % 128 != 0))
+    return NAWS_ERR_UNSUPPORTED;
   NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W2); NAWS_REQUIRE_PTR(scaleW); NAWS_REQUIRE_PTR(Y);
   NAWS_REQUIRE_PTR(amax_in);
   if (!bias && relu) return NAWS_ERR_ARG;

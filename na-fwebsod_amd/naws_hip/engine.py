@@ -188,6 +188,7 @@ class WsddnEngine(object):
         # fp16x2: conv1_2..conv2_2 (the halo-tile kernel) in the 2 x f16 split as well
         self.conv_h2 = True
         self.conv_wino = {}
+        self.conv_direct_h2 = {}
         self._streams = []
         # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
         # parameters: the all-reduce wait and the SGD kernel run on a side stream underneath
@@ -251,7 +252,7 @@ class WsddnEngine(object):
                 # the layer that consumes it, without a pass over its 154 MB output
                 self._c11_bound = (float(w.abs().sum(dim=(1, 2, 3)).max().item()),
                                    float(b.abs().max().item()))
-            elif (x3conv and self.mfma_dtype == 'fp16x2' and self.conv_h2 and dil in (None, 1)
+            elif (x3conv and self.mfma_dtype == 'fp16x2' and self.conv_h2 and dil == 1
                   and w.shape[0] <= 128 and w.shape[0] % 32 == 0 and w.shape[1] % 16 == 0):
                 # f16 hi / lo planes [2][9*Cin/16][Cout][16] + per-channel scales
                 packed = ops.split_f16x2(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
@@ -262,6 +263,10 @@ class WsddnEngine(object):
                 packed = ops.winograd_weight_transform(w)      # [16][Cout][Cin]
                 if self.mfma_dtype == 'fp16x2' and self.wino_h2:
                     packed = ops.split_f16x2(packed)           # F16x2, planes [2][16][Cin/16][Cout][16]
+                    if self.conv_h2 and dil == 1 and w.shape[0] % 128 == 0:
+                        # also the direct form: chosen per input size in _conv_chain
+                        self.conv_direct_h2[name] = ops.split_f16x2(
+                            ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
                 elif self.mfma_dtype in ('fp32x3', 'fp16x2') and self.wino_x3:
                     packed = ops.split_bf16x3(packed)          # planes [3][16][Cin/16][Cout][16]
             else:
@@ -311,6 +316,13 @@ class WsddnEngine(object):
                 else:
                     d = dil if dil is not None else (2 if self.dilation == 2 else 1)
                     dst = out if name == last else None
+                    wd = self.conv_direct_h2.get(name)
+                    if wd is not None and d == 1:
+                        # direct 2 x f16 halo-tile kernel where it fills the chip (>= one 8x32-pixel
+                        # x 128-channel tile per CU: conv3_x at 600x1000), Winograd below that
+                        tiles = x.shape[0] * ((x.shape[1] + 7) // 8) * ((x.shape[2] + 31) // 32)
+                        if tiles * (wd.planes.shape[-2] // 128) >= 256:
+                            wp = wd
                     if isinstance(wp, ops.F16x2) and wp.planes.dim() == 4:
                         mul, add = affine if prev == 0 else (1.0, 0.0)
                         x = ops.conv3x3_nhwc_f16x2(

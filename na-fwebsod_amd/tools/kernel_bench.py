@@ -87,7 +87,7 @@ def main():
             fl = 2.0 * a.images * h * w * cout * 9 * cin
             tot += ms * mult
             extra = ''
-            if dil == 1 and cout <= 128:
+            if dil == 1:
                 w2 = ops.split_f16x2(torch.empty((cout, 9 * cin), device=dev).uniform_(-1, 1))
                 am = ops.amax_word(xx)
                 msh = timeit(lambda: ops.conv3x3_nhwc_f16x2(xx, w2, b, True, out=y, amax_in=am), a.iters)

@@ -256,7 +256,8 @@ def test_amax_word(dev):
 
 
 @pytest.mark.parametrize('cin,cout,h,w,amp', [(64, 64, 37, 53, 1.0), (64, 128, 40, 60, 50.0),
-                                              (128, 128, 8, 32, 1e-2), (128, 128, 67, 97, 1.0)])
+                                              (128, 128, 8, 32, 1e-2), (128, 128, 67, 97, 1.0),
+                                              (128, 256, 19, 23, 1.0), (256, 512, 33, 41, 1.0)])
 def test_conv3x3_f16x2_halo(dev, cin, cout, h, w, amp):
     """The shallow-layer convolution in the 2 x f16 split, held to the tolerance of the fp32-MFMA
     convolution (tests/test_gpu_ops.py) and to the 3 x bf16 form's error; bound handed in exactly,
