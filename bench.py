@@ -249,9 +249,10 @@ def main():
                                        'bf16 MFMA conv/fc6/fc7, fp32 storage/fc8/loss/SGD'
                                        if bf else 'fp32; fc6/fc7 GEMMs as exact 3xbf16 splits on '
                                        'the bf16 MFMA (fp32-accurate), conv/fc8 on the fp32 MFMA'
-                                       if x3 else 'fp32; fc6/fc7 GEMMs as row-scaled 2xf16 splits on '
-                                       'the f16 MFMA (fp32 accumulate, operand error 2^-22), '
-                                       'conv1_2..2_2 as 3xbf16 splits, rest on the fp32 MFMA'
+                                       if x3 else 'fp32; fc6/fc7 GEMMs and conv1_2..conv5_3 as power-of-two-'
+                                       'scaled 2xf16 operand splits on the f16 MFMA (fp32 '
+                                       'accumulate, operand error 2^-22); conv1_1, fc8, '
+                                       'softmaxes, loss, SGD in fp32'
                                        if h2 else 'fp32 MFMA'),
                        'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
                        'lr': args.lr, 'final_loss': round(loss, 5), 'stage_ms': stage_ms},
