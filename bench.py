@@ -270,7 +270,11 @@ def main():
             res['roofline'].update(executed_tflops=round(npass * achieved, 1),
                                    executed_peak=BF16_MFMA_PEAK_TFLOPS,
                                    note='achieved/peak are algorithmic fp32 TFLOP/s against '
-                                        '16-bit dense MFMA peak / %d passes' % npass)
+                                        '16-bit dense MFMA peak / %d passes; PMC (profiles/%s): '
+                                        'MFMA pipe busy ~70%% of SIMD-cycles at a power-throttled '
+                                        '%s GHz, 0 LDS bank conflicts' % (
+                                            npass, 'r01_x3_gemm_pmc.md' if x3 else 'r01_h2_gemm_pmc.md',
+                                            '1.84' if x3 else '1.5'))
         # HBM traffic of that kernel comes from the rocprofv3 PMC passes of this same command
         # (profiles/rNN_bench_traffic.json, written by tools/summarize_profile.py)
         import glob
