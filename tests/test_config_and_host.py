@@ -236,3 +236,35 @@ def test_graph_builders_reproduce_reference_trace(cfgmod):
     assert got == tail['ops'] and m.losses == tail['losses']
     assert m.grad_ops[0].type == 'MinEntropyLossGradient'      # its gradient joins rois_pred_grad
     assert 'rois_pred_grad' in m.grad_ops[0].outputs
+
+
+def test_engine_host_scheduling_helpers():
+    """Host-side arithmetic of the engine that needs no GPU: the fc6-wgrad column cut (whole
+    waves of 256x256 tiles + a small-tile remainder), the all-reduce row chunks it composes with,
+    and views of a split operand."""
+    import torch
+    from naws_hip import ops
+    from naws_hip.engine import WsddnEngine
+    from naws_hip.reducer import row_chunks
+
+    class E(object):
+        k6 = 25088
+    cut = lambda rows, cus=256: WsddnEngine._wgrad_column_cut(E(), rows, cus)
+    # 32 x 98 tiles = 12.25 waves -> 96 column tiles (12 waves) + 512 columns
+    assert cut(8192) == 24576 and cut(4096) == 24576 and cut(2048) == 24576
+    for rows in (8192, 4096, 2048):
+        assert ((rows // 256) * (cut(rows) // 256)) % 256 == 0
+    E.k6 = 8192                      # 32 x 32 tiles = 4 whole waves: no cut
+    assert cut(8192) == 0
+    E.k6 = 25088
+    assert cut(8192, cus=7) == 0     # tail not a whole number of tile columns / more than half full
+    for n in (1, 2, 4):
+        ch = row_chunks(8192, n)
+        assert ch[0][0] == 0 and ch[-1][1] == 8192 and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+        assert all((r1 - r0) % 128 == 0 for r0, r1 in ch)
+    op = ops.F16x2(torch.zeros((2, 2, 4, 96, 16), dtype=torch.float16), torch.zeros((2, 2, 96)))
+    sub = op.rows(32, 64)
+    assert sub.planes.shape == (2, 2, 4, 32, 16) and sub.scales.shape == (2, 2, 32)
+    assert sub.planes.data_ptr() == op.planes[..., 32:64, :].data_ptr()
+    assert op.batches(1).planes.shape == (2, 1, 4, 96, 16) and op.batches(1).inv_scale.shape == (1, 96)
+    assert op.inv_scale.data_ptr() == op.scales[1].data_ptr()
