@@ -323,31 +323,29 @@ class WsddnEngine(object):
                         tiles = x.shape[0] * ((x.shape[1] + 7) // 8) * ((x.shape[2] + 31) // 32)
                         if tiles * (wd.planes.shape[-2] // 128) >= 256:
                             wp = wd
-                    if isinstance(wp, ops.F16x2) and wp.planes.dim() == 4:
-                        mul, add = affine if prev == 0 else (1.0, 0.0)
-                        x = ops.conv3x3_nhwc_f16x2(
-                            x, wp, b, True, out=dst,
-                            amax_in=None if prev is None else amax[prev:prev + 1],
-                            in_mul=mul, in_add=add, amax_out=amax[li:li + 1])
-                        prev = li
-                        continue
                     if isinstance(wp, ops.F16x2):
-                        x = ops.conv3x3_winograd_nhwc_f16x2(
-                            x, wp, b, d, True, out=dst,
-                            amax_in=None if prev is None else amax[prev:prev + 1],
-                            amax_out=amax[li:li + 1])
+                        bound = None if prev is None else amax[prev:prev + 1]
+                        if wp.planes.dim() == 4:         # direct halo-tile kernel
+                            mul, add = affine if prev == 0 else (1.0, 0.0)
+                            x = ops.conv3x3_nhwc_f16x2(x, wp, b, True, out=dst, amax_in=bound,
+                                                       in_mul=mul, in_add=add,
+                                                       amax_out=amax[li:li + 1])
+                        else:                            # Winograd, f16 batch GEMMs
+                            x = ops.conv3x3_winograd_nhwc_f16x2(x, wp, b, d, True, out=dst,
+                                                                amax_in=bound,
+                                                                amax_out=amax[li:li + 1])
                         prev = li
-                        continue
-                    if wp.dtype == torch.bfloat16:
-                        conv = (ops.conv3x3_winograd_nhwc_f32x3 if self.conv_wino[name]
-                                else ops.conv3x3_nhwc_f32x3)
-                    elif self.mfma_dtype == 'bf16':
-                        conv = ops.conv3x3_nhwc_bf16
                     else:
-                        conv = (ops.conv3x3_winograd_nhwc if self.conv_wino[name]
-                                else ops.conv3x3_nhwc)
-                    x = conv(x, wp, b, d, True, out=dst)
-                    prev = None
+                        if wp.dtype == torch.bfloat16:
+                            conv = (ops.conv3x3_winograd_nhwc_f32x3 if self.conv_wino[name]
+                                    else ops.conv3x3_nhwc_f32x3)
+                        elif self.mfma_dtype == 'bf16':
+                            conv = ops.conv3x3_nhwc_bf16
+                        else:
+                            conv = (ops.conv3x3_winograd_nhwc if self.conv_wino[name]
+                                    else ops.conv3x3_nhwc)
+                        x = conv(x, wp, b, d, True, out=dst)
+                        prev = None
         return x
 
     def conv_body(self, data):
@@ -677,6 +675,8 @@ class WsddnEngine(object):
         main = torch.cuda.current_stream(self.device)
         if self._upd_stream is None:
             self._upd_stream = torch.cuda.Stream(device=self.device)
+        # (starting it only after conv1_1 / conv1_2 / conv2_2 / conv3_3 of the next conv body, to keep
+        # it off the HBM-bound first layers, was measured twice: +0.3...0.6 ms per step)
         self._upd_stream.wait_event(main.record_event())
         with torch.cuda.stream(self._upd_stream):
             self._apply_update()
