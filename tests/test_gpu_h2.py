@@ -292,3 +292,28 @@ def test_conv3x3_f16x2_halo(dev, cin, cout, h, w, amp):
     y2 = ops.conv3x3_nhwc_f16x2(xd, w2, None, False)          # no bias / no ReLU
     r2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, padding=1).numpy()
     assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 1e-5 * scale
+
+
+def test_gemm_h2_random_shapes(dev):
+    """Ragged M / N / K (not multiples of any tile, K-slab or vector width), batched and
+    transposed sources, magnitudes from 1e-6 to 1e6: every entry within the fp32 dot-product
+    bound of the float64 result."""
+    from naws_hip import ops
+    rng = np.random.default_rng(51)
+    for case in range(14):
+        m, n, k = int(rng.integers(1, 700)), int(rng.integers(1, 700)), int(rng.integers(1, 3000))
+        batch = int(rng.integers(1, 4)) if case % 3 == 0 else 0
+        tr = case % 2 == 1
+        amp_a, amp_b = 10.0 ** rng.uniform(-6, 6), 10.0 ** rng.uniform(-6, 6)
+        bs = (batch,) if batch else ()
+        a = (rng.standard_normal(bs + ((k, m) if tr else (m, k))) * amp_a).astype(np.float32)
+        b = (rng.standard_normal(bs + ((k, n) if tr else (n, k))) * amp_b).astype(np.float32)
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        if tr:
+            a64, b64 = np.swapaxes(a64, -1, -2), np.swapaxes(b64, -1, -2)
+        ref = a64 @ np.swapaxes(b64, -1, -2)
+        bound = np.abs(a64) @ np.swapaxes(np.abs(b64), -1, -2)
+        c = ops.gemm_f32_f16x2_nt(ops.split_f16x2(_t(a, dev), transpose=tr),
+                                  ops.split_f16x2(_t(b, dev), transpose=tr)).cpu().numpy()
+        assert c.shape == ref.shape
+        assert (np.abs(c - ref) <= 2e-6 * bound + 1e-30).all(), (case, m, n, k, batch, tr)
