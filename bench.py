@@ -47,6 +47,9 @@ def parse():
                     help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
     ap.add_argument('--wino-x3', action='store_true',
                     help='fp32x3 plan: run the Winograd batched GEMMs in the split too (no gain)')
+    ap.add_argument('--no-roi-planes', action='store_true',
+                    help='fp16x2 plan: RoIPoolF writes fp32 features that are then split (two '
+                         'more passes) instead of writing the fc6 operand planes itself')
     ap.add_argument('--no-conv-streams', action='store_true',
                     help='one launch per conv layer for all images instead of one stream per image')
     ap.add_argument('--mfma-dtype', default='fp16x2', choices=['fp16x2', 'fp32x3', 'fp32', 'bf16'],
@@ -156,6 +159,8 @@ def main():
         eng.wino_x3 = True
     if args.no_conv_streams:
         eng.conv_streams = False
+    if args.no_roi_planes:
+        eng.roi_planes = False
     blobs = synthetic.init_blobs(num_fg, seed=11)     # identical on every rank (= broadcast)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)

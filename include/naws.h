@@ -373,6 +373,26 @@ int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* sca
                                 uint32_t* amax_out, void* stream);
 /* out[0] = bit pattern of max|X[0..n)| (non-negative floats order like unsigned words). */
 int naws_amax_f32(const float* X, int64_t n, uint32_t* out, void* stream);
+/* RoIPoolF + RoIFeatureBoost (as naws_roi_pool_f_fwd, NHWC; detectron/ops/roi_pool_f_op.cu:14-127,
+ * roi_feature_boost_op.cc:8-66) written straight as the fp16x2 operand of the fc6 GEMM: planes
+ * f16 [2][K/16][R][16] with K = C*pooled_h*pooled_w holding hi / lo of Y[r][:] * s_r, scales fp32
+ * [2][R] with [1] = 1/s_r.  s_r comes from the bound max|Y[r]| <= max|X[n]| * |boost[r]|:
+ * amax_words[n] = bit pattern of an upper bound of max|X| of image n (n_words entries, the last one
+ * is used for higher batch indices), e.g. the amax_out of the conv body's last layer.
+ * C % 64 == 0, pooled_h*pooled_w <= 256, K % 32 == 0. */
+int naws_roi_pool_f_f16x2_fwd(const float* X, int N, int C, int H, int W, const float* rois, int R,
+                              const float* boost, int pooled_h, int pooled_w, float spatial_scale,
+                              const uint32_t* amax_words, int n_words, void* planes, float* scales,
+                              void* stream);
+/* Q f16 [2][Rpad/16][K][16] = transposition of P f16 [2][K/16][R][16] (Rpad = R rounded up to 32,
+ * rows >= R zero): the K(=rois)-contiguous form of the same scaled matrix, B operand of
+ * fc6's dW = dY^T X with a scale vector of ones, provided dY is split by
+ * naws_split_f16x2_kscaled with rowmul = 1/s_r. */
+int naws_f16_planes_transpose(const void* P, int R, int K, int Rpad, void* Q, void* stream);
+/* naws_split_f16x2 of diag(rowmul) X (rowmul[rows], shared by the batch items; nullable). */
+int naws_split_f16x2_kscaled(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
+                             int transpose, int kpad, void* P, float* scales, const float* rowmul,
+                             void* stream);
 /* bf16 plan on the same pipeline: one plane (operands rounded to bf16), 64-deep K-steps.
  * naws_to_bf16_slab: as naws_split_bf16x3 with a single plane, P[batch][kpad/16][outer][16],
  * kpad = K rounded up to 64.  naws_gemm_bf16_slab_nt: C (+)= A B^T on such operands, K % 64 == 0;

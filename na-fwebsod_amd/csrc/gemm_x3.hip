@@ -364,7 +364,8 @@ constexpr int AMAX_CT = 16;
 template <bool TRANS>
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, int rows, int cols,
                                                    int ld, int outer, long long sx,
-                                                   unsigned* __restrict__ amax) {
+                                                   unsigned* __restrict__ amax,
+                                                   const float* __restrict__ rowmul) {
   __shared__ unsigned red[4][64];
   const float* Xb = X + blockIdx.z * sx;
   unsigned* out = amax + (long long)blockIdx.z * outer;
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = r0 + i * 4 + tr, c = c0 + tc;
-      if (r < rows && c < cols) m = fmaxf(m, fabsf(Xb[(long long)r * ld + c]));
+      if (r < rows && c < cols)
+        m = fmaxf(m, fabsf(Xb[(long long)r * ld + c] * (rowmul ? rowmul[r] : 1.f)));
     }
     red[tr][tc] = __float_as_uint(m);
     __syncthreads();
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, 
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = r0 + i * 4 + tr;
-        if (r < rows) m[i] = fmaxf(m[i], fabsf(Xb[(long long)r * ld + c]));
+        if (r < rows) m[i] = fmaxf(m[i], fabsf(Xb[(long long)r * ld + c] * (rowmul ? rowmul[r] : 1.f)));
       }
     }
 #pragma unroll
@@ -408,15 +410,8 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, 
   }
 }
 
-// amax bits -> (scale, 1/scale); NaN / inf maxima keep scale 1 (the NaN then propagates through
-// the f16 conversion); the scale is capped at 2^101, so rows whose maximum is below 2^-87 sit
-// lower in the f16 range (absolute floor 2^-126, the edge of fp32's own normal range).
 __device__ __forceinline__ void f16x2_scales(unsigned amax_bits, float& s, float& inv) {
-  int e = (int)((amax_bits >> 23) & 0xff);
-  if (amax_bits == 0 || e == 0xff) e = 127 + 14;
-  e = min(max(e, 40), 250);
-  s = __uint_as_float((unsigned)(268 - e) << 23);
-  inv = __uint_as_float((unsigned)(e - 14) << 23);
+  naws_f16x2_scales(amax_bits, s, inv);      // naws_common.h
 }
 
 template <bool TRANS>
@@ -425,7 +420,8 @@ __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ 
                                                       long long plane, long long sp,
                                                       const unsigned* __restrict__ amax,
                                                       float* __restrict__ inv_scale,
-                                                      unsigned short* __restrict__ P) {
+                                                      unsigned short* __restrict__ P,
+                                                      const float* __restrict__ rowmul) {
   __shared__ float tile[64][65];
   const float* Xb = X + blockIdx.z * sx;
   unsigned short* Pb = P + blockIdx.z * sp;
@@ -436,7 +432,7 @@ __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = r0 + i * 4 + tr, c = c0 + tc;
-    tile[i * 4 + tr][tc] = (r < rows && c < cols) ? Xb[(long long)r * ld + c] : 0.f;
+    tile[i * 4 + tr][tc] = (r < rows && c < cols) ? Xb[(long long)r * ld + c] * (rowmul ? rowmul[r] : 1.f) : 0.f;
   }
   __syncthreads();
   const int o0 = TRANS ? c0 : r0;
@@ -1000,9 +996,12 @@ extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t s
 
 // P[2][batch][kpad/16][outer][16] f16 + scales[2][batch][outer]: [0] = |x| maxima (bit patterns,
 // scratch), [1] = 1/scale per outer index, handed to naws_gemm_f32_f16x2_nt.
-extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, int ld,
-                                int64_t strideX, int transpose, int kpad, void* P, float* scales,
-                                void* stream) {
+// As naws_split_f16x2 on X' = diag(rowmul) X (rowmul: one factor per source row, shared by the
+// batch items; powers of two keep it exact): the form dY takes in dW = dY^T X when X's planes
+// carry per-row scales of their own (naws_roi_pool_f_f16x2_fwd + naws_f16_planes_transpose).
+extern "C" int naws_split_f16x2_kscaled(const float* X, int batch, int rows, int cols, int ld,
+                                        int64_t strideX, int transpose, int kpad, void* P,
+                                        float* scales, const float* rowmul, void* stream) {
   if (batch <= 0 || rows <= 0 || cols <= 0 || ld < cols) return NAWS_ERR_SHAPE;
   NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(P); NAWS_REQUIRE_PTR(scales);
   const int kdim = transpose ? rows : cols;
@@ -1023,20 +1022,27 @@ extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, i
   if (!transpose) {
     dim3 grow((unsigned)naws_cdiv(cols, 64 * AMAX_CT), (unsigned)gy_src, batch);
     hipLaunchKernelGGL((amax_kernel<false>), grow, dim3(256), 0, s, X, rows, cols, ld, outer,
-                       (long long)strideX, amax);
+                       (long long)strideX, amax, rowmul);
     dim3 grid((unsigned)naws_cdiv(kpad, 64), (unsigned)gy, batch);
     hipLaunchKernelGGL((split2h_kernel<false>), grid, dim3(256), 0, s, X, rows, cols, ld, outer,
                        kpad / 16, (long long)strideX, plane, sp, (const unsigned*)amax, inv,
-                       (unsigned short*)P);
+                       (unsigned short*)P, rowmul);
   } else {
     hipLaunchKernelGGL((amax_kernel<true>), gsrc, dim3(256), 0, s, X, rows, cols, ld, outer,
-                       (long long)strideX, amax);
+                       (long long)strideX, amax, rowmul);
     dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, batch);
     hipLaunchKernelGGL((split2h_kernel<true>), grid, dim3(256), 0, s, X, rows, cols, ld, outer,
                        kpad / 16, (long long)strideX, plane, sp, (const unsigned*)amax, inv,
-                       (unsigned short*)P);
+                       (unsigned short*)P, rowmul);
   }
   return naws_check_launch();
+}
+
+extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, int ld,
+                                int64_t strideX, int transpose, int kpad, void* P, float* scales,
+                                void* stream) {
+  return naws_split_f16x2_kscaled(X, batch, rows, cols, ld, strideX, transpose, kpad, P, scales,
+                                  nullptr, stream);
 }
 
 static int g_h2_variant = -1;

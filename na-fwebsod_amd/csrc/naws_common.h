@@ -55,3 +55,15 @@ static inline uint32_t naws_drop_threshold(float ratio) {
   if (t > 16777216.0) t = 16777216.0;
   return (uint32_t)t;
 }
+
+// fp16x2 operand scaling: from the bit pattern of an upper bound of max|x| to (scale, 1/scale),
+// scale = 2^(14 - floor(log2 bound)) so that bound * scale lies in [2^14, 2^15).  NaN / inf / zero
+// bounds keep scale 1 (a NaN then propagates through the f16 conversion); the scale is capped at
+// 2^101 (bounds below 2^-87 sit lower in the f16 range: absolute floor 2^-126).
+__device__ __forceinline__ void naws_f16x2_scales(unsigned bound_bits, float& s, float& inv) {
+  int e = (int)((bound_bits >> 23) & 0xff);
+  if (bound_bits == 0 || e == 0xff) e = 127 + 14;
+  e = min(max(e, 40), 250);
+  s = __uint_as_float((unsigned)(268 - e) << 23);
+  inv = __uint_as_float((unsigned)(e - 14) << 23);
+}

@@ -185,10 +185,25 @@ __global__ __launch_bounds__(64) void roi_pool_nhwc_v4_kernel(
 // whole map.  Placement only affects speed.  Lane = (bin group g = lane>>4, channel
 // quad cg = lane&15): four bins of a bin row are pooled concurrently, each 16-lane
 // group reading 256 contiguous bytes per pixel.
+//
+// PLANES: instead of the fp32 feature rows the kernel writes the head GEMM's operand directly -
+// the f16 hi / lo planes P[2][K/16][R][16] of Y[r][:] * s_r (K = C*PH*PW; csrc/gemm_x3.hip,
+// naws_split_f16x2 layout) and 1/s_r.  The scale needs no pass over Y: max|Y[r]| <= max|X| of the
+// roi's image (amax_words[batch], handed over by the conv body) * |boost[r]|.
+struct RoiPlaneOut {
+  unsigned short* P;           // planes
+  float* inv_scale;            // [R]
+  const unsigned* amax_words;  // per image: bit pattern of an upper bound of max|X[n]|
+  int n_words;
+  long long plane;             // elements between the hi and the lo plane (= K * R)
+  int R;
+};
+
+template <bool PLANES>
 __global__ __launch_bounds__(64) void roi_pool_nhwc_xcd_kernel(
     const float* __restrict__ X, int C, int H, int W, const float* __restrict__ rois,
     const float* __restrict__ boost, int PH, int PW, float spatial_scale, int nslices,
-    float* __restrict__ Y) {
+    float* __restrict__ Y, RoiPlaneOut po) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* tile = reinterpret_cast<float*>(smem_raw);  // [64 channels][PH*PW]: the output order
   const int slice = blockIdx.x % nslices;
@@ -268,11 +283,77 @@ __global__ __launch_bounds__(64) void roi_pool_nhwc_xcd_kernel(
       }
     }
   }
-  // the (roi, 64-channel slice) block of the output is one contiguous run of 64*PH*PW floats:
-  // written once, fully coalesced, from the LDS tile
   __syncthreads();
   const int count = 64 * nb;
-  for (int i = lane; i < count; i += 64) Y[obase + i] = tile[i];
+  if constexpr (!PLANES) {
+    // the (roi, 64-channel slice) block of the output is one contiguous run of 64*PH*PW floats:
+    // written once, fully coalesced, from the LDS tile
+    for (int i = lane; i < count; i += 64) Y[obase + i] = tile[i];
+  } else {
+    // the same run is count/16 K-slabs of this roi's operand row: 32-byte pieces, one per slab
+    // (neighbouring rois' pieces are adjacent and are written by the same XCD)
+    const float bound = __uint_as_float(po.amax_words[min(rb.batch, po.n_words - 1)]) * fabsf(scale);
+    float sc, isc;
+    naws_f16x2_scales(__float_as_uint(bound), sc, isc);
+    if (slice == 0 && lane == 0) po.inv_scale[r] = isc;
+    const int slab0 = slice * (count / 16);
+    for (int i = lane; i < count / 8; i += 64) {
+      const int j = i >> 1, hh = i & 1;
+      const float* src = tile + j * 16 + hh * 8;
+      unsigned short hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = src[e] * sc;
+        const _Float16 a = (_Float16)t;
+        float rr = t - (float)a;
+        if (!(fabsf(t) <= 65504.f)) rr = 0.f;
+        const _Float16 b = (_Float16)rr;
+        hi[e] = *reinterpret_cast<const unsigned short*>(&a);
+        lo[e] = *reinterpret_cast<const unsigned short*>(&b);
+      }
+      const long long dst = ((long long)(slab0 + j) * po.R + r) * 16 + hh * 8;
+      uint4 wh, wl;
+      wh.x = hi[0] | ((unsigned)hi[1] << 16); wh.y = hi[2] | ((unsigned)hi[3] << 16);
+      wh.z = hi[4] | ((unsigned)hi[5] << 16); wh.w = hi[6] | ((unsigned)hi[7] << 16);
+      wl.x = lo[0] | ((unsigned)lo[1] << 16); wl.y = lo[2] | ((unsigned)lo[3] << 16);
+      wl.z = lo[4] | ((unsigned)lo[5] << 16); wl.w = lo[6] | ((unsigned)lo[7] << 16);
+      *reinterpret_cast<uint4*>(po.P + dst) = wh;
+      *reinterpret_cast<uint4*>(po.P + po.plane + dst) = wl;
+    }
+  }
+}
+
+// f16 operand planes [2][K/16][R][16] (K-contiguous rows = rois) -> [2][Rpad/16][K][16]
+// (K-contiguous rows = features), the operand form of dW = dY^T X: a blocked 16 x 16 transposition
+// of 2-byte elements; rois >= R are written as zero.  One workgroup = 16 rois x 256 features.
+__global__ __launch_bounds__(256) void planes_transpose_kernel(const unsigned short* __restrict__ P,
+                                                               int R, int K, long long plane_in,
+                                                               long long plane_out,
+                                                               unsigned short* __restrict__ Q) {
+  __shared__ unsigned short t[16][16][18];         // [slab][roi][k % 16], padded
+  const int k0 = blockIdx.x * 256, r0 = blockIdx.y * 16, pl = blockIdx.z;
+  const unsigned short* src = P + pl * plane_in;
+  unsigned short* dst = Q + pl * plane_out;
+  for (int u = threadIdx.x; u < 512; u += 256) {   // 16 slabs x 16 rois x 2 halves of 16 bytes
+    const int hh = u & 1, i = (u >> 1) & 15, sl = u >> 5;
+    const int slab = k0 / 16 + sl;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (slab * 16 < K && r0 + i < R)
+      v = *reinterpret_cast<const uint4*>(src + ((long long)slab * R + r0 + i) * 16 + hh * 8);
+    unsigned short* d = &t[sl][i][hh * 8];
+    d[0] = v.x & 0xffff; d[1] = v.x >> 16; d[2] = v.y & 0xffff; d[3] = v.y >> 16;
+    d[4] = v.z & 0xffff; d[5] = v.z >> 16; d[6] = v.w & 0xffff; d[7] = v.w >> 16;
+  }
+  __syncthreads();
+  const int k = k0 + threadIdx.x;
+  if (k >= K) return;
+  const int sl = threadIdx.x >> 4, kk = threadIdx.x & 15;
+  unsigned w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = t[sl][2 * i][kk] | ((unsigned)t[sl][2 * i + 1][kk] << 16);
+  unsigned short* o = dst + ((long long)blockIdx.y * K + k) * 16;
+  *reinterpret_cast<uint4*>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+  *reinterpret_cast<uint4*>(o + 8) = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 // ---- NCHW: one lane = one output element (op-level API on reference layout)
@@ -371,9 +452,9 @@ extern "C" int naws_roi_pool_f_fwd(const float* X, int layout, int N, int C, int
                          boost, pooled_h, pooled_w, spatial_scale, Y, argmax);
     else if (C % 64 == 0 && ((uintptr_t)X % 16) == 0 && pooled_h * pooled_w <= 256 &&
              (int64_t)R * (C / 64) < 0x7fffffffLL)
-      hipLaunchKernelGGL(roi_pool_nhwc_xcd_kernel, dim3((unsigned)(R * (C / 64))), dim3(64),
+      hipLaunchKernelGGL(roi_pool_nhwc_xcd_kernel<false>, dim3((unsigned)(R * (C / 64))), dim3(64),
                          (size_t)64 * pooled_h * pooled_w * sizeof(float), s, X, C, H, W, rois,
-                         boost, pooled_h, pooled_w, spatial_scale, C / 64, Y);
+                         boost, pooled_h, pooled_w, spatial_scale, C / 64, Y, RoiPlaneOut{});
     else if (C % 4 == 0 && ((uintptr_t)X % 16) == 0 && pooled_w <= 64)
       hipLaunchKernelGGL(roi_pool_nhwc_v4_kernel, dim3(R, (unsigned)naws_cdiv(C, 256)), dim3(64),
                          (size_t)4 * 64 * pooled_w * sizeof(float), s, X, C, H, W, rois, boost,
@@ -387,6 +468,48 @@ extern "C" int naws_roi_pool_f_fwd(const float* X, int layout, int N, int C, int
     hipLaunchKernelGGL(roi_pool_nchw_kernel, dim3(blocks), dim3(256), 0, s, total, X, C, H, W,
                        rois, boost, pooled_h, pooled_w, spatial_scale, Y, argmax);
   }
+  return naws_check_launch();
+}
+
+// RoIPoolF + boost straight into the fp16x2 operand of the head GEMM (see RoiPlaneOut above).
+// planes: f16 [2][K/16][R][16], K = C * pooled_h * pooled_w; scales: fp32 [2][R] ([1] = 1/s_r, [0]
+// unused) - the pair naws_gemm_f32_f16x2_nt takes as (A2, scaleA).
+extern "C" int naws_roi_pool_f_f16x2_fwd(const float* X, int N, int C, int H, int W,
+                                         const float* rois, int R, const float* boost,
+                                         int pooled_h, int pooled_w, float spatial_scale,
+                                         const uint32_t* amax_words, int n_words, void* planes,
+                                         float* scales, void* stream) {
+  if (R <= 0 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0 || n_words <= 0)
+    return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(rois); NAWS_REQUIRE_PTR(amax_words);
+  NAWS_REQUIRE_PTR(planes); NAWS_REQUIRE_PTR(scales);
+  const long long K = (long long)C * pooled_h * pooled_w;
+  if (C % 64 != 0 || pooled_h * pooled_w > 256 || K % 32 != 0 || (int64_t)R * (C / 64) >= 0x7fffffffLL)
+    return NAWS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)X | (uintptr_t)planes) & 15) != 0) return NAWS_ERR_ARG;
+  RoiPlaneOut po;
+  po.P = (unsigned short*)planes; po.inv_scale = scales + R; po.amax_words = (const unsigned*)amax_words;
+  po.n_words = n_words; po.plane = K * R; po.R = R;
+  hipLaunchKernelGGL(roi_pool_nhwc_xcd_kernel<true>, dim3((unsigned)(R * (C / 64))), dim3(64),
+                     (size_t)64 * pooled_h * pooled_w * sizeof(float), (hipStream_t)stream, X, C, H,
+                     W, rois, boost, pooled_h, pooled_w, spatial_scale, C / 64, (float*)nullptr, po);
+  return naws_check_launch();
+}
+
+// Q[2][Rpad/16][K][16] = transposition of the f16 planes P[2][K/16][R][16]; Rpad = R rounded up to
+// 32 (rows >= R zero).  With P = X * s_r this is the B operand of dW = dY^T X once dY's rows carry
+// 1/s_r (naws_split_f16x2_kscaled); its own scale vector is all ones.
+extern "C" int naws_f16_planes_transpose(const void* P, int R, int K, int Rpad, void* Q,
+                                         void* stream) {
+  if (R <= 0 || K <= 0) return NAWS_ERR_SHAPE;
+  if (K % 16 != 0 || Rpad != (R + 31) / 32 * 32) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(P); NAWS_REQUIRE_PTR(Q);
+  if ((((uintptr_t)P | (uintptr_t)Q) & 15) != 0) return NAWS_ERR_ARG;
+  dim3 grid((unsigned)naws_cdiv(K, 256), (unsigned)(Rpad / 16), 2);
+  if (grid.y > 65535) return NAWS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(planes_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)P, R, K, (long long)K * R, (long long)Rpad * K,
+                     (unsigned short*)Q);
   return naws_check_launch();
 }
 

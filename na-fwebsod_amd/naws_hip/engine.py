@@ -188,6 +188,10 @@ class WsddnEngine(object):
         # fp16x2: conv1_2..conv2_2 (the halo-tile kernel) in the 2 x f16 split as well
         self.conv_h2 = True
         self.conv_wino = {}
+        # fp16x2: RoIPoolF writes the fc6 operand planes itself (no fp32 feature matrix, no split
+        # passes over it); its per-roi scale comes from max|conv5_3| of the roi's image
+        self.roi_planes = True
+        self._amax5 = None
         self.conv_direct_h2 = {}
         self._streams = []
         # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
@@ -291,8 +295,9 @@ class WsddnEngine(object):
         return out
 
     # ---------------------------------------------------------------- forward
-    def _conv_chain(self, data, out=None):
-        """data NCHW [b,3,H,W] -> conv5_3 NHWC, on the current stream."""
+    def _conv_chain(self, data, out=None, amax_final=None):
+        """data NCHW [b,3,H,W] -> conv5_3 NHWC, on the current stream.  amax_final (int32 [1],
+        fp16x2 plan): receives the bit pattern of max|conv5_3| for the RoIPool operand scale."""
         x = None
         last = VGG16_CONVS[-1][0]
         # fp16x2 Winograd layers hand max|y| to the next layer (its operand scale needs an upper
@@ -325,15 +330,15 @@ class WsddnEngine(object):
                             wp = wd
                     if isinstance(wp, ops.F16x2):
                         bound = None if prev is None else amax[prev:prev + 1]
+                        word = amax_final if (name == last and amax_final is not None) \
+                            else amax[li:li + 1]
                         if wp.planes.dim() == 4:         # direct halo-tile kernel
                             mul, add = affine if prev == 0 else (1.0, 0.0)
                             x = ops.conv3x3_nhwc_f16x2(x, wp, b, True, out=dst, amax_in=bound,
-                                                       in_mul=mul, in_add=add,
-                                                       amax_out=amax[li:li + 1])
+                                                       in_mul=mul, in_add=add, amax_out=word)
                         else:                            # Winograd, f16 batch GEMMs
                             x = ops.conv3x3_winograd_nhwc_f16x2(x, wp, b, d, True, out=dst,
-                                                                amax_in=bound,
-                                                                amax_out=amax[li:li + 1])
+                                                                amax_in=bound, amax_out=word)
                         prev = li
                     else:
                         if wp.dtype == torch.bfloat16:
@@ -356,8 +361,14 @@ class WsddnEngine(object):
         Images are independent: each image's chain is queued on its own HIP stream and the
         hardware packs the tail of one image's layer with the head of the other's."""
         n = data.shape[0]
-        if n == 1 or not self.conv_streams:
-            return self._conv_chain(data)
+        # fp16x2: max|conv5_3| per image (per chain) for the RoIPool -> fc6 operand scale
+        planes = (self.roi_planes and self.mfma_dtype == 'fp16x2' and self.k6 % 32 == 0
+                  and isinstance(self.conv[VGG16_CONVS[-1][0]][0], ops.F16x2))
+        per_image = n > 1 and self.conv_streams
+        self._amax5 = (torch.empty((n if per_image else 1,), device=self.device, dtype=torch.int32)
+                       if planes else None)
+        if not per_image:
+            return self._conv_chain(data, amax_final=self._amax5)
         h, w = data.shape[2], data.shape[3]
         for _ in range(3):
             h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
@@ -374,7 +385,8 @@ class WsddnEngine(object):
             st = self._streams[i]
             st.wait_event(start)
             with torch.cuda.stream(st):
-                self._conv_chain(data[i:i + 1], out=out[i:i + 1])
+                self._conv_chain(data[i:i + 1], out=out[i:i + 1],
+                                 amax_final=None if self._amax5 is None else self._amax5[i:i + 1])
                 done = st.record_event()
             main.wait_event(done)
         return out
@@ -392,9 +404,20 @@ class WsddnEngine(object):
     def _seed(self, layer):
         return (self.seed * 0x9E3779B1 + self.step_count * 1000003 + layer * 7919) & ((1 << 62) - 1)
 
+    def _roi_features(self, conv5, rois, obn_scores):
+        """RoIPoolF + boost -> the fc6 input: fp32 [Rt, k6], or (fp16x2 plan) the GEMM operand
+        planes written by the pooling kernel itself."""
+        if self._amax5 is not None:
+            return ops.roi_pool_f_f16x2(conv5, rois, self._amax5, self.roi_size, self.roi_size,
+                                        self.spatial_scale, boost=obn_scores.reshape(-1))
+        roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
+                                  boost=obn_scores.reshape(-1), layout='NHWC')
+        return roi_feat.view(rois.shape[0], self.k6)
+
     def head_forward(self, roi_feat, train, both_branches=True):
-        """roi_feat [Rt, k6] -> H6, H7 [Rt, nb*4096], logits L [Rt, nb*2C]."""
-        rt = roi_feat.shape[0]
+        """roi_feat [Rt, k6] (or its F16x2 operand form) -> H6, H7 [Rt, nb*4096], logits L
+        [Rt, nb*2C]."""
+        rt = roi_feat.planes.shape[-2] if isinstance(roi_feat, ops.F16x2) else roi_feat.shape[0]
         nb = 2 if both_branches else 1
         C = self.C
         w6 = self.arena.span(self.params, 'fc6_w', '_[noisy]_fc6_w').view(2 * HIDDEN, self.k6)
@@ -412,7 +435,7 @@ class WsddnEngine(object):
             self._refresh_weight_planes()
         # the activation operand in the plan's form (its own kernels, outside the timed launch)
         if h2:
-            xp = ops.split_f16x2(roi_feat)
+            xp = roi_feat if isinstance(roi_feat, ops.F16x2) else ops.split_f16x2(roi_feat)
         elif x3:
             xp = roi_feat if roi_feat.dtype == torch.bfloat16 else ops.split_bf16x3(roi_feat)
         elif bf:
@@ -499,13 +522,11 @@ class WsddnEngine(object):
         mark('start')
         conv5 = self.conv_body(data)
         mark('conv_body')
-        roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
-                                  boost=obn_scores.reshape(-1), layout='NHWC')
+        x = self._roi_features(conv5, rois, obn_scores)
         del conv5
         mark('roi_pool')
         self.flush()                 # previous iteration's all-reduce + SGD, now overlapped
         mark('join_update')
-        x = roi_feat.view(rt, self.k6)
         h6, h7, lg = self.head_forward(x, train=True)
         mark('head_fwd')
         ld8 = self.ld8
@@ -535,7 +556,7 @@ class WsddnEngine(object):
         return out
 
     def _head_backward(self, x, h6, h7, dl):
-        C, rt = self.C, x.shape[0]
+        C, rt = self.C, h6.shape[0]
         G = self.grads
         scale = 1.0 / (1.0 - self.dropout) if self.dropout > 0 else 1.0
         w7 = self.arena.span(self.params, 'fc7_w', '_[noisy]_fc7_w').view(2, HIDDEN, HIDDEN)
@@ -581,7 +602,12 @@ class WsddnEngine(object):
                      alpha=scale)
         # 2. fc6: dW = dZ6^T X in row chunks (both operands K(=rows)-contiguous through the
         # transposing split); each chunk's all-reduce starts while the next one is computed
-        if h2:
+        if h2 and isinstance(x, ops.F16x2):
+            # x's planes carry per-roi scales s_r: dW = sum_r (dZ6[r] / s_r) (x[r] s_r) - the
+            # transposed planes are used as they are, dZ6's rows take the 1/s_r (exact)
+            dz6t = ops.split_f16x2(dz6, transpose=True, rowmul=x.inv_scale)
+            xt = ops.f16_planes_transpose(x)                   # planes [2, Rt/16, 25088, 16]
+        elif h2:
             dz6t = ops.split_f16x2(dz6, transpose=True)        # planes [2, Rt/16, 8192, 16]
             xt = ops.split_f16x2(x, transpose=True)            # planes [2, Rt/16, 25088, 16]
         elif x3:
@@ -709,9 +735,7 @@ class WsddnEngine(object):
             seg = self.segments(rois, n_img)
         seg_off = torch.tensor(seg, dtype=torch.int32, device=self.device)
         conv5 = self.conv_body(data)
-        roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
-                                  boost=obn_scores.reshape(-1), layout='NHWC')
-        x = roi_feat.view(rois.shape[0], self.k6)
+        x = self._roi_features(conv5, rois, obn_scores)
         _h6, _h7, lg = self.head_forward(x, train=False, both_branches=False)
         C = self.C
         _ac, _ad, rp, _cp = ops.wsddn_outputs(lg[:, :C], lg[:, C:2 * C], None, None, seg_off)

@@ -136,6 +136,43 @@ def roi_pool_f(x, rois, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
     return (y, am) if with_argmax else y
 
 
+def roi_pool_f_f16x2(x, rois, amax_words, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None):
+    """RoIPoolF (+ boost) on NHWC features, written directly as the fp16x2 operand of the fc6
+    GEMM: F16x2 with planes [2, K/16, R, 16], K = C*ph*pw, scaled per roi from the bound
+    max|x| of the roi's image (`amax_words`: int32 [n] bit patterns) * |boost|."""
+    _chk(x, 'x'); _chk(rois, 'rois')
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise L.NawsError('naws_roi_pool_f_f16x2_fwd', L.ERR_SHAPE)
+    n, h, w, c = x.shape
+    r = rois.shape[0]
+    k = c * pooled_h * pooled_w
+    if boost is not None:
+        _chk(boost, 'boost')
+        assert boost.numel() == r
+    if amax_words.dtype != torch.int32 or not amax_words.is_contiguous():
+        raise TypeError('amax_words must be a contiguous int32 tensor')
+    out = F16x2(torch.empty((2, k // 16, r, 16), device=x.device, dtype=torch.float16),
+                torch.empty((2, r), device=x.device, dtype=_f32))
+    L.call('naws_roi_pool_f_f16x2_fwd', x.data_ptr(), n, c, h, w, rois.data_ptr(), r, _ptr(boost),
+           pooled_h, pooled_w, float(spatial_scale), amax_words.data_ptr(), amax_words.numel(),
+           out.planes.data_ptr(), out.scales.data_ptr(), _stream())
+    return out
+
+
+def f16_planes_transpose(op):
+    """F16x2 with planes [2, K/16, R, 16] -> F16x2 with planes [2, Rpad/16, K, 16] holding the same
+    scaled matrix K(=rows)-contiguous (Rpad = R rounded up to 32, zero rows) and scales of ones:
+    the B operand of dW = dY^T X when dY is split with kmul = op.inv_scale."""
+    p = op.planes
+    if p.dim() != 4 or p.dtype != torch.float16 or not p.is_contiguous():
+        raise TypeError('expects contiguous unbatched f16 planes [2, K/16, R, 16]')
+    k, r = p.shape[1] * 16, p.shape[2]
+    rpad = (r + 31) // 32 * 32
+    q = torch.empty((2, rpad // 16, k, 16), device=p.device, dtype=torch.float16)
+    L.call('naws_f16_planes_transpose', p.data_ptr(), r, k, rpad, q.data_ptr(), _stream())
+    return F16x2(q, torch.ones((2, k), device=p.device, dtype=_f32))
+
+
 def roi_feature_boost(x, s, out=None):
     _chk(x, 'X'); _chk(s, 'S')
     if s.shape[0] != s.numel() or x.shape[0] != s.shape[0]:
@@ -529,10 +566,11 @@ class F16x2(object):
         return self.scales[1]
 
 
-def split_f16x2(x, transpose=False, out=None):
+def split_f16x2(x, transpose=False, out=None, rowmul=None):
     """fp32 [rows, cols] or [b, rows, cols] (last dim contiguous) -> F16x2 with planes
     [2, (b,) K/16, outer, 16] (K rounded up to 32, zero-filled) scaled per outer index by a
-    power of two that puts the row maximum in [2^14, 2^15):  x * s = hi + lo to 22+ bits."""
+    power of two that puts the row maximum in [2^14, 2^15):  x * s = hi + lo to 22+ bits.
+    rowmul (fp32 [rows], optional): split diag(rowmul) x instead."""
     batched = x.dim() == 3
     x2 = x[0] if batched else x
     if not x.is_cuda or x.dtype != _f32 or x2.stride(1) != 1:
@@ -546,9 +584,12 @@ def split_f16x2(x, transpose=False, out=None):
         out = F16x2(torch.empty(shape, device=x.device, dtype=torch.float16),
                     torch.empty((2, batch, outer) if batched else (2, outer), device=x.device,
                                 dtype=_f32))
-    L.call('naws_split_f16x2', x.data_ptr(), batch, rows, cols, x2.stride(0),
+    if rowmul is not None and (rowmul.numel() != rows or rowmul.dtype != _f32
+                               or not rowmul.is_contiguous()):
+        raise TypeError('rowmul must be a contiguous fp32 vector with one entry per source row')
+    L.call('naws_split_f16x2_kscaled', x.data_ptr(), batch, rows, cols, x2.stride(0),
            (x.stride(0) if batched else 0), int(transpose), kpad, out.planes.data_ptr(),
-           out.scales.data_ptr(), _stream())
+           out.scales.data_ptr(), _ptr(rowmul), _stream())
     return out
 
 

@@ -317,3 +317,54 @@ def test_gemm_h2_random_shapes(dev):
                                   ops.split_f16x2(_t(b, dev), transpose=tr)).cpu().numpy()
         assert c.shape == ref.shape
         assert (np.abs(c - ref) <= 2e-6 * bound + 1e-30).all(), (case, m, n, k, batch, tr)
+
+
+def test_roi_pool_planes_transpose_and_kscaled_split(dev):
+    """RoIPoolF (+ boost) written as the fc6 operand: the planes hold hi + lo of y * s_r with
+    s_r from the bound max|x| * |boost_r| (never an overflow, the stated representation bound
+    against the bit-exact fp32 op), their transposition is exact, and dW = dY^T Y through
+    (k-scaled split of dY) x (transposed planes) matches the float64 product."""
+    from naws_hip import ops
+    rng = np.random.default_rng(52)
+    n, h, w, c, r, m = 2, 37, 53, 128, 203, 96
+    x = np.maximum(rng.standard_normal((n, h, w, c)), 0).astype(np.float32) * np.float32(7.0)
+    x[1] *= np.float32(0.01)                                   # images with different ranges
+    rois = np.zeros((r, 5), np.float32)
+    rois[:, 0] = rng.integers(0, n, r)
+    x1, y1 = rng.uniform(0, 300, r), rng.uniform(0, 200, r)
+    rois[:, 1], rois[:, 2] = x1, y1
+    rois[:, 3], rois[:, 4] = x1 + rng.uniform(0, 200, r), y1 + rng.uniform(0, 150, r)
+    boost = rng.uniform(0.2, 2.0, r).astype(np.float32)
+    xd, rd, bd = _t(x, dev), _t(rois, dev), _t(boost, dev)
+    words = torch.stack([ops.amax_word(xd[i]) for i in range(n)]).reshape(-1)
+    ref = ops.roi_pool_f(xd, rd, 7, 7, 0.125, boost=bd, layout='NHWC').reshape(r, -1).double().cpu().numpy()
+    op = ops.roi_pool_f_f16x2(xd, rd, words, 7, 7, 0.125, boost=bd)
+    k = c * 49
+    assert op.planes.shape == (2, k // 16, r, 16) and op.scales.shape == (2, r)
+    dense, inv, scaled = _dense(op, k)
+    assert np.isfinite(scaled).all() and np.abs(scaled).max() < 2.0 ** 15
+    amax_img = np.array([np.abs(x[i]).max() for i in range(n)])
+    bound = amax_img[rois[:, 0].astype(int)] * boost
+    assert (ref.max(axis=1) <= bound).all()
+    top = bound / inv
+    assert (top >= 2.0 ** 14).all() and (top < 2.0 ** 15).all()
+    assert (np.abs(dense - ref) <= np.maximum(2.0 ** -22 * np.abs(ref), 2.0 ** -25 * inv[:, None])).all()
+    # transposition: same numbers, K = rois, zero pad rows
+    tp = ops.f16_planes_transpose(op)
+    rpad = (r + 31) // 32 * 32
+    assert tp.planes.shape == (2, rpad // 16, k, 16) and (tp.inv_scale == 1).all()
+    q = tp.planes.double()
+    qs = (q[0] + q[1]).movedim(-3, -2).reshape(k, rpad).cpu().numpy()      # [k, rpad]
+    assert np.array_equal(qs[:, :r], scaled[:, :k].T) and not qs[:, r:].any()
+    # fc6 wgrad through the scaled planes
+    dy = rng.standard_normal((r, m)).astype(np.float32)
+    want = dy.astype(np.float64).T @ ref
+    a2 = ops.split_f16x2(_t(dy, dev), transpose=True, rowmul=op.inv_scale)
+    got = ops.gemm_f32_f16x2_nt(a2, tp).cpu().numpy()
+    bnd = np.abs(dy).astype(np.float64).T @ np.abs(ref)
+    assert (np.abs(got - want) <= 2e-6 * bnd + 1e-30).all()
+    # and fc6 forward: planes x weight planes
+    wgt = (rng.standard_normal((m, k)) * 0.01).astype(np.float32)
+    fwd = ops.gemm_f32_f16x2_nt(op, ops.split_f16x2(_t(wgt, dev))).cpu().numpy()
+    want2 = ref @ wgt.astype(np.float64).T
+    assert (np.abs(fwd - want2) <= 2e-6 * (np.abs(ref) @ np.abs(wgt).astype(np.float64).T) + 1e-30).all()
