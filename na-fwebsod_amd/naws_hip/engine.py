@@ -125,13 +125,16 @@ class WsddnEngine(object):
         self.pg, self.world_size = process_group, int(world_size)
         self.reducer = ArenaReducer(process_group, world_size)
         # fc6_w's gradient (822 MB of the 958 MB all-reduce) can be reduced in row chunks while
-        # the rest of its wgrad GEMM still runs.  0 = auto: one message when the collective fits
-        # under the tail of the backward pass + the next iteration's parameter-free conv body +
-        # RoIPool (~6.5 ms: 4 and 8 ranks use 3 / 7 xGMI links per GPU, ~7 / ~4 ms), four chunks
-        # at world_size 2, where a single link carries the whole exchange (~11-13 ms) and the
-        # ~1 ms the chunked GEMMs lose to tile quantisation is the cheaper side
+        # the rest of its wgrad GEMM still runs.  0 = auto.  The collective has the tail of the
+        # backward pass + the next iteration's parameter-free conv body + RoIPool (~5.7 ms) to
+        # hide in; expected exchange: ~4 ms at 8 ranks (7 xGMI links per GPU, less when RCCL shares
+        # the CUs with the conv kernels), ~7 ms at 4 (3 links), ~11-13 ms at 2 (one link).  Chunking
+        # starts it earlier at the price of wgrad tile quantisation, measured on one GPU with
+        # --force-dist: 2 chunks +0.15 ms, 4 chunks +0.4 ms per step.  Auto: 4 chunks at 2 ranks,
+        # 2 chunks from 3 ranks up (cheap insurance at 8), 1 for a single rank.
         ac = int(allreduce_chunks)
-        self.allreduce_chunks = ac if ac >= 1 else (4 if int(world_size) == 2 else 1)
+        ws = int(world_size)
+        self.allreduce_chunks = ac if ac >= 1 else (4 if ws == 2 else 2 if ws > 2 else 1)
         self.k6 = 512 * roi_size * roi_size
         self.ld8 = (2 * self.C + 3) // 4 * 4       # per-branch column block of the logit matrices
 
