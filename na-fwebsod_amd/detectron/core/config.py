@@ -133,7 +133,7 @@ def _defaults():
         # MI355X-native additions (not in the reference)
         'NAWS': {
             'IMS_PER_GPU': 1,        # images per GPU process (the reference supports only 1)
-            'ALLREDUCE_CHUNKS': 0,   # 0 = auto (2 at world_size 2, else 1); >1: cut fc6 wgrad into row chunks, each all-reduced while
+            'ALLREDUCE_CHUNKS': 0,   # 0 = auto (4 at world_size 2, 2 above, 1 alone); >1: cut fc6 wgrad into row chunks, each all-reduced while
                                      # the next chunk's GEMM runs (default: one launch; the
                                      # collective hides under the next iteration's conv body)
             'DEVICE_PREP': True,     # loader + inference: float conversion / mean / flip / crop / resize / CHW padding
