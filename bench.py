@@ -47,6 +47,8 @@ def parse():
                     help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
     ap.add_argument('--wino-x3', action='store_true',
                     help='fp32x3 plan: run the Winograd batched GEMMs in the split too (no gain)')
+    ap.add_argument('--no-fuse-pool', action='store_true',
+                    help='fp16x2 plan: pool1..pool3 as separate kernels instead of in the conv epilogue')
     ap.add_argument('--no-roi-planes', action='store_true',
                     help='fp16x2 plan: RoIPoolF writes fp32 features that are then split (two '
                          'more passes) instead of writing the fc6 operand planes itself')
@@ -161,6 +163,8 @@ def main():
         eng.conv_streams = False
     if args.no_roi_planes:
         eng.roi_planes = False
+    if args.no_fuse_pool:
+        eng.fuse_pool = False
     blobs = synthetic.init_blobs(num_fg, seed=11)     # identical on every rank (= broadcast)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)

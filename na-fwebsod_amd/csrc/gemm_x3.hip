@@ -491,6 +491,7 @@ struct CArgs {
   const unsigned* amax_in;   // bit pattern of an upper bound b of max|X| ...
   float in_mul, in_add;      // ... the bound used is b * in_mul + in_add
   unsigned* amax_out;        // receives the bit pattern of max|Y| (nullable)
+  int pool;                  // 1: write maxpool2x2/stride 2 of the output instead of the output
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -847,6 +848,38 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
   }
 
   float vmax = 0.f;
+  bool pooled = false;
+  if constexpr (F16) pooled = g.pool != 0;
+  if (pooled) {
+    // max-pool 2x2 / stride 2 fused: a lane's accumulators hold the four pixels of a window
+    // (rows 2*wid, 2*wid + 1 of the tile = i; register pairs (e, e+1) = adjacent columns), and
+    // max commutes exactly with the monotone epilogue (x * 2^k + b, ReLU)
+    const int Ho = g.H / 2, Wo = g.W / 2;
+    const int yo = (ty0 + 2 * wid) >> 1;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + j * 32 + l31;
+      if (col >= g.Cout) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+      const float un = iscA * g.scaleB[col];
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const int xo = (tx0 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1;
+        if (yo >= Ho || xo >= Wo) continue;
+        float v = -3.4028234e38f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            float t = acc[i][j][e + d] * un + bv;
+            if (g.relu) t = fmaxf(t, 0.f);
+            v = fmaxf(v, t);
+          }
+        g.Y[((long long)(img * Ho + yo) * Wo + xo) * g.Cout + col] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int col = n0 + j * 32 + l31;
@@ -869,6 +902,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
         if constexpr (F16) vmax = fmaxf(vmax, fabsf(v));
       }
     }
+  }
   }
   if constexpr (F16) {
     if (g.amax_out) {
@@ -1187,7 +1221,7 @@ extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const
                                            const float* bias, int N, int H, int W, int Cin,
                                            int Cout, int relu, float* Y, const uint32_t* amax_in,
                                            float in_mul, float in_add, uint32_t* amax_out,
-                                           void* stream) {
+                                           int pool2, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
   if (Cin % 16 != 0 || (9 * Cin) % 32 != 0 || Cout % 32 != 0 || (Cout > 128 && Cout % 128 != 0))
     return NAWS_ERR_UNSUPPORTED;
@@ -1206,6 +1240,8 @@ extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const
   g.bytesX = (unsigned)(pix * Cin * 4);
   g.scaleB = scaleW; g.amax_in = (const unsigned*)amax_in; g.in_mul = in_mul; g.in_add = in_add;
   g.amax_out = (unsigned*)amax_out;
+  g.pool = pool2 ? 1 : 0;
+  if (pool2 && (H < 2 || W < 2)) return NAWS_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (amax_out && hipMemsetAsync(amax_out, 0, sizeof(uint32_t), s) != hipSuccess) return NAWS_ERR_LAUNCH;
   if (Cout <= 64) return launch_conv_x3_halo<64, true>(g, N, s);

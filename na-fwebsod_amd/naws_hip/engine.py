@@ -194,6 +194,8 @@ class WsddnEngine(object):
         # fp16x2: RoIPoolF writes the fc6 operand planes itself (no fp32 feature matrix, no split
         # passes over it); its per-roi scale comes from max|conv5_3| of the roi's image
         self.roi_planes = True
+        # fp16x2: pool1..pool3 inside the epilogue of the direct conv kernel that feeds them
+        self.fuse_pool = True
         self._amax5 = None
         self.conv_direct_h2 = {}
         self._streams = []
@@ -307,9 +309,12 @@ class WsddnEngine(object):
         # bound of max|x|; a max-pool in between only lowers it), saving that layer's own pass
         amax = torch.empty((len(VGG16_CONVS),), device=self.device, dtype=torch.int32)
         prev, affine = None, (1.0, 0.0)  # slot holding the bound for the current x, if any
+        fused_pool = False               # the previous layer's epilogue already pooled
         for li, item in enumerate(VGG16_CONVS):
             if item[0] == 'pool':
-                x = ops.maxpool2x2_nhwc(x, 2)
+                if not fused_pool:
+                    x = ops.maxpool2x2_nhwc(x, 2)
+                fused_pool = False
             elif item[0] == 'pool4':
                 x = ops.maxpool2x2_nhwc(x, 1 if self.dilation == 2 else 2)
             else:
@@ -337,8 +342,12 @@ class WsddnEngine(object):
                             else amax[li:li + 1]
                         if wp.planes.dim() == 4:         # direct halo-tile kernel
                             mul, add = affine if prev == 0 else (1.0, 0.0)
+                            # a 2x2 / stride-2 max-pool that follows is taken in the epilogue
+                            fused_pool = (self.fuse_pool and li + 1 < len(VGG16_CONVS)
+                                          and VGG16_CONVS[li + 1][0] == 'pool')
                             x = ops.conv3x3_nhwc_f16x2(x, wp, b, True, out=dst, amax_in=bound,
-                                                       in_mul=mul, in_add=add, amax_out=word)
+                                                       in_mul=mul, in_add=add, amax_out=word,
+                                                       pool2=fused_pool)
                         else:                            # Winograd, f16 batch GEMMs
                             x = ops.conv3x3_winograd_nhwc_f16x2(x, wp, b, d, True, out=dst,
                                                                 amax_in=bound, amax_out=word)

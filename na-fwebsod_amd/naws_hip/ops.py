@@ -357,10 +357,11 @@ def amax_word(x, out=None):
 
 
 def conv3x3_nhwc_f16x2(x, w2, bias, relu=True, out=None, amax_in=None, in_mul=1.0, in_add=0.0,
-                       amax_out=None):
+                       amax_out=None, pool2=False):
     """3x3 / pad 1 conv (shallow layers) with w2 = split_f16x2(packed weight viewed
     [Cout, 9*Cin]); amax_in: int32 [1] bit pattern of a bound b, max|x| <= b * in_mul + in_add
-    (measured here when None); amax_out: int32 [1] receiving the bit pattern of max|y|."""
+    (measured here when None); amax_out: int32 [1] receiving the bit pattern of max|y|;
+    pool2: return MaxPool 2x2 / stride 2 of the layer's output ([n, h//2, w//2, cout]) instead."""
     _chk(x, 'x')
     n, h, w, cin = x.shape
     cout = w2.planes.shape[-2]
@@ -368,10 +369,11 @@ def conv3x3_nhwc_f16x2(x, w2, bias, relu=True, out=None, amax_in=None, in_mul=1.
         raise TypeError('w2 must hold the f16 planes [2, 9*Cin/16, Cout, 16] of the packed weight')
     if amax_in is None:
         amax_in, in_mul, in_add = amax_word(x), 1.0, 0.0
-    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    shape = (n, h // 2, w // 2, cout) if pool2 else (n, h, w, cout)
+    y = out if out is not None else torch.empty(shape, device=x.device, dtype=_f32)
     L.call('naws_conv3x3_nhwc_f16x2_fwd', x.data_ptr(), w2.planes.data_ptr(),
            w2.inv_scale.data_ptr(), _ptr(bias), n, h, w, cin, cout, int(relu), y.data_ptr(),
-           amax_in.data_ptr(), float(in_mul), float(in_add), _ptr(amax_out), _stream())
+           amax_in.data_ptr(), float(in_mul), float(in_add), _ptr(amax_out), int(pool2), _stream())
     return y
 
 

@@ -292,6 +292,12 @@ def test_conv3x3_f16x2_halo(dev, cin, cout, h, w, amp):
     y2 = ops.conv3x3_nhwc_f16x2(xd, w2, None, False)          # no bias / no ReLU
     r2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, padding=1).numpy()
     assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 1e-5 * scale
+    # max-pool 2x2 / stride 2 taken in the epilogue == the pooling kernel on the full output, bit for bit
+    am2 = torch.zeros((1,), device=dev, dtype=torch.int32)
+    yp = ops.conv3x3_nhwc_f16x2(xd, w2, _t(b, dev), True, amax_in=am[0:1], amax_out=am2, pool2=True)
+    want = ops.maxpool2x2_nhwc(outs[1], 2)
+    assert yp.shape == want.shape == (n, h // 2, w // 2, cout) and torch.equal(yp, want)
+    assert np.int32(am2.item()).view(np.float32) == np.float32(want.max().item())
 
 
 def test_gemm_h2_random_shapes(dev):
