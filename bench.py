@@ -19,14 +19,16 @@ sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense v_mfma_f32_32x32x16_bf16
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense v_mfma_f32_32x32x16_bf16 / _f16
+HBM_ACHIEVABLE_GBPS = 6300.0    # same guide: ~6.3 TB/s achievable of the 8 TB/s HBM3E spec
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=20,
+                    help='SURVEY.md 8(d): discard the first 20 iterations')
     ap.add_argument('--images-per-gpu', type=int, default=2)
     ap.add_argument('--rois', type=int, default=2000)
     ap.add_argument('--height', type=int, default=600)
@@ -41,7 +43,9 @@ def parse():
                          '(exercises the N>1 code path on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-plan', action='store_true',
-                    help='skip the extra fp32-MFMA-only measurement of the same workload')
+                    help='skip the extra measurements of the same workload under the exact-split '
+                         '(fp32x3) and the fp32-MFMA-only plans')
+    ap.add_argument('--alt-steps', type=int, default=20)
     ap.add_argument('--allreduce-chunks', type=int, default=0, help='0 = auto (engine.py)')
     ap.add_argument('--no-conv-x3', action='store_true',
                     help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
@@ -110,7 +114,8 @@ def alt_plan(args, dev, num_fg, B, t, seg, mode):
     eng.set_head_blobs(blobs)
     del blobs
     eng.set_lr(args.lr)
-    steps = max(1, min(args.steps, 5))
+    steps = max(1, args.alt_steps)
+    warm = 3
 
     def run(n):
         for _ in range(n):
@@ -119,12 +124,14 @@ def alt_plan(args, dev, num_fg, B, t, seg, mode):
         eng.flush()
         torch.cuda.synchronize()
         return out
-    run(2)
+    run(warm)
     t0 = time.perf_counter()
     out = run(steps)
     dt = time.perf_counter() - t0
+    del eng
+    torch.cuda.empty_cache()
     return {'mfma_dtype': mode, 'value': round(B * steps / dt, 3), 'unit': 'images/sec',
-            'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': 2,
+            'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warm,
             'final_loss': round(float(out['loss_cls'].sum().item() +
                                       out['loss_cls_noise'].sum().item()), 5)}
 
@@ -133,6 +140,12 @@ def main():
     args = parse()
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        # one process per GPU: N > 1 is launched through torch.distributed.run (which sets
+        # WORLD_SIZE); a bare `python bench.py --gpus 8` would silently measure one GPU
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python -m '
+                 'torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 '
+                 'bench.py --gpus %d ...`' % (args.gpus, world, args.gpus, args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
@@ -180,16 +193,18 @@ def main():
     # live timing of the dominant kernel (fc6 forward GEMM, N = 8192) with HIP events on
     # the launch stream
     ev = []
-
     pev = []
+    uev = []     # the fused SGD kernel, on the update stream
 
     def step(timed):
         if timed:
             eng.timing_events = ev
             eng.phase_events = pev
+            eng.update_events = uev
         else:
             eng.timing_events = None
             eng.phase_events = None
+            eng.update_events = None
         out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
         eng.sgd_step()
         return out
@@ -244,6 +259,73 @@ def main():
                  'gemm_x3_kernel<256,256,2x4 waves,2 stages,2 planes x 2 K-slabs,f16> = 3 x '
                  'v_mfma_f32_32x32x16_f16 per fp32 product' if h2 else
                  'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
+        dtype = ('bf16 (bf16 MFMA operands, fp32 accumulate/storage/loss)' if bf else
+                 'f32 (exact 3xbf16 operand split, 6-pass bf16 MFMA, fp32 accumulate)' if x3 else
+                 'f32 (2xf16 split, 3-pass f16 MFMA, fp32 accumulate)' if h2 else
+                 'f32 (fp32 MFMA)')
+        arith = ('bf16 MFMA conv/fc6/fc7, fp32 storage/fc8/loss/SGD' if bf else
+                 'fp32 via exact 3xbf16 splits (fc6/fc7, conv1_2-2_2), rest fp32 MFMA' if x3 else
+                 'fp32 via 2xf16 row-scaled splits (fc6/fc7, conv1_2-5_3), rest fp32' if h2 else
+                 'fp32 MFMA')
+        # algorithmic work of the configuration's stages (per image at 600x1000,
+        # R = 2000: conv 463.7 GFLOP; RoIPool+boost reads the 18.8 MB feature map and writes the
+        # 200.7 MB roi_feat; SGD moves 5 x 957.7 MB)
+        headline = (args.height, args.width, args.rois, num_fg) == (600, 1000, 2000, 20)
+        conv_gflop = 463.7 * B if headline else None
+        roipool_bytes = B * (512 * 74 * 124 * 4 + args.rois * 25088 * 4 + args.rois * 24) if headline else None
+        sgd_bytes = 5 * 4 * eng.arena.total
+        sgd_ms = sum(s.elapsed_time(e) for s, e in uev) / max(len(uev), 1)
+        roof = {'bound': 'mfma', 'kernel': 'fc6 fwd (both branches, M=%d N=8192 K=%d): %s' % (rt, k6, kname),
+                'achieved': round(achieved, 2) if achieved else None,
+                'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak, 4) if achieved else None,
+                'traffic': None, 'kernel_ms': round(kern_ms, 4)}
+        if (x3 or h2) and achieved:
+            # 6 (3) executed 16-bit MFMA flops per algorithmic flop: the same fraction against
+            # the instruction's own peak
+            npass = 6 if x3 else 3
+            roof.update(executed_tflops=round(npass * achieved, 1),
+                        executed_peak=BF16_MFMA_PEAK_TFLOPS, mfma_passes=npass)
+        # the conv stack against the fp32 MFMA peak, RoIPool and
+        # SGD against the achievable HBM rate - all from HIP events of THIS run (the conv body and
+        # RoIPool stages on the main stream; the SGD kernel on the update stream, where it runs
+        # underneath the next iteration's conv body)
+        if conv_gflop and stage_ms.get('conv_body'):
+            tf = conv_gflop / stage_ms['conv_body']
+            roof.update(conv_stack_ms=stage_ms['conv_body'], conv_stack_tflops=round(tf, 1),
+                        conv_stack_frac_vs_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 3))
+        if roipool_bytes and stage_ms.get('roi_pool'):
+            gbs = roipool_bytes / stage_ms['roi_pool'] / 1e6
+            roof.update(roipool_ms=stage_ms['roi_pool'], roipool_GBps=round(gbs, 1),
+                        roipool_frac_vs_hbm_6300=round(gbs / HBM_ACHIEVABLE_GBPS, 3))
+        if sgd_ms > 0:
+            gbs = sgd_bytes / sgd_ms / 1e6
+            roof.update(sgd_ms=round(sgd_ms, 4), sgd_GBps=round(gbs, 1),
+                        sgd_frac_vs_hbm_6300=round(gbs / HBM_ACHIEVABLE_GBPS, 3))
+        # HBM traffic of the dominant kernel is NOT measured by this run: it comes from the
+        # rocprofv3 PMC passes of this same command (profiles/rNN_bench_*traffic.json, written by
+        # tools/summarize_profile.py); the field says where it was read from
+        import glob
+        tj = [f for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench*traffic*.json')))
+              if json.load(open(f)).get('mfma_dtype', 'fp32') == args.mfma_dtype]
+        roof['traffic_measured_in_run'] = False
+        if tj and headline and B == 2:
+            roof['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
+            roof['traffic_source'] = os.path.relpath(tj[-1], ROOT)
+        pmc = {'fp16x2': 'profiles/r01_h2_gemm_pmc.md', 'fp32x3': 'profiles/r01_x3_gemm_pmc.md'}
+        if args.mfma_dtype in pmc:
+            roof['profile_ref'] = pmc[args.mfma_dtype]
+        cfg = {'workload': 'configs[1] flickr_voc na_wsddn_V-16-C5_1x C=%d: %d img %dx%d/GPU x %d '
+                           'rois, fwd+bwd+allreduce+SGD' % (num_fg, B, args.height, args.width,
+                                                            args.rois),
+               'arithmetic': arith,
+               'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
+               'lr': args.lr, 'final_loss': round(loss, 5),
+               'rccl_backend': (torch.distributed.get_backend() if pg is not None else 'none'),
+               'rccl_world_size': (torch.distributed.get_world_size() if pg is not None else 1),
+               'allreduce_chunks': eng.allreduce_chunks if eng.reducer.active else 0}
+        for k, v in stage_ms.items():                 # flat: the driver's parser drops nested dicts
+            cfg['stage_ms_' + k] = v
         res = {
             'metric': 'images/sec (600px, 2000 proposals) VGG16-C5 WSDDN fwd+bwd',
             'value': round(world * B * args.steps / dt, 3),
@@ -251,53 +333,18 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if bf else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'flickr_voc na_wsddn_V-16-C5_1x (= BASELINE.json webly_wsddn_V-16-C5_1x; C=%d): %d images %dx%d per '
-                                   'GPU x %d proposals, fwd+bwd+allreduce+SGD, %s' % (
-                                       num_fg, B, args.height, args.width, args.rois,
-                                       'bf16 MFMA conv/fc6/fc7, fp32 storage/fc8/loss/SGD'
-                                       if bf else 'fp32; fc6/fc7 GEMMs as exact 3xbf16 splits on '
-                                       'the bf16 MFMA (fp32-accurate), conv/fc8 on the fp32 MFMA'
-                                       if x3 else 'fp32; fc6/fc7 GEMMs and conv1_2..conv5_3 as power-of-two-'
-                                       'scaled 2xf16 operand splits on the f16 MFMA (fp32 '
-                                       'accumulate, operand error 2^-22); conv1_1, fc8, '
-                                       'softmaxes, loss, SGD in fp32'
-                                       if h2 else 'fp32 MFMA'),
-                       'global_batch_images': world * B, 'parallelism': 'dp%d' % world,
-                       'lr': args.lr, 'final_loss': round(loss, 5), 'stage_ms': stage_ms},
-            'roofline': {'bound': 'mfma', 'kernel': '%s (fc6 fwd, both branches, M=%d N=8192 K=%d)' % (
-                kname, rt, k6),
-                         'achieved': round(achieved, 2) if achieved else None,
-                         'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / peak, 4) if achieved else None,
-                         'traffic': None, 'kernel_ms': round(kern_ms, 4)},
+            'dtype': dtype, 'data': 'synthetic', 'config': cfg, 'roofline': roof,
         }
-        if (x3 or h2) and achieved:
-            # 6 (3) executed 16-bit MFMA flops per algorithmic flop: the same fraction against
-            # the instruction's own peak
-            npass = 6 if x3 else 3
-            res['roofline'].update(executed_tflops=round(npass * achieved, 1),
-                                   executed_peak=BF16_MFMA_PEAK_TFLOPS,
-                                   note='achieved/peak are algorithmic fp32 TFLOP/s against '
-                                        '16-bit dense MFMA peak / %d passes; PMC (profiles/%s): '
-                                        'MFMA pipe busy ~70%% of SIMD-cycles at a power-throttled '
-                                        '%s GHz, 0 LDS bank conflicts' % (
-                                            npass, 'r01_x3_gemm_pmc.md' if x3 else 'r01_h2_gemm_pmc.md',
-                                            '1.84' if x3 else '1.5'))
-        # HBM traffic of that kernel comes from the rocprofv3 PMC passes of this same command
-        # (profiles/rNN_bench_traffic.json, written by tools/summarize_profile.py)
-        import glob
-        tj = [f for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench*traffic*.json')))
-              if json.load(open(f)).get('mfma_dtype', 'fp32') == args.mfma_dtype]
-        if tj and args.rois == 2000 and B == 2:
-            res['roofline']['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
-            res['roofline']['traffic_source'] = os.path.relpath(tj[-1], ROOT)
-        if world == 1 and args.mfma_dtype in ('fp16x2', 'fp32x3') and not args.no_alt_plan:
-            # the same workload with every GEMM on v_mfma_f32_32x32x2_f32, measured in this run,
-            # for readers who want the number without the 3xbf16 operand split
+        if world == 1 and args.mfma_dtype == 'fp16x2' and not args.no_alt_plan:
+            # the same workload, measured in this run, (a) with the exact 3 x bf16 operand split
+            # and (b) with every GEMM on v_mfma_f32_32x32x2_f32, for readers who want the number
+            # without the 2 x f16 operand representation
             del eng
             torch.cuda.empty_cache()
-            res['fp32_mfma_plan'] = alt_plan(args, dev, num_fg, B, t, seg, 'fp32')
+            for mode, key in (('fp32x3', 'fp32x3_plan'), ('fp32', 'fp32_mfma_plan')):
+                res[key] = alt_plan(args, dev, num_fg, B, t, seg, mode)
+                cfg[key + '_images_per_sec'] = res[key]['value']
+                cfg[key + '_ms_per_step'] = res[key]['ms_per_step']
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, num_fg)
         print(json.dumps(res))

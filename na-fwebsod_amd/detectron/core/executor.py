@@ -84,7 +84,8 @@ class NetExecutor(object):
                 weight_decay=cfg.SOLVER.WEIGHT_DECAY, iter_size=cfg.WSL.ITER_SIZE,
                 gpu_num=self.world * self.ims, seed=cfg.RNG_SEED, process_group=process_group,
                 world_size=world_size, allreduce_chunks=cfg.NAWS.ALLREDUCE_CHUNKS,
-                mfma_dtype=cfg.NAWS.MFMA_DTYPE)
+                mfma_dtype=cfg.NAWS.MFMA_DTYPE, scale_momentum=cfg.SOLVER.SCALE_MOMENTUM,
+                scale_momentum_threshold=cfg.SOLVER.SCALE_MOMENTUM_THRESHOLD)
         else:
             if self.ims != 1:
                 raise NotImplementedError('the op-by-op plan follows the reference: one image '

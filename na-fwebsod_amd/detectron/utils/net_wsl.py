@@ -63,7 +63,7 @@ def initialize_from_weights_file(model, weights_file, executor, broadcast=True):
                 np.asarray(src_blobs[s + '_momentum'], np.float32))
     used = set(resolve_source_name(n, src_blobs) for n in model.params)
     for k, v in src_blobs.items():       # keep unconsumed blobs for re-saving (:129-137)
-        if k not in used and not k.endswith('_momentum'):
+        if k not in used and not k.endswith('_momentum') and v is not None:
             preserved['__preserve__/' + k] = v
     model.preserved_blobs = preserved
     executor.load_blobs(blobs)
@@ -78,8 +78,12 @@ def save_model_to_weights_file(weights_file, model, executor):
         if k in model.params or (k.endswith('_momentum') and
                                  k[:-len('_momentum')] in model.TrainableParams()):
             blobs[k] = v.detach().cpu().numpy()
+    # preserved blobs are saved under their UNSCOPED name ('__preserve__/fc1000_w' -> 'fc1000_w',
+    # net_wsl.py:170-178 / c2.py:97-102), never over a blob saved above
     for k, v in getattr(model, 'preserved_blobs', {}).items():
-        blobs[k] = v
+        unscoped = k[k.rfind('/') + 1:]
+        if unscoped not in blobs:
+            blobs[unscoped] = v
     cfg_yaml = yaml.dump(_plain(cfg))
     save_object(dict(blobs=blobs, cfg=cfg_yaml), weights_file)
 

@@ -90,7 +90,7 @@ class WsddnEngine(object):
     def __init__(self, num_classes, device, dilation=2, roi_size=7, dropout=0.5, is_mean=True,
                  momentum=0.9, weight_decay=5e-4, iter_size=1, gpu_num=1, seed=11,
                  process_group=None, world_size=1, allreduce_chunks=0, freeze_conv_body=True,
-                 mfma_dtype='fp16x2'):
+                 mfma_dtype='fp16x2', scale_momentum=True, scale_momentum_threshold=1.1):
         if not freeze_conv_body:
             raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
                                       '(SURVEY.md fact 2): the conv body has no backward')
@@ -122,6 +122,9 @@ class WsddnEngine(object):
         self.iter_size = int(iter_size)
         self.gpu_num = int(gpu_num)
         self.seed = int(seed)
+        # SOLVER.SCALE_MOMENTUM / SCALE_MOMENTUM_THRESHOLD (detector.py:527-559)
+        self.scale_momentum = bool(scale_momentum)
+        self.scale_momentum_threshold = float(scale_momentum_threshold)
         self.pg, self.world_size = process_group, int(world_size)
         self.reducer = ArenaReducer(process_group, world_size)
         # fc6_w's gradient (822 MB of the 958 MB all-reduce) can be reduced in row chunks while
@@ -697,7 +700,7 @@ class WsddnEngine(object):
         if cur != new_lr:
             ratio = max(new_lr / max(cur, 1e-10), cur / max(new_lr, 1e-10))
             self.lr.fill_(new_lr)
-            if cur > 1e-7 and ratio > 1.1:
+            if self.scale_momentum and cur > 1e-7 and ratio > self.scale_momentum_threshold:
                 ops.unary(L.UN_SCALE, self.momentum_buf, new_lr / cur, out=self.momentum_buf)
         return new_lr
 
@@ -728,20 +731,27 @@ class WsddnEngine(object):
 
     def _apply_update(self):
         self.wait_allreduce()
+        uev = getattr(self, 'update_events', None)   # bench.py: HIP events on the update stream
+        if uev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         ops.acm_sgd_update(self.grads, self.momentum_buf, self.lr, self.params, self.acmgrad,
                            self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
                            self.iter_size, self.gpu_num, self.sgd_iter_count)
+        if uev is not None:
+            e1.record()
+            uev.append((e0, e1))
         self.sgd_iter_count += 1
         if self.mfma_dtype != 'fp32' and self._wplanes is not None:
             self._refresh_weight_planes()      # same stream as the update: hidden with it
 
     # -------------------------------------------------------------- inference
     def infer(self, data, rois, obn_scores, seg=None):
+        """Test-mode forward: cls_prob [R, C+1] = Concat(rois_pred[:, :1], rois_pred)
+        (wsl_heads.py:58-67); no dropout; only the clean branch is fetched (test_wsl.py:151)."""
         if rois.shape[0] == 0:
             raise ValueError('infer: no proposals (rois is empty)')
         self.flush()
-        """Test-mode forward: cls_prob [R, C+1] = Concat(rois_pred[:, :1], rois_pred)
-        (wsl_heads.py:58-67); no dropout; only the clean branch is fetched (test_wsl.py:151)."""
         n_img = data.shape[0]
         if seg is None:
             seg = self.segments(rois, n_img)

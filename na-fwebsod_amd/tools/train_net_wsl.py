@@ -13,6 +13,7 @@ import argparse
 import logging
 import os
 import pprint
+import random
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -54,7 +55,13 @@ def main(argv=None):
     assert_and_infer_cfg()
     logger.info('Training with config:')
     logger.info(pprint.pformat(cfg))
-    np.random.seed(cfg.RNG_SEED)
+    # The reference's loader threads of all GPUs draw scale / distortion / crop / mixup values from
+    # ONE process-wide stream (tools/train_net_wsl.py:113), so every GPU sees different values;
+    # with one process per GPU each rank needs its own stream (rank 0 keeps the reference seed).
+    # Python's `random` (mixup partner, loader_wsl.py:136-144) is seeded too.
+    rank = int(os.environ.get('RANK', '0'))
+    np.random.seed(cfg.RNG_SEED + rank)
+    random.seed(cfg.RNG_SEED + rank)
     from detectron.utils import train_wsl
     checkpoints = train_wsl.train_model(max_iter=args.max_iter)
     if not args.skip_test and int(os.environ.get('RANK', '0')) == 0:

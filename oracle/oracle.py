@@ -399,20 +399,26 @@ def loss_tail(fc8, rois, labels_oh, is_mean=True):
 
 
 def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatial_scale=0.125,
-                          roi_size=7, train=True):
+                          roi_size=7, train=True, conv5=None, roi_feat=None, backward=True):
     """Whole hot path on the CPU for a minibatch of B images (each image is one reference
     'GPU': per-image softmax-over-proposals / ReduceSum / gate / loss; gradients summed over
     images, exactly what the all-reduce does).
     blobs: torch CPU tensors in the reference layouts; mb: dict of numpy loader blobs;
     masks: dict of 0/1 keep masks [Rt,4096] for drop6, drop7, _[noisy]_drop6, _[noisy]_drop7.
+    conv5 / roi_feat: results of an earlier call on the same images / proposals (they do not
+    depend on the head parameters), to skip recomputing them; backward=False stops after the
+    per-image loss tails.
     Returns dict(losses per image, grads per trainable blob, intermediates)."""
     import torch
-    data = torch.from_numpy(mb['data'])
-    with torch.no_grad():
-        conv5 = vgg16_conv5_body(data, blobs)                # StopGradient: forward only
     rois = mb['rois']
-    pooled, _ = roi_pool_f(conv5.numpy(), rois, roi_size, roi_size, spatial_scale)
-    roi_feat = roi_feature_boost(pooled, mb['obn_scores'].reshape(-1))
+    argmax = None
+    if conv5 is None:
+        data = torch.from_numpy(mb['data'])
+        with torch.no_grad():
+            conv5 = vgg16_conv5_body(data, blobs).numpy()    # StopGradient: forward only
+    if roi_feat is None:
+        pooled, argmax = roi_pool_f(conv5, rois, roi_size, roi_size, spatial_scale)
+        roi_feat = roi_feature_boost(pooled, mb['obn_scores'].reshape(-1))
     x = torch.from_numpy(roi_feat.reshape(rois.shape[0], -1))
     names = ['fc6_w', 'fc6_b', 'fc7_w', 'fc7_b', '_[noisy]_fc6_w', '_[noisy]_fc6_b',
              '_[noisy]_fc7_w', '_[noisy]_fc7_b', 'fc8c_w', 'fc8c_b', 'fc8d_w', 'fc8d_b',
@@ -430,9 +436,60 @@ def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatia
         tails.append(t)
         for k in dl:
             dl[k][sel] = t['d_' + k]
-    outs = [act[k] for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
-    gouts = [torch.from_numpy(dl[k]) for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
-    grads = torch.autograd.grad(outs, [params[n] for n in names], gouts)
-    return dict(conv5_3=conv5.numpy(), roi_feat=roi_feat, act={k: v.detach().numpy()
-                                                               for k, v in act.items()},
-                tails=tails, d_logits=dl, grads={n: g.numpy() for n, g in zip(names, grads)})
+    res = dict(conv5_3=conv5, roi_feat=roi_feat, roi_argmax=argmax,
+               act={k: v.detach().numpy() for k, v in act.items()}, tails=tails, d_logits=dl)
+    if backward:
+        outs = [act[k] for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
+        gouts = [torch.from_numpy(dl[k]) for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
+        grads = torch.autograd.grad(outs, [params[n] for n in names], gouts)
+        res['grads'] = {n: g.numpy() for n, g in zip(names, grads)}
+    return res
+
+
+def head_float64(roi_feat, rois, labels_oh, blobs, masks, class_weights, is_mean=True, train=True):
+    """The ARBITER for gradient comparisons: the two 2-fc branches, the WSDDN outputs, both
+    weighted cross entropies and their backward, evaluated in float64 by torch autograd from the
+    mathematical definitions (wsl_heads.py:29-56,213-227,674-679, webly_heads.py:36-74,167-197,
+    cross_entropy_wsl_op.cc:87-132 without its 1e-20 / 1e4 clamps, which never bind on finite
+    probabilities).  Two fp32 evaluations (this oracle's, the HIP path's) of the
+    cancellation-heavy softmax backward differ from each other by more than either differs from
+    this one; tests bound both distances.  The entropy-gate weights are StopGradient constants
+    (webly_heads.py:390-391): `class_weights` = [(class_weight, class_weight_noise)] per image,
+    taken from the fp32 evaluation.  -> dict(losses, d_logits [R,4C], grads per blob), float64."""
+    import torch
+    f64 = torch.float64
+    x = torch.from_numpy(np.asarray(roi_feat, np.float32).reshape(rois.shape[0], -1)).to(f64)
+    names = ['fc6_w', 'fc6_b', 'fc7_w', 'fc7_b', '_[noisy]_fc6_w', '_[noisy]_fc6_b',
+             '_[noisy]_fc7_w', '_[noisy]_fc7_b', 'fc8c_w', 'fc8c_b', 'fc8d_w', 'fc8d_b',
+             'noisy_fc8c_w', 'noisy_fc8c_b', 'noisy_fc8d_w', 'noisy_fc8d_b']
+    params = {n: blobs[n].detach().to(f64).requires_grad_(True) for n in names}
+    tmasks = {k: torch.from_numpy(np.asarray(v, np.float32)).to(f64)
+              for k, v in (masks or {}).items()}
+    act = head_forward(x, params, tmasks, train=train)
+    for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d'):
+        act[k].retain_grad()
+    b = torch.from_numpy(rois[:, 0].astype(np.int64))
+    lab = torch.from_numpy(np.asarray(labels_oh, np.float32)).to(f64)
+    n_img, c = lab.shape
+    norm = float(c) if is_mean else 1.0
+    total, losses, probs = 0.0, [], []
+    for i in range(n_img):
+        sel = torch.nonzero(b == i).reshape(-1)
+        per = []
+        for zc, zd, w in ((act['fc8c'], act['fc8d'], class_weights[i][0]),
+                          (act['fc8c'] + act['noisy_fc8c'], act['fc8d'] + act['noisy_fc8d'],
+                           class_weights[i][1])):
+            p = (torch.softmax(zc[sel], 1) * torch.softmax(zd[sel], 0)).sum(0)
+            wt = torch.from_numpy(np.asarray(w, np.float32).reshape(-1)).to(f64)
+            ce = -(lab[i] * torch.log(p) + (1 - lab[i]) * torch.log(1 - p)) * wt
+            per.append(ce.sum() / norm)
+            probs.append(p.detach().numpy())
+            total = total + per[-1]
+        losses.append([float(v.detach()) for v in per])
+    total.backward()
+    dl = torch.cat([act[k].grad for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')], 1)
+    return dict(losses=losses, d_logits=dl.numpy(),
+                cls_prob=np.stack(probs[0::2]), cls_prob_noise=np.stack(probs[1::2]),
+                logits=torch.cat([act[k].detach() for k in
+                                  ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')], 1).numpy(),
+                grads={n: params[n].grad.numpy() for n in names})

@@ -268,3 +268,47 @@ def test_engine_host_scheduling_helpers():
     assert sub.planes.data_ptr() == op.planes[..., 32:64, :].data_ptr()
     assert op.batches(1).planes.shape == (2, 1, 4, 96, 16) and op.batches(1).inv_scale.shape == (1, 96)
     assert op.inv_scale.data_ptr() == op.scales[1].data_ptr()
+
+
+def test_checkpoint_preserved_blobs_round_trip(tmp_path, cfgmod):
+    """Blobs of the weights file that the model does not use are carried through load -> save
+    under their UNSCOPED names (reference net_wsl.py:129-137 keeps them as '__preserve__/<name>'
+    in the workspace and :170-178 writes UnscopeName() of that), stable over resume cycles."""
+    import torch
+    from detectron.utils import net_wsl
+
+    class Model(object):
+        params = ['fc6_w']
+        param_shapes = {'fc6_w': (2, 3)}
+
+        def TrainableParams(self):
+            return ['fc6_w']
+
+    class Executor(object):
+        def __init__(self):
+            self.b = {'fc6_w': torch.zeros(2, 3), 'fc6_w_momentum': torch.zeros(2, 3)}
+
+        def blobs(self, with_momentum=True):
+            return {k: v for k, v in self.b.items()
+                    if with_momentum or not k.endswith('_momentum')}
+
+        def load_blobs(self, blobs):
+            self.b.update(blobs)
+
+        def broadcast_parameters(self):
+            pass
+
+    src = str(tmp_path / 'vgg.pkl')
+    w6 = np.arange(6, dtype=np.float32).reshape(2, 3)
+    w1000 = np.arange(8, dtype=np.float32).reshape(4, 2)
+    net_wsl.save_object({'blobs': {'fc6_w': w6, 'fc1000_w': w1000}}, src)
+    path = src
+    for cycle in range(2):
+        model, ex = Model(), Executor()
+        net_wsl.initialize_from_weights_file(model, path, ex)
+        assert list(model.preserved_blobs) == ['__preserve__/fc1000_w']
+        path = str(tmp_path / ('model_iter%d.pkl' % cycle))
+        net_wsl.save_model_to_weights_file(path, model, ex)
+        saved = net_wsl.load_object(path)['blobs']
+        assert sorted(saved) == ['fc1000_w', 'fc6_w', 'fc6_w_momentum'], sorted(saved)
+        assert np.array_equal(saved['fc1000_w'], w1000) and np.array_equal(saved['fc6_w'], w6)
