@@ -253,11 +253,11 @@ def main():
         peak = (BF16_MFMA_PEAK_TFLOPS if bf else
                 round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if x3 else
                 round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1) if h2 else FP32_MFMA_PEAK_TFLOPS)
-        kname = ('gemm_x3_kernel<256,256,2x4 waves,2 stages,1 plane x 4 K-slabs> (bf16 slab operands)' if bf else
+        kname = ('gemm_x3_m16_kernel<256,256,4x2 waves,2 stages,1 plane x 4 K-slabs> (bf16 slab operands, v_mfma_f32_16x16x32_bf16)' if bf else
                  'gemm_x3_kernel<256,256,2x4 waves,3 stages> = 6 x v_mfma_f32_32x32x16_bf16 per '
                  'fp32 product' if x3 else
-                 'gemm_x3_kernel<256,256,2x4 waves,2 stages,2 planes x 2 K-slabs,f16> = 3 x '
-                 'v_mfma_f32_32x32x16_f16 per fp32 product' if h2 else
+                 'gemm_x3_m16_kernel<256,256,4x2 waves,2 stages,2 planes x 2 K-slabs,f16> = 3 x '
+                 'v_mfma_f32_16x16x32_f16 per fp32 product' if h2 else
                  'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
         dtype = ('bf16 (bf16 MFMA operands, fp32 accumulate/storage/loss)' if bf else
                  'f32 (exact 3xbf16 operand split, 6-pass bf16 MFMA, fp32 accumulate)' if x3 else

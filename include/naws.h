@@ -345,6 +345,39 @@ int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA, i
                            int64_t strideScaleB, int epilogue, const float* bias,
                            int64_t strideBias, const float* aux, int ldaux, float alpha,
                            float drop_ratio, uint64_t seed, int accumulate, void* stream);
+/* The producer reports the maxima, the consumer's split reads X once.
+ * naws_gemm_f32_f16x2_nt_amax / naws_gemm_f32_amax: as naws_gemm_f32_f16x2_nt / naws_gemm_f32 (same
+ * reference operators: Caffe2 FC / FCGradient, wsl_heads.py:674-679, webly_heads.py:490-498), and
+ * the epilogue additionally folds |C| of the values it stores into
+ *   rowmax [batch][nseg][M]  max over the columns of segment n / rowmax_seg_cols (0 = one segment;
+ *                            otherwise a multiple of 256), nullable
+ *   colmax [batch][N]        max over rows of |C[m][n] * colmax_rowmul[m]| (colmax_rowmul nullable)
+ * as uint32 bit patterns by atomic max: the caller zeroes them.  NaNs are skipped as fmaxf skips
+ * them, so the maxima equal those of naws_split_f16x2's own pass bit for bit.
+ * naws_split_f16x2_dual: X fp32 [batch][rows][ld] -> Pn f16 [2][batch][kpad_n/16][rows][16] scaled
+ * per row from rowmax [batch][rows] and / or Pt f16 [2][batch][kpad_t/16][cols][16] = planes of
+ * (diag(rowmul) X)^T scaled per column from colmax [batch][cols]; scales_n / scales_t as
+ * naws_split_f16x2's scales ([1] receives 1/scale; [0] untouched).  Pn or Pt may be null. */
+int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, int64_t slabA, int64_t planeA,
+                                const float* scaleA, const void* B2, int64_t slabB, int64_t planeB,
+                                const float* scaleB, float* C, int ldc, int batch, int64_t strideA,
+                                int64_t strideB, int64_t strideC, int64_t strideScaleA,
+                                int64_t strideScaleB, int epilogue, const float* bias,
+                                int64_t strideBias, const float* aux, int ldaux, float alpha,
+                                float drop_ratio, uint64_t seed, int accumulate, uint32_t* rowmax,
+                                int rowmax_seg_cols, uint32_t* colmax, const float* colmax_rowmul,
+                                void* stream);
+int naws_gemm_f32_amax(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                       const float* B, int ldb, float* C, int ldc, int batch, int64_t strideA,
+                       int64_t strideB, int64_t strideC, int epilogue, const float* bias,
+                       int64_t strideBias, const float* aux, int ldaux, float alpha,
+                       float drop_ratio, uint64_t seed, int accumulate, uint32_t* rowmax,
+                       int rowmax_seg_cols, uint32_t* colmax, const float* colmax_rowmul,
+                       void* stream);
+int naws_split_f16x2_dual(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
+                          const uint32_t* rowmax, const uint32_t* colmax, const float* rowmul,
+                          void* Pn, float* scales_n, int kpad_n, void* Pt, float* scales_t,
+                          int kpad_t, void* stream);
 /* Winograd F(2x2,3x3) convolution (as naws_conv3x3_winograd_nhwc_fwd: reference
  * detectron/modeling/VGG16.py:24-46, conv3_x .. conv5_x) with the 16 batched GEMMs in the 2 x f16
  * split: the input transform scales by one power of two per tensor (|B^T d B| <= 4 max|x|) and

@@ -51,6 +51,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   // implicit-GEMM conv (A gather): NHWC input [Nimg,H,W,Cin]
   int H, W, Cin, dil;
+  NawsAmax am;   // |C| maxima for the consumer's fp16x2 operand split (naws_common.h)
 };
 
 constexpr int PADK = 4;                // K-contiguous LDS row pad (floats)
@@ -359,9 +360,12 @@ void gemm_f32_kernel(GemmArgs g) {
         float* dst = C + (long long)row * g.ldc + col;
         if (g.accumulate) v += *dst;
         *dst = v;
+        acc[i][j][e] = v;
       }
     }
   }
+  if (g.am.rowmax || g.am.colmax)
+    naws_tile_amax_32<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
 }
 
 // Tuning knob for A/B experiments (tools/kernel_bench.py): NAWS_GEMM_VARIANT
@@ -441,12 +445,13 @@ constexpr long long MAX_EXTENT = 0xFFFFFFF0LL - 64;  // 32-bit buffer byte offse
 
 }  // namespace
 
-extern "C" int naws_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
-                             const float* B, int ldb, float* C, int ldc, int batch,
-                             int64_t strideA, int64_t strideB, int64_t strideC, int epilogue,
-                             const float* bias, int64_t strideBias, const float* aux, int ldaux,
-                             float alpha, float drop_ratio, uint64_t seed, int accumulate,
-                             void* stream) {
+extern "C" int naws_gemm_f32_amax(int transA, int transB, int M, int N, int K, const float* A,
+                                  int lda, const float* B, int ldb, float* C, int ldc, int batch,
+                                  int64_t strideA, int64_t strideB, int64_t strideC, int epilogue,
+                                  const float* bias, int64_t strideBias, const float* aux,
+                                  int ldaux, float alpha, float drop_ratio, uint64_t seed,
+                                  int accumulate, uint32_t* rowmax, int rowmax_seg_cols,
+                                  uint32_t* colmax, const float* colmax_rowmul, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return NAWS_ERR_SHAPE;
   NAWS_REQUIRE_PTR(A); NAWS_REQUIRE_PTR(B); NAWS_REQUIRE_PTR(C);
   if (epilogue < NAWS_EPI_NONE || epilogue > NAWS_EPI_GATE_POS) return NAWS_ERR_ARG;
@@ -473,12 +478,31 @@ extern "C" int naws_gemm_f32(int transA, int transB, int M, int N, int K, const 
   g.drop_thr = naws_drop_threshold(drop_ratio);
   g.drop_scale = (float)(1.0 / (1.0 - (double)drop_ratio));
   g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
+  if (rowmax || colmax) {
+    const int seg = rowmax_seg_cols > 0 ? rowmax_seg_cols : N;
+    if (rowmax && seg < N && seg % 256 != 0) return NAWS_ERR_ARG;
+    const int nseg = (int)naws_cdiv(N, seg);
+    g.am.rowmax = rowmax; g.am.colmax = colmax; g.am.colmul = colmax_rowmul;
+    g.am.seg_cols = seg >= N ? 0x40000000 : seg;
+    g.am.sRow = (long long)nseg * M; g.am.sCol = N;
+  }
   hipStream_t s = (hipStream_t)stream;
   const bool a_kc = !transA, b_kc = transB != 0;
   if (a_kc && b_kc) return dispatch<true, true, false>(g, batch, s);
   if (a_kc && !b_kc) return dispatch<true, false, false>(g, batch, s);
   if (!a_kc && b_kc) return dispatch<false, true, false>(g, batch, s);
   return dispatch<false, false, false>(g, batch, s);
+}
+
+extern "C" int naws_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                             const float* B, int ldb, float* C, int ldc, int batch,
+                             int64_t strideA, int64_t strideB, int64_t strideC, int epilogue,
+                             const float* bias, int64_t strideBias, const float* aux, int ldaux,
+                             float alpha, float drop_ratio, uint64_t seed, int accumulate,
+                             void* stream) {
+  return naws_gemm_f32_amax(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, batch, strideA,
+                            strideB, strideC, epilogue, bias, strideBias, aux, ldaux, alpha,
+                            drop_ratio, seed, accumulate, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int naws_conv3x3_nhwc_fwd(const float* X, const float* Wp, const float* bias, int N,

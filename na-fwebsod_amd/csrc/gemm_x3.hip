@@ -59,6 +59,7 @@ struct XArgs {
   const float* rs;           // fp16x2: per-row / per-column power-of-two factors undoing the
   const float* cs;           //         operand scaling (null otherwise)
   long long sRs, sCs;
+  NawsAmax am;               // |C| maxima for the consumer's operand split (naws_common.h)
 };
 
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -270,9 +271,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
         const int idx = row * g.ldc + col;      // < 2^31, checked on the host
         if (g.accumulate) v += C[idx];
         C[idx] = v;
+        acc[i][j][e] = v;
       }
     }
   }
+  if (g.am.rowmax || g.am.colmax)
+    naws_tile_amax_32<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1, bool F16 = false>
@@ -281,6 +285,215 @@ int launch_x3(XArgs& g, int batch, hipStream_t s) {
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;
   auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
+  return naws_check_launch();
+}
+
+// ---- the same pipeline on the 16x16x32 MFMA shape ------------------------------------------------
+// MI355X_MICROARCH.md 'DVFS give-back' item 7: in power-limited 16-bit MFMA loops the chip holds a
+// higher clock on v_mfma_f32_16x16x32 than on 32x32x16 at equal cycles per flop (measured there:
+// 1.12-1.14x the flop/s with every operand re-read from LDS).  The fc6 GEMMs are exactly that
+// regime (PMC: 1.5 GHz under the 32x32x16 form).  Same operand planes, same LDS-DMA ring, same
+// bytes read from LDS per flop; differences:
+//   * a 32-deep MFMA K = two 16-deep slabs: lane l reads row (l & 15) of slab (l >> 5), k-half
+//     (l >> 4) & 1; with THIS lane->address map the un-swizzled [row][2 x 16 B] image is the
+//     conflict-free one for ds_read_b128's 16-lane groups (rows r and r+8 of a group carry opposite
+//     k-halves), so the DMA source keeps its natural order;
+//   * accumulator block = 16x16, 4 registers per lane: row (l >> 4) * 4 + e, column l & 15.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma32(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL, int KS, bool F16>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_m16_kernel(XArgs g) {
+  static_assert(KS % 2 == 0, "a 16x16x32 MFMA spans two 16-deep slabs");
+  static_assert(NPL <= 2, "one- or two-plane operands");
+  typedef typename OperandVec<F16>::type vec_t;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TI = WTM / 16, TJ = WTN / 16;
+  constexpr int IH = TI >= 8 ? 2 : 1, TIH = TI / IH;        // A fragments are read in row halves
+  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;
+  constexpr int NQ = NPL * KS;
+  constexpr int STAGE = NQ * (A_PLANE + B_PLANE);
+  constexpr int PIECE_ROWS = NT / 2;
+  constexpr int PA = BM / PIECE_ROWS, PB = BN / PIECE_ROWS;
+  constexpr int G = NQ * (PA + PB);
+  static_assert(BM % PIECE_ROWS == 0 && BN % PIECE_ROWS == 0, "tile vs workgroup");
+  static_assert((STAGES - 2) * G <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int lid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, rem = ntiles & 7, xcd = lid & 7, within = lid >> 3;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * g.tiles_n;
+  const int grp = lid / per_group;
+  const int first_m = grp * GM;
+  const int gsz = min(g.tiles_m - first_m, GM);
+  const int tm = first_m + (lid % per_group) % gsz;
+  const int tn = (lid % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const long long bz = blockIdx.z;
+  const unsigned short* A = g.A + bz * g.sA;
+  const unsigned short* B = g.B + bz * g.sB;
+  float* C = g.C + bz * g.sC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int l15 = lane & 15, kg = lane >> 4;
+
+  const int lrow = tid >> 1;
+  const int kslot = (tid & 1) * 8;
+  const unsigned short* srcA[PA];
+  const unsigned short* srcB[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p)
+    srcA[p] = A + (long long)min(m0 + p * PIECE_ROWS + lrow, g.M - 1) * 16 + kslot;
+#pragma unroll
+  for (int p = 0; p < PB; ++p)
+    srcB[p] = B + (long long)min(n0 + p * PIECE_ROWS + lrow, g.N - 1) * 16 + kslot;
+
+  auto issue = [&](int t, int st) {
+    unsigned char* base = smx + st * STAGE + wid * 1024;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int pl = q / KS, ks = q % KS;
+      const long long ka = (long long)(t * KS + ks) * g.slabA, kb = (long long)(t * KS + ks) * g.slabB;
+#pragma unroll
+      for (int p = 0; p < PA; ++p)
+        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcA[p] + pl * g.planeA + ka),
+                                         NAWS_LDS_PTR(base + q * A_PLANE + p * (NT * 16)), 16, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PB; ++p)
+        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcB[p] + pl * g.planeB + kb),
+                                         NAWS_LDS_PTR(base + NQ * A_PLANE + q * B_PLANE + p * (NT * 16)),
+                                         16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  // lane -> (row l15, slab kg >> 1 of the pair, k-half kg & 1)
+  const int rd_a = (wm * WTM + l15) * 32 + (kg & 1) * 16 + (kg >> 1) * A_PLANE;
+  const int rd_b = NQ * A_PLANE + (wn * WTN + l15) * 32 + (kg & 1) * 16 + (kg >> 1) * B_PLANE;
+
+  const int T = g.K / (16 * KS);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < T) issue(s, s);
+  int st_cur = 0, st_fill = STAGES - 1;
+  for (int t = 0; t < T; ++t) {
+    if (t + STAGES - 2 < T) wait_vmcnt<(STAGES - 2) * G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + STAGES - 1 < T) issue(t + STAGES - 1, st_fill);
+    const unsigned char* st = smx + st_cur * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < KS / 2; ++kk) {
+      vec_t b[NPL][TJ];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          b[pl][j] = *reinterpret_cast<const vec_t*>(st + rd_b + (pl * KS + 2 * kk) * B_PLANE + j * 512);
+#pragma unroll
+      for (int ih = 0; ih < IH; ++ih) {
+        vec_t a[NPL][TIH];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+          for (int i = 0; i < TIH; ++i)
+            a[pl][i] = *reinterpret_cast<const vec_t*>(st + rd_a + (pl * KS + 2 * kk) * A_PLANE +
+                                                       (ih * TIH + i) * 512);
+#define NAWS_M16_TERM(P, Q)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TIH; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
+      acc[ih * TIH + i][j] = mfma32(a[P][i], b[Q][j], acc[ih * TIH + i][j]);
+        NAWS_M16_TERM(0, 0)
+        if constexpr (NPL == 2) {
+          NAWS_M16_TERM(0, 1)
+          NAWS_M16_TERM(1, 0)
+        }
+#undef NAWS_M16_TERM
+      }
+    }
+    st_cur = (st_cur + 1 == STAGES) ? 0 : st_cur + 1;
+    st_fill = (st_fill + 1 == STAGES) ? 0 : st_fill + 1;
+  }
+
+  const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
+  const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
+  const int epi = g.epilogue;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int row0 = m0 + wm * WTM + i * 16 + kg * 4;
+    float rsv[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (F16) {
+      const float* rs = g.rs + bz * g.sRs;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rsv[e] = rs[min(row0 + e, g.M - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + wn * WTN + j * 16 + l15;
+      if (col >= g.N) continue;
+      const float bv = (bias && epi >= NAWS_EPI_BIAS && epi <= NAWS_EPI_BIAS_RELU_DROP) ? bias[col] : 0.f;
+      float cscale = 1.f;
+      if constexpr (F16) cscale = g.cs[bz * g.sCs + col];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = row0 + e;
+        if (row >= g.M) continue;
+        float v = acc[i][j][e];
+        if constexpr (F16) v = v * rsv[e] * cscale;       // powers of two: exact, in this order
+        v += bv;
+        if (epi == NAWS_EPI_BIAS_RELU || epi == NAWS_EPI_BIAS_RELU_DROP) v = fmaxf(v, 0.f);
+        if (epi == NAWS_EPI_BIAS_RELU_DROP) {
+          const unsigned long long idx =
+              (unsigned long long)bz * g.M * g.N + (unsigned long long)row * g.N + col;
+          v = naws_keep(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+        } else if (epi == NAWS_EPI_GATE_POS) {
+          v = (aux[row * g.ldaux + col] > 0.f) ? v * g.alpha : 0.f;
+        }
+        const int idx = row * g.ldc + col;
+        if (g.accumulate) v += C[idx];
+        C[idx] = v;
+        acc[i][j][e] = v;
+      }
+    }
+  }
+  if (g.am.rowmax || g.am.colmax)
+    naws_tile_amax_16<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL, int KS, bool F16>
+int launch_x3_m16(XArgs& g, int batch, hipStream_t s) {
+  g.tiles_m = (int)naws_cdiv(g.M, BM);
+  g.tiles_n = (int)naws_cdiv(g.N, BN);
+  const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;
+  auto kern = gemm_x3_m16_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -466,6 +679,83 @@ __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ 
       w.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
       w.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
       *reinterpret_cast<u32x4*>(Pb + pl * plane + dst) = w;
+    }
+  }
+}
+
+// One pass over X writing BOTH operand forms of the fp16x2 GEMM from maxima that the producer of
+// X has already reported (NawsAmax): the row-scaled planes Pn[2][batch][kn/16][rows][16] (X as an NT
+// operand, K = cols) and / or the column-scaled transposed planes Pt[2][batch][kt/16][cols][16]
+// (X^T as an NT operand, K = rows; of diag(rowmul) X when rowmul is given).  Replaces
+// amax + split + amax<T> + split<T> (4 reads of X) by one read.
+__device__ __forceinline__ void split2h_pack(const float (&t)[8], float sc, u32x4& hi4, u32x4& lo4) {
+  unsigned short q[2][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = t[e] * sc;
+    const _Float16 hi = (_Float16)v;
+    float r = v - (float)hi;
+    if (!(fabsf(v) <= 65504.f)) r = 0.f;             // NaN / overflow live in the hi plane only
+    const _Float16 lo = (_Float16)r;
+    q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+    q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+  }
+  hi4.x = q[0][0] | ((unsigned)q[0][1] << 16); hi4.y = q[0][2] | ((unsigned)q[0][3] << 16);
+  hi4.z = q[0][4] | ((unsigned)q[0][5] << 16); hi4.w = q[0][6] | ((unsigned)q[0][7] << 16);
+  lo4.x = q[1][0] | ((unsigned)q[1][1] << 16); lo4.y = q[1][2] | ((unsigned)q[1][3] << 16);
+  lo4.z = q[1][4] | ((unsigned)q[1][5] << 16); lo4.w = q[1][6] | ((unsigned)q[1][7] << 16);
+}
+
+__global__ __launch_bounds__(256) void split2h_dual_kernel(
+    const float* __restrict__ X, int rows, int cols, int ld, long long sx,
+    const unsigned* __restrict__ rowmax, const unsigned* __restrict__ colmax,
+    const float* __restrict__ rowmul, unsigned short* __restrict__ Pn, float* __restrict__ inv_n,
+    int slabs_n, unsigned short* __restrict__ Pt, float* __restrict__ inv_t, int slabs_t, int batch) {
+  __shared__ float tile[64][65];
+  const int bz = blockIdx.z;
+  const float* Xb = X + bz * sx;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + i * 4 + tr, c = c0 + tc;
+    tile[i * 4 + tr][tc] = (r < rows && c < cols) ? Xb[(long long)r * ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int u = threadIdx.x + it * 256;           // (slab s, outer o, half hh), hh fastest
+    const int hh = u & 1, o = (u >> 1) & 63, s = u >> 7;
+    if (Pn && r0 + o < rows && c0 / 16 + s < slabs_n) {
+      float sc, isc;
+      f16x2_scales(rowmax[(long long)bz * rows + r0 + o], sc, isc);
+      if (c0 == 0 && s == 0 && hh == 0) inv_n[(long long)bz * rows + r0 + o] = isc;
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = tile[o][s * 16 + hh * 8 + e];
+      u32x4 hi4, lo4;
+      split2h_pack(t, sc, hi4, lo4);
+      const long long sp = (long long)slabs_n * 16 * rows, plane = (long long)batch * sp;
+      const long long dst = bz * sp + ((long long)(c0 / 16 + s) * rows + (r0 + o)) * 16 + hh * 8;
+      *reinterpret_cast<u32x4*>(Pn + dst) = hi4;
+      *reinterpret_cast<u32x4*>(Pn + plane + dst) = lo4;
+    }
+    if (Pt && c0 + o < cols && r0 / 16 + s < slabs_t) {
+      float sc, isc;
+      f16x2_scales(colmax[(long long)bz * cols + c0 + o], sc, isc);
+      if (r0 == 0 && s == 0 && hh == 0) inv_t[(long long)bz * cols + c0 + o] = isc;
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kk = s * 16 + hh * 8 + e;
+        t[e] = tile[kk][o] * ((rowmul && r0 + kk < rows) ? rowmul[r0 + kk] : 1.f);
+      }
+      u32x4 hi4, lo4;
+      split2h_pack(t, sc, hi4, lo4);
+      const long long sp = (long long)slabs_t * 16 * cols, plane = (long long)batch * sp;
+      const long long dst = bz * sp + ((long long)(r0 / 16 + s) * cols + (c0 + o)) * 16 + hh * 8;
+      *reinterpret_cast<u32x4*>(Pt + dst) = hi4;
+      *reinterpret_cast<u32x4*>(Pt + plane + dst) = lo4;
     }
   }
 }
@@ -1072,6 +1362,36 @@ extern "C" int naws_split_f16x2_kscaled(const float* X, int batch, int rows, int
   return naws_check_launch();
 }
 
+// naws_split_f16x2_dual: see split2h_dual_kernel.  rowmax [batch][rows] / colmax [batch][cols]: bit
+// patterns of max|x| per row / per column of diag(rowmul) X (as reported by a *_amax GEMM).  Pn /
+// Pt nullable (at least one); scales_n [2][batch][rows] / scales_t [2][batch][cols]: [1] receives
+// 1/scale ([0] is free for the caller - typically it IS the rowmax / colmax vector).
+extern "C" int naws_split_f16x2_dual(const float* X, int batch, int rows, int cols, int ld,
+                                     int64_t strideX, const uint32_t* rowmax, const uint32_t* colmax,
+                                     const float* rowmul, void* Pn, float* scales_n, int kpad_n,
+                                     void* Pt, float* scales_t, int kpad_t, void* stream) {
+  if (batch <= 0 || rows <= 0 || cols <= 0 || ld < cols) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X);
+  if (!Pn && !Pt) return NAWS_ERR_NULL;
+  if (Pn) {
+    NAWS_REQUIRE_PTR(rowmax); NAWS_REQUIRE_PTR(scales_n);
+    if (kpad_n != (cols + 31) / 32 * 32 || ((uintptr_t)Pn & 15) != 0) return NAWS_ERR_ARG;
+  }
+  if (Pt) {
+    NAWS_REQUIRE_PTR(colmax); NAWS_REQUIRE_PTR(scales_t);
+    if (kpad_t != (rows + 31) / 32 * 32 || ((uintptr_t)Pt & 15) != 0) return NAWS_ERR_ARG;
+  }
+  const long long gy = naws_cdiv(rows, 64);
+  if (batch > 65535 || gy > 65535) return NAWS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, batch);
+  hipLaunchKernelGGL(split2h_dual_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, rows, cols, ld,
+                     (long long)strideX, (const unsigned*)rowmax, (const unsigned*)colmax, rowmul,
+                     (unsigned short*)Pn, Pn ? scales_n + (long long)batch * rows : nullptr,
+                     kpad_n / 16, (unsigned short*)Pt, Pt ? scales_t + (long long)batch * cols : nullptr,
+                     kpad_t / 16, batch);
+  return naws_check_launch();
+}
+
 extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, int ld,
                                 int64_t strideX, int transpose, int kpad, void* P, float* scales,
                                 void* stream) {
@@ -1081,14 +1401,17 @@ extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, i
 
 static int g_h2_variant = -1;
 
-extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA,
-                                      int64_t planeA, const float* scaleA, const void* B2,
-                                      int64_t slabB, int64_t planeB, const float* scaleB, float* C,
-                                      int ldc, int batch, int64_t strideA, int64_t strideB,
-                                      int64_t strideC, int64_t strideScaleA, int64_t strideScaleB,
-                                      int epilogue, const float* bias, int64_t strideBias,
-                                      const float* aux, int ldaux, float alpha, float drop_ratio,
-                                      uint64_t seed, int accumulate, void* stream) {
+extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, int64_t slabA,
+                                           int64_t planeA, const float* scaleA, const void* B2,
+                                           int64_t slabB, int64_t planeB, const float* scaleB,
+                                           float* C, int ldc, int batch, int64_t strideA,
+                                           int64_t strideB, int64_t strideC, int64_t strideScaleA,
+                                           int64_t strideScaleB, int epilogue, const float* bias,
+                                           int64_t strideBias, const float* aux, int ldaux,
+                                           float alpha, float drop_ratio, uint64_t seed,
+                                           int accumulate, uint32_t* rowmax, int rowmax_seg_cols,
+                                           uint32_t* colmax, const float* colmax_rowmul,
+                                           void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return NAWS_ERR_SHAPE;
   NAWS_REQUIRE_PTR(A2); NAWS_REQUIRE_PTR(B2); NAWS_REQUIRE_PTR(C);
   NAWS_REQUIRE_PTR(scaleA); NAWS_REQUIRE_PTR(scaleB);
@@ -1114,6 +1437,15 @@ extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64
   g.drop_scale = (float)(1.0 / (1.0 - (double)drop_ratio));
   g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
   g.rs = scaleA; g.cs = scaleB; g.sRs = strideScaleA; g.sCs = strideScaleB;
+  if (rowmax || colmax) {
+    // a wave's columns must lie in one rowmax segment: segments are multiples of the widest tile
+    const int seg = rowmax_seg_cols > 0 ? rowmax_seg_cols : N;
+    if (rowmax && seg < N && seg % 256 != 0) return NAWS_ERR_ARG;
+    const int nseg = (int)naws_cdiv(N, seg);
+    g.am.rowmax = rowmax; g.am.colmax = colmax; g.am.colmul = colmax_rowmul;
+    g.am.seg_cols = seg >= N ? 0x40000000 : seg;
+    g.am.sRow = (long long)nseg * M; g.am.sCol = N;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (g_h2_variant < 0) {
     const char* e = getenv("NAWS_H2_VARIANT");
@@ -1134,8 +1466,29 @@ extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64
     case 2: return launch_x3<256, 256, 2, 4, 4, 2, 1, true>(g, batch, s);
     case 3: return launch_x3<256, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
     case 4: return launch_x3<256, 128, 2, 2, 3, 2, 2, true>(g, batch, s);
-    default: return launch_x3<256, 256, 2, 4, 2, 2, 2, true>(g, batch, s);
+    case 7: return launch_x3_m16<256, 256, 2, 4, 2, 2, 2, true>(g, batch, s);
+    case 10: return launch_x3_m16<256, 256, 4, 2, 2, 2, 2, true>(g, batch, s);
+    case 11: return launch_x3_m16<256, 128, 2, 2, 3, 2, 2, true>(g, batch, s);
+    case 9: return launch_x3<256, 256, 2, 4, 2, 2, 2, true>(g, batch, s);
+    // 16x16x32 MFMAs, 4 x 2 waves (64 x 128 per wave): the chip holds a higher clock on this shape
+    // in the power-limited long-K GEMMs (tools/ab_h2.py, interleaved: fc6 fwd 3.62 vs 3.83 ms)
+    default: return launch_x3_m16<256, 256, 4, 2, 2, 2, 2, true>(g, batch, s);
   }
+}
+
+extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA,
+                                      int64_t planeA, const float* scaleA, const void* B2,
+                                      int64_t slabB, int64_t planeB, const float* scaleB, float* C,
+                                      int ldc, int batch, int64_t strideA, int64_t strideB,
+                                      int64_t strideC, int64_t strideScaleA, int64_t strideScaleB,
+                                      int epilogue, const float* bias, int64_t strideBias,
+                                      const float* aux, int ldaux, float alpha, float drop_ratio,
+                                      uint64_t seed, int accumulate, void* stream) {
+  return naws_gemm_f32_f16x2_nt_amax(M, N, K, A2, slabA, planeA, scaleA, B2, slabB, planeB, scaleB,
+                                     C, ldc, batch, strideA, strideB, strideC, strideScaleA,
+                                     strideScaleB, epilogue, bias, strideBias, aux, ldaux, alpha,
+                                     drop_ratio, seed, accumulate, nullptr, 0, nullptr, nullptr,
+                                     stream);
 }
 
 extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const float* bias,
@@ -1278,5 +1631,10 @@ extern "C" int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_
   g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
   hipStream_t s = (hipStream_t)stream;
   if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 1, 4>(g, batch, s);
-  return launch_x3<256, 256, 2, 4, 2, 1, 4>(g, batch, s);
+  if (g_h2_variant < 0) {
+    const char* e = getenv("NAWS_H2_VARIANT");
+    g_h2_variant = e ? atoi(e) : 0;
+  }
+  if (g_h2_variant == 9) return launch_x3<256, 256, 2, 4, 2, 1, 4>(g, batch, s);
+  return launch_x3_m16<256, 256, 4, 2, 2, 1, 4, false>(g, batch, s);
 }

@@ -67,3 +67,112 @@ __device__ __forceinline__ void naws_f16x2_scales(unsigned bound_bits, float& s,
   s = __uint_as_float((unsigned)(268 - e) << 23);
   inv = __uint_as_float((unsigned)(e - 14) << 23);
 }
+
+// ---- |C| maxima reported by a GEMM epilogue ---------------------------------------------------------
+// The fp16x2 operand split needs max|x| per row (NT operand) and / or per column (transposed
+// operand) of a matrix a GEMM has just produced.  Instead of re-reading the matrix, the producing
+// kernel folds the values it stores into two device vectors of bit patterns (non-negative floats
+// order like unsigned words): registers -> wave shuffles -> one guarded atomicMax per row / column
+// per wave.  NaNs are skipped exactly as fmaxf skips them in the stand-alone pass (amax_kernel), so
+// the maxima - and therefore the planes - are bit-identical to the two-pass route.
+struct NawsAmax {
+  unsigned* rowmax;      // [batch][nseg][M]: max over the columns of segment col / seg_cols (nullable)
+  unsigned* colmax;      // [batch][N] (nullable)
+  const float* colmul;   // colmax is taken over |C[m][n] * colmul[m]| (nullable = 1)
+  int seg_cols;          // columns per rowmax segment (a multiple of the widest tile, or >= N)
+  long long sRow, sCol;  // elements between batch items
+};
+
+__device__ __forceinline__ void naws_atomic_max_bits(unsigned* p, float v) {
+  const unsigned b = __float_as_uint(v);
+  if (b > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, b);
+}
+
+// acc[i][j] = 32x32 blocks in the v_mfma_f32_32x32x* C/D layout (col = lane & 31,
+// row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)), holding the values as stored.
+template <int TI, int TJ, typename V16>
+__device__ __forceinline__ void naws_tile_amax_32(const V16 (&acc)[TI][TJ], int row_base, int col_base,
+                                                  int M, int N, int lane, const NawsAmax& a,
+                                                  long long bz) {
+  const int l31 = lane & 31, h = lane >> 5;
+  float colm[TJ];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) colm[j] = 0.f;
+  unsigned* rowmax = a.rowmax ? a.rowmax + bz * a.sRow + (long long)(col_base / a.seg_cols) * M : nullptr;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const float cmul = (a.colmul && row < M) ? fabsf(a.colmul[row]) : 1.f;
+      float rm = 0.f;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = col_base + j * 32 + l31;
+        if (row < M && col < N) {
+          const float av = fabsf(acc[i][j][e]);
+          rm = fmaxf(rm, av);
+          colm[j] = fmaxf(colm[j], av * cmul);
+        }
+      }
+      if (rowmax) {
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) rm = fmaxf(rm, __shfl_xor(rm, d));
+        if (l31 == 0 && row < M && rm > 0.f) naws_atomic_max_bits(rowmax + row, rm);
+      }
+    }
+  }
+  if (a.colmax) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const float cm = fmaxf(colm[j], __shfl_xor(colm[j], 32));
+      const int col = col_base + j * 32 + l31;
+      if (h == 0 && col < N && cm > 0.f) naws_atomic_max_bits(a.colmax + bz * a.sCol + col, cm);
+    }
+  }
+}
+
+// acc[i][j] = 16x16 blocks in the v_mfma_f32_16x16x* C/D layout (col = lane & 15,
+// row = (lane >> 4) * 4 + e).
+template <int TI, int TJ, typename V4>
+__device__ __forceinline__ void naws_tile_amax_16(const V4 (&acc)[TI][TJ], int row_base, int col_base,
+                                                  int M, int N, int lane, const NawsAmax& a,
+                                                  long long bz) {
+  const int l15 = lane & 15, kg = lane >> 4;
+  float colm[TJ];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) colm[j] = 0.f;
+  unsigned* rowmax = a.rowmax ? a.rowmax + bz * a.sRow + (long long)(col_base / a.seg_cols) * M : nullptr;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = row_base + i * 16 + kg * 4 + e;
+      const float cmul = (a.colmul && row < M) ? fabsf(a.colmul[row]) : 1.f;
+      float rm = 0.f;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = col_base + j * 16 + l15;
+        if (row < M && col < N) {
+          const float av = fabsf(acc[i][j][e]);
+          rm = fmaxf(rm, av);
+          colm[j] = fmaxf(colm[j], av * cmul);
+        }
+      }
+      if (rowmax) {
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) rm = fmaxf(rm, __shfl_xor(rm, d));
+        if (l15 == 0 && row < M && rm > 0.f) naws_atomic_max_bits(rowmax + row, rm);
+      }
+    }
+  }
+  if (a.colmax) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      float cm = fmaxf(colm[j], __shfl_xor(colm[j], 16));
+      cm = fmaxf(cm, __shfl_xor(cm, 32));
+      const int col = col_base + j * 16 + l15;
+      if (kg == 0 && col < N && cm > 0.f) naws_atomic_max_bits(a.colmax + bz * a.sCol + col, cm);
+    }
+  }
+}

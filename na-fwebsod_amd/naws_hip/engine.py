@@ -460,9 +460,16 @@ class WsddnEngine(object):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if h2:
+            # the GEMM epilogue reports max|h6| per row of each branch (fc7's operand scale) and,
+            # in training, per column (fc7 wgrad's): no pass over h6 for the maxima
+            self._new_amax_arena(rt, nb)
+            sc6n = self._scales(nb, rt)
+            sc6t = self._scales(nb, HIDDEN) if train else None
             h6 = ops.gemm_f32_f16x2_nt(xp, self._wplanes['w6'].rows(0, nb * HIDDEN), epilogue=epi,
                                        bias=b6, drop_ratio=self.dropout if drop else 0.0,
-                                       seed=self._seed(6))
+                                       seed=self._seed(6), rowmax=ops.amax_words(sc6n),
+                                       rowmax_seg=HIDDEN,
+                                       colmax=None if sc6t is None else ops.amax_words(sc6t))
         elif x3:
             h6 = ops.gemm_f32x3_nt(xp, self._wplanes['w6'][:, :, :nb * HIDDEN], epilogue=epi,
                                    bias=b6, drop_ratio=self.dropout if drop else 0.0,
@@ -481,9 +488,12 @@ class WsddnEngine(object):
         h7 = torch.empty((rt, nb * HIDDEN), device=self.device, dtype=torch.float32)
         h7v = h7.view(rt, nb, HIDDEN).permute(1, 0, 2)
         if h2:
-            ops.gemm_f32_f16x2_nt(ops.split_f16x2(h6v), self._wplanes['w7'].batches(nb), out=h7v,
+            # one pass over h6 writes both operand forms (rows for fc7, columns for fc7's wgrad)
+            h6n, self._h6t = ops.split_f16x2_dual(h6v, sc6n, sc6t)
+            ops.gemm_f32_f16x2_nt(h6n, self._wplanes['w7'].batches(nb), out=h7v,
                                   epilogue=epi, bias=b7, drop_ratio=self.dropout if drop else 0.0,
                                   seed=self._seed(7))
+            del h6n
         elif x3:
             ops.gemm_f32x3_nt(ops.split_bf16x3(h6v), self._wplanes['w7'][:, :nb], out=h7v,
                               epilogue=epi, bias=b7, drop_ratio=self.dropout if drop else 0.0,
@@ -504,6 +514,20 @@ class WsddnEngine(object):
         lgv = lg.view(rt, nb, ld8).permute(1, 0, 2)
         ops.gemm(h7v, w8g[:nb], False, True, out=lgv, epilogue=L.EPI_BIAS, bias=b8g)
         return h6, h7, lg
+
+    def _new_amax_arena(self, rt, nb):
+        """One zero-fill per step for every |.| maxima vector the GEMM epilogues accumulate into
+        (h6 rows + columns, dZ7 rows + columns, dZ6 columns)."""
+        need = 2 * (2 * nb * rt + 2 * nb * HIDDEN + 2 * HIDDEN) + 64
+        self._amax_arena = torch.zeros((need,), device=self.device, dtype=torch.float32)
+        self._amax_used = 0
+
+    def _scales(self, batch, outer):
+        n = 2 * batch * outer
+        o = self._amax_used
+        self._amax_used = (o + n + 3) // 4 * 4
+        assert self._amax_used <= self._amax_arena.numel()
+        return self._amax_arena[o:o + n].view(2, batch, outer)
 
     def _fc8_operands(self, w8, b8):
         C, ld8 = self.C, self.ld8
@@ -600,12 +624,28 @@ class WsddnEngine(object):
                                      .view(2, 2 * C))[0]
         dz7 = torch.empty_like(h7)
         dz7v = dz7.view(rt, 2, HIDDEN).permute(1, 0, 2)
-        ops.gemm(dlv, w8g, False, False, out=dz7v, epilogue=L.EPI_GATE_POS, aux=h7v, alpha=scale)
         dz6 = torch.empty_like(h6)
         dz6v = dz6.view(rt, 2, HIDDEN).permute(1, 0, 2)
-        if h2:      # dX = dZ W: W^T planes are kept beside the W planes
-            ops.gemm_f32_f16x2_nt(ops.split_f16x2(dz7v), self._wplanes['w7t'], out=dz6v,
-                                  epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
+        planes_x = h2 and isinstance(x, ops.F16x2)
+        if h2:
+            # every GEMM reports the maxima its consumer's operand split needs; each of dZ7 / dZ6
+            # is then read once by a split that writes all the forms in which it is multiplied
+            sc7n, sc7t, sc6t = self._scales(2, rt), self._scales(2, HIDDEN), self._scales(1, 2 * HIDDEN)
+            amax7 = dict(rowmax=ops.amax_words(sc7n), colmax=ops.amax_words(sc7t))
+        else:
+            amax7 = {}
+        ops.gemm(dlv, w8g, False, False, out=dz7v, epilogue=L.EPI_GATE_POS, aux=h7v, alpha=scale,
+                 **amax7)
+        if h2:
+            dz7n, dz7t = ops.split_f16x2_dual(dz7v, sc7n, sc7t)
+            # dX = dZ W: W^T planes are kept beside the W planes.  x's planes carry per-roi scales
+            # s_r: dW6 = sum_r (dZ6[r] / s_r) (x[r] s_r), so dZ6's column maxima are taken over
+            # dZ6[r] / s_r (exact: powers of two)
+            ops.gemm_f32_f16x2_nt(dz7n, self._wplanes['w7t'], out=dz6v,
+                                  epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale,
+                                  colmax=ops.amax_words(sc6t),
+                                  colmax_rowmul=x.inv_scale if planes_x else None)
+            del dz7n
         elif x3:
             ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v), self._wplanes['w7t'], out=dz6v,
                               epilogue=L.EPI_GATE_POS, aux=h6v, alpha=scale)
@@ -617,14 +657,13 @@ class WsddnEngine(object):
                      alpha=scale)
         # 2. fc6: dW = dZ6^T X in row chunks (both operands K(=rows)-contiguous through the
         # transposing split); each chunk's all-reduce starts while the next one is computed
-        if h2 and isinstance(x, ops.F16x2):
-            # x's planes carry per-roi scales s_r: dW = sum_r (dZ6[r] / s_r) (x[r] s_r) - the
-            # transposed planes are used as they are, dZ6's rows take the 1/s_r (exact)
-            dz6t = ops.split_f16x2(dz6, transpose=True, rowmul=x.inv_scale)
-            xt = ops.f16_planes_transpose(x)                   # planes [2, Rt/16, 25088, 16]
-        elif h2:
-            dz6t = ops.split_f16x2(dz6, transpose=True)        # planes [2, Rt/16, 8192, 16]
-            xt = ops.split_f16x2(x, transpose=True)            # planes [2, Rt/16, 25088, 16]
+        if h2:
+            # planes [2, Rt/16, 8192, 16] of (diag(1/s_r) dZ6)^T; x^T: the pooling kernel's planes
+            # transposed as they are, or a transposing split of the fp32 features
+            dz6t = ops.split_f16x2_dual(dz6, None, sc6t.view(2, 2 * HIDDEN),
+                                        rowmul=x.inv_scale if planes_x else None)[1]
+            xt = (ops.f16_planes_transpose(x) if planes_x           # planes [2, Rt/16, 25088, 16]
+                  else ops.split_f16x2(x, transpose=True))
         elif x3:
             dz6t = ops.split_bf16x3(dz6, transpose=True)       # [3, Rt/16, 8192, 16]
             xt = ops.split_bf16x3(x, transpose=True)           # [3, Rt/16, 25088, 16]
@@ -653,8 +692,8 @@ class WsddnEngine(object):
         # fc8 dW = dL^T H7, db
         ops.colsum(dz6, out=gb6)
         if h2:
-            ops.gemm_f32_f16x2_nt(ops.split_f16x2(dz7v, transpose=True),
-                                  ops.split_f16x2(h6v, transpose=True), out=gw7)
+            ops.gemm_f32_f16x2_nt(dz7t, self._h6t, out=gw7)
+            self._h6t = None
         elif x3:
             ops.gemm_f32x3_nt(ops.split_bf16x3(dz7v, transpose=True),
                               ops.split_bf16x3(h6v, transpose=True), out=gw7)

@@ -209,10 +209,22 @@ def roi_iou(rois):
 # ----------------------------------------------------------------------------
 # GEMM / FC
 # ----------------------------------------------------------------------------
+def _amax_args(rowmax, rowmax_seg, colmax, colmax_rowmul):
+    for t in (rowmax, colmax):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise TypeError('rowmax / colmax must be contiguous int32 (bit pattern) tensors')
+    if colmax_rowmul is not None:
+        _chk(colmax_rowmul, 'colmax_rowmul')
+    return (_ptr(rowmax), int(rowmax_seg), _ptr(colmax), _ptr(colmax_rowmul))
+
+
 def gemm(a, b, trans_a=False, trans_b=False, out=None, epilogue=L.EPI_NONE, bias=None, aux=None,
-         alpha=1.0, drop_ratio=0.0, seed=0, accumulate=False):
+         alpha=1.0, drop_ratio=0.0, seed=0, accumulate=False, rowmax=None, rowmax_seg=0,
+         colmax=None, colmax_rowmul=None):
     """C[M,N] (+)= op(A) op(B) on row-major 2-D (or batched 3-D) tensors.  Inputs may be
-    row-strided views (last dim contiguous)."""
+    row-strided views (last dim contiguous).  rowmax / colmax (zeroed int32 [batch, nseg, M] /
+    [batch, N]): receive the bit patterns of max|C| per row (per column segment of rowmax_seg
+    columns) / per column (of diag(colmax_rowmul) C) - what split_f16x2_dual consumes."""
     batched = a.dim() == 3
     if batched:
         batch = a.shape[0]
@@ -237,11 +249,12 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, epilogue=L.EPI_NONE, bias
     sbias = 0
     if bias is not None and bias.dim() == 2:
         sbias = bias.stride(0)
-    L.call('naws_gemm_f32', int(trans_a), int(trans_b), m, n, k, a.data_ptr(), a2.stride(0),
+    L.call('naws_gemm_f32_amax', int(trans_a), int(trans_b), m, n, k, a.data_ptr(), a2.stride(0),
            b.data_ptr(), b2.stride(0), out.data_ptr(), c2.stride(0), batch, sa, sb, sc,
            epilogue, _ptr(bias), sbias, _ptr(aux),
            (aux.stride(-2) if aux is not None else 0), float(alpha), float(drop_ratio),
-           int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate), _stream())
+           int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate),
+           *_amax_args(rowmax, rowmax_seg, colmax, colmax_rowmul), _stream())
     return out
 
 
@@ -596,9 +609,11 @@ def split_f16x2(x, transpose=False, out=None, rowmul=None):
 
 
 def gemm_f32_f16x2_nt(a, b, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, alpha=1.0,
-                      drop_ratio=0.0, seed=0, accumulate=False):
+                      drop_ratio=0.0, seed=0, accumulate=False, rowmax=None, rowmax_seg=0,
+                      colmax=None, colmax_rowmul=None):
     """C[M,N] (+)= A B^T from F16x2 operands (split_f16x2); fp32 in / fp32 accumulate / fp32 out
-    on the f16 MFMA with three products per K-slab.  Row-sliced operands (`.rows`) are fine."""
+    on the f16 MFMA with three products per K-slab.  Row-sliced operands (`.rows`) are fine.
+    rowmax / rowmax_seg / colmax / colmax_rowmul: as `gemm`."""
     a3, b3 = a.planes, b.planes
     batched = a3.dim() == 5
     for t in (a3, b3):
@@ -617,15 +632,62 @@ def gemm_f32_f16x2_nt(a, b, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, 
         out = torch.empty(((batch, mm, nn) if batched else (mm, nn)), device=a3.device, dtype=_f32)
     c2 = out[0] if batched else out
     sbias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
-    L.call('naws_gemm_f32_f16x2_nt', mm, nn, k, a3.data_ptr(), a3.stride(-3), a3.stride(0),
+    L.call('naws_gemm_f32_f16x2_nt_amax', mm, nn, k, a3.data_ptr(), a3.stride(-3), a3.stride(0),
            sa.data_ptr(), b3.data_ptr(), b3.stride(-3), b3.stride(0), sb.data_ptr(),
            out.data_ptr(), c2.stride(0), batch,
            (a3.stride(1) if batched else 0), (b3.stride(1) if batched else 0),
            (out.stride(0) if batched else 0), (sa.stride(0) if batched else 0),
            (sb.stride(0) if batched else 0), epilogue, _ptr(bias), sbias, _ptr(aux),
            (aux.stride(-2) if aux is not None else 0), float(alpha), float(drop_ratio),
-           int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate), _stream())
+           int(seed) & 0xFFFFFFFFFFFFFFFF, int(accumulate),
+           *_amax_args(rowmax, rowmax_seg, colmax, colmax_rowmul), _stream())
     return out
+
+
+def amax_scales(batch, outer, device):
+    """Zeroed scale block [2, (batch,) outer] of an F16x2 whose maxima a GEMM epilogue will report:
+    [0] (viewed as int32 bit patterns: `amax_words`) is the rowmax / colmax accumulator, [1]
+    receives 1/scale from split_f16x2_dual."""
+    return torch.zeros((2, batch, outer) if batch else (2, outer), device=device, dtype=_f32)
+
+
+def amax_words(scales):
+    return scales[0].view(torch.int32)
+
+
+def split_f16x2_dual(x, scales_n=None, scales_t=None, rowmul=None):
+    """One pass over x (fp32 [rows, cols] or [b, rows, cols], last dim contiguous) -> the
+    row-scaled planes (F16x2, outer = rows, K = cols) when `scales_n` is given and / or the
+    column-scaled transposed planes of diag(rowmul) x (outer = cols, K = rows) when `scales_t` is
+    given.  scales_* are `amax_scales` blocks whose [0] already holds the maxima (bit patterns)
+    reported by the GEMM that produced x.  Returns (normal or None, transposed or None)."""
+    batched = x.dim() == 3
+    x2 = x[0] if batched else x
+    if not x.is_cuda or x.dtype != _f32 or x2.stride(1) != 1:
+        raise TypeError('x must be a HIP fp32 tensor with a contiguous last dim')
+    batch = x.shape[0] if batched else 1
+    rows, cols = x2.shape
+    kn, kt = (cols + 31) // 32 * 32, (rows + 31) // 32 * 32
+    bs = (batch,) if batched else ()
+    pn = pt = None
+    if scales_n is not None:
+        pn = F16x2(torch.empty((2, *bs, kn // 16, rows, 16), device=x.device, dtype=torch.float16),
+                   scales_n)
+    if scales_t is not None:
+        pt = F16x2(torch.empty((2, *bs, kt // 16, cols, 16), device=x.device, dtype=torch.float16),
+                   scales_t)
+    for sc, outer in ((scales_n, rows), (scales_t, cols)):
+        if sc is not None and (tuple(sc.shape) != (2, *bs, outer) or sc.dtype != _f32
+                               or not sc.is_contiguous()):
+            raise TypeError('scales must be contiguous fp32 [2, (batch,) outer] blocks')
+    if rowmul is not None and (rowmul.numel() != rows or rowmul.dtype != _f32
+                               or not rowmul.is_contiguous()):
+        raise TypeError('rowmul must be a contiguous fp32 vector with one entry per source row')
+    L.call('naws_split_f16x2_dual', x.data_ptr(), batch, rows, cols, x2.stride(0),
+           (x.stride(0) if batched else 0), _ptr(scales_n), _ptr(scales_t), _ptr(rowmul),
+           _ptr(pn.planes if pn else None), _ptr(scales_n), kn,
+           _ptr(pt.planes if pt else None), _ptr(scales_t), kt, _stream())
+    return pn, pt
 
 
 def dropout_mask(seed, ratio, n, device):

@@ -374,3 +374,52 @@ def test_roi_pool_planes_transpose_and_kscaled_split(dev):
     fwd = ops.gemm_f32_f16x2_nt(op, ops.split_f16x2(_t(wgt, dev))).cpu().numpy()
     want2 = ref @ wgt.astype(np.float64).T
     assert (np.abs(fwd - want2) <= 2e-6 * (np.abs(ref) @ np.abs(wgt).astype(np.float64).T) + 1e-30).all()
+
+
+@pytest.mark.parametrize('m,n,k,seg,kind', [
+    (300, 512, 96, 256, 'h2'),          # 128x128 tiles (32x32 MFMA layout), two rowmax segments
+    (4096, 4096, 1056, 0, 'h2'),        # 256x256 tiles on the 16x16x32 MFMA layout, one segment
+    (4000, 8192, 1056, 4096, 'h2'),     # fc6's shape in M / N: ragged rows, two branches
+    (333, 768, 40, 256, 'f32'),         # the fp32-MFMA kernel (dZ7 = dL W8)
+])
+def test_gemm_reported_maxima_and_dual_split_are_bit_identical(dev, m, n, k, seg, kind):
+    """The maxima a GEMM epilogue reports (per row of each column segment, per column of
+    diag(rowmul) C) and the one-pass dual split give exactly the planes and scales of the
+    stand-alone amax + split passes they replace - incl. gated (zero) entries, NaN and inf."""
+    from naws_hip import ops, lib as L
+    g = torch.Generator(device=dev).manual_seed(m + n)
+    a = torch.randn((m, k), device=dev, generator=g)
+    b = torch.randn((n, k), device=dev, generator=g) * 0.05
+    aux = torch.randn((m, n), device=dev, generator=g)
+    rowmul = torch.exp2(torch.randint(-6, 7, (m,), device=dev, generator=g).float())
+    nseg = 1 if seg == 0 else n // seg
+    sc_n = ops.amax_scales(nseg, m, dev)
+    sc_t = ops.amax_scales(0, n, dev)
+    kw = dict(epilogue=L.EPI_GATE_POS, aux=aux, alpha=2.0, rowmax=ops.amax_words(sc_n),
+              rowmax_seg=seg, colmax=ops.amax_words(sc_t), colmax_rowmul=rowmul)
+    if kind == 'h2':
+        a[5, 3] = float('nan')
+        a[9, 1] = float('inf')
+        c = ops.gemm_f32_f16x2_nt(ops.split_f16x2(a), ops.split_f16x2(b), **kw)
+    else:
+        c = ops.gemm(a, b, False, True, **kw)
+    cv = c.view(m, nseg, n // nseg).permute(1, 0, 2)            # the branches as a batch
+    want_n = ops.split_f16x2(cv)
+    want_t = ops.split_f16x2(c, transpose=True, rowmul=rowmul)
+    got_n, got_t = ops.split_f16x2_dual(cv, sc_n, None)[0], \
+        ops.split_f16x2_dual(c, None, sc_t, rowmul=rowmul)[1]
+    for got, want in ((got_n, want_n), (got_t, want_t)):
+        assert torch.equal(got.inv_scale, want.inv_scale)
+        assert torch.equal(got.planes.view(torch.int16), want.planes.view(torch.int16))
+    # both forms from one launch (no rowmul on either side)
+    sc_n2, sc_t2 = ops.amax_scales(0, m, dev), ops.amax_scales(0, n, dev)
+    if kind == 'h2':
+        c2 = ops.gemm_f32_f16x2_nt(ops.split_f16x2(a), ops.split_f16x2(b),
+                                   rowmax=ops.amax_words(sc_n2), colmax=ops.amax_words(sc_t2))
+    else:
+        c2 = ops.gemm(a, b, False, True, rowmax=ops.amax_words(sc_n2), colmax=ops.amax_words(sc_t2))
+    gn, gt = ops.split_f16x2_dual(c2, sc_n2, sc_t2)
+    wn, wt = ops.split_f16x2(c2), ops.split_f16x2(c2, transpose=True)
+    for got, want in ((gn, wn), (gt, wt)):
+        assert torch.equal(got.inv_scale, want.inv_scale)
+        assert torch.equal(got.planes.view(torch.int16), want.planes.view(torch.int16))
