@@ -235,6 +235,18 @@ int naws_acm_sgd_update(const float* grad, float* momentum_buf, const float* lr,
                         const float* seg_lr_mult, const float* seg_wd, int nseg,
                         float momentum, int nesterov, int iter_size, int gpu_num,
                         int64_t iter_count, void* stream);
+/* The same update, additionally reporting max|updated parameter| per matrix row of up to 4
+ * regions of the arena (for the fp16x2 re-split of the weights that follows: naws_split_f16x2_dual
+ * then needs no maxima pass).  rm_table_host: HOST int64 [n_rm][4] = {first element, end element,
+ * row length, first index in rowmax}, n_rm <= 4, starts and row lengths multiples of 256 floats
+ * (passed to the kernel by value).  rowmax: uint32 bit patterns, atomically max-ed into (the
+ * caller zeroes them); untouched on iterations that only accumulate. */
+int naws_acm_sgd_update_rowmax(const float* grad, float* momentum_buf, const float* lr,
+                               float* param, float* acmgrad, int64_t total, const int64_t* seg_end,
+                               const float* seg_lr_mult, const float* seg_wd, int nseg,
+                               float momentum, int nesterov, int iter_size, int gpu_num,
+                               int64_t iter_count, uint32_t* rowmax, const int64_t* rm_table_host,
+                               int n_rm, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * a-14  Stat accumulate   ref: detectron/ops/stat_op.cu:14-20, :24-78

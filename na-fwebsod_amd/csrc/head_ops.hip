@@ -333,12 +333,17 @@ __global__ void stat_kernel(const float* __restrict__ I, const float* __restrict
 }
 
 // ---- fused ACM weight-decay momentum SGD over a parameter arena ------------
+struct SgdRowmaxRegions {      // rows whose max|updated parameter| is reported (fp16x2 re-split)
+  long long start[4], end[4], rowlen[4], out[4];
+  int n;
+};
+
 __global__ __launch_bounds__(TB) void acm_sgd_kernel(
     const float4* __restrict__ grad, float4* __restrict__ mom, const float* __restrict__ lr,
     float4* __restrict__ param, float4* __restrict__ acm, int64_t total4,
     const int64_t* __restrict__ seg_end, const float* __restrict__ seg_lr_mult,
     const float* __restrict__ seg_wd, int nseg, float momentum, int nesterov, float scale,
-    int do_update, int first) {
+    int do_update, int first, unsigned* __restrict__ rowmax, SgdRowmaxRegions rm) {
   const float base_lr = lr[0];
   for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total4;
        i += (int64_t)gridDim.x * TB) {
@@ -378,6 +383,28 @@ __global__ __launch_bounds__(TB) void acm_sgd_kernel(
     mom[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
     param[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
     if (acm) acm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rowmax) {
+      // max|updated parameter| per matrix row, for the fp16x2 re-split of the weights that
+      // follows (saves its 0.96 GB maxima pass).  A wave's 64 float4s are 256 consecutive floats
+      // and the regions' starts / row lengths are multiples of 256 (checked on the host): the
+      // wave lies in one row.
+      // (region table in SGPRs; the atomic has no return value and nothing waits for it)
+      const int64_t i0 = i - (threadIdx.x & 63);          // wave-uniform: keep it on the scalar unit
+      const int64_t e0 = (((int64_t)__builtin_amdgcn_readfirstlane((int)(i0 >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)i0)) * 4;
+      float m = fmaxf(fmaxf(fabsf(pv[0]), fabsf(pv[1])), fmaxf(fabsf(pv[2]), fabsf(pv[3])));
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r < rm.n && e0 >= rm.start[r] && e0 < rm.end[r]) {
+          // 256-float chunk index / chunks per row (both < 2^24)
+          const unsigned row = (unsigned)((e0 - rm.start[r]) >> 8) / (unsigned)(rm.rowlen[r] >> 8);
+          if ((threadIdx.x & 63) == 0 && m > 0.f)
+            atomicMax(rowmax + rm.out[r] + row, __float_as_uint(m));
+        }
+      }
+    }
   }
 }
 
@@ -535,11 +562,13 @@ extern "C" int naws_stat_accumulate(const float* I, const float* L, int n, int i
   return naws_check_launch();
 }
 
-extern "C" int naws_acm_sgd_update(const float* grad, float* momentum_buf, const float* lr,
-                                   float* param, float* acmgrad, int64_t total,
-                                   const int64_t* seg_end, const float* seg_lr_mult,
-                                   const float* seg_wd, int nseg, float momentum, int nesterov,
-                                   int iter_size, int gpu_num, int64_t iter_count, void* stream) {
+extern "C" int naws_acm_sgd_update_rowmax(const float* grad, float* momentum_buf, const float* lr,
+                                          float* param, float* acmgrad, int64_t total,
+                                          const int64_t* seg_end, const float* seg_lr_mult,
+                                          const float* seg_wd, int nseg, float momentum,
+                                          int nesterov, int iter_size, int gpu_num,
+                                          int64_t iter_count, uint32_t* rowmax,
+                                          const int64_t* rm_table_host, int n_rm, void* stream) {
   if (total <= 0 || nseg <= 0 || iter_size <= 0 || gpu_num <= 0 || iter_count < 0)
     return NAWS_ERR_SHAPE;
   if (total % 4 != 0) return NAWS_ERR_ARG;
@@ -549,6 +578,18 @@ extern "C" int naws_acm_sgd_update(const float* grad, float* momentum_buf, const
   NAWS_REQUIRE_PTR(seg_lr_mult); NAWS_REQUIRE_PTR(seg_wd);
   if ((((uintptr_t)grad | (uintptr_t)momentum_buf | (uintptr_t)param | (uintptr_t)acmgrad) % 16))
     return NAWS_ERR_ARG;
+  SgdRowmaxRegions rm{};
+  if (rowmax) {
+    if (n_rm <= 0 || n_rm > 4) return NAWS_ERR_ARG;
+    NAWS_REQUIRE_PTR(rm_table_host);
+    for (int r = 0; r < n_rm; ++r) {
+      const int64_t* t = rm_table_host + 4 * r;
+      if (t[0] < 0 || t[1] > total || t[0] >= t[1] || t[2] <= 0 || t[3] < 0) return NAWS_ERR_SHAPE;
+      if (t[0] % 256 != 0 || t[2] % 256 != 0 || (t[1] - t[0]) % t[2] != 0) return NAWS_ERR_ARG;
+      rm.start[r] = t[0]; rm.end[r] = t[1]; rm.rowlen[r] = t[2]; rm.out[r] = t[3];
+    }
+    rm.n = n_rm;
+  }
   const int64_t total4 = total / 4;
   const int do_update = ((iter_count + 1) % iter_size == 0) ? 1 : 0;
   const float scale = (float)(1.0 / ((double)iter_size * (double)gpu_num));
@@ -556,8 +597,19 @@ extern "C" int naws_acm_sgd_update(const float* grad, float* momentum_buf, const
   hipLaunchKernelGGL(acm_sgd_kernel, dim3(blocks), dim3(TB), 0, (hipStream_t)stream,
                      (const float4*)grad, (float4*)momentum_buf, lr, (float4*)param, (float4*)acmgrad,
                      total4, seg_end, seg_lr_mult, seg_wd, nseg, momentum, nesterov, scale,
-                     do_update, iter_count == 0 ? 1 : 0);
+                     do_update, iter_count == 0 ? 1 : 0, (unsigned*)(do_update ? rowmax : nullptr),
+                     rm);
   return naws_check_launch();
+}
+
+extern "C" int naws_acm_sgd_update(const float* grad, float* momentum_buf, const float* lr,
+                                   float* param, float* acmgrad, int64_t total,
+                                   const int64_t* seg_end, const float* seg_lr_mult,
+                                   const float* seg_wd, int nseg, float momentum, int nesterov,
+                                   int iter_size, int gpu_num, int64_t iter_count, void* stream) {
+  return naws_acm_sgd_update_rowmax(grad, momentum_buf, lr, param, acmgrad, total, seg_end,
+                                    seg_lr_mult, seg_wd, nseg, momentum, nesterov, iter_size,
+                                    gpu_num, iter_count, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int naws_min_entropy_loss_fwd(const float* X, const float* L, int N, int C, float* Y,

@@ -199,6 +199,10 @@ class WsddnEngine(object):
         self.roi_planes = True
         # fp16x2: pool1..pool3 inside the epilogue of the direct conv kernel that feeds them
         self.fuse_pool = True
+        # fp16x2: the SGD kernel reports the updated weight rows' maxima (no maxima pass in the
+        # re-split that follows it on the update stream)
+        self.fused_wmax = True
+        self._rm_table = None
         self._amax5 = None
         self.conv_direct_h2 = {}
         self._streams = []
@@ -230,7 +234,21 @@ class WsddnEngine(object):
         w6, w7 = self._weight_views()
         cv = {'fp32x3': ops.split_bf16x3, 'fp16x2': ops.split_f16x2}.get(self.mfma_dtype,
                                                                          ops.to_bf16_slab)
-        if self._wplanes is None:
+        if self._wplanes is None and self.mfma_dtype == 'fp16x2':
+            # the scale blocks of w6 / w7 live in one arena, [operand][maxima | 1/scale][8192], so
+            # that the fused SGD kernel can report the updated rows' maxima straight into them
+            n6 = 2 * HIDDEN
+            self._wscales = torch.zeros((4 * n6,), device=self.device, dtype=torch.float32)
+            f16 = dict(device=self.device, dtype=torch.float16)
+            p6 = ops.F16x2(torch.empty((2, self.k6 // 16, n6, 16), **f16),
+                           self._wscales[:2 * n6].view(2, n6))
+            p7 = ops.F16x2(torch.empty((2, 2, HIDDEN // 16, HIDDEN, 16), **f16),
+                           self._wscales[2 * n6:].view(2, 2, HIDDEN))
+            self._wplanes = dict(w6=cv(w6, out=p6), w7=cv(w7, out=p7), w7t=cv(w7, transpose=True))
+            o6, o7 = self.arena.offsets['fc6_w'][0], self.arena.offsets['fc7_w'][0]
+            self._rm_table = ops.RowmaxTable([(o6, o6 + n6 * self.k6, self.k6, 0),
+                                              (o7, o7 + n6 * HIDDEN, HIDDEN, 2 * n6)], self.device)
+        elif self._wplanes is None:
             self._wplanes = dict(w6=cv(w6), w7=cv(w7), w7t=cv(w7, transpose=True))
         else:
             cv(w6, out=self._wplanes['w6'])
@@ -774,15 +792,33 @@ class WsddnEngine(object):
         if uev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        # fp16x2: the SGD kernel reports max|w| of every updated fc6_w / fc7_w row into the scale
+        # blocks of their operand planes, so the re-split reads the weights once (k6 % 256: a
+        # wave's 256 floats stay in one row)
+        fused = (self.fused_wmax and self.mfma_dtype == 'fp16x2' and self._wplanes is not None
+                 and self.iter_size == 1 and self.k6 % 256 == 0)
+        rowmax = None
+        if fused:
+            self._wscales.view(2, 2, 2 * HIDDEN)[:, 0].zero_()
+            rowmax = self._wscales.view(torch.int32)
         ops.acm_sgd_update(self.grads, self.momentum_buf, self.lr, self.params, self.acmgrad,
                            self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
-                           self.iter_size, self.gpu_num, self.sgd_iter_count)
+                           self.iter_size, self.gpu_num, self.sgd_iter_count, rowmax=rowmax,
+                           rm_table=self._rm_table if fused else None)
         if uev is not None:
             e1.record()
             uev.append((e0, e1))
         self.sgd_iter_count += 1
-        if self.mfma_dtype != 'fp32' and self._wplanes is not None:
-            self._refresh_weight_planes()      # same stream as the update: hidden with it
+        if fused:                              # same stream as the update: hidden with it
+            w6, w7 = self._weight_views()
+            wp = self._wplanes
+            q6 = ops.split_f16x2_dual(w6, wp['w6'].scales, None, out_n=wp['w6'])[0]
+            q7 = ops.split_f16x2_dual(w7, wp['w7'].scales, None, out_n=wp['w7'])[0]
+            assert q6 is wp['w6'] and q7 is wp['w7']
+            ops.split_f16x2(w7, transpose=True, out=wp['w7t'])
+            self._planes_dirty = False
+        elif self.mfma_dtype != 'fp32' and self._wplanes is not None:
+            self._refresh_weight_planes()
 
     # -------------------------------------------------------------- inference
     def infer(self, data, rois, obn_scores, seg=None):

@@ -47,6 +47,8 @@ PROTOTYPES = {
     'naws_weighted_ce_fwd': [p, p, p, i32, i32, i32, i32, p, p],
     'naws_weighted_ce_bwd': [p, p, p, p, i32, i32, i32, i32, p, p],
     'naws_acm_sgd_update': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p],
+    'naws_acm_sgd_update_rowmax': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p, p,
+                                   i32, p],
     'naws_stat_accumulate': [p, p, i32, i32, p, p, p],
     'naws_unary_f32': [i32, p, i64, f32, f32, p, p],
     'naws_binary_f32': [i32, p, i32, i32, p, i32, i32, p, i32, i32, p],

@@ -655,7 +655,7 @@ def amax_words(scales):
     return scales[0].view(torch.int32)
 
 
-def split_f16x2_dual(x, scales_n=None, scales_t=None, rowmul=None):
+def split_f16x2_dual(x, scales_n=None, scales_t=None, rowmul=None, out_n=None, out_t=None):
     """One pass over x (fp32 [rows, cols] or [b, rows, cols], last dim contiguous) -> the
     row-scaled planes (F16x2, outer = rows, K = cols) when `scales_n` is given and / or the
     column-scaled transposed planes of diag(rowmul) x (outer = cols, K = rows) when `scales_t` is
@@ -671,11 +671,16 @@ def split_f16x2_dual(x, scales_n=None, scales_t=None, rowmul=None):
     bs = (batch,) if batched else ()
     pn = pt = None
     if scales_n is not None:
-        pn = F16x2(torch.empty((2, *bs, kn // 16, rows, 16), device=x.device, dtype=torch.float16),
-                   scales_n)
+        pn = out_n if out_n is not None else F16x2(
+            torch.empty((2, *bs, kn // 16, rows, 16), device=x.device, dtype=torch.float16), scales_n)
     if scales_t is not None:
-        pt = F16x2(torch.empty((2, *bs, kt // 16, cols, 16), device=x.device, dtype=torch.float16),
-                   scales_t)
+        pt = out_t if out_t is not None else F16x2(
+            torch.empty((2, *bs, kt // 16, cols, 16), device=x.device, dtype=torch.float16), scales_t)
+    for o, sc, shape in ((pn, scales_n, (2, *bs, kn // 16, rows, 16)),
+                         (pt, scales_t, (2, *bs, kt // 16, cols, 16))):
+        if o is not None and (tuple(o.planes.shape) != shape or not o.planes.is_contiguous()
+                              or o.scales.data_ptr() != sc.data_ptr()):
+            raise TypeError('out planes must be contiguous %s with the given scales block' % (shape,))
     for sc, outer in ((scales_n, rows), (scales_t, cols)):
         if sc is not None and (tuple(sc.shape) != (2, *bs, outer) or sc.dtype != _f32
                                or not sc.is_contiguous()):
@@ -792,12 +797,29 @@ def weighted_ce_grad(x, l, w, dy, is_mean, nprob=1):
 
 
 def acm_sgd_update(grad, momentum_buf, lr, param, acmgrad, seg_end, seg_lr_mult, seg_wd,
-                   momentum, nesterov, iter_size, gpu_num, iter_count):
+                   momentum, nesterov, iter_size, gpu_num, iter_count, rowmax=None, rm_table=None):
+    """rowmax (zeroed int32 words) + rm_table (RowmaxTable): also report max|updated parameter|
+    per matrix row of the table's arena regions."""
     total = param.numel()
+    if rowmax is not None:
+        L.call('naws_acm_sgd_update_rowmax', grad.data_ptr(), momentum_buf.data_ptr(),
+               lr.data_ptr(), param.data_ptr(), _ptr(acmgrad), total, seg_end.data_ptr(),
+               seg_lr_mult.data_ptr(), seg_wd.data_ptr(), seg_end.numel(), float(momentum),
+               int(nesterov), int(iter_size), int(gpu_num), int(iter_count), rowmax.data_ptr(),
+               rm_table.host.ctypes.data, rm_table.n, _stream())
+        return
     L.call('naws_acm_sgd_update', grad.data_ptr(), momentum_buf.data_ptr(), lr.data_ptr(),
            param.data_ptr(), _ptr(acmgrad), total, seg_end.data_ptr(), seg_lr_mult.data_ptr(),
            seg_wd.data_ptr(), seg_end.numel(), float(momentum), int(nesterov), int(iter_size),
            int(gpu_num), int(iter_count), _stream())
+
+
+class RowmaxTable(object):
+    """[(first element, end element, row length, first rowmax index)] for acm_sgd_update."""
+
+    def __init__(self, rows, device):
+        self.host = np.ascontiguousarray(np.asarray(rows, dtype=np.int64).reshape(-1, 4))
+        self.n = self.host.shape[0]
 
 
 def stat_accumulate(i, l, ai, al, init):

@@ -230,3 +230,24 @@ def test_rccl_chunked_allreduce_single_rank(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_weight_planes_after_fused_update_match_fresh_split(dev):
+    """fp16x2: the SGD kernel reports the updated rows' maxima and the re-split reads the weights
+    once - the operand planes must equal a from-scratch split of the updated parameters."""
+    from naws_hip import ops
+    eng, mb, _blobs = _setup(dev, mfma_dtype='fp16x2')
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    eng.set_lr(1e-2)
+    for _ in range(2):
+        eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+        eng.sgd_step()
+    eng.flush()
+    torch.cuda.synchronize()
+    assert eng._rm_table is not None and not eng._planes_dirty
+    w6, w7 = eng._weight_views()
+    for key, fresh in (('w6', ops.split_f16x2(w6)), ('w7', ops.split_f16x2(w7)),
+                       ('w7t', ops.split_f16x2(w7, transpose=True))):
+        got = eng._wplanes[key]
+        assert torch.equal(got.inv_scale, fresh.inv_scale), key
+        assert torch.equal(got.planes.view(torch.int16), fresh.planes.view(torch.int16)), key
