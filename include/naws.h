@@ -432,6 +432,21 @@ int naws_roi_pool_f_f16x2_fwd(const float* X, int N, int C, int H, int W, const 
                               const float* boost, int pooled_h, int pooled_w, float spatial_scale,
                               const uint32_t* amax_words, int n_words, void* planes, float* scales,
                               void* stream);
+/* Hierarchical forms of RoIPoolF (+ boost) on NHWC features (same operator, same values bit for
+ * bit: reference detectron/modeling/detector.py:319-329, detectron/ops/roi_loop_pool_op.cu:31-101):
+ * the bin maxima are taken over precomputed 2x2 / 4x4 block maxima (max is idempotent), which cuts
+ * the window gather ~8x.  workspace: naws_roi_pool_workspace_floats(N, C, H, W) floats (the two
+ * block-maxima maps, built by the call).  C % 64 == 0; no argmax.
+ * naws_roi_pool_f_nhwc_hier_fwd writes Y fp32 [R][C][ph][pw]; naws_roi_pool_f_f16x2_hier_fwd the
+ * fp16x2 operand planes exactly as naws_roi_pool_f_f16x2_fwd. */
+int64_t naws_roi_pool_workspace_floats(int N, int C, int H, int W);
+int naws_roi_pool_f_nhwc_hier_fwd(const float* X, int N, int C, int H, int W, const float* rois,
+                                  int R, const float* boost, int pooled_h, int pooled_w,
+                                  float spatial_scale, float* workspace, float* Y, void* stream);
+int naws_roi_pool_f_f16x2_hier_fwd(const float* X, int N, int C, int H, int W, const float* rois,
+                                   int R, const float* boost, int pooled_h, int pooled_w,
+                                   float spatial_scale, const uint32_t* amax_words, int n_words,
+                                   float* workspace, void* planes, float* scales, void* stream);
 /* Q f16 [2][Rpad/16][K][16] = transposition of P f16 [2][K/16][R][16] (Rpad = R rounded up to 32,
  * rows >= R zero): the K(=rois)-contiguous form of the same scaled matrix, B operand of
  * fc6's dW = dY^T X with a scale vector of ones, provided dY is split by

@@ -17,6 +17,15 @@ def dedup_rois(rois, dedup_boxes):
     return rois[index, :], index, inv_index
 
 
+def project_rois(boxes, im_scale):
+    """[n,4] image boxes -> the [n,5] rois blob: the product is taken in float64 and the blob cast
+    to float32 afterwards, as the reference does (core/test_wsl.py:998-1026: `im_rois.astype(np.float)
+    * scales`, then `astype(np.float32)`) - a float32 product can differ in the last bit, which
+    moves a RoIPool bin edge when a coordinate sits on a rounding boundary."""
+    rois = np.asarray(boxes).astype(np.float64) * im_scale
+    return np.hstack((np.zeros((rois.shape[0], 1)), rois)).astype(np.float32)
+
+
 def _device_image_blob(dev, im, im_scale, flip):
     """The [1,3,H',W'] input blob prepared on the GPU (naws_prep_image_fwd: mean/std, optional
     flip, cv2-semantics bilinear resize) when the image holds 8-bit pixel values; None otherwise."""
@@ -44,7 +53,7 @@ def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_score
         imh = np.ascontiguousarray(im[:, ::-1, :]) if flip else im
         blob_im, im_scale = prep_im_for_blob(imh, cfg.PIXEL_MEANS, target_scale, target_max_size)
         data = torch.from_numpy(im_list_to_blob([blob_im])).to(dev)
-    rois = np.hstack((np.zeros((boxes.shape[0], 1), np.float32), boxes * im_scale)).astype(np.float32)
+    rois = project_rois(boxes, im_scale)
     obn = (obn_scores + 1.0).astype(np.float32)
     inv_index = None
     if cfg.DEDUP_BOXES > 0:
@@ -102,7 +111,7 @@ def im_detect_bbox_pair(executor, im, target_scale, target_max_size, boxes, obn_
         return s0, s1
     rois, obns, invs, seg = [], [], [], [0]
     for b, bx in enumerate((boxes, flip_boxes(boxes, im.shape[1]))):
-        r = np.hstack((np.zeros((bx.shape[0], 1), np.float32), bx * im_scale)).astype(np.float32)
+        r = project_rois(bx, im_scale)
         o = (obn_scores + 1.0).astype(np.float32)
         inv = None
         if cfg.DEDUP_BOXES > 0:

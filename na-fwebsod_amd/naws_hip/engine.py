@@ -203,6 +203,9 @@ class WsddnEngine(object):
         # re-split that follows it on the update stream)
         self.fused_wmax = True
         self._rm_table = None
+        # RoIPoolF over 2x2 / 4x4 block maxima of conv5_3 (csrc/roi_ops.hip): same values, ~8x less
+        # gather traffic
+        self.roi_hier = True
         self._amax5 = None
         self.conv_direct_h2 = {}
         self._streams = []
@@ -442,9 +445,10 @@ class WsddnEngine(object):
         planes written by the pooling kernel itself."""
         if self._amax5 is not None:
             return ops.roi_pool_f_f16x2(conv5, rois, self._amax5, self.roi_size, self.roi_size,
-                                        self.spatial_scale, boost=obn_scores.reshape(-1))
+                                        self.spatial_scale, boost=obn_scores.reshape(-1),
+                                        hier=self.roi_hier)
         roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
-                                  boost=obn_scores.reshape(-1), layout='NHWC')
+                                  boost=obn_scores.reshape(-1), layout='NHWC', hier=self.roi_hier)
         return roi_feat.view(rois.shape[0], self.k6)
 
     def head_forward(self, roi_feat, train, both_branches=True):

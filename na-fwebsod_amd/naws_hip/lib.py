@@ -77,6 +77,9 @@ PROTOTYPES = {
     'naws_split_f16x2_kscaled': [p, i32, i32, i32, i32, i64, i32, i32, p, p, p, p],
     'naws_roi_pool_f_f16x2_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, i32, p, p, p],
     'naws_f16_planes_transpose': [p, i32, i32, i32, p, p],
+    'naws_roi_pool_f_nhwc_hier_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, p, p],
+    'naws_roi_pool_f_f16x2_hier_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, i32, p, p, p,
+                                       p],
     'naws_conv3x3_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, p, p, f32, f32, p, i32, p],
     'naws_amax_f32': [p, i64, p, p],
     'naws_conv3x3_winograd_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p],
@@ -95,6 +98,7 @@ SPECIAL = {
     'naws_entropy_gate_workspace_floats': ([i32, i32, i32, i32], i64),
     'naws_winograd_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
     'naws_nms_workspace_bytes': ([i32, i32], i64),
+    'naws_roi_pool_workspace_floats': ([i32, i32, i32, i32], i64),
     'naws_winograd_f32x3_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
     'naws_winograd_f16x2_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
 }

@@ -111,7 +111,7 @@ def nhwc_to_nchw(x):
 # RoI ops
 # ----------------------------------------------------------------------------
 def roi_pool_f(x, rois, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
-               layout='NCHW', with_argmax=False, out=None):
+               layout='NCHW', with_argmax=False, out=None, hier=False):
     _chk(x, 'x'); _chk(rois, 'rois')
     if rois.dim() != 2 or rois.shape[1] != 5:
         raise L.NawsError('naws_roi_pool_f_fwd', L.ERR_SHAPE)
@@ -129,6 +129,14 @@ def roi_pool_f(x, rois, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
         assert boost.numel() == r
     y = out if out is not None else torch.empty((r, c, pooled_h, pooled_w), device=x.device,
                                                 dtype=_f32)
+    if hier and layout == 'NHWC' and not with_argmax and c % 64 == 0 and r > 0:
+        # bin maxima over precomputed 2x2 / 4x4 block maxima: same values, ~8x less gather
+        ws = torch.empty((L.load().naws_roi_pool_workspace_floats(n, c, h, w),), device=x.device,
+                         dtype=_f32)
+        L.call('naws_roi_pool_f_nhwc_hier_fwd', x.data_ptr(), n, c, h, w, rois.data_ptr(), r,
+               _ptr(boost), pooled_h, pooled_w, float(spatial_scale), ws.data_ptr(), y.data_ptr(),
+               _stream())
+        return y
     am = torch.empty((r, c, pooled_h, pooled_w), device=x.device, dtype=torch.int32) \
         if with_argmax else None
     L.call('naws_roi_pool_f_fwd', x.data_ptr(), lay, n, c, h, w, rois.data_ptr(), r, _ptr(boost),
@@ -136,7 +144,8 @@ def roi_pool_f(x, rois, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
     return (y, am) if with_argmax else y
 
 
-def roi_pool_f_f16x2(x, rois, amax_words, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None):
+def roi_pool_f_f16x2(x, rois, amax_words, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
+                     hier=True):
     """RoIPoolF (+ boost) on NHWC features, written directly as the fp16x2 operand of the fc6
     GEMM: F16x2 with planes [2, K/16, R, 16], K = C*ph*pw, scaled per roi from the bound
     max|x| of the roi's image (`amax_words`: int32 [n] bit patterns) * |boost|."""
@@ -153,6 +162,14 @@ def roi_pool_f_f16x2(x, rois, amax_words, pooled_h=7, pooled_w=7, spatial_scale=
         raise TypeError('amax_words must be a contiguous int32 tensor')
     out = F16x2(torch.empty((2, k // 16, r, 16), device=x.device, dtype=torch.float16),
                 torch.empty((2, r), device=x.device, dtype=_f32))
+    if hier:
+        ws = torch.empty((L.load().naws_roi_pool_workspace_floats(n, c, h, w),), device=x.device,
+                         dtype=_f32)
+        L.call('naws_roi_pool_f_f16x2_hier_fwd', x.data_ptr(), n, c, h, w, rois.data_ptr(), r,
+               _ptr(boost), pooled_h, pooled_w, float(spatial_scale), amax_words.data_ptr(),
+               amax_words.numel(), ws.data_ptr(), out.planes.data_ptr(), out.scales.data_ptr(),
+               _stream())
+        return out
     L.call('naws_roi_pool_f_f16x2_fwd', x.data_ptr(), n, c, h, w, rois.data_ptr(), r, _ptr(boost),
            pooled_h, pooled_w, float(spatial_scale), amax_words.data_ptr(), amax_words.numel(),
            out.planes.data_ptr(), out.scales.data_ptr(), _stream())

@@ -312,3 +312,48 @@ def test_checkpoint_preserved_blobs_round_trip(tmp_path, cfgmod):
         saved = net_wsl.load_object(path)['blobs']
         assert sorted(saved) == ['fc1000_w', 'fc6_w', 'fc6_w_momentum'], sorted(saved)
         assert np.array_equal(saved['fc1000_w'], w1000) and np.array_equal(saved['fc6_w'], w6)
+
+
+HOST = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_host_paths.npz'))
+
+
+def test_dedup_hash_and_scatter_back_match_reference(cfgmod):
+    """Pairs captured from the reference's own im_detect_bbox (core/test_wsl.py:102-178) run with a
+    recording workspace: the rois it feeds after projection (float64 product) + dedup hash, and the
+    scores it returns after the scatter-back."""
+    from detectron.core import test_wsl
+    boxes, obn = HOST['dedup_boxes'], HOST['dedup_obn']
+    rois = test_wsl.project_rois(boxes, float(HOST['dedup_im_scale']))
+    uniq, index, inv = test_wsl.dedup_rois(rois, float(HOST['dedup_factor']))
+    assert uniq.dtype == np.float32 and np.array_equal(uniq, HOST['dedup_fed_rois'])
+    assert np.array_equal((obn + 1.0).astype(np.float32)[index], HOST['dedup_fed_obn'])
+    assert uniq.shape[0] < rois.shape[0]
+    # the fixture's "network": scores are a function of the fed rows only
+    k = HOST['dedup_scores'].shape[1]
+    base = (uniq[:, 1:5].sum(1, keepdims=True) * 0.001 + HOST['dedup_fed_obn']).astype(np.float32)
+    scores = (base + np.arange(k, dtype=np.float32)[None, :] * 0.01).astype(np.float32)
+    assert np.array_equal(scores[inv], HOST['dedup_scores'])
+    assert np.array_equal(np.tile(boxes, (1, k)), HOST['dedup_pred_boxes'])
+
+
+def test_image_id_blob_matches_reference():
+    from detectron.roi_data import minibatch_wsl
+    blob = minibatch_wsl._get_image_id_blob([{'image': str(s)} for s in HOST['imgid_names']])
+    assert blob.dtype == np.int32 and np.array_equal(blob, HOST['imgid_blob'])
+
+
+def test_bagging_mixup_blend_matches_reference(cfgmod):
+    """The blended minibatch RoIDataLoader.get_next_minibatch produced in the reference
+    (loader_wsl.py:130-168) from a captured two-image minibatch and its seeded lambda."""
+    from detectron.roi_data import loader_wsl
+    two = {k[len('mixup_in_'):]: HOST[k] for k in HOST.files if k.startswith('mixup_in_')}
+    want = {k[len('mixup_out_'):]: HOST[k] for k in HOST.files if k.startswith('mixup_out_')}
+    got = loader_wsl.mixup_blobs(two, float(HOST['mixup_lam']))
+    assert set(want) <= set(got)
+    for k, v in want.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape, k
+        assert np.array_equal(got[k], v), k         # float32 products, float32 sum: bit for bit
+    # and the stream: the same numpy draws give the same branch decision and lambda
+    np.random.seed(int(HOST['mixup_seed']))
+    assert np.random.random() > 0.8
+    assert np.random.beta(float(HOST['mixup_alpha']), float(HOST['mixup_alpha'])) == float(HOST['mixup_lam'])

@@ -50,6 +50,35 @@ def test_roi_pool_bitexact(dev, layout, c, with_boost):
     assert np.array_equal(y2.cpu().numpy(), y_ref)
 
 
+@pytest.mark.parametrize('h,w,nroi', [(20, 30, 40), (74, 124, 300), (5, 7, 24)])
+def test_roi_pool_hierarchical_bitexact(dev, h, w, nroi):
+    """RoIPoolF over the precomputed 2x2 / 4x4 block maxima (naws_roi_pool_f_nhwc_hier_fwd,
+    naws_roi_pool_f_f16x2_hier_fwd) == the oracle's pixel loop, value for value: windows of every
+    size incl. 1-px, malformed, outside-the-image and whole-image rois, negative data and NaNs
+    (the reference's strict '>' never lets a NaN win)."""
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(h * w)
+    n, c = 2, 128
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    x[0, :, h // 2, w // 3] = np.nan
+    x[1, 5, :, :] = -3.0                         # a constant negative channel
+    rois = make_rois(rng, n, nroi, h * 8, w * 8)
+    boost = (rng.uniform(0, 1, rois.shape[0]) + 1).astype(np.float32)
+    y_ref = oracle.roi_feature_boost(oracle.roi_pool_f(x, rois, 7, 7, 0.125)[0], boost)
+    xd = _t(x, dev).permute(0, 2, 3, 1).contiguous()
+    y = ops.roi_pool_f(xd, _t(rois, dev), 7, 7, 0.125, boost=_t(boost, dev), layout='NHWC', hier=True)
+    assert np.array_equal(y.cpu().numpy(), y_ref, equal_nan=True)
+    # the operand-plane form: identical planes and scales to the direct kernel's
+    amax = torch.full((n,), 0, device=dev, dtype=torch.int32)
+    amax.copy_(torch.tensor([np.float32(8.0).view(np.int32)] * n))
+    xz = torch.nan_to_num(xd)
+    a = ops.roi_pool_f_f16x2(xz, _t(rois, dev), amax, 7, 7, 0.125, boost=_t(boost, dev), hier=True)
+    b = ops.roi_pool_f_f16x2(xz, _t(rois, dev), amax, 7, 7, 0.125, boost=_t(boost, dev), hier=False)
+    assert torch.equal(a.planes.view(torch.int16), b.planes.view(torch.int16))
+    assert torch.equal(a.inv_scale, b.inv_scale)
+
+
 def test_roi_pool_empty_and_errors(dev):
     from naws_hip import ops, lib
     x = torch.zeros((1, 4, 5, 5), device=dev)
