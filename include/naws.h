@@ -516,6 +516,41 @@ int naws_min_entropy_loss_fwd(const float* X, const float* L, int N, int C, floa
 int naws_min_entropy_loss_bwd(const float* X, const float* L, const float* dY, int N, int C,
                               float* dX, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * f-4  OICR refinement operators (WSL.OICR: wsl_heads.py:134-156, :512-560) and the mining gate's
+ *      RoIEntropy (webly_heads.py:219-262).
+ *
+ * naws_roi_label_fwd — RoILabel, ref: detectron/ops/roi_label_op.cc:10-123, schema :133-145.
+ *   S fp32 [n][cs] scores (cs == c, or c + 1 with a background column 0), U fp32 [n][n] IoU,
+ *   L fp32 [c] image labels, CW fp32 [c] class weights (nullable) -> RL int32 [n], RW fp32 [n];
+ *   stats fp32 [4] += {fg rois, bg rois, fg weight, bg weight} (the op's display counters).
+ *   Errors: cs not in {c, c+1} -> SHAPE (ENFORCE :19); num_pos / num_neg < n -> UNSUPPORTED (a
+ *   binding cap makes the result depend on the reference's time-seeded shuffle, :62-70).
+ *   workspace: naws_roi_label_workspace_bytes(n, c, top_k) bytes.
+ * naws_softmax_with_loss_n_fwd / _bwd — SoftmaxWithLossN(+Gradient), label mode, ref:
+ *   detectron/ops/softmax_with_loss_n_op.cc:152-263 / :265-357.  X fp32 [N][D], T int32 [N], W fp32
+ *   [N] (nullable) -> P fp32 [N][D], loss fp32 [1] = scale * sum(-w log P[i][T_i]) / sum(w) (0 when
+ *   sum(w) == 0).  bwd: dX = (P - onehot) * w * scale / total * dloss[0], total = #{w > 1e-12} with
+ *   weights, N without.  A label outside [0, D) (the ENFORCE at :192) makes the loss NaN.
+ *   workspace: naws_softmax_with_loss_n_workspace_floats(N) floats.
+ * naws_roi_entropy_fwd — RoIEntropy, ref: detectron/ops/roi_entropy_op.cu:24-112.  S fp32 [n]
+ *   scores, C fp32 [n] class ids -> E fp32 [num_classes] = 1 - normalised entropy per class; mean
+ *   (nullable) is the op's running accumulator (zeroed first when init != 0).
+ * ------------------------------------------------------------------------ */
+int64_t naws_roi_label_workspace_bytes(int n, int c, int top_k);
+int naws_roi_label_fwd(const float* S, const float* U, const float* L, const float* CW, int n, int cs,
+                       int c, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo, int top_k,
+                       int num_pos, int num_neg, void* workspace, int32_t* RL, float* RW,
+                       float* stats, void* stream);
+int64_t naws_softmax_with_loss_n_workspace_floats(int N);
+int naws_softmax_with_loss_n_fwd(const float* X, const int32_t* T, const float* W, int N, int D,
+                                 float scale, float* workspace, float* P, float* loss, void* stream);
+int naws_softmax_with_loss_n_bwd(const int32_t* T, const float* W, const float* P,
+                                 const float* dloss, int N, int D, float scale, float* workspace,
+                                 float* dX, void* stream);
+int naws_roi_entropy_fwd(const float* S, const float* C, int n, int num_classes, int rm_bg, float* E,
+                         float* mean, int init, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,9 @@ Custom ops (reference detectron/ops/*):
   WeightedCrossEntropyWithLogits(+Grad.)  cross_entropy_wsl_op.cc:87-180, schema :242-266
   CrossEntropyWithLogits(+Gradient)       cross_entropy_wsl_op.cc:7-85, schema :214-233
   Stat                                    stat_op.cu:24-78, stat_op.cc:11-23
+  RoILabel                                roi_label_op.cc:10-123          (WSL.OICR)
+  SoftmaxWithLossN(+Gradient)             softmax_with_loss_n_op.cc:152-357
+  RoIEntropy, BoxWithNMSLimit (gate form) roi_entropy_op.cu:24-142, webly_heads.py:238-248
   ACMWeightDecayMomentumSGDUpdate         acm_weightdecay_momentum_sgd_op.h:48-112
 Caffe2 built-ins used by the path (pytorch v1.3.0 caffe2/operators, restated): RoIPoolF,
 Conv, Relu, MaxPool, FC, Dropout, Softmax, Transpose, Add/Sub/Mul/Div (numpy-style
@@ -118,6 +121,119 @@ class Stat(object):
         return self.AI, self.AL
 
 
+# ------------------------------------------------ OICR refinement / mining gate (f-4)
+class RoILabel(object):
+    """detectron/ops/roi_label_op.cc:10-123 (schema :133-145, state roi_label_op.h:14-56): pseudo
+    labels of the OICR refinement branches.  (S [n,c(+1)], U [n,n], L [1,c][, CW [c]]) ->
+    (RL int32 [n], RW [n]).  State = the op's display counters; every `display` calls it prints
+    the reference's line.  num_pos / num_neg below n would make the result depend on the
+    reference's time-seeded shuffle: rejected (NawsError, UNSUPPORTED)."""
+
+    def __init__(self, display=1280, uuid=0, fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=-1.0,
+                 num_pos=9999, num_neg=9999, top_k=1, debug_info=False, printer=print):
+        self.display, self.uuid, self.printer = int(display), int(uuid), printer
+        self.fg_thresh, self.bg_thresh_hi, self.bg_thresh_lo = fg_thresh, bg_thresh_hi, bg_thresh_lo
+        self.num_pos, self.num_neg, self.top_k = int(num_pos), int(num_neg), int(top_k)
+        self.cur_iter, self.stats = 0, None
+
+    def __call__(self, S, U, L, CW=None):
+        if self.stats is None:
+            self.stats = torch.zeros((4,), device=S.device, dtype=torch.float32)
+        rl, rw = _k.roi_label(S.contiguous(), U.contiguous(), L.contiguous(),
+                              None if CW is None else CW.contiguous().reshape(-1),
+                              self.fg_thresh, self.bg_thresh_hi, self.bg_thresh_lo, self.top_k,
+                              self.num_pos, self.num_neg, stats=self.stats)
+        self.cur_iter += 1
+        if self.cur_iter % self.display == 0:
+            fg, bg, fw, bw = self.stats.cpu().tolist()
+            with np.errstate(divide='ignore', invalid='ignore'):
+                self.printer('RoILabel %d\tfg_rois: %d\tbg_rois: %d\tfg_weight: %f\tbg_weight: %f' % (
+                    self.uuid, int(fg) // self.display, int(bg) // self.display,
+                    float(np.float32(fw) / np.float32(fg)), float(np.float32(bw) / np.float32(bg))))
+            self.stats.zero_()
+        return rl, rw
+
+
+def SoftmaxWithLossN(X, T, W=None, scale=1.0):
+    """detectron/ops/softmax_with_loss_n_op.cc:152-263 (label mode, axis 1): -> (P, loss [])."""
+    p, loss = _k.softmax_with_loss_n(X.contiguous(), T.contiguous().reshape(-1),
+                                     None if W is None else W.contiguous().reshape(-1), scale)
+    return p, loss.reshape(())
+
+
+def SoftmaxWithLossNGradient(X, T, W, P, d_avg_loss, scale=1.0):
+    """detectron/ops/softmax_with_loss_n_op.cc:265-357 -> dX."""
+    return _k.softmax_with_loss_n_grad(T.contiguous().reshape(-1),
+                                       None if W is None else W.contiguous().reshape(-1),
+                                       P.contiguous(), d_avg_loss.reshape(1).contiguous(), scale)
+
+
+class RoIEntropy(object):
+    """detectron/ops/roi_entropy_op.cu:69-142 (state roi_entropy_op.h:14-39): (S [n], C [n]) ->
+    E [1, num_classes]; keeps the op's running mean_ and prints it every `display` calls."""
+
+    def __init__(self, display=1280, num_classes=20, rm_bg=True, debug_info=False, printer=print):
+        self.display, self.num_classes, self.rm_bg = int(display), int(num_classes), bool(rm_bg)
+        self.printer = printer
+        self.cur_iter, self.init, self.mean = 0, True, None
+
+    def __call__(self, S, C):
+        if self.mean is None:
+            self.mean = torch.zeros((self.num_classes,), device=S.device, dtype=torch.float32)
+        e = _k.roi_entropy(S.contiguous().reshape(-1), C.contiguous().reshape(-1), self.num_classes,
+                           self.rm_bg, mean=self.mean, init=self.init)
+        self.init = False
+        self.cur_iter += 1
+        if self.cur_iter % self.display == 0 or self.cur_iter == 1:
+            self.printer('RoIEntropy #iter_: %d' % self.cur_iter)
+            self.printer(''.join('  %g' % v for v in self.mean.cpu().tolist()))
+            self.init = True
+        return e
+
+
+def BoxWithNMSLimit(scores, boxes, score_thresh=0.05, nms=0.3, detections_per_im=100):
+    """Caffe2 BoxWithNMSLimit as webly_heads.py:238-248 uses it (hard NMS, one image): scores
+    [n, K] (column 0 = background), boxes [n, 4K] class-tiled -> (scores_nms [m], boxes_nms [m,4],
+    classes_nms [m] float): per class 1..K-1 the candidates above score_thresh after greedy NMS
+    (naws_nms_sorted_fwd: all classes in one launch pair), in descending score order, classes
+    concatenated; the image-wide detections_per_im cut keeps the highest scores."""
+    n, k = scores.shape
+    fg = scores[:, 1:].contiguous()
+    keep = _k.nms_per_class(boxes.contiguous(), fg, score_thresh, nms)            # [K-1, n] bool
+    st = fg.t()
+    key = torch.where(keep, st, torch.full_like(st, -float('inf')))
+    order = torch.sort(key, dim=1, descending=True, stable=True).indices           # kept ones first
+    cnt = keep.sum(dim=1)
+    sel = torch.arange(n, device=scores.device)[None, :] < cnt[:, None]            # [K-1, n]
+    cls = torch.arange(1, k, device=scores.device)[:, None].expand(k - 1, n)
+    rows = order[sel]
+    classes = cls[sel]
+    s = st[classes - 1, rows]
+    b = boxes.view(n, k, 4)[rows, classes]
+    if detections_per_im > 0 and s.numel() > detections_per_im:
+        th = torch.sort(s).values[-detections_per_im]
+        m = s >= th
+        s, b, classes = s[m], b[m], classes[m]
+    return s.contiguous(), b.contiguous(), classes.to(torch.float32)
+
+
+def Mean(*Xs):
+    """Elementwise mean of equally shaped blobs (wsl_heads.py:156: the OICR test-time ensemble)."""
+    acc = Xs[0]
+    for x in Xs[1:]:
+        acc = _bin(_L.BIN_ADD, acc, x).view(Xs[0].shape)
+    return _k.unary(_L.UN_SCALE, acc.contiguous(), 1.0 / len(Xs)).view(Xs[0].shape)
+
+
+def Max(A, B):
+    """Elementwise maximum (webly_heads.py:259)."""
+    return torch.maximum(A, B)
+
+
+def Tile(X, tiles=1, axis=1):
+    return X.repeat_interleave(1, dim=axis).repeat(*[tiles if d == axis else 1 for d in range(X.dim())])
+
+
 class ACMWeightDecayMomentumSGDUpdate(object):
     """One instance per parameter blob, state = iter_count_.  In place on momentum / param /
     acmgrad like the reference op; grad is read-only."""
@@ -178,14 +294,39 @@ def MaxPool(X, kernel=2, pad=0, stride=2):
     return _k.nhwc_to_nchw(_k.maxpool2x2_nhwc(_k.nchw_to_nhwc(X), stride))
 
 
+def _pad_rows4(t):
+    """[n, k] -> [n4, k] with n4 = n rounded up to 4 (zero rows): the MFMA GEMM's 16-byte loads
+    want output widths that are multiples of 4 (cls_score has num_classes = 21 / 81 outputs)."""
+    n = t.shape[0]
+    n4 = (n + 3) // 4 * 4
+    if n4 == n:
+        return t
+    out = torch.zeros((n4,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    out[:n] = t
+    return out
+
+
 def FC(X, W, b):
     x2 = X.reshape(X.shape[0], -1)
-    return _k.gemm(x2, W, False, True, epilogue=_L.EPI_BIAS, bias=b)
+    n = W.shape[0]
+    if n % 4 == 0:
+        return _k.gemm(x2, W, False, True, epilogue=_L.EPI_BIAS, bias=b)
+    return _k.gemm(x2, _pad_rows4(W), False, True, epilogue=_L.EPI_BIAS,
+                   bias=_pad_rows4(b))[:, :n].contiguous()
 
 
 def FCGradient(X, W, dY):
     """-> dW, db, dX."""
     x2 = X.reshape(X.shape[0], -1)
+    n = W.shape[0]
+    if n % 4 != 0:
+        n4 = (n + 3) // 4 * 4
+        dYp = torch.zeros((dY.shape[0], n4), device=dY.device, dtype=dY.dtype)
+        dYp[:, :n] = dY
+        dW = _k.gemm(dYp, x2, True, False)[:n].contiguous()
+        db = _k.colsum(dYp)[:n].contiguous()
+        dX = _k.gemm(dYp, _pad_rows4(W), False, False)
+        return dW, db, dX.view(X.shape)
     dW = _k.gemm(dY, x2, True, False)
     db = _k.colsum(dY)
     dX = _k.gemm(dY, W, False, False)

@@ -49,6 +49,10 @@ PROTOTYPES = {
     'naws_acm_sgd_update': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p],
     'naws_acm_sgd_update_rowmax': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p, p,
                                    i32, p],
+    'naws_roi_label_fwd': [p, p, p, p, i32, i32, i32, f32, f32, f32, i32, i32, i32, p, p, p, p, p],
+    'naws_softmax_with_loss_n_fwd': [p, p, p, i32, i32, f32, p, p, p, p],
+    'naws_softmax_with_loss_n_bwd': [p, p, p, p, i32, i32, f32, p, p, p],
+    'naws_roi_entropy_fwd': [p, p, i32, i32, i32, p, p, i32, p],
     'naws_stat_accumulate': [p, p, i32, i32, p, p, p],
     'naws_unary_f32': [i32, p, i64, f32, f32, p, p],
     'naws_binary_f32': [i32, p, i32, i32, p, i32, i32, p, i32, i32, p],
@@ -98,6 +102,8 @@ SPECIAL = {
     'naws_entropy_gate_workspace_floats': ([i32, i32, i32, i32], i64),
     'naws_winograd_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
     'naws_nms_workspace_bytes': ([i32, i32], i64),
+    'naws_roi_label_workspace_bytes': ([i32, i32, i32], i64),
+    'naws_softmax_with_loss_n_workspace_floats': ([i32], i64),
     'naws_roi_pool_workspace_floats': ([i32, i32, i32, i32], i64),
     'naws_winograd_f32x3_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
     'naws_winograd_f16x2_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),

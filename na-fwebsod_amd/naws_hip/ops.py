@@ -831,6 +831,73 @@ def acm_sgd_update(grad, momentum_buf, lr, param, acmgrad, seg_end, seg_lr_mult,
            int(gpu_num), int(iter_count), _stream())
 
 
+# ----------------------------------------------------------------------------
+# OICR refinement operators
+# ----------------------------------------------------------------------------
+def roi_label(s, u, l, cw=None, fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=-1.0, top_k=1,
+              num_pos=9999, num_neg=9999, stats=None):
+    """-> (RL int32 [n], RW fp32 [n]); stats (fp32 [4], optional) accumulates the op's counters."""
+    _chk(s, 'S'); _chk(u, 'U'); _chk(l, 'L')
+    if s.dim() != 2 or u.dim() != 2 or l.dim() != 2 or l.shape[0] != 1 or \
+            u.shape[0] != u.shape[1] or s.shape[0] != u.shape[0]:
+        raise L.NawsError('naws_roi_label_fwd', L.ERR_SHAPE)        # ENFORCE sites :13-22
+    n, cs = s.shape
+    c = l.shape[1]
+    if cw is not None:
+        _chk(cw, 'CW')
+    dev = s.device
+    ws = torch.empty((max(L.load().naws_roi_label_workspace_bytes(n, c, top_k), 16) // 4,),
+                     device=dev, dtype=torch.int32)
+    rl = torch.empty((n,), device=dev, dtype=torch.int32)
+    rw = torch.empty((n,), device=dev, dtype=_f32)
+    st = stats if stats is not None else torch.zeros((4,), device=dev, dtype=_f32)
+    L.call('naws_roi_label_fwd', s.data_ptr(), u.data_ptr(), l.data_ptr(), _ptr(cw), n, cs, c,
+           float(fg_thresh), float(bg_thresh_hi), float(bg_thresh_lo), int(top_k), int(num_pos),
+           int(num_neg), ws.data_ptr(), rl.data_ptr(), rw.data_ptr(), st.data_ptr(), _stream())
+    return rl, rw
+
+
+def softmax_with_loss_n(x, t, w=None, scale=1.0):
+    """-> (P [N,D], loss [1])."""
+    _chk(x, 'X'); _chk(t, 'T', torch.int32)
+    if x.dim() != 2 or t.numel() != x.shape[0] or (w is not None and w.numel() != x.shape[0]):
+        raise L.NawsError('naws_softmax_with_loss_n_fwd', L.ERR_SHAPE)
+    if w is not None:
+        _chk(w, 'W')
+    n, d = x.shape
+    ws = torch.empty((L.load().naws_softmax_with_loss_n_workspace_floats(n),), device=x.device,
+                     dtype=_f32)
+    p = torch.empty_like(x)
+    loss = torch.empty((1,), device=x.device, dtype=_f32)
+    L.call('naws_softmax_with_loss_n_fwd', x.data_ptr(), t.data_ptr(), _ptr(w), n, d, float(scale),
+           ws.data_ptr(), p.data_ptr(), loss.data_ptr(), _stream())
+    return p, loss
+
+
+def softmax_with_loss_n_grad(t, w, p, dloss, scale=1.0):
+    _chk(p, 'P'); _chk(t, 'T', torch.int32); _chk(dloss, 'd_avg_loss')
+    if w is not None:
+        _chk(w, 'W')
+    n, d = p.shape
+    ws = torch.empty((L.load().naws_softmax_with_loss_n_workspace_floats(n),), device=p.device,
+                     dtype=_f32)
+    dx = torch.empty_like(p)
+    L.call('naws_softmax_with_loss_n_bwd', t.data_ptr(), _ptr(w), p.data_ptr(), dloss.data_ptr(), n,
+           d, float(scale), ws.data_ptr(), dx.data_ptr(), _stream())
+    return dx
+
+
+def roi_entropy(s, c, num_classes, rm_bg=True, mean=None, init=True):
+    """-> E [1, num_classes]; `mean` (fp32 [num_classes]) is the op's running accumulator."""
+    _chk(s, 'S'); _chk(c, 'C')
+    if s.dim() != 1 or c.dim() != 1 or s.shape[0] != c.shape[0]:
+        raise L.NawsError('naws_roi_entropy_fwd', L.ERR_SHAPE)       # ENFORCE sites :73-75
+    e = torch.empty((1, int(num_classes)), device=s.device, dtype=_f32)
+    L.call('naws_roi_entropy_fwd', s.data_ptr(), c.data_ptr(), s.shape[0], int(num_classes),
+           int(bool(rm_bg)), e.data_ptr(), _ptr(mean), int(bool(init)), _stream())
+    return e
+
+
 class RowmaxTable(object):
     """[(first element, end element, row length, first rowmax index)] for acm_sgd_update."""
 

@@ -401,3 +401,155 @@ void oracle_min_entropy_bwd(const float* X, const float* L, float dY, int N, int
       dX[n * C + c] = g < 1e4f ? g : 1e4f;
     }
 }
+
+/* ---------------------------------------------------------------------------
+ * f-4: OICR refinement operators (one cfg flag from the hot path: WSL.OICR).
+ *
+ * RoILabel.  ref: detectron/ops/roi_label_op.cc:10-123 (CPU op; the .cu registers nothing else).
+ * S [n, cs] proposal scores (cs = c or c+1 columns: with a background column the class columns
+ * start at offset cs - c), U [n, n] IoU matrix, L [1, c] image labels, CW [c] optional class
+ * weights.  Per labelled class (L[c] == 1), top_k times: the not-yet-picked proposal with the
+ * strictly largest score (first index wins ties; the picked list is shared by all classes, :43-58).
+ * Every proposal n then takes the picked proposal of largest IoU U[n, g] (first wins, :77-84):
+ * IoU >= fg_thresh -> label class+1, weight = CW[class] or the pick's score; bg_lo <= IoU < bg_hi
+ * -> label 0, same weight; otherwise label class+1 with weight 0 (:89-104).
+ * The reference visits the proposals in a time-seeded std::random_shuffle order (:62-70), which
+ * only matters through the num_pos / num_neg caps; with the op's defaults (9999) the caps never
+ * bind for n < 9999 and the result is order-independent - this restatement (and the HIP op)
+ * covers exactly that case and rejects binding caps.  stats[4] += {fg rois, bg rois, fg weight,
+ * bg weight} (the op's display counters, :90-101).
+ * ------------------------------------------------------------------------- */
+int oracle_roi_label(const float* S, const float* U, const float* L, const float* CW, int n, int cs,
+                     int c, float fg_thresh, float bg_thresh_hi, float bg_thresh_lo, int top_k,
+                     int num_pos, int num_neg, int32_t* RL, float* RW, float* stats) {
+  if (num_pos < n || num_neg < n) return -1;
+  const int off = cs - c;
+  int* hn = (int*)malloc(sizeof(int) * (size_t)(c * top_k + 1));
+  int* hc = (int*)malloc(sizeof(int) * (size_t)(c * top_k + 1));
+  float* hp = (float*)malloc(sizeof(float) * (size_t)(c * top_k + 1));
+  int nh = 0;
+  for (int cc = 0; cc < c; ++cc) {
+    if (L[cc] != 1.f) continue;
+    for (int k = 0; k < top_k; ++k) {
+      float max_pred = -FLT_MAX;
+      int max_idx = -1;
+      for (int i = 0; i < n; ++i) {
+        if (max_pred < S[i * cs + cc + off]) {
+          int seen = 0;
+          for (int j = 0; j < nh; ++j) seen |= (hn[j] == i);
+          if (!seen) {
+            max_pred = S[i * cs + cc + off];
+            max_idx = i;
+          }
+        }
+      }
+      hn[nh] = max_idx; hc[nh] = cc; hp[nh] = max_pred; ++nh;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    float max_iou = -FLT_MAX;
+    int max_idx = -1;
+    for (int j = 0; j < nh; ++j) {
+      const int g = hn[j];
+      if (g >= 0 && max_iou < U[(size_t)i * n + g]) {
+        max_iou = U[(size_t)i * n + g];
+        max_idx = j;
+      }
+    }
+    if (max_idx < 0) { RL[i] = 0; RW[i] = 0.f; continue; }   /* no labelled class: UB upstream */
+    int assign_c = hc[max_idx];
+    float assign_w = CW ? CW[assign_c] : hp[max_idx];
+    if (max_iou >= fg_thresh) {
+      assign_c = assign_c + 1;
+      stats[0] += 1.f; stats[2] += assign_w;
+    } else if (max_iou >= bg_thresh_lo && max_iou < bg_thresh_hi) {
+      assign_c = 0;
+      stats[1] += 1.f; stats[3] += assign_w;
+    } else {
+      assign_c = assign_c + 1;
+      assign_w = 0.f;
+    }
+    RL[i] = assign_c;
+    RW[i] = assign_w;
+  }
+  free(hn); free(hc); free(hp);
+  return 0;
+}
+
+/* SoftmaxWithLossN forward.  ref: detectron/ops/softmax_with_loss_n_op.cc:152-263 (label mode).
+ * X [N, D] logits, T int32 [N] labels, W [N] optional sample weights -> P [N, D] softmax,
+ * loss = scale * sum_i(-w_i log P[i, T_i]) / sum_i w_i  (0 when the weights sum to 0).
+ * The row softmax is Caffe2's softmax_utils::SoftmaxCPU in its logarithmic form (third-party,
+ * pytorch v1.3.0 caffe2/operators/softmax_utils.cc - restated from its published algorithm: row
+ * max, x - max, exp, row sum, log-softmax = x - max - log(sum); P = exp(log-softmax), :206).
+ * Serial fp32 sums in index order.  Returns -1 on a label outside [0, D) (the ENFORCE at :192). */
+int oracle_softmax_with_loss_n_fwd(const float* X, const int32_t* T, const float* W, int N, int D,
+                                   float scale, float* P, float* loss) {
+  float loss_sum = 0.f, weight_sum = 0.f;
+  for (int i = 0; i < N; ++i) {
+    const float* x = X + (size_t)i * D;
+    float* p = P + (size_t)i * D;
+    float m = x[0];
+    for (int d = 1; d < D; ++d) m = x[d] > m ? x[d] : m;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) { p[d] = expf(x[d] - m); s += p[d]; }
+    const float ls = logf(s);
+    for (int d = 0; d < D; ++d) p[d] = (x[d] - m) - ls;        /* log-softmax */
+    if (T[i] < 0 || T[i] >= D) return -1;
+    const float w = W ? W[i] : 1.f;
+    loss_sum += -p[T[i]] * w;
+    weight_sum += w;
+    for (int d = 0; d < D; ++d) p[d] = expf(p[d]);
+  }
+  *loss = weight_sum != 0.f ? loss_sum * scale / weight_sum : 0.f;
+  return 0;
+}
+
+/* SoftmaxWithLossNGradient.  ref: softmax_with_loss_n_op.cc:265-357 (label mode): dX = (P -
+ * onehot(T)) * w_i, then scaled by scale / total * dloss where total = the NUMBER of samples with
+ * w_i > 1e-12 when weights are given (:309-311: the weight sum is commented out upstream), N
+ * otherwise; left unscaled when total == 0. */
+void oracle_softmax_with_loss_n_bwd(const int32_t* T, const float* W, const float* P, float dloss,
+                                    int N, int D, float scale, float* dX) {
+  float total = 0.f;
+  for (int i = 0; i < N; ++i) {
+    for (int d = 0; d < D; ++d) dX[(size_t)i * D + d] = P[(size_t)i * D + d];
+    dX[(size_t)i * D + T[i]] = P[(size_t)i * D + T[i]] - 1.0f;
+    if (W) {
+      for (int d = 0; d < D; ++d) dX[(size_t)i * D + d] *= W[i];
+      if (W[i] > 1e-12) total += 1.f;
+    }
+  }
+  if (!W) total = (float)N;
+  if (total > 0) {
+    const float a = scale / total * dloss;
+    for (size_t k = 0; k < (size_t)N * D; ++k) dX[k] *= a;
+  }
+}
+
+/* RoIEntropy.  ref: detectron/ops/roi_entropy_op.cu:24-62, 69-112 (CUDA only upstream).
+ * S [n] scores and C [n] class ids (as floats) of the detections BoxWithNMSLimit kept; per class
+ * c = C - rm_bg: N_c = count, CS_c = sum of scores, and
+ *   E_c = 1 + sum_i (p_i log p_i) / log N_c,  p_i = S_i / CS_c   (E_c = 1 when N_c is 0 or 1)
+ * i.e. one minus the normalised entropy of the class's score distribution (:64-66; the kernel
+ * adds val = +p log p because of its "-1 * -1").  E [num_classes] starts at 1 (:82-84). */
+void oracle_roi_entropy(const float* S, const float* C, int n, int num_classes, int rm_bg, float* E) {
+  const int off = rm_bg ? -1 : 0;
+  float* N = (float*)calloc((size_t)num_classes, sizeof(float));
+  float* CS = (float*)calloc((size_t)num_classes, sizeof(float));
+  for (int c = 0; c < num_classes; ++c) E[c] = 1.f;
+  for (int i = 0; i < n; ++i) {
+    const int c = (int)C[i] + off;
+    N[c] += 1.f;
+    CS[c] += S[i];
+  }
+  for (int i = 0; i < n; ++i) {
+    const int c = (int)C[i] + off;
+    const float p = S[i] / CS[c];
+    float val = -1.0f * -1.0f * p * logf(p);
+    if (N[c] == 1) val = 0.f;
+    else val = val / logf(N[c]);
+    E[c] += val;
+  }
+  free(N); free(CS);
+}

@@ -222,6 +222,97 @@ def nms(dets, thresh):
     return np.where(sup == 0)[0]
 
 
+def roi_label(S, U, L_, CW=None, fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=-1.0, top_k=1,
+              num_pos=9999, num_neg=9999, stats=None):
+    """ref: detectron/ops/roi_label_op.cc:10-123 (see naws_oracle.c).  -> (RL int32 [n], RW [n])."""
+    S, sp = _f(S)
+    U, up = _f(U)
+    Lh, lp = _f(np.reshape(L_, (-1,)))
+    cwp = None
+    if CW is not None:
+        CW, cwp = _f(np.reshape(CW, (-1,)))
+    n, cs = S.shape
+    rl = np.empty((n,), np.int32)
+    rw = np.empty((n,), np.float32)
+    st = stats if stats is not None else np.zeros((4,), np.float32)
+    rc = L().oracle_roi_label(sp, up, lp, cwp, n, cs, Lh.size, C.c_float(fg_thresh),
+                              C.c_float(bg_thresh_hi), C.c_float(bg_thresh_lo), int(top_k),
+                              int(num_pos), int(num_neg), rl.ctypes.data_as(_ip),
+                              rw.ctypes.data_as(_fp), st.ctypes.data_as(_fp))
+    if rc != 0:
+        raise ValueError('binding num_pos / num_neg caps depend on the reference\'s time-seeded '
+                         'shuffle: not reproducible')
+    return rl, rw
+
+
+def softmax_with_loss_n(X, T, W=None, scale=1.0):
+    """ref: detectron/ops/softmax_with_loss_n_op.cc:152-263.  -> (P [N,D], loss)."""
+    X, xp = _f(X)
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    wp = None
+    if W is not None:
+        W, wp = _f(W)
+    n, d = X.shape
+    P = np.empty_like(X)
+    loss = np.zeros((1,), np.float32)
+    rc = L().oracle_softmax_with_loss_n_fwd(xp, T.ctypes.data_as(_ip), wp, n, d, C.c_float(scale),
+                                            P.ctypes.data_as(_fp), loss.ctypes.data_as(_fp))
+    if rc != 0:
+        raise ValueError('Label seems incorrect: label value larger than number of classes')
+    return P, loss[0]
+
+
+def softmax_with_loss_n_grad(T, W, P, dloss, scale=1.0):
+    """ref: detectron/ops/softmax_with_loss_n_op.cc:265-357.  -> dX [N,D]."""
+    P, pp = _f(P)
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    wp = None
+    if W is not None:
+        W, wp = _f(W)
+    n, d = P.shape
+    dX = np.empty_like(P)
+    L().oracle_softmax_with_loss_n_bwd(T.ctypes.data_as(_ip), wp, pp, C.c_float(float(dloss)), n, d,
+                                       C.c_float(scale), dX.ctypes.data_as(_fp))
+    return dX
+
+
+def roi_entropy(S, Cls, num_classes, rm_bg=True):
+    """ref: detectron/ops/roi_entropy_op.cu:24-112.  -> E [1, num_classes]."""
+    S, sp = _f(np.reshape(S, (-1,)))
+    Cl, cp = _f(np.reshape(Cls, (-1,)))
+    E = np.empty((1, num_classes), np.float32)
+    L().oracle_roi_entropy(sp, cp, S.size, int(num_classes), int(bool(rm_bg)), E.ctypes.data_as(_fp))
+    return E
+
+
+def box_with_nms_limit(scores, boxes, score_thresh=0.05, nms_thresh=0.3, detections_per_im=100):
+    """Caffe2 BoxWithNMSLimit in the form webly_heads.py:238-248 uses it (hard NMS, no soft-nms, one
+    image): scores [n, K] (column 0 = background, skipped), boxes [n, 4K] class-tiled.  For
+    j = 1..K-1: candidates scores[:, j] > score_thresh, greedy NMS (utils/cython_nms.pyx
+    arithmetic), kept in descending score order; the per-class results are concatenated in class
+    order; when more than detections_per_im remain, the lowest-scored are dropped per the
+    image-wide threshold.  Third-party (pytorch v1.3.0 caffe2/operators/box_with_nms_limit_op.cc,
+    un-vendored): restated from its published algorithm, PARITY UNPINNED.
+    -> (scores_nms [m], boxes_nms [m,4], classes_nms [m] float)."""
+    scores = np.asarray(scores, np.float32)
+    boxes = np.asarray(boxes, np.float32)
+    k = scores.shape[1]
+    out_s, out_b, out_c = [], [], []
+    for j in range(1, k):
+        inds = np.where(scores[:, j] > score_thresh)[0]
+        dets = np.hstack([boxes[inds, 4 * j:4 * j + 4], scores[inds, j:j + 1]]).astype(np.float32)
+        keep = nms(dets, nms_thresh)
+        keep = keep[np.argsort(-dets[keep, 4], kind='stable')]
+        out_s.append(dets[keep, 4]); out_b.append(dets[keep, :4])
+        out_c.append(np.full((keep.size,), j, np.float32))
+    s, b, c = np.concatenate(out_s), np.concatenate(out_b), np.concatenate(out_c)
+    if detections_per_im > 0 and s.size > detections_per_im:
+        th = np.sort(s)[-detections_per_im]
+        m = s >= th
+        s, b, c = s[m], b[m], c[m]
+    return s, b.reshape(-1, 4), c
+
+
 def resize_bilinear_cv2(im, im_scale):
     """cv2.resize(im, None, None, fx=im_scale, fy=im_scale, interpolation=cv2.INTER_LINEAR) for a
     float32 HxWxC image.  OpenCV is an un-vendored dependency of the reference

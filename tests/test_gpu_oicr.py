@@ -1,0 +1,104 @@
+"""GPU parity of the f-4 operators (OICR refinement + the mining gate's RoIEntropy) against the
+oracle's restatements of detectron/ops/roi_label_op.cc, softmax_with_loss_n_op.cc and
+roi_entropy_op.cu: integer outputs bit-exact, floating point within 1e-6 / 1e-5 (serial fp32 sums
+on the CPU vs fixed-order trees on the GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_rois
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize('n,c,bg_col,top_k', [(300, 20, True, 1), (2000, 20, True, 1),
+                                               (517, 80, False, 2), (5, 3, True, 1)])
+def test_roi_label_bitexact(dev, n, c, bg_col, top_k):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(n + c)
+    rois = make_rois(rng, 1, n, 600, 1000, degenerate=n >= 8)
+    U = oracle.roi_iou(rois)
+    cs = c + (1 if bg_col else 0)
+    S = rng.uniform(0, 1, (n, cs)).astype(np.float32)
+    S[rng.integers(0, n, 7), rng.integers(0, cs, 7)] = S.max()          # ties for the maxima
+    L = np.zeros((1, c), np.float32)
+    L[0, rng.choice(c, size=min(3, c), replace=False)] = 1
+    for cw in (None, rng.uniform(0, 1, (c,)).astype(np.float32)):
+        st_ref = np.zeros((4,), np.float32)
+        rl_ref, rw_ref = oracle.roi_label(S, U, L, cw, fg_thresh=0.5, bg_thresh_hi=0.5,
+                                          bg_thresh_lo=0.1, top_k=top_k, stats=st_ref)
+        st = torch.zeros((4,), device=dev)
+        rl, rw = ops.roi_label(_t(S, dev), _t(U, dev), _t(L, dev), None if cw is None else _t(cw, dev),
+                               0.5, 0.5, 0.1, top_k, stats=st)
+        assert np.array_equal(rl.cpu().numpy(), rl_ref)
+        assert np.array_equal(rw.cpu().numpy(), rw_ref)
+        np.testing.assert_allclose(st.cpu().numpy(), st_ref, rtol=1e-5)
+    # the reference's ENFORCE sites and the irreproducible capped mode
+    from naws_hip import lib
+    with pytest.raises(lib.NawsError):
+        ops.roi_label(_t(S, dev), _t(U, dev), _t(np.zeros((1, cs + 1), np.float32), dev))   # cs < c
+    with pytest.raises(lib.NawsError):
+        ops.roi_label(_t(S, dev), _t(U, dev), _t(L, dev), num_pos=n - 1)
+
+
+@pytest.mark.parametrize('n,d', [(2000, 21), (333, 81), (1, 5)])
+def test_softmax_with_loss_n_fwd_bwd(dev, n, d):
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(n)
+    X = (rng.standard_normal((n, d)) * 4).astype(np.float32)
+    T = rng.integers(0, d, (n,)).astype(np.int32)
+    W = rng.uniform(0, 1, (n,)).astype(np.float32)
+    W[rng.integers(0, n, max(n // 3, 1))] = 0                          # OICR gives many zero weights
+    for w in (None, W):
+        p_ref, l_ref = oracle.softmax_with_loss_n(X, T, w, scale=1.0)
+        p, l = ops.softmax_with_loss_n(_t(X, dev), _t(T, dev), None if w is None else _t(w, dev), 1.0)
+        np.testing.assert_allclose(p.cpu().numpy(), p_ref, rtol=2e-6, atol=1e-9)
+        assert abs(float(l) - float(l_ref)) <= 1e-5 * abs(float(l_ref))
+        g_ref = oracle.softmax_with_loss_n_grad(T, w, p_ref, 0.7)
+        g = ops.softmax_with_loss_n_grad(_t(T, dev), None if w is None else _t(w, dev), p,
+                                         torch.tensor([0.7], device=dev), 1.0)
+        np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=1e-5, atol=1e-10)
+    # the docstring example of the reference op (.cc:60-75)
+    p, l = ops.softmax_with_loss_n(_t(np.array([[.1, .4, .7, 1.5, .2]], np.float32), dev),
+                                   _t(np.array([4], np.int32), dev), None, 5.0)
+    assert abs(float(l) - 10.667433) < 1e-5
+    # all-zero weights: loss 0, gradient unscaled zeros; a bad label poisons the loss
+    z = torch.zeros((n,), device=dev)
+    p, l = ops.softmax_with_loss_n(_t(X, dev), _t(T, dev), z, 1.0)
+    assert float(l) == 0.0
+    bad = T.copy(); bad[0] = d
+    assert np.isnan(float(ops.softmax_with_loss_n(_t(X, dev), _t(bad, dev), None, 1.0)[1]))
+
+
+def test_roi_entropy_and_box_with_nms_limit(dev):
+    import detectron.ops as O
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    n, k = 400, 21
+    rois = make_rois(rng, 1, n, 600, 1000, degenerate=False)
+    boxes = np.tile(rois[:, 1:5], (1, k)).astype(np.float32)
+    scores = rng.uniform(0, 1, (n, k)).astype(np.float32) ** 4
+    scores[:, 7] = 0                                                   # a class with no detection
+    s_ref, b_ref, c_ref = oracle.box_with_nms_limit(scores, boxes, 1e-11, 0.9, 999999)
+    s, b, c = O.BoxWithNMSLimit(_t(scores, dev), _t(boxes, dev), score_thresh=1e-11, nms=0.9,
+                                detections_per_im=999999)
+    assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(c.cpu().numpy(), c_ref)
+    assert np.array_equal(b.cpu().numpy(), b_ref)
+    lines = []
+    op = O.RoIEntropy(display=2, num_classes=k - 1, printer=lines.append)
+    e = op(s, c)
+    e_ref = oracle.roi_entropy(s_ref, c_ref, k - 1)
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=1e-5, atol=1e-6)
+    assert e_ref[0, 6] == 1.0 and lines[0] == 'RoIEntropy #iter_: 1'
+    # running mean: E accumulates where E != 1 (Add_A_not_1), reset after a print
+    e2 = op(s, c)
+    want = np.where(e_ref[0] != 1, 2 * e_ref[0], 0)     # iter 1 printed -> init; then +E twice? no:
+    # iteration 1 printed (init -> True): iteration 2 starts from zero and adds E once, prints again
+    np.testing.assert_allclose(op.mean.cpu().numpy(), np.where(e_ref[0] != 1, e_ref[0], 0), rtol=1e-5)
+    assert torch.equal(e, e2) and len(lines) == 4

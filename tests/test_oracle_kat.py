@@ -1,6 +1,7 @@
 """Known-answer tests that pin the CPU oracle (oracle/README.md): hand-derived values, the one
 recorded reference output, and fixtures generated from the imported reference Python."""
 import numpy as np
+import pytest
 
 from oracle import oracle
 
@@ -189,3 +190,84 @@ def test_min_entropy_loss_known_answer():
     g0 = oracle.min_entropy_loss_grad(np.zeros((1, 2), np.float32), l, 1e6)
     assert g0[0, 0] == np.float32(1e4) and g0[0, 1] == 0
     assert oracle.min_entropy_loss(np.zeros((3, 2), np.float32), l) == np.float32(1e-20 * -np.log(np.float32(1e-20)))
+
+
+def test_roi_label_known_answers():
+    """roi_label_op.cc:10-123 by hand.  4 proposals, 3 classes (scores with a background column 0),
+    labels {class 0, class 2}: picks = argmax of column 1 and of column 3 (first index wins a tie,
+    a proposal is picked once), then every proposal follows the pick it overlaps most."""
+    from oracle import oracle
+    S = np.array([[.1, .7, .0, .2],
+                  [.1, .7, .0, .9],      # ties with row 0 on class 0 -> row 0 wins; best of class 2
+                  [.1, .1, .0, .3],
+                  [.1, .2, .0, .1]], np.float32)
+    L = np.array([[1, 0, 1]], np.float32)
+    U = np.array([[1.0, .3, .6, .05],
+                  [.3, 1.0, .2, .45],
+                  [.6, .2, 1.0, .0],
+                  [.05, .45, .0, 1.0]], np.float32)
+    st = np.zeros((4,), np.float32)
+    rl, rw = oracle.roi_label(S, U, L, fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=0.1, stats=st)
+    # picks: (n=0, class 0, p=.7), (n=1, class 2, p=.9)
+    # roi 0: IoU 1.0 with pick 0 -> fg, label 1, w .7;  roi 1: IoU 1.0 with pick 1 -> label 3, w .9
+    # roi 2: IoU .6 with pick 0 -> fg label 1 w .7;  roi 3: best IoU .45 (pick 1) in [.1,.5) -> bg, w .9
+    assert rl.tolist() == [1, 3, 1, 0]
+    assert np.allclose(rw, [.7, .9, .7, .9])
+    assert np.allclose(st, [3, 1, .7 + .9 + .7, .9])
+    # below bg_lo: the class label with weight 0; class weights replace the pick's score
+    rl, rw = oracle.roi_label(S, U, L, CW=np.array([.25, .5, .75], np.float32), fg_thresh=0.5,
+                              bg_thresh_hi=0.5, bg_thresh_lo=0.46)
+    assert rl.tolist() == [1, 3, 1, 3] and np.allclose(rw, [.25, .75, .25, 0])
+    # a score matrix without the background column, top_k = 2: the picked list is shared
+    rl, rw = oracle.roi_label(S[:, 1:], U, L, top_k=2)
+    # class 0 picks rows 0 then 1 (tie .7); class 2 picks the best REMAINING of column 2: row 2
+    # (.3), then row 3 (.1): every proposal is a pick and follows itself (IoU 1)
+    assert rl.tolist() == [1, 1, 3, 3]
+    assert np.allclose(rw, [.7, .7, .3, .1])
+    with pytest.raises(ValueError):
+        oracle.roi_label(S, U, L, num_pos=2)   # a binding cap needs the reference's random order
+
+
+def test_softmax_with_loss_n_known_answers():
+    """softmax_with_loss_n_op.cc:152-357 by hand, incl. the docstring example of the op itself
+    (.cc:60-75: logits [.1,.4,.7,1.5,.2], label 4, scale 5 -> loss 10.667433)."""
+    from oracle import oracle
+    x = np.array([[.1, .4, .7, 1.5, .2]], np.float32)
+    p, loss = oracle.softmax_with_loss_n(x, np.array([4], np.int32), None, scale=5.0)
+    assert np.allclose(p, [[0.10715417, 0.144643, 0.19524762, 0.4345316, 0.11842369]], atol=1e-7)
+    assert abs(float(loss) - 10.667433) < 2e-6
+    # weights: loss = sum(-w log p_t) / sum(w); gradient divides by the COUNT of w > 1e-12
+    x = np.log(np.array([[.5, .25, .25], [.1, .2, .7], [.3, .3, .4]], np.float32))
+    t = np.array([0, 2, 1], np.int32)
+    w = np.array([2.0, 0.0, 0.5], np.float32)
+    p, loss = oracle.softmax_with_loss_n(x, t, w)
+    assert np.allclose(p, np.exp(x), atol=1e-7)
+    assert abs(float(loss) - (-(2 * np.log(.5) + .5 * np.log(.3)) / 2.5)) < 1e-6
+    g = oracle.softmax_with_loss_n_grad(t, w, p, 3.0)
+    want = (np.exp(x) - np.eye(3, dtype=np.float32)[t]) * w[:, None] * 3.0 / 2.0
+    assert np.allclose(g, want, atol=1e-6)
+    # all weights zero: loss 0 and the gradient is left unscaled (all zeros here)
+    p, loss = oracle.softmax_with_loss_n(x, t, np.zeros((3,), np.float32))
+    assert loss == 0 and not oracle.softmax_with_loss_n_grad(t, np.zeros((3,), np.float32), p, 1.0).any()
+    with pytest.raises(ValueError):
+        oracle.softmax_with_loss_n(x, np.array([0, 3, 1], np.int32))
+
+
+def test_roi_entropy_and_box_with_nms_limit_known_answers():
+    """roi_entropy_op.cu:24-112: E_c = 1 - H(p)/log N_c over the kept detections of class c."""
+    from oracle import oracle
+    # class 1 (rm_bg -> slot 0): uniform over 4 -> E 0; class 2: one detection -> E 1;
+    # class 3: p = (.75, .25) -> 1 - H/log 2
+    S = np.array([.2, .2, .2, .2, .9, .3, .1], np.float32)
+    C = np.array([1, 1, 1, 1, 2, 3, 3], np.float32)
+    E = oracle.roi_entropy(S, C, 4)
+    h = -(.75 * np.log(.75) + .25 * np.log(.25)) / np.log(2)
+    assert np.allclose(E, [[0, 1, 1 - h, 1]], atol=1e-6)      # class 4 has no detection: stays 1
+    # BoxWithNMSLimit, gate form: per class, score filter -> NMS -> descending score
+    boxes = np.array([[0, 0, 9, 9], [1, 1, 10, 10], [20, 20, 29, 29]], np.float32)
+    scores = np.array([[.1, .9, .0], [.1, .8, .6], [.1, .5, .7]], np.float32)
+    s, b, c = oracle.box_with_nms_limit(scores, np.tile(boxes, (1, 3)), score_thresh=1e-11,
+                                        nms_thresh=0.5, detections_per_im=999999)
+    # class 1: boxes 0 and 1 overlap (IoU 81/119 > .5): keep 0 (.9) and 2 (.5); class 2: .7 then .6
+    assert np.allclose(s, [.9, .5, .7, .6]) and c.tolist() == [1, 1, 2, 2]
+    assert np.array_equal(b, boxes[[0, 2, 2, 1]])
