@@ -154,7 +154,7 @@ def _defaults():
 _OFF_PATH_SWITCHES = (
     'MODEL.MASK_ON', 'MODEL.KEYPOINTS_ON', 'MODEL.RPN_ONLY', 'MODEL.FASTER_RCNN', 'RPN.RPN_ON',
     'FPN.FPN_ON', 'RETINANET.RETINANET_ON', 'WSL.CPG', 'WSL.CSC', 'WSL.CENTER_LOSS',
-    'WSL.CONTEXT', 'WSL.OICR', 'WSL.PCL', 'WSL.CMIL', 'WEBLY.MINING',
+    'WSL.CONTEXT', 'WSL.PCL', 'WSL.CMIL',
 )
 
 cfg = CfgNode(_defaults())

@@ -284,6 +284,31 @@ class NetExecutor(object):
             ws[out[0]] = O.MinEntropyLoss(x[0], x[1])
         elif t == 'Accuracy':
             ws[out[0]] = O.Accuracy(x[0], x[1])
+        elif t == 'RoILabel':
+            if idx not in self._stats:
+                keys = ('display', 'uuid', 'fg_thresh', 'bg_thresh_hi', 'bg_thresh_lo', 'num_pos',
+                        'num_neg', 'top_k')
+                self._stats[idx] = O.RoILabel(**{k: a[k] for k in keys if k in a})
+            ws[out[0]], ws[out[1]] = self._stats[idx](*x)
+        elif t == 'SoftmaxWithLossN':
+            ws[out[0]], ws[out[1]] = O.SoftmaxWithLossN(x[0], x[1], x[2] if len(x) > 2 else None,
+                                                        scale=a.get('scale', 1.0))
+        elif t == 'RoIEntropy':
+            if idx not in self._stats:
+                self._stats[idx] = O.RoIEntropy(display=a.get('display', 1280),
+                                                num_classes=a.get('num_classes', 20),
+                                                rm_bg=a.get('rm_bg', True))
+            ws[out[0]] = self._stats[idx](x[0], x[1])
+        elif t == 'BoxWithNMSLimit':
+            ws[out[0]], ws[out[1]], ws[out[2]] = O.BoxWithNMSLimit(
+                x[0], x[1], score_thresh=a.get('score_thresh', 0.05), nms=a.get('nms', 0.3),
+                detections_per_im=a.get('detections_per_im', 100))
+        elif t == 'Mean':
+            ws[out[0]] = O.Mean(*x)
+        elif t == 'Max':
+            ws[out[0]] = O.Max(x[0], x[1])
+        elif t == 'Tile':
+            ws[out[0]] = O.Tile(x[0], tiles=a.get('tiles', 1), axis=a.get('axis', 1))
         elif t == 'Split':
             parts = torch.split(x[0], a['split'], dim=a.get('axis', 1))
             for n, p in zip(out, parts):
@@ -329,6 +354,10 @@ class NetExecutor(object):
             res = [O.RoIFeatureBoostGradient(gout[0], ws[ins[1]])]
         elif t == 'MinEntropyLoss':
             res = [O.MinEntropyLossGradient(ws[ins[0]], ws[ins[1]], gout[0])]
+        elif t == 'SoftmaxWithLossN':      # inputs X, T[, W]; outputs P, loss; seed = d(loss)
+            res = [O.SoftmaxWithLossNGradient(ws[ins[0]], ws[ins[1]],
+                                              ws[ins[2]] if n_in > 2 else None, ws[outs[0]],
+                                              gout[1], scale=a.get('scale', 1.0))] + [None] * (n_in - 1)
         else:
             raise NotImplementedError('gradient of ' + t)
         for i, g in enumerate(a['_gin']):

@@ -50,10 +50,10 @@ _GRAD_INPUTS = {
     'FC': (0, 1, 2), 'Relu': (0,), 'Dropout': (0,), 'Softmax': (0,), 'Transpose': (0,),
     'Mul': (0, 1), 'Add': (0, 1), 'ReduceSum': (0,), 'AveragedLoss': (0,),
     'WeightedCrossEntropyWithLogits': (0,), 'CrossEntropyWithLogits': (0,),
-    'RoIFeatureBoost': (0,), 'MinEntropyLoss': (0,),
+    'RoIFeatureBoost': (0,), 'MinEntropyLoss': (0,), 'SoftmaxWithLossN': (0,),
 }
 _NO_GRAD = {'StopGradient', 'RoIIoU', 'Stat', 'Accuracy', 'ConstantFill', 'Shape', 'Cast',
-            'DequeueBlobs'}
+            'DequeueBlobs', 'RoILabel', 'RoIEntropy', 'BoxWithNMSLimit'}
 
 
 class DetectionModelHelper(object):

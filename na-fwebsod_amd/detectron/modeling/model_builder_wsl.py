@@ -57,10 +57,12 @@ def build_generic_wsl_detection_model(model, add_conv_body_func, add_roi_box_hea
             model.StopGradient(blob_conv, blob_conv)
         if cfg.RPN.RPN_ON or cfg.FPN.FPN_ON or cfg.MODEL.MASK_ON or cfg.MODEL.KEYPOINTS_ON:
             raise NotImplementedError('RPN / FPN / mask / keypoint heads are outside the hot path')
-        if not cfg.WEBLY.WEBLY_ON:
-            raise NotImplementedError('only the WEBLY (noise-aware) head is on the hot path')
-        loss_gradients = _add_webly_head(model, add_roi_box_head_func, blob_conv, dim_conv,
-                                         spatial_scale_conv)
+        if cfg.WEBLY.WEBLY_ON:
+            loss_gradients = _add_webly_head(model, add_roi_box_head_func, blob_conv, dim_conv,
+                                             spatial_scale_conv)
+        else:
+            loss_gradients = _add_wsl_head(model, add_roi_box_head_func, blob_conv, dim_conv,
+                                           spatial_scale_conv)
         return loss_gradients if model.train else None
 
     optim_wsl.build_data_parallel_model(model, _single_gpu_build_func)
@@ -71,8 +73,21 @@ def _add_webly_head(model, add_roi_box_head_func, blob_in, dim_in, spatial_scale
     blob_frcn, dim_frcn = add_roi_box_head_func(model, blob_in, dim_in, spatial_scale_in)
     webly_heads.add_webly_outputs(model, blob_frcn, dim_frcn)
     if model.train and cfg.WEBLY.MINING:
-        raise NotImplementedError('WEBLY.MINING is outside the hot path')
+        # The reference's branch (model_builder_wsl.py:443-452) calls webly_heads.add_webly_mining
+        # and get_func(ROI_BOX_HEAD + '_shared') - neither function exists anywhere in the
+        # reference tree, so WEBLY.MINING: True dies there with exactly this error.
+        raise AttributeError("module 'detectron.modeling.webly_heads' has no attribute "
+                             "'add_webly_mining' (nor does the reference: WEBLY.MINING is dead code "
+                             "upstream, model_builder_wsl.py:443-452)")
     return webly_heads.add_webly_losses(model) if model.train else None
+
+
+def _add_wsl_head(model, add_roi_box_head_func, blob_in, dim_in, spatial_scale_in):
+    """model_builder_wsl.py:404-431 without the webly head: plain WSDDN (+ WSL.OICR refinement)."""
+    import detectron.modeling.wsl_heads as wsl_heads
+    blob_frcn, dim_frcn = add_roi_box_head_func(model, blob_in, dim_in, spatial_scale_in)
+    wsl_heads.add_wsl_outputs(model, blob_frcn, dim_frcn)
+    return wsl_heads.add_wsl_losses(model) if model.train else None
 
 
 def add_training_inputs(model, roidb=None, rank=0, world_size=1):

@@ -49,6 +49,30 @@ def add_webly_losses(model, prefix=''):
     return loss_gradients
 
 
+def add_entropy_weight(model, rois_pred_blob, rois_blob):
+    """webly_heads.py:219-262 - the class weights from the entropy of the NMS-ed detections
+    (BoxWithNMSLimit at NMS 0.9 -> RoIEntropy -> max with 1 - labels).  The reference defines it
+    but never calls it (the call at :131 is commented out; add_spatial_entropy_weight replaced it);
+    it is mirrored so that a user builder can."""
+    model.net.Split(rois_pred_blob, [rois_pred_blob + '_bg', rois_pred_blob + '_useless'],
+                    split=[1, model.num_classes - 2], axis=1)
+    model.net.Concat([rois_pred_blob + '_bg', rois_pred_blob],
+                     [rois_pred_blob + '_fgbg', rois_pred_blob + '_fgbg_concat_dims'], axis=1)
+    model.net.Split(rois_blob, [rois_blob + '_useless', rois_blob + '_4'], split=[1, 4], axis=1)
+    model.net.Tile(rois_blob + '_4', rois_blob + '_fgbg', axis=1, tiles=model.num_classes)
+    model.net.BoxWithNMSLimit(
+        [rois_pred_blob + '_fgbg', rois_blob + '_fgbg'],
+        [rois_pred_blob + '_nms', rois_blob + '_nms', rois_blob + '_classes_nms'],
+        score_thresh=0.00000000001, nms=0.9, detections_per_im=999999)
+    model.net.RoIEntropy([rois_pred_blob + '_nms', rois_blob + '_classes_nms'],
+                         [rois_blob + '_entropy'], display=int(1280 / cfg.NUM_GPUS),
+                         num_classes=model.num_classes - 1)
+    model.net.ConstantFill('labels_oh', 'labels_oh_one', value=1.0)
+    model.net.Sub(['labels_oh_one', 'labels_oh'], 'labels_oh_inv')
+    model.net.Max([rois_blob + '_entropy', 'labels_oh_inv'], rois_blob + '_class_weight')
+    return rois_blob + '_class_weight'
+
+
 def add_spatial_entropy_weight(model, rois_pred, cls_prob, rois):
     """Per-class loss weights from the IoU-graph-smoothed proposal entropy (no gradient)."""
     net = model.net

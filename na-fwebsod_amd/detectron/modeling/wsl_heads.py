@@ -1,10 +1,12 @@
 """WSDDN heads on the hot path.  Mirrors, from detectron/modeling/wsl_heads.py:
 add_wsl_outputs (:23-78), add_cls_pred (:213-227), add_cross_entropy_loss (:292-302),
-add_VGG16_roi_2fc_head (:654-681), DropoutIfTraining (:1259-1267).  The OICR / PCL / CMIL /
-CSC / context / center-loss heads of that file are other WSOD methods (cfg switches that
-core/config.py rejects)."""
+add_VGG16_roi_2fc_head (:654-681), DropoutIfTraining (:1259-1267); and, one cfg flag away
+(WSL.OICR): add_wsl_oicr_outputs (:134-156), add_wsl_losses (:375-458),
+add_oicr_losses (:512-560).  The PCL / CMIL / CSC / context / center-loss heads of that file are
+other WSOD methods (cfg switches that core/config.py rejects)."""
 from detectron.core.config import cfg
-from detectron.utils.c2 import const_fill
+from detectron.utils.c2 import const_fill, gauss_fill
+import detectron.utils.blob as blob_utils
 
 
 def add_wsl_outputs(model, blob_in, dim, prefix=''):
@@ -21,6 +23,71 @@ def add_wsl_outputs(model, blob_in, dim, prefix=''):
                         split=[1, model.num_classes - 2], axis=1)
         model.net.Concat([prefix + 'rois_bg_pred', prefix + 'rois_pred'],
                          [prefix + 'cls_prob', prefix + 'cls_prob_concat_dims'], axis=1)
+    if cfg.WSL.OICR:
+        add_wsl_oicr_outputs(model, blob_in, dim, prefix=prefix)
+
+
+def add_wsl_oicr_outputs(model, blob_in, dim, prefix=''):
+    """The K = 3 OICR refinement classifiers (num_classes outputs incl. background); at test time
+    their softmaxes are averaged into cls_prob (wsl_heads.py:134-156)."""
+    K = 3
+    for k in range(1, K + 1):
+        model.FC(blob_in, prefix + 'cls_score' + str(k), dim, model.num_classes,
+                 weight_init=gauss_fill(0.01), bias_init=const_fill(0.0))
+    if not model.train:
+        all_cls_prob = []
+        for k in range(1, K + 1):
+            all_cls_prob.append(model.Softmax(prefix + 'cls_score' + str(k),
+                                              prefix + 'cls_prob' + str(k), axis=1))
+        model.net.Mean(all_cls_prob, prefix + 'cls_prob')
+
+
+def add_wsl_losses(model, prefix=''):
+    """The plain WSDDN image-level loss (+ OICR refinement losses): wsl_heads.py:375-458 for the
+    switches the MI355X path accepts (no CPG / CSC / center loss / CMIL / PCL)."""
+    add_cls_pred(prefix + 'rois_pred', prefix + 'cls_prob', model, prefix='')
+    add_cross_entropy_loss(model, prefix + 'cls_prob', 'labels_oh', prefix + 'cross_entropy',
+                           weight=None, cpg=None)
+    loss_cls = model.net.AveragedLoss([prefix + 'cross_entropy'], [prefix + 'loss_cls'])
+    loss_gradients = blob_utils.get_loss_gradients(model, [loss_cls])
+    model.Accuracy([prefix + 'cls_prob', 'labels_int32'], prefix + 'accuracy_cls')
+    model.AddLosses([prefix + 'loss_cls'])
+    model.AddMetrics(prefix + 'accuracy_cls')
+    if cfg.WSL.MIN_ENTROPY_LOSS:
+        loss_gradients.update(add_min_entropy_loss(model, prefix + 'rois_pred', 'labels_oh',
+                                                   prefix + 'loss_entropy', cpg=None))
+    if cfg.WSL.OICR:
+        loss_gradients.update(add_oicr_losses(model, prefix))
+    return loss_gradients
+
+
+def add_oicr_losses(model, prefix=''):
+    """wsl_heads.py:512-560: RoIIoU once; per branch k RoILabel (pseudo labels from the previous
+    branch's scores - rois_pred for k = 1) -> SoftmaxWithLossN on cls_score_k."""
+    loss_gradients = {}
+    model.net.RoIIoU([prefix + 'rois'], [prefix + 'rois_iou'])
+    import uuid
+    uu = uuid.uuid4().int % 10000
+    K = 3
+    for k in range(1, K + 1):
+        first = prefix + 'rois_pred' if k == 1 else prefix + 'cls_prob' + str(k - 1)
+        model.net.RoILabel([first, prefix + 'rois_iou', 'labels_oh', prefix + 'cls_prob'],
+                           [prefix + 'rois_labels_int32' + str(k), prefix + 'rois_weight' + str(k)],
+                           display=int(1280 / cfg.NUM_GPUS), uuid=uu)
+        cls_prob, loss_cls = model.net.SoftmaxWithLossN(
+            [prefix + 'cls_score' + str(k), prefix + 'rois_labels_int32' + str(k),
+             prefix + 'rois_weight' + str(k)],
+            [prefix + 'cls_prob' + str(k), prefix + 'loss_cls' + str(k)])
+        if cfg.WSL.MEAN_LOSS:
+            lg = blob_utils.get_loss_gradients(model, [loss_cls])
+        else:
+            lg = get_loss_gradients_weighted(model, [loss_cls], 1. * (cfg.MODEL.NUM_CLASSES - 1))
+        loss_gradients.update(lg)
+        model.Accuracy([prefix + 'cls_prob' + str(k), prefix + 'rois_labels_int32' + str(k)],
+                       prefix + 'accuracy_cls' + str(k))
+        model.AddLosses([prefix + 'loss_cls' + str(k)])
+        model.AddMetrics(prefix + 'accuracy_cls' + str(k))
+    return loss_gradients
 
 
 def _dual_softmax(model, fc8c, fc8d, prefix, suffix):

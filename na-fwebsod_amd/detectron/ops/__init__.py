@@ -251,7 +251,16 @@ class ACMWeightDecayMomentumSGDUpdate(object):
             raise NawsError('ACMWeightDecayMomentumSGDUpdate', _L.ERR_SHAPE)
         n = param.numel()
         if n % 4 != 0:
-            raise NawsError('ACMWeightDecayMomentumSGDUpdate', _L.ERR_ARG)
+            # the fused kernel works on float4s: blobs such as the 21-entry cls_score biases go
+            # through zero-padded copies (elementwise op: the padding never mixes in)
+            n4 = (n + 3) // 4 * 4
+            pads = [torch.zeros((n4,), device=param.device, dtype=torch.float32) for _ in range(4)]
+            for dst, src in zip(pads, (grad, momentum, param, acmgrad)):
+                dst[:n] = src.reshape(-1)
+            self.__call__(pads[0], pads[1], lr, pads[2], pads[3])
+            for dst, src in zip((momentum, param, acmgrad), pads[1:]):
+                dst.reshape(-1).copy_(src[:n])
+            return grad, momentum, param, acmgrad
         if self._tables is None or self._tables[0].item() != n:
             d = param.device
             self._tables = (torch.tensor([n], dtype=torch.int64, device=d),

@@ -357,3 +357,69 @@ def test_bagging_mixup_blend_matches_reference(cfgmod):
     np.random.seed(int(HOST['mixup_seed']))
     assert np.random.random() > 0.8
     assert np.random.beta(float(HOST['mixup_alpha']), float(HOST['mixup_alpha'])) == float(HOST['mixup_lam'])
+
+
+OICR = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference_oicr.json')))
+
+
+def _norm_ops(ops_):
+    out = []
+    for o in ops_:
+        ins, outs, args = list(o.inputs), list(o.outputs), dict(o.args)
+        if o.type in ('Conv', 'FC'):
+            ins = ins[:1]
+        if o.type == 'Dropout':
+            outs = outs[:1]
+        if 'uuid' in args:
+            args['uuid'] = 0             # random per build upstream (uuid4)
+        out.append([o.type, ins, outs, args])
+    return out
+
+
+def test_oicr_builders_reproduce_reference_trace(cfgmod):
+    """WSL.OICR on the plain (non-webly) generalized_wsl model - the op lists of
+    wsl_heads.add_wsl_outputs / add_wsl_oicr_outputs / add_wsl_losses / add_oicr_losses == the
+    trace recorded from the reference builders (tests/golden/make_golden_oicr.py), train and test
+    mode, incl. the RoILabel / SoftmaxWithLossN arguments; and the backward plan reaches the three
+    refinement classifiers."""
+    c = cfgmod
+    c.merge_cfg_from_file(YAML)
+    c.merge_cfg_from_list(['NUM_GPUS', 4, 'WEBLY.WEBLY_ON', False, 'WSL.OICR', True,
+                           'FAST_RCNN.ROI_BOX_HEAD', 'wsl_heads.add_VGG16_roi_2fc_head'])
+    c.assert_and_infer_cfg(make_immutable=False)       # WSL.OICR is an accepted switch now
+    import detectron.modeling.model_builder_wsl as mb
+    for train, key in ((True, 'wsl_oicr_train'), (False, 'wsl_oicr_test')):
+        m = mb.create(c.cfg.MODEL.TYPE, train=train)
+        want = OICR[key]
+        got = _norm_ops(m.net.ops)
+        assert [g[:3] for g in got] == [w[:3] for w in want['ops']]
+        for g, w in zip(got, want['ops']):
+            if g[0] in ('RoILabel', 'SoftmaxWithLossN', 'Mean', 'Split', 'Concat'):
+                assert g[3] == w[3], g
+        assert m.losses == want['losses'] and m.metrics == want['metrics']
+    m = mb.create(c.cfg.MODEL.TYPE, train=True)
+    for k in (1, 2, 3):
+        assert m.param_shapes['cls_score%d_w' % k] == (21, 4096)
+        assert m.param_to_grad['cls_score%d_w' % k] == 'cls_score%d_w_grad' % k
+    gtypes = [o.type for o in m.grad_ops]
+    assert gtypes.count('SoftmaxWithLossNGradient') == 3
+    # drop7 feeds fc8c, fc8d and the three cls_score FCs: its gradient accumulates five times
+    acc = [o for o in m.grad_ops if o.type == 'FCGradient' and o.inputs[0] == 'drop7']
+    assert len(acc) == 5 and sum(o.args['_accumulate'][0] for o in acc) == 4
+    # WEBLY.MINING is dead code upstream (add_webly_mining does not exist): same failure here
+    c.merge_cfg_from_list(['WEBLY.WEBLY_ON', True, 'WEBLY.MINING', True, 'WSL.OICR', False,
+                           'FAST_RCNN.ROI_BOX_HEAD', 'webly_heads.add_VGG16_roi_2fc_noise_head'])
+    with pytest.raises(AttributeError):
+        mb.create(c.cfg.MODEL.TYPE, train=True)
+
+
+def test_entropy_weight_builder_reproduces_reference_trace(cfgmod):
+    c = cfgmod
+    c.merge_cfg_from_file(YAML)
+    c.merge_cfg_from_list(['NUM_GPUS', 4])
+    from detectron.modeling.detector import DetectionModelHelper
+    from detectron.modeling import webly_heads
+    m = DetectionModelHelper(name='t', train=True, num_classes=c.cfg.MODEL.NUM_CLASSES)
+    w = webly_heads.add_entropy_weight(m, 'rois_pred', 'rois')
+    assert w == OICR['entropy_weight']['weight']
+    assert _norm_ops(m.net.ops) == OICR['entropy_weight']['ops']

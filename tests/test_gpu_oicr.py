@@ -102,3 +102,97 @@ def test_roi_entropy_and_box_with_nms_limit(dev):
     # iteration 1 printed (init -> True): iteration 2 starts from zero and adds E once, prints again
     np.testing.assert_allclose(op.mean.cpu().numpy(), np.where(e_ref[0] != 1, e_ref[0], 0), rtol=1e-5)
     assert torch.equal(e, e2) and len(lines) == 4
+
+
+def test_oicr_graph_trains_and_matches_oracle(dev):
+    """WSL.OICR on the plain WSDDN model (WEBLY off), run by the op-by-op plan: one training
+    iteration (dropout off) against an oracle composition - torch-CPU conv / fc + the C
+    restatements of RoIPoolF, RoIIoU, the WSDDN outputs, CrossEntropyWithLogits, RoILabel and
+    SoftmaxWithLossN(+Gradient) - on logits, pseudo labels (bit-exact), the four losses and the
+    gradients of the three refinement classifiers; then the test-mode ensemble."""
+    import os
+    from detectron.core import config as c
+    from detectron.datasets import synthetic
+    from detectron.core.executor import NetExecutor
+    import detectron.modeling.model_builder_wsl as mbld
+    from oracle import oracle
+    import torch.nn.functional as F
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c.reset_cfg()
+    try:
+        c.merge_cfg_from_file(os.path.join(root, 'na-fwebsod_amd', 'configs', 'flickr_voc',
+                                           'na_wsddn_V-16-C5_1x.yaml'))
+        c.merge_cfg_from_list(['NUM_GPUS', 1, 'WEBLY.WEBLY_ON', False, 'WSL.OICR', True,
+                               'FAST_RCNN.ROI_BOX_HEAD', 'wsl_heads.add_VGG16_roi_2fc_head'])
+        nfg = 20
+        model = mbld.create('generalized_wsl', train=True)
+        ex = NetExecutor(model, dev, disable_dropout=True)
+        assert ex.plan == 'interpreted'
+        blobs = synthetic.init_blobs(nfg, seed=3)
+        g = torch.Generator().manual_seed(5)
+        for k in (1, 2, 3):
+            blobs['cls_score%d_w' % k] = torch.randn((nfg + 1, 4096), generator=g) * 0.01
+            blobs['cls_score%d_b' % k] = torch.randn((nfg + 1,), generator=g) * 0.01
+        ex.load_blobs(blobs)
+        mb = synthetic.make_minibatch(synthetic.make_roidb(1, 48, nfg, 64, 96, seed=5), nfg)
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        model.UpdateWorkspaceLr(0, 0.0)          # lr 0: parameters stay, gradients are inspected
+        ex.feed(t)
+        ex.run()
+        # ---- oracle
+        with torch.no_grad():
+            conv5 = oracle.vgg16_conv5_body(torch.from_numpy(mb['data']), blobs).numpy()
+        pooled, _ = oracle.roi_pool_f(conv5, mb['rois'], 7, 7, 0.125)
+        feat = torch.from_numpy(oracle.roi_feature_boost(pooled, mb['obn_scores'].reshape(-1)))
+        x = feat.reshape(feat.shape[0], -1)
+        h = F.relu(F.linear(x, blobs['fc6_w'], blobs['fc6_b']))
+        h7 = F.relu(F.linear(h, blobs['fc7_w'], blobs['fc7_b']))
+        fc8c = F.linear(h7, blobs['fc8c_w'], blobs['fc8c_b']).numpy()
+        fc8d = F.linear(h7, blobs['fc8d_w'], blobs['fc8d_b']).numpy()
+        _ac, _ad, rois_pred, cls_prob = oracle.wsddn_outputs(fc8c, fc8d)
+        loss0 = oracle.weighted_ce(cls_prob, mb['labels_oh'], None, True)
+        U = oracle.roi_iou(mb['rois'])
+        prev, want = rois_pred, {}
+        for k in (1, 2, 3):
+            score = F.linear(h7, blobs['cls_score%d_w' % k], blobs['cls_score%d_b' % k]).numpy()
+            rl, rw = oracle.roi_label(prev, U, mb['labels_oh'], cls_prob.reshape(-1))
+            p, loss = oracle.softmax_with_loss_n(score, rl, rw)
+            dscore = oracle.softmax_with_loss_n_grad(rl, rw, p, 1.0)
+            want[k] = dict(score=score, rl=rl, rw=rw, p=p, loss=loss,
+                           dW=dscore.T @ h7.numpy(), db=dscore.sum(0))
+            prev = p
+        ws = ex.ws
+        np.testing.assert_allclose(ws['rois_pred'].cpu().numpy(), rois_pred, rtol=1e-4, atol=1e-9)
+        assert abs(float(ws['loss_cls'].reshape(-1)[0]) - float(loss0)) <= 1e-4 * abs(float(loss0))
+        for k in (1, 2, 3):
+            w = want[k]
+            assert np.array_equal(ws['rois_labels_int32%d' % k].cpu().numpy(), w['rl']), k
+            np.testing.assert_allclose(ws['rois_weight%d' % k].cpu().numpy(), w['rw'], rtol=1e-4)
+            sc = ws['cls_score%d' % k].cpu().numpy()
+            assert np.abs(sc - w['score']).max() <= 1e-4 * np.abs(w['score']).max(), k
+            np.testing.assert_allclose(ws['cls_prob%d' % k].cpu().numpy(), w['p'], rtol=1e-3,
+                                       atol=1e-4 * w['p'].max())   # exp() of 1e-5-accurate logits
+            got = float(ws['loss_cls%d' % k].reshape(-1)[0])
+            assert abs(got - float(w['loss'])) <= 1e-4 * abs(float(w['loss'])), k
+            gw = ws[model.param_to_grad['cls_score%d_w' % k]].cpu().numpy()
+            gb = ws[model.param_to_grad['cls_score%d_b' % k]].cpu().numpy()
+            assert np.abs(gw - w['dW']).max() <= 1e-4 * np.abs(w['dW']).max() + 1e-9, k
+            assert np.abs(gb - w['db']).max() <= 1e-4 * np.abs(w['db']).max() + 1e-9, k
+        # one real step moves the refinement classifiers
+        model.UpdateWorkspaceLr(1, 1e-2)
+        ex.feed(t)
+        ex.run()
+        after = ex.blobs(with_momentum=False)
+        assert not torch.equal(after['cls_score2_w'].cpu(), blobs['cls_score2_w'])
+        assert torch.equal(after['conv3_2_w'].cpu(), blobs['conv3_2_w'])       # frozen body
+        # ---- test mode: cls_prob = mean of the three branch softmaxes (wsl_heads.py:147-156)
+        tmodel = mbld.create('generalized_wsl', train=False)
+        tex = NetExecutor(tmodel, dev)
+        tex.load_blobs(blobs)
+        tex.feed(t)
+        tex.run()
+        ens = np.mean([np.exp(F.log_softmax(torch.from_numpy(want[k]['score']), 1).numpy())
+                       for k in (1, 2, 3)], 0)
+        np.testing.assert_allclose(tex.fetch('cls_prob').cpu().numpy(), ens, rtol=1e-3, atol=1e-4 * ens.max())
+    finally:
+        c.reset_cfg()
