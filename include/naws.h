@@ -551,6 +551,43 @@ int naws_softmax_with_loss_n_bwd(const int32_t* T, const float* W, const float* 
 int naws_roi_entropy_fwd(const float* S, const float* C, int n, int num_classes, int rm_bg, float* E,
                          float* mean, int init, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * f-2  Inference post-processing on the GPU (BASELINE configs[4]: multi-scale TTA).
+ *
+ * naws_roi_dedup_fwd — per TTA pass p (one workgroup each): project the image boxes into the pass's
+ *   input frame, de-duplicate them on the DEDUP_BOXES grid and emit the network's roi blobs.
+ *   ref: detectron/core/test_wsl.py:998-1026 (float64 product, float32 blob), :293-301 (flip),
+ *   :125-133 (hash + np.unique), :1058 (obn + 1).
+ *   boxes fp32 [n][4] image coordinates, obn_scores fp32 [n]; passes: DEVICE array of npass
+ *   naws_dedup_pass records.  Outputs per pass (stride n): rois_out fp32 [npass][n][5] (the unique
+ *   rois in np.unique's ascending-hash order, column 0 = batch_index), obn_out fp32 [npass][n],
+ *   index_out int32 [npass][n] (first occurrence of each unique roi), inv_out int32 [npass][n]
+ *   (scores_unique[inv] = scores in proposal order), count_out int32 [npass].  n <= 16384.
+ * naws_tta_accumulate — acc[n][k] (=, when first) += scores[inv_index[r]][:] (inv_index nullable =
+ *   identity): the scatter-back of :173-176 fused with the running sum of np.mean (:260-261).
+ * naws_tta_finish — acc = float32(double(acc) / npass) (numpy's mean division).
+ * naws_det_limit_fwd — the image-wide DETECTIONS_PER_IM cut of :849-863 after the per-class NMS
+ *   (naws_nms_sorted_fwd): scores fp32 [R][K] (K = C + 1, column 0 background), keep uint8 [C][R];
+ *   limit == 0 keeps everything.  Outputs (class ascending, row ascending - the reference's
+ *   order): out_count int32 [1] (may exceed cap: then only cap triples were written), out_cls /
+ *   out_row int32 [cap], out_score fp32 [cap].
+ * ------------------------------------------------------------------------ */
+typedef struct naws_dedup_pass {
+  double im_scale;      /* target_scale / short side (capped by max size), as the host computes it */
+  float im_width;       /* width of the (un-scaled) image: used when flip != 0 */
+  int32_t flip;         /* horizontally mirrored pass */
+  float batch_index;    /* column 0 of the emitted rois */
+} naws_dedup_pass;
+int naws_roi_dedup_fwd(const float* boxes, const float* obn_scores, int n, int npass,
+                       const void* passes, float dedup_boxes, float* rois_out, float* obn_out,
+                       int32_t* index_out, int32_t* inv_out, int32_t* count_out, void* stream);
+int naws_tta_accumulate(const float* scores, const int32_t* inv_index, int n, int k, int first,
+                        float* acc, void* stream);
+int naws_tta_finish(float* acc, int64_t total, int npass, void* stream);
+int naws_det_limit_fwd(const float* scores, const uint8_t* keep, int C, int R, int K, int limit,
+                       int cap, int32_t* out_count, int32_t* out_cls, int32_t* out_row,
+                       float* out_score, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,6 +140,9 @@ def _defaults():
                                      # of the images on the GPU (naws_prep_image_fwd); threads only decode
             'HOST_NMS': False,       # True: per-class NMS with the numpy loop instead of the HIP kernel
             'TTA_PAIR_FLIPS': True,  # inference TTA: a scale's plain + mirrored pass as one batch of 2
+            'DEVICE_POST': True,     # inference: roi projection / dedup hash / scatter-back / TTA mean /
+                                     # DETECTIONS_PER_IM cut on the GPU (csrc/infer_ops.hip): one result
+                                     # download per image; False = the numpy path of the reference
             'MFMA_DTYPE': 'fp16x2',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact
                                      # 3-way bf16 splits on the bf16 MFMA (fp32-accurate, faster);
                                      # 'fp16x2': the same GEMMs as row-scaled 2-way f16 splits on

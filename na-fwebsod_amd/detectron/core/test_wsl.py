@@ -267,7 +267,127 @@ def box_results_with_nms_and_limit(scores, boxes):
     return im_results[:, -1], im_results[:, :-1], cls_boxes
 
 
+def tta_passes():
+    """[(target_scale, max_size, flip)] in the order the reference adds them (:181-281): hflip at
+    TEST.SCALE, every BBOX_AUG scale (+ its flip), the identity pass last; one plain pass without
+    BBOX_AUG."""
+    aug = cfg.TEST.BBOX_AUG
+    if not aug.ENABLED:
+        return [(cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, False)]
+    out = []
+    if aug.H_FLIP:
+        out.append((cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, True))
+    for scale in aug.SCALES:
+        out.append((scale, aug.MAX_SIZE, False))
+        if aug.SCALE_H_FLIP:
+            out.append((scale, aug.MAX_SIZE, True))
+    out.append((cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, False))
+    return out
+
+
+def device_post_supported(executor, im):
+    aug = cfg.TEST.BBOX_AUG
+    return bool(cfg.NAWS.DEVICE_POST and cfg.NAWS.DEVICE_PREP and cfg.DEDUP_BOXES > 0
+                and not cfg.NAWS.HOST_NMS and getattr(executor, 'engine', None) is not None
+                and im.dtype == np.uint8
+                and (not aug.ENABLED or (aug.SCORE_HEUR in ('AVG', 'ID') and aug.COORD_HEUR == 'ID'
+                                         and not aug.ASPECT_RATIOS and not aug.SCALE_SIZE_DEP)))
+
+
+def im_detect_all_device(executor, im, box_proposals, obn_scores):
+    """The whole per-image inference of `im_detect_all` with every intermediate in HBM
+    (SURVEY.md 8 f-2): one upload of the pixels / proposals, per pass the device image
+    preparation (naws_prep_image_fwd), roi projection + dedup hash + np.unique
+    (naws_roi_dedup_fwd, all passes in one launch), the forward pass, the scatter-back fused with
+    the running TTA sum (naws_tta_accumulate), then the mean, the per-class NMS
+    (naws_nms_sorted_fwd) and the DETECTIONS_PER_IM cut (naws_det_limit_fwd).  Downloads: the
+    per-pass unique counts (a few ints, they size the launches) and ONE packed result buffer.
+    Bit-identical kept sets and scores to the numpy path (tests/test_gpu_infer_post.py)."""
+    from naws_hip import ops
+    dev = executor.device
+    n = box_proposals.shape[0]
+    num_classes = cfg.MODEL.NUM_CLASSES
+    passes = tta_passes()
+    avg = cfg.TEST.BBOX_AUG.ENABLED and cfg.TEST.BBOX_AUG.SCORE_HEUR == 'AVG'
+    if cfg.TEST.BBOX_AUG.ENABLED and not avg:
+        passes = passes[-1:]                       # 'ID': only the identity pass is used
+    h, w = im.shape[:2]
+    scales = [get_im_scale((h, w), s, m) for s, m, _f in passes]
+    boxes_d = torch.from_numpy(np.ascontiguousarray(box_proposals, np.float32)).to(dev)
+    obn_d = torch.from_numpy(np.ascontiguousarray(obn_scores, np.float32).reshape(-1)).to(dev)
+    im_d = torch.from_numpy(np.ascontiguousarray(im)).to(dev)
+    # plain + mirrored pass of one scale share a forward pass (two images, per-image segments)
+    pair_of = {}
+    if cfg.NAWS.TTA_PAIR_FLIPS:
+        for i, (s, m, f) in enumerate(passes):
+            if f:
+                for j, (s2, m2, f2) in enumerate(passes):
+                    if not f2 and (s2, m2) == (s, m) and j not in pair_of.values():
+                        pair_of[i] = j
+                        break
+    specs = [(scales[i], w, f, 1.0 if i in pair_of else 0.0) for i, (_s, _m, f) in enumerate(passes)]
+    dd = ops.roi_dedup(boxes_d, obn_d, specs, cfg.DEDUP_BOXES)
+    counts = dd['count'].cpu().tolist()
+
+    def blob(i):
+        s, fl = scales[i], passes[i][2]
+        oh, ow = int(np.round(h * s)), int(np.round(w * s))
+        data = torch.zeros((1, 3, oh, ow), device=dev, dtype=torch.float32)
+        ops.prep_image(im_d, data[0], s, flip=fl, means=cfg.PIXEL_MEANS.reshape(-1)[:3],
+                       stds=np.asarray(cfg.PIXEL_STDS).reshape(-1)[:3])
+        return data
+
+    results = {}                                   # pass -> unique-roi scores [m, K] on the device
+    done = set()
+    for i in range(len(passes)):
+        if i in done:
+            continue
+        group = [i]
+        if i in pair_of:
+            group = [pair_of[i], i]                # batch 0 = plain, batch 1 = mirrored
+        elif i in pair_of.values():
+            group = [i, [k for k, v in pair_of.items() if v == i][0]]
+        seg = [0]
+        for p in group:
+            seg.append(seg[-1] + counts[p])
+        executor.feed(dict(
+            data=torch.cat([blob(p) for p in group], 0) if len(group) > 1 else blob(group[0]),
+            rois=torch.cat([dd['rois'][p, :counts[p]] for p in group], 0),
+            obn_scores=torch.cat([dd['obn'][p, :counts[p]] for p in group], 0).reshape(-1, 1),
+            _seg=seg))
+        executor.run()
+        sc = executor.fetch('cls_prob')
+        for b, p in enumerate(group):
+            results[p] = sc[seg[b]:seg[b + 1]]
+            done.add(p)
+    acc = torch.empty((n, num_classes), device=dev, dtype=torch.float32)
+    for i in range(len(passes)):                   # the reference's summation order
+        ops.tta_accumulate(results[i].contiguous(), dd['inv'][i], acc, first=(i == 0))
+    if len(passes) > 1:
+        ops.tta_finish(acc, len(passes))
+    keep = ops.nms_per_class(boxes_d, acc[:, 1:].contiguous(), cfg.TEST.SCORE_THRESH, cfg.TEST.NMS)
+    limit = int(cfg.TEST.DETECTIONS_PER_IM)
+    cap = max(4 * limit, 1024) if limit > 0 else n * (num_classes - 1)
+    while True:
+        ints, sc = ops.det_limit(acc, keep, limit, cap)
+        packed = torch.cat([ints, sc.view(torch.int32)]).cpu().numpy()      # the one result download
+        cnt = int(packed[0])
+        if cnt <= cap:
+            break
+        cap = cnt                                  # more ties at the threshold than the buffer held
+    cls_i, row_i = packed[1:1 + cnt], packed[1 + cap:1 + cap + cnt]
+    score = packed[1 + 2 * cap:1 + 2 * cap + cnt].view(np.float32)
+    cls_boxes = [np.zeros((0, 5), np.float32) for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        m = cls_i == j
+        cls_boxes[j] = np.hstack((box_proposals[row_i[m]].astype(np.float32, copy=False),
+                                  score[m][:, np.newaxis])).astype(np.float32, copy=False)
+    return cls_boxes
+
+
 def im_detect_all(executor, im, box_proposals, obn_scores):
+    if device_post_supported(executor, im):
+        return im_detect_all_device(executor, im, box_proposals, obn_scores)
     if cfg.TEST.BBOX_AUG.ENABLED:
         scores, boxes = im_detect_bbox_aug(executor, im, box_proposals, obn_scores)
     else:

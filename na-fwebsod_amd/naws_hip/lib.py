@@ -53,6 +53,10 @@ PROTOTYPES = {
     'naws_softmax_with_loss_n_fwd': [p, p, p, i32, i32, f32, p, p, p, p],
     'naws_softmax_with_loss_n_bwd': [p, p, p, p, i32, i32, f32, p, p, p],
     'naws_roi_entropy_fwd': [p, p, i32, i32, i32, p, p, i32, p],
+    'naws_roi_dedup_fwd': [p, p, i32, i32, p, f32, p, p, p, p, p, p],
+    'naws_tta_accumulate': [p, p, i32, i32, i32, p, p],
+    'naws_tta_finish': [p, i64, i32, p],
+    'naws_det_limit_fwd': [p, p, i32, i32, i32, i32, i32, p, p, p, p, p],
     'naws_stat_accumulate': [p, p, i32, i32, p, p, p],
     'naws_unary_f32': [i32, p, i64, f32, f32, p, p],
     'naws_binary_f32': [i32, p, i32, i32, p, i32, i32, p, i32, i32, p],

@@ -898,6 +898,68 @@ def roi_entropy(s, c, num_classes, rm_bg=True, mean=None, init=True):
     return e
 
 
+# ----------------------------------------------------------------------------
+# inference post-processing on the device
+# ----------------------------------------------------------------------------
+DEDUP_PASS_DTYPE = np.dtype([('im_scale', '<f8'), ('im_width', '<f4'), ('flip', '<i4'),
+                             ('batch_index', '<f4')], align=True)      # = struct naws_dedup_pass
+
+
+def roi_dedup(boxes, obn_scores, passes, dedup_boxes):
+    """boxes [n,4], obn_scores [n] (device fp32); passes: list of (im_scale, im_width, flip,
+    batch_index).  -> dict(rois [P,n,5], obn [P,n], index [P,n], inv [P,n], count [P]) on the device
+    (rows >= count[p] of rois / obn / index are unspecified)."""
+    _chk(boxes, 'boxes'); _chk(obn_scores, 'obn_scores')
+    n = boxes.shape[0]
+    if boxes.dim() != 2 or boxes.shape[1] != 4 or obn_scores.numel() != n:
+        raise L.NawsError('naws_roi_dedup_fwd', L.ERR_SHAPE)
+    rec = np.zeros((len(passes),), DEDUP_PASS_DTYPE)
+    for i, (sc, w, fl, b) in enumerate(passes):
+        rec[i] = (float(sc), float(w), int(bool(fl)), float(b))
+    dev = boxes.device
+    pd = torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev)
+    npass = len(passes)
+    out = dict(rois=torch.empty((npass, n, 5), device=dev, dtype=_f32),
+               obn=torch.empty((npass, n), device=dev, dtype=_f32),
+               index=torch.empty((npass, n), device=dev, dtype=torch.int32),
+               inv=torch.empty((npass, n), device=dev, dtype=torch.int32),
+               count=torch.empty((npass,), device=dev, dtype=torch.int32))
+    L.call('naws_roi_dedup_fwd', boxes.data_ptr(), obn_scores.data_ptr(), n, npass, pd.data_ptr(),
+           float(dedup_boxes), out['rois'].data_ptr(), out['obn'].data_ptr(),
+           out['index'].data_ptr(), out['inv'].data_ptr(), out['count'].data_ptr(), _stream())
+    return out
+
+
+def tta_accumulate(scores, inv_index, acc, first):
+    """acc[n,k] (=|+=) scores[inv_index]."""
+    _chk(scores, 'scores'); _chk(acc, 'acc')
+    n, k = acc.shape
+    L.call('naws_tta_accumulate', scores.data_ptr(), _ptr(inv_index), n, k, int(bool(first)),
+           acc.data_ptr(), _stream())
+    return acc
+
+
+def tta_finish(acc, npass):
+    L.call('naws_tta_finish', acc.data_ptr(), acc.numel(), int(npass), _stream())
+    return acc
+
+
+def det_limit(scores, keep, limit, cap):
+    """scores [R,K] fp32, keep [C,R] bool -> (count [1], cls [cap], row [cap], score [cap]), one
+    packed int32 / fp32 device buffer each; see naws_det_limit_fwd."""
+    _chk(scores, 'scores')
+    r, k = scores.shape
+    c = keep.shape[0]
+    if keep.dtype != torch.bool or tuple(keep.shape) != (c, r) or not keep.is_contiguous():
+        raise TypeError('keep must be a contiguous bool [C, R] tensor')
+    dev = scores.device
+    ints = torch.empty((1 + 2 * cap,), device=dev, dtype=torch.int32)
+    sc = torch.empty((cap,), device=dev, dtype=_f32)
+    L.call('naws_det_limit_fwd', scores.data_ptr(), keep.data_ptr(), c, r, k, int(limit), int(cap),
+           ints.data_ptr(), ints[1:].data_ptr(), ints[1 + cap:].data_ptr(), sc.data_ptr(), _stream())
+    return ints, sc
+
+
 class RowmaxTable(object):
     """[(first element, end element, row length, first rowmax index)] for acm_sgd_update."""
 
