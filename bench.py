@@ -67,7 +67,87 @@ def parse():
                          "test_gpu_h2.py).  bf16 = the configs[3] option (operands rounded to bf16, "
                          "fp32 storage + loss)")
     ap.add_argument('--cpu-rois', type=int, default=500)
+    ap.add_argument('--infer', action='store_true',
+                    help='BASELINE configs[4] instead of the training step: inference with the '
+                         'yaml\'s 10-pass multi-scale + flip TTA (scales 480/576/688/864/1200) on a '
+                         'synthetic image with --infer-rois proposals; a step = one image end to '
+                         'end (device image prep, dedup, 10 forward passes, TTA mean, NMS, top-100)')
+    ap.add_argument('--infer-rois', type=int, default=4000)
+    ap.add_argument('--infer-height', type=int, default=375)
+    ap.add_argument('--infer-width', type=int, default=500)
     return ap.parse_args()
+
+
+def infer_main(args):
+    """python bench.py --infer: ms per image of configs[4] on one GPU (no data-parallel path:
+    images are independent; N GPUs = N replicas)."""
+    import numpy as np
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    from detectron.core import config as c
+    from detectron.core import test_wsl
+    from detectron.core.executor import NetExecutor
+    from detectron.datasets import synthetic
+    from detectron.roi_data.minibatch_wsl import get_im_scale
+    import detectron.modeling.model_builder_wsl as mb
+    c.merge_cfg_from_file(os.path.join(ROOT, 'na-fwebsod_amd', 'configs', 'flickr_voc',
+                                       'na_wsddn_V-16-C5_1x.yaml'))
+    c.merge_cfg_from_list(['NUM_GPUS', 1, 'TEST.BBOX_AUG.ENABLED', True,
+                           'NAWS.MFMA_DTYPE', args.mfma_dtype])
+    cfg = c.cfg
+    num_fg = cfg.MODEL.NUM_CLASSES - 1
+    model = mb.create(cfg.MODEL.TYPE, train=False)
+    ex = NetExecutor(model, dev)
+    ex.load_blobs(synthetic.init_blobs(num_fg, seed=11))
+    h, w = args.infer_height, args.infer_width
+    entries = synthetic.make_roidb(4, args.infer_rois, num_fg, h, w, seed=11)
+    ims = [np.random.default_rng(e['seed']).integers(0, 256, (h, w, 3), dtype=np.uint8)
+           for e in entries]
+    assert test_wsl.device_post_supported(ex, ims[0])
+
+    def run(k):
+        n = 0
+        for i in range(k):
+            e = entries[i % len(entries)]
+            cls_boxes = test_wsl.im_detect_all(ex, ims[i % len(ims)], e['boxes'], e['obn_scores'])
+            n += sum(len(b) for b in cls_boxes[1:])
+        torch.cuda.synchronize()
+        return n
+    run(max(args.warmup // 4, 2))
+    steps = max(args.steps // 4, 4)
+    t0 = time.perf_counter()
+    ndet = run(steps)
+    dt = time.perf_counter() - t0
+    passes = test_wsl.tta_passes()
+    # algorithmic work per image (SURVEY.md 8(d): conv 463.7 GFLOP at 600x1000, scaled by the
+    # input area; one head branch: fc6 + fc7 + fc8 on the proposals that survive the dedup)
+    conv, head = 0.0, 0.0
+    for s, m, _f in passes:
+        sc = get_im_scale((h, w), s, m)
+        conv += 463.7e9 * (round(h * sc) * round(w * sc)) / 600000.0
+        head += 2.0 * args.infer_rois * 4096 * (25088 + 4096 + 2 * num_fg)
+    tf = (conv + head) / (dt / steps) / 1e12
+    peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1) if args.mfma_dtype == 'fp16x2' else FP32_MFMA_PEAK_TFLOPS
+    res = {
+        'metric': 'inference images/sec, %d-pass multi-scale+flip TTA, %d proposals '
+                  '(BASELINE configs[4])' % (len(passes), args.infer_rois),
+        'value': round(steps / dt, 3), 'unit': 'images/sec', 'n_gpus': 1, 'steps': steps,
+        'warmup': max(args.warmup // 4, 2), 'ms_per_step': round(dt / steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (2xf16 split, 3-pass f16 MFMA, fp32 accumulate)' if args.mfma_dtype == 'fp16x2'
+                 else args.mfma_dtype,
+        'data': 'synthetic',
+        'config': {'workload': 'configs[4] flickr_voc na_wsddn TTA inference: image %dx%d, scales '
+                               '480/576/688/864/1200 +flip, %d proposals' % (h, w, args.infer_rois),
+                   'passes': len(passes), 'detections_per_image': round(ndet / steps, 1),
+                   'device_post': bool(cfg.NAWS.DEVICE_POST)},
+        'roofline': {'bound': 'mfma', 'kernel': 'whole image: conv bodies + fc6/fc7 of all passes',
+                     'achieved': round(tf, 1), 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': round(tf / peak, 4), 'traffic': None,
+                     'algorithmic_gflop_per_image': round((conv + head) / 1e9, 1)},
+    }
+    print(json.dumps(res))
 
 
 def cpu_baseline(args, num_fg):
@@ -138,6 +218,8 @@ def alt_plan(args, dev, num_fg, B, t, seg, mode):
 
 def main():
     args = parse()
+    if args.infer:
+        return infer_main(args)
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world:
