@@ -410,7 +410,8 @@ int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const f
  * two derived from the bound (*amax_in) * in_mul + in_add >= max|X| (amax_in: bit pattern of a
  * float on the device, e.g. the amax_out of the producing layer with in_mul = 1, in_add = 0, or
  * naws_amax_f32 of the network input with the producing layer's weight L1 norm / bias maximum).
- * amax_out (nullable, != amax_in) receives the bit pattern of max|Y|.
+ * amax_out (nullable, != amax_in) receives the bit pattern of max|Y| (atomic max: the word is
+ * zeroed by the call unless amax_out_zeroed != 0 says the caller already did).
  * pool2 != 0: Y is [N][H/2][W/2][Cout] = MaxPool 2x2 / stride 2 (VGG16.py pool1..pool3) of the
  * layer's output, taken in the epilogue (identical values: max commutes with the monotone
  * bias / ReLU epilogue); the full-resolution output is not written.
@@ -418,7 +419,7 @@ int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const f
 int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,
                                 const float* bias, int N, int H, int W, int Cin, int Cout, int relu,
                                 float* Y, const uint32_t* amax_in, float in_mul, float in_add,
-                                uint32_t* amax_out, int pool2, void* stream);
+                                uint32_t* amax_out, int amax_out_zeroed, int pool2, void* stream);
 /* out[0] = bit pattern of max|X[0..n)| (non-negative floats order like unsigned words). */
 int naws_amax_f32(const float* X, int64_t n, uint32_t* out, void* stream);
 /* RoIPoolF + RoIFeatureBoost (as naws_roi_pool_f_fwd, NHWC; detectron/ops/roi_pool_f_op.cu:14-127,

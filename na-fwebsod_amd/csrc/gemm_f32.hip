@@ -368,6 +368,112 @@ void gemm_f32_kernel(GemmArgs g) {
     naws_tile_amax_32<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
 }
 
+// ---- C = epilogue(A B) for a SHORT inner dimension (K <= 64): dZ7 = gate(dL W8) -----------------
+// With K = 2C = 40 the product has 80 flops per output element: the 128x128 MFMA tile form spends
+// its life in the epilogue (dependent aux loads, 244 us for 131 MB out + 131 MB aux).  Here a
+// workgroup owns 32 rows x 1024 columns; a thread keeps its four columns of B - K float4s - in
+// registers for all 32 rows, A's row (K floats, workgroup-uniform) comes through the scalar cache,
+// and every output float4 is one coalesced aux load + one coalesced store: HBM-bound.  Sums run in
+// k order like the MFMA chain.  Also reports |C| row / column maxima (NawsAmax).
+constexpr int SK_ROWS = 32, SK_MAXK = 64, SK_RG = 4;
+template <int KMAX>
+__global__ __launch_bounds__(256) void gemm_smallk_nn_kernel(GemmArgs g) {
+  __shared__ float s_rm[SK_ROWS][4];
+  __shared__ __attribute__((aligned(16))) float s_a[SK_ROWS][KMAX];   // the block's rows of A
+  const long long bz = blockIdx.z;
+  const float* A = g.A + bz * g.sA;
+  const float* B = g.B + bz * g.sB;
+  float* C = g.C + bz * g.sC;
+  const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
+  const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int r0 = blockIdx.y * SK_ROWS;
+  const bool col_ok = col < g.N;                       // N % 4 == 0: a float4 is all in or all out
+  float4 b[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    b[k] = (k < g.K && col_ok) ? *reinterpret_cast<const float4*>(B + (long long)k * g.ldb + col)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = threadIdx.x; i < SK_ROWS * KMAX; i += 256) {
+    const int r = i / KMAX, k = i - r * KMAX;
+    s_a[r][k] = (r0 + r < g.M && k < g.K) ? A[(long long)(r0 + r) * g.lda + k] : 0.f;
+  }
+  __syncthreads();
+  float4 cm = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool gate = g.epilogue == NAWS_EPI_GATE_POS;
+  // rows in groups of SK_RG: the group's aux loads are in flight together, and the row maxima go
+  // through LDS so that the guarded atomics are issued once, in parallel, at the end
+  for (int rg = 0; rg < SK_ROWS; rg += SK_RG) {
+    float4 x[SK_RG], acc[SK_RG];
+#pragma unroll
+    for (int j = 0; j < SK_RG; ++j) {
+      const int r = r0 + rg + j;
+      x[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (gate && col_ok && r < g.M)
+        x[j] = *reinterpret_cast<const float4*>(aux + (long long)r * g.ldaux + col);
+      acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < KMAX / 4; ++k4) {              // (zero-padded beyond K: adds exact zeros)
+#pragma unroll
+      for (int j = 0; j < SK_RG; ++j) {
+        const float4 av = *reinterpret_cast<const float4*>(&s_a[rg + j][k4 * 4]);   // LDS broadcast
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 bb = b[k4 * 4 + u];
+          acc[j].x = fmaf(a4[u], bb.x, acc[j].x); acc[j].y = fmaf(a4[u], bb.y, acc[j].y);
+          acc[j].z = fmaf(a4[u], bb.z, acc[j].z); acc[j].w = fmaf(a4[u], bb.w, acc[j].w);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SK_RG; ++j) {
+      const int r = r0 + rg + j;
+      float rm = 0.f;
+      if (col_ok && r < g.M) {
+        float4 v = acc[j];
+        if (gate) {
+          v.x = x[j].x > 0.f ? v.x * g.alpha : 0.f; v.y = x[j].y > 0.f ? v.y * g.alpha : 0.f;
+          v.z = x[j].z > 0.f ? v.z * g.alpha : 0.f; v.w = x[j].w > 0.f ? v.w * g.alpha : 0.f;
+        }
+        float4* dst = reinterpret_cast<float4*>(C + (long long)r * g.ldc + col);
+        if (g.accumulate) {
+          const float4 o = *dst;
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *dst = v;
+        const float cmul = g.am.colmul ? fabsf(g.am.colmul[r]) : 1.f;
+        const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z), aw = fabsf(v.w);
+        rm = fmaxf(fmaxf(ax, ay), fmaxf(az, aw));
+        cm.x = fmaxf(cm.x, ax * cmul); cm.y = fmaxf(cm.y, ay * cmul);
+        cm.z = fmaxf(cm.z, az * cmul); cm.w = fmaxf(cm.w, aw * cmul);
+      }
+      if (g.am.rowmax) {
+        rm = wave_max(rm);
+        if (lane == 0) s_rm[rg + j][wave] = rm;
+      }
+    }
+  }
+  if (g.am.rowmax) {
+    __syncthreads();
+    if (threadIdx.x < SK_ROWS && r0 + threadIdx.x < g.M) {
+      const float m = fmaxf(fmaxf(s_rm[threadIdx.x][0], s_rm[threadIdx.x][1]),
+                            fmaxf(s_rm[threadIdx.x][2], s_rm[threadIdx.x][3]));
+      unsigned* rowmax = g.am.rowmax + bz * g.am.sRow +
+                         (long long)((blockIdx.x * 1024) / g.am.seg_cols) * g.M;
+      if (m > 0.f) naws_atomic_max_bits(rowmax + r0 + threadIdx.x, m);
+    }
+  }
+  if (g.am.colmax && col_ok) {
+    unsigned* cmx = g.am.colmax + bz * g.am.sCol + col;
+    if (cm.x > 0.f) naws_atomic_max_bits(cmx + 0, cm.x);
+    if (cm.y > 0.f) naws_atomic_max_bits(cmx + 1, cm.y);
+    if (cm.z > 0.f) naws_atomic_max_bits(cmx + 2, cm.z);
+    if (cm.w > 0.f) naws_atomic_max_bits(cmx + 3, cm.w);
+  }
+}
+
 // Tuning knob for A/B experiments (tools/kernel_bench.py): NAWS_GEMM_VARIANT
 //   0 default, 2: pad LDS so only 1 workgroup fits a CU, 4: BK=32 tile forms
 int gemm_variant() {
@@ -487,6 +593,20 @@ extern "C" int naws_gemm_f32_amax(int transA, int transB, int M, int N, int K, c
     g.am.sRow = (long long)nseg * M; g.am.sCol = N;
   }
   hipStream_t s = (hipStream_t)stream;
+  // short inner dimension, plain NN form (dZ7 = gate(dL W8), K = 2C): the register-resident kernel
+  if (!transA && !transB && K <= SK_MAXK && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
+      strideC % 4 == 0 && (epilogue == NAWS_EPI_NONE || epilogue == NAWS_EPI_GATE_POS) &&
+      (!aux || (ldaux % 4 == 0 && ((uintptr_t)aux & 15) == 0)) && (long long)M * N >= (1 << 20) &&
+      (!rowmax || g.am.seg_cols % 1024 == 0 || g.am.seg_cols >= N) && gemm_variant() != 7) {
+    dim3 grid((unsigned)naws_cdiv(N, 1024), (unsigned)naws_cdiv(M, SK_ROWS), batch);
+    if (grid.y <= 65535) {
+      if (K <= 40)
+        hipLaunchKernelGGL(gemm_smallk_nn_kernel<40>, grid, dim3(256), 0, s, g);
+      else
+        hipLaunchKernelGGL(gemm_smallk_nn_kernel<64>, grid, dim3(256), 0, s, g);
+      return naws_check_launch();
+    }
+  }
   const bool a_kc = !transA, b_kc = transB != 0;
   if (a_kc && b_kc) return dispatch<true, true, false>(g, batch, s);
   if (a_kc && !b_kc) return dispatch<true, false, false>(g, batch, s);

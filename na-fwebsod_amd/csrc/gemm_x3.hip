@@ -1574,7 +1574,7 @@ extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const
                                            const float* bias, int N, int H, int W, int Cin,
                                            int Cout, int relu, float* Y, const uint32_t* amax_in,
                                            float in_mul, float in_add, uint32_t* amax_out,
-                                           int pool2, void* stream) {
+                                           int amax_out_zeroed, int pool2, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
   if (Cin % 16 != 0 || (9 * Cin) % 32 != 0 || Cout % 32 != 0 || (Cout > 128 && Cout % 128 != 0))
     return NAWS_ERR_UNSUPPORTED;
@@ -1596,7 +1596,10 @@ extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const
   g.pool = pool2 ? 1 : 0;
   if (pool2 && (H < 2 || W < 2)) return NAWS_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (amax_out && hipMemsetAsync(amax_out, 0, sizeof(uint32_t), s) != hipSuccess) return NAWS_ERR_LAUNCH;
+  // (a chain of layers zeroes all its words with one fill and passes amax_out_zeroed = 1: a
+  // memset per layer is a 6 us kernel plus a launch gap in a dependent chain)
+  if (amax_out && !amax_out_zeroed && hipMemsetAsync(amax_out, 0, sizeof(uint32_t), s) != hipSuccess)
+    return NAWS_ERR_LAUNCH;
   if (Cout <= 64) return launch_conv_x3_halo<64, true>(g, N, s);
   return launch_conv_x3_halo<128, true>(g, N, s);
 }

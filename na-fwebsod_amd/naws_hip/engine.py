@@ -29,7 +29,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .reducer import ArenaReducer, row_chunks
+from .reducer import ArenaReducer, message_plan, message_slice
 
 VGG16_CONVS = [
     # (name, cin, cout, dilation) and pool markers
@@ -331,7 +331,7 @@ class WsddnEngine(object):
         last = VGG16_CONVS[-1][0]
         # fp16x2 Winograd layers hand max|y| to the next layer (its operand scale needs an upper
         # bound of max|x|; a max-pool in between only lowers it), saving that layer's own pass
-        amax = torch.empty((len(VGG16_CONVS),), device=self.device, dtype=torch.int32)
+        amax = torch.zeros((len(VGG16_CONVS),), device=self.device, dtype=torch.int32)   # one fill
         prev, affine = None, (1.0, 0.0)  # slot holding the bound for the current x, if any
         fused_pool = False               # the previous layer's epilogue already pooled
         for li, item in enumerate(VGG16_CONVS):
@@ -371,7 +371,8 @@ class WsddnEngine(object):
                                           and VGG16_CONVS[li + 1][0] == 'pool')
                             x = ops.conv3x3_nhwc_f16x2(x, wp, b, True, out=dst, amax_in=bound,
                                                        in_mul=mul, in_add=add, amax_out=word,
-                                                       pool2=fused_pool)
+                                                       pool2=fused_pool,
+                                                       amax_out_zeroed=word is not amax_final)
                         else:                            # Winograd, f16 batch GEMMs
                             x = ops.conv3x3_winograd_nhwc_f16x2(x, wp, b, d, True, out=dst,
                                                                 amax_in=bound, amax_out=word)
@@ -692,7 +693,9 @@ class WsddnEngine(object):
         elif bf:
             dz6t = ops.to_bf16_slab(dz6, transpose=True)       # [Rt/16, 8192, 16]
             xt = ops.to_bf16_slab(x, transpose=True)           # [Rt/16, 25088, 16]
-        for r0, r1 in row_chunks(2 * HIDDEN, self.allreduce_chunks if red.active else 1):
+        plan = message_plan(self.arena, 2 * HIDDEN, self.allreduce_chunks, red.active)
+        for kind, rows in plan[:-1]:
+            r0, r1 = rows
             if h2:
                 # 25088 = 98 column tiles of 256: 32 x 98 = 12.25 waves of 256 CUs.  96 column
                 # tiles make 12 full waves; the last 512 columns go out as one wave of 128x128 tiles
@@ -709,7 +712,7 @@ class WsddnEngine(object):
                 ops.gemm_bf16_slab_nt(dz6t[:, r0:r1], xt, out=gw6[r0:r1])
             else:
                 ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
-            red.reduce_async(gw6[r0:r1].reshape(-1))
+            red.reduce_async(message_slice(self.arena, G, kind, rows, self.k6))
         # 3. the small gradients (under the fc6_w exchange): fc6 db; fc7 dW = dZ7^T H6, db;
         # fc8 dW = dL^T H7, db
         ops.colsum(dz6, out=gb6)
@@ -733,7 +736,7 @@ class WsddnEngine(object):
         else:
             ops.gemm(dlv, h7v, True, False, out=gw8)
             ops.colsum(dl, out=gb8)
-        red.reduce_async(self.arena.span(G, 'fc6_b', 'noisy_fc8d_b'))
+        red.reduce_async(message_slice(self.arena, G, *plan[-1], self.k6))
 
     def _wgrad_column_cut(self, rows, cus=256):
         """fc6 wgrad tile quantisation: with 256x256 tiles the [rows, k6] output is tm x tn tiles;

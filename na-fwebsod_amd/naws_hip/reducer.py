@@ -22,6 +22,26 @@ def row_chunks(rows, n_chunks, align=128):
     return out
 
 
+def message_plan(arena, rows6, allreduce_chunks, active):
+    """The gradient messages of one iteration, in the order backward produces and hands them to
+    the collective: fc6_w's gradient (86 % of the bytes) in row chunks - each chunk is reduced as
+    soon as its wgrad GEMM is queued - then ONE message with every other gradient (fc6 / fc7
+    biases, fc7_w, fc8*: contiguous in the arena).  -> [('fc6_w', (r0, r1)), ..., ('small', None)].
+    The engine walks this list (engine._head_backward); tests/test_distributed_cpu.py replays it
+    on a CPU arena over gloo."""
+    plan = [('fc6_w', rc) for rc in row_chunks(rows6, allreduce_chunks if active else 1)]
+    plan.append(('small', None))
+    return plan
+
+
+def message_slice(arena, grads, kind, rows, k6):
+    """The contiguous arena slice a message of `message_plan` covers."""
+    if kind == 'fc6_w':
+        o6 = arena.offsets['fc6_w'][0]
+        return grads[o6 + rows[0] * k6:o6 + rows[1] * k6]
+    return arena.span(grads, 'fc6_b', 'noisy_fc8d_b')
+
+
 class ArenaReducer(object):
     def __init__(self, process_group=None, world_size=1):
         self.pg = process_group

@@ -59,6 +59,93 @@ def test_allreduce_schedule_and_sharding_gloo_world2():
     assert sorted(res[0][2] + res[1][2]) == sorted(res[0][3])       # disjoint, complete
 
 
+def _replay_worker(rank, world, port, q):
+    """One rank of the engine's iteration on a CPU arena: per-rank gradients, the engine's message
+    plan (naws_hip.reducer.message_plan: fc6_w row chunks in the auto chunk count of this world
+    size, then the small-gradient message) through ArenaReducer over gloo, the wait the deferred
+    update does, then the ACM SGD restatement with gpu_num = world * B."""
+    sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from naws_hip.reducer import ArenaReducer, message_plan, message_slice
+    arena, params, grads_of, k6, rows6, sgd = _replay_setup()
+    B = 2
+    g = grads_of(rank)
+    red = ArenaReducer(dist.group.WORLD, world)
+    chunks = 4 if world == 2 else 2           # engine.py: auto ALLREDUCE_CHUNKS
+    plan = message_plan(arena, rows6, chunks, red.active)
+    sizes = []
+    for kind, rows in plan:
+        sl = message_slice(arena, g, kind, rows, k6)
+        sizes.append(sl.numel())
+        red.reduce_async(sl)
+    red.wait()
+    p, m = sgd(params.clone(), g, gpu_num=world * B)
+    q.put((rank, p.numpy(), m.numpy(), [k for k, _ in plan], sizes))
+    dist.destroy_process_group()
+
+
+def _replay_setup():
+    from naws_hip.engine import ParamArena, head_param_specs
+    from oracle import oracle
+    specs = [(n, (s[0] // 16, s[1] // 64) if len(s) == 2 and s[0] == 4096 else
+              ((s[0] // 16,) if s == (4096,) else s)) for n, s in head_param_specs(20)]
+    arena = ParamArena(specs, torch.device('cpu'))
+    k6 = specs[0][1][1]
+    rows6 = 2 * specs[0][1][0]
+    gen = torch.Generator().manual_seed(3)
+    params = torch.randn((arena.total,), generator=gen)
+
+    def grads_of(rank):
+        return torch.randn((arena.total,), generator=torch.Generator().manual_seed(100 + rank))
+
+    def sgd(p, g, gpu_num):
+        """optimizer_wsl.py:96-137 per blob (bias: lr x2, no decay) through the oracle's
+        restatement of ACMWeightDecayMomentumSGDUpdate; two steps so momentum is exercised."""
+        pn, gn = p.numpy().copy(), g.numpy()
+        mom = np.zeros_like(pn)
+        for name, _shape in specs:
+            off, n, _s = arena.offsets[name]
+            bias = name.endswith('_b')
+            it = 0
+            for _ in range(2):
+                acm = np.zeros((n,), np.float32)
+                pv, mv = pn[off:off + n].copy(), mom[off:off + n].copy()
+                it = oracle.acm_sgd(np.ascontiguousarray(gn[off:off + n]), mv,
+                                    np.array([1e-2], np.float32), pv, acm, 0.9, 0,
+                                    0.0 if bias else 5e-4, 1, gpu_num, 2.0 if bias else 1.0, it)
+                pn[off:off + n], mom[off:off + n] = pv, mv
+        return torch.from_numpy(pn), torch.from_numpy(mom)
+    return arena, params, grads_of, k6, rows6, sgd
+
+
+def test_engine_message_order_replayed_over_gloo_equals_single_rank():
+    """the engine's exact message order (fc6_w row chunks, then the
+    small-gradient message), reduced over a world-2 gloo group on a CPU arena and followed by the
+    SGD restatement, gives bit-identical parameters and momentum to ONE process that holds both
+    ranks' gradients summed and updates with gpu_num = 2 * B."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replay_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+    arena, params, grads_of, k6, rows6, sgd = _replay_setup()
+    want_p, want_m = sgd(params.clone(), grads_of(0) + grads_of(1), gpu_num=4)
+    for rank, p, m, kinds, sizes in res:
+        assert np.array_equal(p, want_p.numpy()) and np.array_equal(m, want_m.numpy()), rank
+        # 4 row chunks of fc6_w's gradient first, everything else as ONE message last
+        assert kinds == ['fc6_w'] * 4 + ['small']
+        assert sum(sizes) == arena.total and sum(sizes[:4]) == rows6 * k6
+
+
 def test_row_chunks_cover():
     from naws_hip.reducer import row_chunks
     for rows, n in [(8192, 8), (8192, 3), (100, 8), (128, 1)]:

@@ -381,6 +381,7 @@ def test_roi_pool_planes_transpose_and_kscaled_split(dev):
     (4096, 4096, 1056, 0, 'h2'),        # 256x256 tiles on the 16x16x32 MFMA layout, one segment
     (4000, 8192, 1056, 4096, 'h2'),     # fc6's shape in M / N: ragged rows, two branches
     (333, 768, 40, 256, 'f32'),         # the fp32-MFMA kernel (dZ7 = dL W8)
+    (2000, 4096, 40, 0, 'f32nn'),       # the register-resident short-K kernel (NN form, K = 2C)
 ])
 def test_gemm_reported_maxima_and_dual_split_are_bit_identical(dev, m, n, k, seg, kind):
     """The maxima a GEMM epilogue reports (per row of each column segment, per column of
@@ -401,6 +402,11 @@ def test_gemm_reported_maxima_and_dual_split_are_bit_identical(dev, m, n, k, seg
         a[5, 3] = float('nan')
         a[9, 1] = float('inf')
         c = ops.gemm_f32_f16x2_nt(ops.split_f16x2(a), ops.split_f16x2(b), **kw)
+    elif kind == 'f32nn':
+        bt = b.t().contiguous()                                 # [k, n]: the NN operand
+        c = ops.gemm(a, bt, False, False, **kw)
+        ref = (a.double() @ bt.double()) * (aux > 0) * 2.0
+        assert float((c.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     else:
         c = ops.gemm(a, b, False, True, **kw)
     cv = c.view(m, nseg, n // nseg).permute(1, 0, 2)            # the branches as a batch
@@ -416,6 +422,9 @@ def test_gemm_reported_maxima_and_dual_split_are_bit_identical(dev, m, n, k, seg
     if kind == 'h2':
         c2 = ops.gemm_f32_f16x2_nt(ops.split_f16x2(a), ops.split_f16x2(b),
                                    rowmax=ops.amax_words(sc_n2), colmax=ops.amax_words(sc_t2))
+    elif kind == 'f32nn':
+        c2 = ops.gemm(a, b.t().contiguous(), False, False, rowmax=ops.amax_words(sc_n2),
+                      colmax=ops.amax_words(sc_t2))
     else:
         c2 = ops.gemm(a, b, False, True, rowmax=ops.amax_words(sc_n2), colmax=ops.amax_words(sc_t2))
     gn, gt = ops.split_f16x2_dual(c2, sc_n2, sc_t2)
@@ -423,3 +432,42 @@ def test_gemm_reported_maxima_and_dual_split_are_bit_identical(dev, m, n, k, seg
     for got, want in ((gn, wn), (gt, wt)):
         assert torch.equal(got.inv_scale, want.inv_scale)
         assert torch.equal(got.planes.view(torch.int16), want.planes.view(torch.int16))
+
+
+@pytest.mark.parametrize('log2_ratio', [-20, -30, -45])
+def test_gemm_h2_within_row_dynamic_range_bound(dev, log2_ratio):
+    """within-row ratios beyond the old 2^-23 test.  Half of every operand row
+    is scaled by 2^log2_ratio.  The documented representation bound is block floating point per
+    row: |x s - hi - lo| <= max(2^-22 |x s|, 2^-25), i.e. an ABSOLUTE floor of 2^-39 of the row
+    maximum.  (a) Ordinary outputs (large and small terms mixed) stay within the fp32-class
+    componentwise bound; (b) outputs made ONLY of the small half - weights exactly zero on the
+    large half - are where fp16x2 departs from the exact-split fp32x3 kernel: their error is
+    bounded by the floor K * 2^-39 * rowmax(a) * max|b| (asserted), while fp32x3 stays relative.
+    No tensor of the network puts structural zeros against a row's large entries (fc weights are
+    dense, activations post-ReLU), so this stays a documented property, not a default change."""
+    from naws_hip import ops
+    g = torch.Generator(device=dev).manual_seed(-log2_ratio)
+    m, n, k = 256, 256, 4096
+    ratio = 2.0 ** log2_ratio
+    a = torch.rand((m, k), device=dev, generator=g) + 0.5
+    b = (torch.rand((n, k), device=dev, generator=g) - 0.5)
+    a[:, k // 2:] *= ratio                                   # small half of every A row
+    b_small_only = b.clone()
+    b_small_only[:, :k // 2] = 0                             # sees only A's small half
+    for bb, small_only in ((b, False), (b_small_only, True)):
+        ref = a.double() @ bb.double().t()
+        mag = a.double().abs() @ bb.double().abs().t()
+        h2 = ops.gemm_f32_f16x2_nt(ops.split_f16x2(a), ops.split_f16x2(bb)).double()
+        x3 = ops.gemm_f32x3_nt(ops.split_bf16x3(a), ops.split_bf16x3(bb)).double()
+        e_h2 = float(((h2 - ref).abs() / mag).max())
+        e_x3 = float(((x3 - ref).abs() / mag).max())
+        print('\nratio 2^%d %s: error / sum|a||b|: fp16x2 %.1e, fp32x3 %.1e' % (
+            log2_ratio, 'small-only outputs' if small_only else 'mixed outputs', e_h2, e_x3))
+        assert e_x3 <= 2e-6                                  # exact split: always relative
+        if not small_only:
+            assert e_h2 <= 2e-6
+        else:
+            floor = k * 2.0 ** -39 * float(a.abs().max()) * float(bb.abs().max())
+            assert float((h2 - ref).abs().max()) <= floor + 2e-6 * float(mag.max())
+            if log2_ratio >= -20:
+                assert e_h2 <= 1e-4                          # still ~19 bits per small element
