@@ -417,9 +417,10 @@ int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const f
  * bias / ReLU epilogue); the full-resolution output is not written.
  * Cin % 16 == 0, Cout % 32 == 0, Cout <= 128 or a multiple of 128. */
 int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,
-                                const float* bias, int N, int H, int W, int Cin, int Cout, int relu,
-                                float* Y, const uint32_t* amax_in, float in_mul, float in_add,
-                                uint32_t* amax_out, int amax_out_zeroed, int pool2, void* stream);
+                                const float* bias, int N, int H, int W, int Cin, int Cout,
+                                int dilation, int relu, float* Y, const uint32_t* amax_in,
+                                float in_mul, float in_add, uint32_t* amax_out, int amax_out_zeroed,
+                                int pool2, void* stream);
 /* out[0] = bit pattern of max|X[0..n)| (non-negative floats order like unsigned words). */
 int naws_amax_f32(const float* X, int64_t n, uint32_t* out, void* stream);
 /* RoIPoolF + RoIFeatureBoost (as naws_roi_pool_f_fwd, NHWC; detectron/ops/roi_pool_f_op.cu:14-127,

@@ -973,14 +973,15 @@ int launch_conv_x3(CArgs& g, hipStream_t s) {
 // of max|X| handed in by the producer of X), split into f16 hi / lo planes in registers; weight
 // planes from naws_split_f16x2 (per-output-channel scales); 3 MFMA terms instead of 6; the
 // accumulator is un-scaled in the epilogue, which also reports max|Y| for the next layer.
-template <int BN, bool F16 = false>
+template <int BN, bool F16 = false, int DIL = 1>
 __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(CArgs g) {
   constexpr int NPL = F16 ? 2 : 3;
   typedef typename OperandVec<F16>::type vec_t;
   // BN = 64: one halo stage (refilled behind an extra barrier every 9th step) keeps the
   // workgroup at 45 KB of LDS, so three of them share a CU; BN = 128: two halo stages
   constexpr int ASTAGES = BN <= 64 ? 1 : 2;
-  constexpr int TH = 8, TW = 32, HWD = TW + 2, HPIX = (TH + 2) * HWD;     // 340 halo pixels
+  // DIL = 2 (conv5_x): the taps sit 2 pixels apart, the halo is (8+4) x (32+4) = 432 pixels
+  constexpr int TH = 8, TW = 32, HWD = TW + 2 * DIL, HPIX = (TH + 2 * DIL) * HWD;   // 340 halo pixels
   constexpr int A_ROWS = (HPIX + 7) / 8 * 8;
   constexpr int A_PLANE = A_ROWS * 32, A_STAGE = NPL * A_PLANE;
   constexpr int B_PLANE = BN * 32, B_STAGE = NPL * B_PLANE;
@@ -1018,7 +1019,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
   for (int r = 0; r < UR; ++r) {
     const int u = tid + r * 256;
     const int hp = u >> 1, half = u & 1;
-    const int y = ty0 - 1 + hp / HWD, x = tx0 - 1 + hp % HWD;
+    const int y = ty0 - DIL + hp / HWD, x = tx0 - DIL + hp % HWD;
     const bool ok = hp < HPIX && y >= 0 && y < g.H && x >= 0 && x < g.W;
     abase[r] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)g.Cin + half * 8) * 4u : OOB;
     awr[r] = hp < HPIX ? hp * 32 + ((half ^ ((hp >> 3) & 1)) * 16) : -1;
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
     vec_t a[NPL][TI], b[NPL][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-      const int hp = (2 * wid + i + 1 + dy) * HWD + (l31 + 1 + dx);
+      const int hp = (2 * wid + i + DIL + dy * DIL) * HWD + (l31 + DIL + dx * DIL);
       const int off = hp * 32 + ((h ^ ((hp >> 3) & 1)) * 16);
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl)
@@ -1211,15 +1212,15 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
   }
 }
 
-template <int BN, bool F16 = false>
+template <int BN, bool F16 = false, int DIL = 1>
 int launch_conv_x3_halo(CArgs& g, int N, hipStream_t s) {
   g.tiles_n = (int)naws_cdiv(g.Cout, BN);
   const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
   if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
-  constexpr int A_ROWS = (10 * 34 + 7) / 8 * 8;
+  constexpr int A_ROWS = ((8 + 2 * DIL) * (32 + 2 * DIL) + 7) / 8 * 8;
   constexpr int NPL = F16 ? 2 : 3;
   const size_t lds = (size_t)(BN <= 64 ? 1 : 2) * NPL * A_ROWS * 32 + (size_t)2 * NPL * BN * 32;
-  auto kern = conv_x3_halo_kernel<BN, F16>;
+  auto kern = conv_x3_halo_kernel<BN, F16, DIL>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1459,7 +1460,14 @@ extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, 
   // epilogue with the other's K loop
   if (K <= 1024 && g_h2_variant != 5) {
     if (g_h2_variant == 6) return launch_x3<256, 128, 2, 2, 2, 2, 1, true>(g, batch, s);
-    return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+    if (g_h2_variant == 12) return launch_x3<128, 128, 2, 2, 4, 2, 1, true>(g, batch, s);
+    if (g_h2_variant == 14) return launch_x3<128, 128, 2, 2, 3, 2, 2, true>(g, batch, s);
+    if (g_h2_variant == 15) return launch_x3_m16<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+    if (g_h2_variant == 17) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+    // 16-deep K-steps on a ring of 3 stages (48 KB: still two workgroups per CU): the DMA runs two
+    // steps ahead instead of one, which is what a 16..32-step tile needs (tools/ab_h2.py, the
+    // Winograd batch GEMM of conv4_2: 0.101 vs 0.114 ms with 32-deep steps and 2 stages)
+    return launch_x3<128, 128, 2, 2, 3, 2, 1, true>(g, batch, s);
   }
   switch (g_h2_variant) {
     case 1: return launch_x3<256, 256, 2, 4, 3, 2, 1, true>(g, batch, s);
@@ -1572,10 +1580,13 @@ extern "C" int naws_amax_f32(const float* X, int64_t n, uint32_t* out, void* str
 // *amax_in * in_mul + in_add (an upper bound of max|X|); dilation 1, Cout <= 128, Cout % 32 == 0.
 extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,
                                            const float* bias, int N, int H, int W, int Cin,
-                                           int Cout, int relu, float* Y, const uint32_t* amax_in,
-                                           float in_mul, float in_add, uint32_t* amax_out,
-                                           int amax_out_zeroed, int pool2, void* stream) {
+                                           int Cout, int dilation, int relu, float* Y,
+                                           const uint32_t* amax_in, float in_mul, float in_add,
+                                           uint32_t* amax_out, int amax_out_zeroed, int pool2,
+                                           void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (dilation != 1 && dilation != 2) return NAWS_ERR_UNSUPPORTED;
+  if (dilation == 2 && pool2) return NAWS_ERR_ARG;
   if (Cin % 16 != 0 || (9 * Cin) % 32 != 0 || Cout % 32 != 0 || (Cout > 128 && Cout % 128 != 0))
     return NAWS_ERR_UNSUPPORTED;
   NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W2); NAWS_REQUIRE_PTR(scaleW); NAWS_REQUIRE_PTR(Y);
@@ -1587,7 +1598,7 @@ extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const
   if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
   CArgs g{};
   g.X = X; g.B = (const unsigned short*)W2; g.bias = bias; g.Y = Y;
-  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = 1; g.relu = relu;
+  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = dilation; g.relu = relu;
   g.slabB = (long long)Cout * 16;
   g.planeB = (long long)9 * Cin * Cout;
   g.bytesX = (unsigned)(pix * Cin * 4);
@@ -1600,8 +1611,19 @@ extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const
   // memset per layer is a 6 us kernel plus a launch gap in a dependent chain)
   if (amax_out && !amax_out_zeroed && hipMemsetAsync(amax_out, 0, sizeof(uint32_t), s) != hipSuccess)
     return NAWS_ERR_LAUNCH;
-  if (Cout <= 64) return launch_conv_x3_halo<64, true>(g, N, s);
-  return launch_conv_x3_halo<128, true>(g, N, s);
+  // 64-wide channel tiles (3 workgroups per CU) where 128-wide ones leave CUs idle or the layer is
+  // deep: measured per layer at 2 images (tools/kernel_bench.py --what x3): conv3_x 0.137 / 0.259
+  // vs 0.156 / 0.289 ms, conv4_2 0.282 vs 0.297; conv2_2 (608 tiles of 128) keeps 128
+  bool bn64 = Cout <= 64;
+  if (!bn64 && Cout % 64 == 0) {
+    const long long t128 = (long long)N * naws_cdiv(H, 8) * naws_cdiv(W, 32) * naws_cdiv(Cout, 128);
+    bn64 = Cin >= 128 && Cout >= 256 && t128 < 4 * 512;
+    const char* e = getenv("NAWS_CONV_BN");            // A/B knob (tools/kernel_bench.py)
+    if (e) bn64 = atoi(e) == 64;
+  }
+  if (dilation == 2)
+    return bn64 ? launch_conv_x3_halo<64, true, 2>(g, N, s) : launch_conv_x3_halo<128, true, 2>(g, N, s);
+  return bn64 ? launch_conv_x3_halo<64, true>(g, N, s) : launch_conv_x3_halo<128, true>(g, N, s);
 }
 
 extern "C" int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_t slabA,

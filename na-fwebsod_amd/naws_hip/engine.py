@@ -206,6 +206,15 @@ class WsddnEngine(object):
         # RoIPoolF over 2x2 / 4x4 block maxima of conv5_3 (csrc/roi_ops.hip): same values, ~8x less
         # gather traffic
         self.roi_hier = True
+        # fp16x2, optional: conv4_1..conv5_3 through the direct halo-tile kernel (dilation 2 for
+        # conv5_x) as ONE launch per layer for all images after the per-image streams have joined
+        # behind pool3.  Kernel for kernel it wins (tools/kernel_bench.py --what x3: 0.28 ms per
+        # layer for two images vs 2 x 0.17 ms of Winograd transform + 16 batch GEMMs + transform),
+        # but the serial tail loses what the two per-image Winograd chains gain by overlapping:
+        # interleaved in one process (tools/ab_engine.py --attr deep_direct) 14.10 vs 14.02 ms per
+        # step.  Off by default; the direct kernel still takes any deep layer whose single launch
+        # has >= 256 tiles (the larger TTA scales).
+        self.deep_direct = False
         self._amax5 = None
         self.conv_direct_h2 = {}
         self._streams = []
@@ -296,7 +305,8 @@ class WsddnEngine(object):
                 packed = ops.winograd_weight_transform(w)      # [16][Cout][Cin]
                 if self.mfma_dtype == 'fp16x2' and self.wino_h2:
                     packed = ops.split_f16x2(packed)           # F16x2, planes [2][16][Cin/16][Cout][16]
-                    if self.conv_h2 and dil == 1 and w.shape[0] % 128 == 0:
+                    if self.conv_h2 and w.shape[0] % 128 == 0 and \
+                            (dil == 1 or (dil is None and self.dilation in (1, 2))):
                         # also the direct form: chosen per input size in _conv_chain
                         self.conv_direct_h2[name] = ops.split_f16x2(
                             ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
@@ -324,19 +334,31 @@ class WsddnEngine(object):
         return out
 
     # ---------------------------------------------------------------- forward
-    def _conv_chain(self, data, out=None, amax_final=None):
+    DEEP_FIRST = 10                      # index of conv4_1 in VGG16_CONVS
+
+    def _conv_chain(self, data, out=None, amax_final=None, first=0, end=None, x=None,
+                    bound_in=None, amax_last=None):
         """data NCHW [b,3,H,W] -> conv5_3 NHWC, on the current stream.  amax_final (int32 [1],
-        fp16x2 plan): receives the bit pattern of max|conv5_3| for the RoIPool operand scale."""
-        x = None
+        fp16x2 plan): receives the bit pattern of max|conv5_3| for the RoIPool operand scale.
+        first / end: run only VGG16_CONVS[first:end] (x = the input of layer `first`, bound_in = the
+        word holding an upper bound of max|x|); amax_last: a pre-zeroed word that the LAST layer of
+        the range max-es its max|y| into (shared by the per-image chains)."""
         last = VGG16_CONVS[-1][0]
+        end = len(VGG16_CONVS) if end is None else end
         # fp16x2 Winograd layers hand max|y| to the next layer (its operand scale needs an upper
         # bound of max|x|; a max-pool in between only lowers it), saving that layer's own pass
-        amax = torch.zeros((len(VGG16_CONVS),), device=self.device, dtype=torch.int32)   # one fill
+        amax = torch.zeros((len(VGG16_CONVS) + 1,), device=self.device, dtype=torch.int32)   # one fill
         prev, affine = None, (1.0, 0.0)  # slot holding the bound for the current x, if any
+        if bound_in is not None:
+            amax[-1:].copy_(bound_in)
+            prev = len(VGG16_CONVS)
         fused_pool = False               # the previous layer's epilogue already pooled
+        last_conv = max(i for i in range(first, end) if not VGG16_CONVS[i][0].startswith('pool'))
         for li, item in enumerate(VGG16_CONVS):
+            if li < first or li >= end:
+                continue
             if item[0] == 'pool':
-                if not fused_pool:
+                if not fused_pool and not (li == first and self._pool_done):
                     x = ops.maxpool2x2_nhwc(x, 2)
                 fused_pool = False
             elif item[0] == 'pool4':
@@ -354,16 +376,22 @@ class WsddnEngine(object):
                     d = dil if dil is not None else (2 if self.dilation == 2 else 1)
                     dst = out if name == last else None
                     wd = self.conv_direct_h2.get(name)
-                    if wd is not None and d == 1:
+                    if wd is not None and d in (1, 2):
                         # direct 2 x f16 halo-tile kernel where it fills the chip (>= one 8x32-pixel
-                        # x 128-channel tile per CU: conv3_x at 600x1000), Winograd below that
+                        # x 128-channel tile per CU: conv3_x at 600x1000, and every deep layer once
+                        # the images share a launch), Winograd below that
                         tiles = x.shape[0] * ((x.shape[1] + 7) // 8) * ((x.shape[2] + 31) // 32)
-                        if tiles * (wd.planes.shape[-2] // 128) >= 256:
+                        if (self.deep_direct and li >= self.DEEP_FIRST
+                                and tiles * (wd.planes.shape[-2] // 64) >= 512) or \
+                                tiles * (wd.planes.shape[-2] // 128) >= 256:
                             wp = wd
                     if isinstance(wp, ops.F16x2):
                         bound = None if prev is None else amax[prev:prev + 1]
                         word = amax_final if (name == last and amax_final is not None) \
                             else amax[li:li + 1]
+                        zeroed = word is not amax_final
+                        if li == last_conv and amax_last is not None:
+                            word, zeroed = amax_last, True
                         if wp.planes.dim() == 4:         # direct halo-tile kernel
                             mul, add = affine if prev == 0 else (1.0, 0.0)
                             # a 2x2 / stride-2 max-pool that follows is taken in the epilogue
@@ -371,8 +399,8 @@ class WsddnEngine(object):
                                           and VGG16_CONVS[li + 1][0] == 'pool')
                             x = ops.conv3x3_nhwc_f16x2(x, wp, b, True, out=dst, amax_in=bound,
                                                        in_mul=mul, in_add=add, amax_out=word,
-                                                       pool2=fused_pool,
-                                                       amax_out_zeroed=word is not amax_final)
+                                                       pool2=fused_pool, amax_out_zeroed=zeroed,
+                                                       dilation=d)
                         else:                            # Winograd, f16 batch GEMMs
                             x = ops.conv3x3_winograd_nhwc_f16x2(x, wp, b, d, True, out=dst,
                                                                 amax_in=bound, amax_out=word)
@@ -388,6 +416,7 @@ class WsddnEngine(object):
                                     else ops.conv3x3_nhwc)
                         x = conv(x, wp, b, d, True, out=dst)
                         prev = None
+        self._pool_done = fused_pool     # a range that ends on a fused pool: the next one skips it
         return x
 
     def conv_body(self, data):
@@ -402,10 +431,16 @@ class WsddnEngine(object):
         planes = (self.roi_planes and self.mfma_dtype == 'fp16x2' and self.k6 % 32 == 0
                   and isinstance(self.conv[VGG16_CONVS[-1][0]][0], ops.F16x2))
         per_image = n > 1 and self.conv_streams
-        self._amax5 = (torch.empty((n if per_image else 1,), device=self.device, dtype=torch.int32)
-                       if planes else None)
+        self._pool_done = False
+        # the deep layers of all images as one launch per layer (see deep_direct above)
+        deep = (per_image and self.deep_direct and self.mfma_dtype == 'fp16x2' and self.conv_h2
+                and all(k in self.conv_direct_h2 for k in ('conv4_1', 'conv5_3')))
+        self._amax5 = (torch.empty((n if per_image and not deep else 1,), device=self.device,
+                                   dtype=torch.int32) if planes else None)
         if not per_image:
             return self._conv_chain(data, amax_final=self._amax5)
+        if deep:
+            return self._conv_body_deep_batched(data)
         h, w = data.shape[2], data.shape[3]
         for _ in range(3):
             h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
@@ -427,6 +462,31 @@ class WsddnEngine(object):
                 done = st.record_event()
             main.wait_event(done)
         return out
+
+    def _conv_body_deep_batched(self, data):
+        """conv1_1 .. pool3 of every image on its own stream, then conv4_1 .. conv5_3 for all images
+        in one launch per layer on the main stream."""
+        n = data.shape[0]
+        cut = self.DEEP_FIRST               # VGG16_CONVS[cut] = conv4_1 (pool3 is VGG16_CONVS[cut - 1])
+        h, w = data.shape[2], data.shape[3]
+        for _ in range(3):
+            h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+        mid = torch.empty((n, h, w, 256), device=self.device, dtype=torch.float32)
+        shared = torch.zeros((1,), device=self.device, dtype=torch.int32)   # max|pool3| over images
+        main = torch.cuda.current_stream(self.device)
+        start = main.record_event()
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        for i in range(n):
+            st = self._streams[i]
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                y = self._conv_chain(data[i:i + 1], first=0, end=cut, amax_last=shared)
+                mid[i:i + 1].copy_(y)
+                done = st.record_event()
+            main.wait_event(done)
+        self._pool_done = True              # pool3 was taken (fused or not) inside the chains
+        return self._conv_chain(None, amax_final=self._amax5, first=cut, x=mid, bound_in=shared)
 
     @staticmethod
     def segments(rois, n_img):

@@ -88,8 +88,8 @@ PROTOTYPES = {
     'naws_roi_pool_f_nhwc_hier_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, p, p],
     'naws_roi_pool_f_f16x2_hier_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, i32, p, p, p,
                                        p],
-    'naws_conv3x3_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, p, p, f32, f32, p, i32, i32,
-                                    p],
+    'naws_conv3x3_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, f32, f32, p, i32,
+                                    i32, p],
     'naws_amax_f32': [p, i64, p, p],
     'naws_conv3x3_winograd_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p],
     'naws_gemm_f32_f16x2_nt_amax': [i32, i32, i32, p, i64, i64, p, p, i64, i64, p, p, i32, i32,

@@ -387,7 +387,7 @@ def amax_word(x, out=None):
 
 
 def conv3x3_nhwc_f16x2(x, w2, bias, relu=True, out=None, amax_in=None, in_mul=1.0, in_add=0.0,
-                       amax_out=None, pool2=False, amax_out_zeroed=False):
+                       amax_out=None, pool2=False, amax_out_zeroed=False, dilation=1):
     """3x3 / pad 1 conv (shallow layers) with w2 = split_f16x2(packed weight viewed
     [Cout, 9*Cin]); amax_in: int32 [1] bit pattern of a bound b, max|x| <= b * in_mul + in_add
     (measured here when None); amax_out: int32 [1] receiving the bit pattern of max|y|;
@@ -402,7 +402,8 @@ def conv3x3_nhwc_f16x2(x, w2, bias, relu=True, out=None, amax_in=None, in_mul=1.
     shape = (n, h // 2, w // 2, cout) if pool2 else (n, h, w, cout)
     y = out if out is not None else torch.empty(shape, device=x.device, dtype=_f32)
     L.call('naws_conv3x3_nhwc_f16x2_fwd', x.data_ptr(), w2.planes.data_ptr(),
-           w2.inv_scale.data_ptr(), _ptr(bias), n, h, w, cin, cout, int(relu), y.data_ptr(),
+           w2.inv_scale.data_ptr(), _ptr(bias), n, h, w, cin, cout, int(dilation), int(relu),
+           y.data_ptr(),
            amax_in.data_ptr(), float(in_mul), float(in_add), _ptr(amax_out),
            int(bool(amax_out_zeroed)), int(pool2), _stream())
     return y

@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--variants', type=int, nargs='+', default=[0, 7])
     ap.add_argument('--rounds', type=int, default=9)
     ap.add_argument('--rows', type=int, default=4000)
+    ap.add_argument('--only', default='')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     st = torch.cuda.current_stream().cuda_stream
@@ -74,9 +75,13 @@ def main():
     cases = [('fc6 fwd  ', (R, 25088), (8192, 25088), None),
              ('fc6 wgrad', (8192, kr), (24576, kr), None),
              ('fc7 fwd  ', (2, R, 4096), (2, 4096, 4096), None),
-             ('fc7 wgrad', (2, 4096, kr), (2, 4096, kr), None)]
+             ('fc7 wgrad', (2, 4096, kr), (2, 4096, kr), None),
+             ('wino conv4_2', (16, 2394, 512), (16, 512, 512), None),
+             ('wino conv4_1', (16, 2394, 256), (16, 512, 256), None)]
     g = torch.Generator(device=dev).manual_seed(1)
     for name, sa, sb, _ in cases:
+        if a.only and a.only not in name:
+            continue
         A = torch.randn(sa, device=dev, generator=g).relu_() if 'fwd' in name else \
             torch.randn(sa, device=dev, generator=g)
         B = torch.randn(sb, device=dev, generator=g) * 0.01

@@ -33,8 +33,8 @@ def main():
     dom_sub, dom_name, alg_gb, dom_grid = {
         'fp32': ('gemm_f32_kernel<256, 256, 16, true, true, false, 4, 4>',
                  'gemm_f32_kernel<256,256,16,KC,KC,4x4> fc6 fwd', 1.354, None),
-        'fp16x2': ('gemm_x3_kernel<256, 256, 2, 4, 2, 2, 2, true>',
-                   'gemm_x3_kernel<256,256,2x4,2 stages,2 planes x 2 slabs,f16> fc6 fwd', 1.354, '262144'),
+        'fp16x2': ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>',
+                   'gemm_x3_m16_kernel<256,256,4x2,2 stages,2 planes x 2 slabs,f16> fc6 fwd', 1.354, '262144'),
         'fp32x3': ('gemm_x3_kernel<256, 256, 2, 4, 3, 3, 1', 'gemm_x3_kernel<256,256,2x4,3 stages> fc6 fwd',
                    1.966, '262144'),
         'bf16': ('gemm_bf16_kernel<256, 128, 4, 2, false, false, false>',
@@ -42,7 +42,7 @@ def main():
     }[mode]
     rows = list(csv.DictReader(open(_find(stats_dir, '*_kernel_stats.csv')[0])))
     lines = ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
-    for r in rows[:24]:
+    for r in rows[:30]:
         lines.append('| %s | %s | %.3f | %.1f | %.2f |' % (
             short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
             float(r['AverageNs']) / 1e3, float(r['Percentage'])))

@@ -471,3 +471,34 @@ def test_gemm_h2_within_row_dynamic_range_bound(dev, log2_ratio):
             assert float((h2 - ref).abs().max()) <= floor + 2e-6 * float(mag.max())
             if log2_ratio >= -20:
                 assert e_h2 <= 1e-4                          # still ~19 bits per small element
+
+
+@pytest.mark.parametrize('cin,cout,h,w,dil', [(512, 512, 37, 45, 2), (256, 512, 19, 70, 2),
+                                              (512, 512, 74, 124, 2), (512, 512, 75, 125, 1),
+                                              (128, 256, 33, 41, 2)])
+def test_conv3x3_f16x2_halo_dilated_and_deep(dev, cin, cout, h, w, dil):
+    """The halo-tile kernel on the deep layers: conv4_x (dilation 1, 64-wide channel tiles chosen by
+    the launcher) and conv5_x (dilation 2, pad 2: a 12 x 36 halo), against a float64 convolution
+    at the tolerance of the shallow-layer test, and against the Winograd f16x2 path it replaces."""
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(cin + h)
+    n = 2
+    x = np.maximum(rng.standard_normal((n, cin, h, w)), 0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    w2 = ops.split_f16x2(ops.conv3x3_pack_weight(_t(wt, dev)).view(cout, 9 * cin))
+    am = torch.zeros((2,), device=dev, dtype=torch.int32)
+    ops.amax_word(xd, out=am[0:1])
+    y = ops.conv3x3_nhwc_f16x2(xd, w2, _t(b, dev), True, amax_in=am[0:1], amax_out=am[1:2],
+                               dilation=dil)
+    yn = ops.nhwc_to_nchw(y).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(yn - ref).max() < 1e-5 * scale
+    assert np.int32(am[1].item()).view(np.float32) == np.float32(yn.max())
+    u2 = ops.split_f16x2(ops.winograd_weight_transform(_t(wt, dev)))
+    yw = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc_f16x2(xd, u2, _t(b, dev), dil, True)).cpu().numpy()
+    assert np.abs(yn - ref).max() <= 2.0 * np.abs(yw - ref).max() + 1e-6 * scale
