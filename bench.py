@@ -394,7 +394,7 @@ def main():
         if tj and headline and B == 2:
             roof['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
             roof['traffic_source'] = os.path.relpath(tj[-1], ROOT)
-        pmc = {'fp16x2': 'profiles/r01_h2_gemm_pmc.md', 'fp32x3': 'profiles/r01_x3_gemm_pmc.md'}
+        pmc = {'fp16x2': 'profiles/r02_default_plan_pmc.md', 'fp32x3': 'profiles/r01_x3_gemm_pmc.md'}
         if args.mfma_dtype in pmc:
             roof['profile_ref'] = pmc[args.mfma_dtype]
         cfg = {'workload': 'configs[1] flickr_voc na_wsddn_V-16-C5_1x C=%d: %d img %dx%d/GPU x %d '

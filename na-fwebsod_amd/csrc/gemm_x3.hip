@@ -960,6 +960,89 @@ int launch_conv_x3(CArgs& g, hipStream_t s) {
 }
 
 
+// Epilogue of the halo-tile kernels: un-scale, bias, ReLU, optional fused 2x2 max pool, store, and
+// the workgroup's max|Y| for the next layer's operand scale.  acc[i][j]: tile row 2 * wid + i,
+// channel block j (32x32x16 MFMA accumulator layout).
+template <int BN, bool F16>
+__device__ __forceinline__ void halo_epilogue(const CArgs& g, f32x16 (&acc)[2][BN / 32], int img,
+                                              int ty0, int tx0, int n0, int wid, int lane,
+                                              float iscA, unsigned char* smx) {
+  constexpr int TJ = BN / 32, TI = 2;
+  const int tid = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  float vmax = 0.f;
+  bool pooled = false;
+  if constexpr (F16) pooled = g.pool != 0;
+  if (pooled) {
+    // max-pool 2x2 / stride 2 fused: a lane's accumulators hold the four pixels of a window
+    // (rows 2*wid, 2*wid + 1 of the tile = i; register pairs (e, e+1) = adjacent columns), and
+    // max commutes exactly with the monotone epilogue (x * 2^k + b, ReLU)
+    const int Ho = g.H / 2, Wo = g.W / 2;
+    const int yo = (ty0 + 2 * wid) >> 1;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + j * 32 + l31;
+      if (col >= g.Cout) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+      const float un = iscA * g.scaleB[col];
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const int xo = (tx0 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1;
+        if (yo >= Ho || xo >= Wo) continue;
+        float v = -3.4028234e38f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            float t = acc[i][j][e + d] * un + bv;
+            if (g.relu) t = fmaxf(t, 0.f);
+            v = fmaxf(v, t);
+          }
+        g.Y[((long long)(img * Ho + yo) * Wo + xo) * g.Cout + col] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  } else {
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + j * 32 + l31;
+    if (col >= g.Cout) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    float un = 1.f;
+    if constexpr (F16) un = iscA * g.scaleB[col];        // powers of two: exact
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int y = ty0 + 2 * wid + i;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int x = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (y >= g.H || x >= g.W) continue;
+        float v = acc[i][j][e];
+        if constexpr (F16) v *= un;
+        v += bv;
+        if (g.relu) v = fmaxf(v, 0.f);
+        g.Y[((long long)(img * g.H + y) * g.W + x) * g.Cout + col] = v;
+        if constexpr (F16) vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  }
+  }
+  if constexpr (F16) {
+    if (g.amax_out) {
+      float* red = reinterpret_cast<float*>(smx);     // the operand stages are no longer read
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+      __syncthreads();
+      if (lane == 0) red[wid] = vmax;
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        if (v > __hip_atomic_load(g.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicMax(g.amax_out, v);
+      }
+    }
+  }
+}
+
 // ---- 3x3 conv, fp32x3, with the input halo tile staged once per channel slab -------------------
 // The linear-pixel kernel above gathers every tap's activations again: 9 x 64 B per output pixel
 // per 16-channel slab.  For the wide shallow layers (Cout <= 128: conv1_2, conv2_1, conv2_2) that
@@ -1138,78 +1221,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
     }
   }
 
-  float vmax = 0.f;
-  bool pooled = false;
-  if constexpr (F16) pooled = g.pool != 0;
-  if (pooled) {
-    // max-pool 2x2 / stride 2 fused: a lane's accumulators hold the four pixels of a window
-    // (rows 2*wid, 2*wid + 1 of the tile = i; register pairs (e, e+1) = adjacent columns), and
-    // max commutes exactly with the monotone epilogue (x * 2^k + b, ReLU)
-    const int Ho = g.H / 2, Wo = g.W / 2;
-    const int yo = (ty0 + 2 * wid) >> 1;
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int col = n0 + j * 32 + l31;
-      if (col >= g.Cout) continue;
-      const float bv = g.bias ? g.bias[col] : 0.f;
-      const float un = iscA * g.scaleB[col];
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const int xo = (tx0 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1;
-        if (yo >= Ho || xo >= Wo) continue;
-        float v = -3.4028234e38f;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            float t = acc[i][j][e + d] * un + bv;
-            if (g.relu) t = fmaxf(t, 0.f);
-            v = fmaxf(v, t);
-          }
-        g.Y[((long long)(img * Ho + yo) * Wo + xo) * g.Cout + col] = v;
-        vmax = fmaxf(vmax, fabsf(v));
-      }
-    }
-  } else {
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const int col = n0 + j * 32 + l31;
-    if (col >= g.Cout) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-    float un = 1.f;
-    if constexpr (F16) un = iscA * g.scaleB[col];        // powers of two: exact
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      const int y = ty0 + 2 * wid + i;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int x = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (y >= g.H || x >= g.W) continue;
-        float v = acc[i][j][e];
-        if constexpr (F16) v *= un;
-        v += bv;
-        if (g.relu) v = fmaxf(v, 0.f);
-        g.Y[((long long)(img * g.H + y) * g.W + x) * g.Cout + col] = v;
-        if constexpr (F16) vmax = fmaxf(vmax, fabsf(v));
-      }
-    }
-  }
-  }
-  if constexpr (F16) {
-    if (g.amax_out) {
-      float* red = reinterpret_cast<float*>(smx);     // the operand stages are no longer read
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
-      __syncthreads();
-      if (lane == 0) red[wid] = vmax;
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-        if (v > __hip_atomic_load(g.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-          atomicMax(g.amax_out, v);
-      }
-    }
-  }
+  halo_epilogue<BN, F16>(g, acc, img, ty0, tx0, n0, wid, lane, iscA, smx);
 }
 
 template <int BN, bool F16 = false, int DIL = 1>
