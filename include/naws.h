@@ -590,6 +590,13 @@ int naws_det_limit_fwd(const float* scores, const uint8_t* keep, int C, int R, i
                        int cap, int32_t* out_count, int32_t* out_cls, int32_t* out_row,
                        float* out_score, void* stream);
 
+/* ---- diagnostics (no reference counterpart) ------------------------------------------------- */
+/* With a device buffer of 8 x 4 x workgroups uint64 words set (NULL: off), the fp16x2 halo-tile
+ * conv launches that take the ring-4 / dilation-1 route run a stamped build and leave per-wave
+ * cycle sums of the step phases {counted wait, barrier, DMA issue, LDS fragment reads, MFMAs,
+ * halo refill} there (na-fwebsod_amd/tools/ab_conv.py --stamp).  Outputs are unchanged. */
+int naws_debug_conv_stamp_buffer(void* buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,1214 @@
+// 3x3 convolutions on the split-operand MFMA path (NHWC activations, weights as operand planes
+// [plane][(tap, Cin/16)][Cout][16]): the linear-pixel fp32x3 kernel, the halo-tile kernel
+// (fp32x3 and fp16x2) and the fp16x2 halo-tile kernel with a deep weight ring.  Reference op:
+// /root/reference/detectron/modeling/VGG16.py:9-48 (Conv 3x3 pad = dilation, bias, Relu).
+#include "x3_common.h"
+
+static int g_x3_variant = -1;
+
+namespace {
+// ---- 3x3 convolution (NHWC fp32 activations) as an fp32x3 implicit GEMM -------------------------
+// A = activations gathered straight from the fp32 NHWC tensor (branch-free buffer loads, halo ->
+// 0), split into the three bf16 planes in registers (8 VALU ops per element, < 5 % of the MFMA
+// time of a step) and written into the same swizzled LDS image the DMA path uses; B = weight
+// planes [3][9*Cin/16][Cout][16] (naws_split_bf16x3 of the packed [Cout][3][3][Cin] weight) by
+// LDS-DMA.  A K-step is 16 channels of one tap.  Two LDS stages: step t+1's activations are
+// loaded at the top of step t and split/written after its MFMAs.
+struct CArgs {
+  const float* X;            // NHWC
+  const unsigned short* B;   // weight planes
+  const float* bias;
+  float* Y;                  // NHWC
+  int M, Cout, Cin, H, W, dil, relu;
+  long long planeB, slabB;
+  unsigned bytesX;
+  int tiles_m, tiles_n;
+  // fp16x2 form of the halo kernel
+  const float* scaleB;       // 1/scale per output channel (naws_split_f16x2 of the weight)
+  const unsigned* amax_in;   // bit pattern of an upper bound b of max|X| ...
+  float in_mul, in_add;      // ... the bound used is b * in_mul + in_add
+  unsigned* amax_out;        // receives the bit pattern of max|Y| (nullable)
+  int pool;                  // 1: write maxpool2x2/stride 2 of the output instead of the output
+  unsigned long long* dbg;   // diagnostic build only: per-wave phase cycle sums (null otherwise)
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void conv_x3_kernel(CArgs g) {
+  constexpr int NT = 64 * WM * WN, NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TI = WTM / 32, TJ = WTN / 32;
+  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;
+  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  constexpr int UA = BM * 2 / NT;                 // (row, 8-channel half) units per thread
+  constexpr int BPIECES = 3 * BN / 32;            // 1 KB DMA pieces of the weight stage
+  static_assert(BM * 2 % NT == 0, "tile vs workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int lid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, rem = ntiles & 7, xcd = lid & 7, within = lid >> 3;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+  }
+  // all Cout tiles of one pixel tile are neighbours: the gathered activations are shared in L2
+  const int tm = lid / g.tiles_n, tn = lid % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  int py[UA], px[UA];
+  unsigned abase[UA];
+  int awr[UA];
+#pragma unroll
+  for (int i = 0; i < UA; ++i) {
+    const int u = tid + i * NT;
+    const int row = u >> 1, half = u & 1;
+    const int gm = m0 + row;
+    if (gm < g.M) {
+      px[i] = gm % g.W; py[i] = (gm / g.W) % g.H;
+      abase[i] = ((unsigned)gm * (unsigned)g.Cin + half * 8) * 4u;
+    } else { px[i] = 0; py[i] = 0; abase[i] = OOB; }
+    awr[i] = row * 32 + ((half ^ ((row >> 3) & 1)) * 16);
+  }
+  const int bslot = ((lane & 1) ^ ((lane >> 4) & 1)) * 8;
+
+  u32x4 ra[UA][2];
+  auto loadA = [&](int t) {
+    const int k0 = t * 16;
+    const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+    const int dy = (tap / 3 - 1) * g.dil, dx = (tap % 3 - 1) * g.dil;
+    const int delta = ((dy * g.W + dx) * g.Cin + c0) * 4;
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = (abase[i] != OOB) && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+      const unsigned off = ok ? (unsigned)((int)abase[i] + delta) : OOB;
+      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
+      ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? (int)(off + 16) : (int)OOB, 0, 0);
+    }
+  };
+  auto storeA = [&](int st) {
+    unsigned char* base = smx + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+      unsigned short q[3][8];
+      const unsigned w[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w,
+                             ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        u32x4 v;
+        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[i]) = v;
+      }
+    }
+  };
+  auto issueB = [&](int t, int st) {
+    unsigned char* base = smx + st * STAGE + 3 * A_PLANE;
+#pragma unroll
+    for (int r = 0; r < (BPIECES + NW - 1) / NW; ++r) {
+      const int piece = wid + r * NW;             // wave-uniform
+      if (piece < BPIECES) {
+        const int pl = piece / (BN / 32), rb = piece % (BN / 32);
+        // weight rows past Cout re-read the last row (their columns are never stored)
+        const int wrow = min(n0 + rb * 32 + (lane >> 1), g.Cout - 1);
+        __builtin_amdgcn_global_load_lds(
+            NAWS_GLB_PTR(g.B + pl * g.planeB + t * g.slabB + (long long)wrow * 16 + bslot),
+            NAWS_LDS_PTR(base + pl * B_PLANE + rb * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int rd_a = (wm * WTM + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+  const int rd_b = 3 * A_PLANE + (wn * WTN + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+
+  const int T = 9 * g.Cin / 16;
+  issueB(0, 0);
+  loadA(0);
+  storeA(0);
+  for (int t = 0; t < T; ++t) {
+    __syncthreads();                     // stage t&1 complete (DMA drained + LDS writes visible)
+    const bool more = t + 1 < T;
+    if (more) { issueB(t + 1, (t + 1) & 1); loadA(t + 1); }
+    const unsigned char* st = smx + (t & 1) * STAGE;
+    bf16x8 a[3][TI], b[3][TJ];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        a[pl][i] = *reinterpret_cast<const bf16x8*>(st + rd_a + pl * A_PLANE + i * 1024);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        b[pl][j] = *reinterpret_cast<const bf16x8*>(st + rd_b + pl * B_PLANE + j * 1024);
+    }
+#define NAWS_X3_TERM(P, Q)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][i], b[Q][j], acc[i][j], 0, 0, 0);
+    NAWS_X3_TERM(0, 0)
+    NAWS_X3_TERM(0, 1)
+    NAWS_X3_TERM(1, 0)
+    NAWS_X3_TERM(1, 1)
+    NAWS_X3_TERM(0, 2)
+    NAWS_X3_TERM(2, 0)
+#undef NAWS_X3_TERM
+    if (more) storeA((t + 1) & 1);
+  }
+
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+    if (col >= g.Cout) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        float v = acc[i][j][e] + bv;
+        if (g.relu) v = fmaxf(v, 0.f);
+        g.Y[(long long)row * g.Cout + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv_x3(CArgs& g, hipStream_t s) {
+  g.tiles_m = (int)naws_cdiv(g.M, BM);
+  g.tiles_n = (int)naws_cdiv(g.Cout, BN);
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
+  auto kern = conv_x3_kernel<BM, BN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * WM * WN), lds, s, g);
+  return naws_check_launch();
+}
+
+
+// Epilogue of the halo-tile kernels: un-scale, bias, ReLU, optional fused 2x2 max pool, store, and
+// the workgroup's max|Y| for the next layer's operand scale.  acc[i][j]: tile row 2 * wid + i,
+// channel block j (32x32x16 MFMA accumulator layout).
+template <int BN, bool F16>
+__device__ __forceinline__ void halo_epilogue(const CArgs& g, f32x16 (&acc)[2][BN / 32], int img,
+                                              int ty0, int tx0, int n0, int wid, int lane,
+                                              float iscA, unsigned char* smx) {
+  constexpr int TJ = BN / 32, TI = 2;
+  const int tid = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  float vmax = 0.f;
+  bool pooled = false;
+  if constexpr (F16) pooled = g.pool != 0;
+  if (pooled) {
+    // max-pool 2x2 / stride 2 fused: a lane's accumulators hold the four pixels of a window
+    // (rows 2*wid, 2*wid + 1 of the tile = i; register pairs (e, e+1) = adjacent columns), and
+    // max commutes exactly with the monotone epilogue (x * 2^k + b, ReLU)
+    const int Ho = g.H / 2, Wo = g.W / 2;
+    const int yo = (ty0 + 2 * wid) >> 1;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + j * 32 + l31;
+      if (col >= g.Cout) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+      const float un = iscA * g.scaleB[col];
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const int xo = (tx0 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1;
+        if (yo >= Ho || xo >= Wo) continue;
+        float v = -3.4028234e38f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            float t = acc[i][j][e + d] * un + bv;
+            if (g.relu) t = fmaxf(t, 0.f);
+            v = fmaxf(v, t);
+          }
+        g.Y[((long long)(img * Ho + yo) * Wo + xo) * g.Cout + col] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  } else {
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + j * 32 + l31;
+    if (col >= g.Cout) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    float un = 1.f;
+    if constexpr (F16) un = iscA * g.scaleB[col];        // powers of two: exact
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int y = ty0 + 2 * wid + i;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int x = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (y >= g.H || x >= g.W) continue;
+        float v = acc[i][j][e];
+        if constexpr (F16) v *= un;
+        v += bv;
+        if (g.relu) v = fmaxf(v, 0.f);
+        g.Y[((long long)(img * g.H + y) * g.W + x) * g.Cout + col] = v;
+        if constexpr (F16) vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  }
+  }
+  if constexpr (F16) {
+    if (g.amax_out) {
+      float* red = reinterpret_cast<float*>(smx);     // the operand stages are no longer read
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+      __syncthreads();
+      if (lane == 0) red[wid] = vmax;
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        if (v > __hip_atomic_load(g.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicMax(g.amax_out, v);
+      }
+    }
+  }
+}
+
+// ---- 3x3 conv, fp32x3, with the input halo tile staged once per channel slab -------------------
+// The linear-pixel kernel above gathers every tap's activations again: 9 x 64 B per output pixel
+// per 16-channel slab.  For the wide shallow layers (Cout <= 128: conv1_2, conv2_1, conv2_2) that
+// gather, not the MFMA, sets the pace.  Here a workgroup owns an 8-row x 32-column pixel tile:
+// for each 16-channel slab the (8+2) x (32+2) halo is gathered, split and written to LDS ONCE
+// (340 pixels instead of 9 x 256), and the nine taps read their A fragments from it at shifted
+// rows - a wave's 32-lane fragment is one image row of the tile, so a tap is just a row offset
+// (dy * 34 + dx) into the halo image.  Same LDS row format and bank swizzle as everywhere else;
+// weights per (tap, slab) by LDS-DMA, double buffered.  dilation 1, stride 1.
+// F16: the fp16x2 form - activations scaled by one power of two per tensor (from an upper bound
+// of max|X| handed in by the producer of X), split into f16 hi / lo planes in registers; weight
+// planes from naws_split_f16x2 (per-output-channel scales); 3 MFMA terms instead of 6; the
+// accumulator is un-scaled in the epilogue, which also reports max|Y| for the next layer.
+template <int BN, bool F16 = false, int DIL = 1>
+__global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(CArgs g) {
+  constexpr int NPL = F16 ? 2 : 3;
+  typedef typename OperandVec<F16>::type vec_t;
+  // BN = 64: one halo stage (refilled behind an extra barrier every 9th step) keeps the
+  // workgroup at 45 KB of LDS, so three of them share a CU; BN = 128: two halo stages
+  constexpr int ASTAGES = BN <= 64 ? 1 : 2;
+  // DIL = 2 (conv5_x): the taps sit 2 pixels apart, the halo is (8+4) x (32+4) = 432 pixels
+  constexpr int TH = 8, TW = 32, HWD = TW + 2 * DIL, HPIX = (TH + 2 * DIL) * HWD;   // 340 halo pixels
+  constexpr int A_ROWS = (HPIX + 7) / 8 * 8;
+  constexpr int A_PLANE = A_ROWS * 32, A_STAGE = NPL * A_PLANE;
+  constexpr int B_PLANE = BN * 32, B_STAGE = NPL * B_PLANE;
+  constexpr int TJ = BN / 32, TI = 2;
+  constexpr int UR = (HPIX * 2 + 255) / 256;                                // staging rounds (3)
+  constexpr int BPIECES = NPL * BN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  unsigned char* smA = smx;
+  unsigned char* smB = smx + ASTAGES * A_STAGE;
+
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  int lid = blockIdx.x;
+  const int tn = lid % g.tiles_n;
+  lid /= g.tiles_n;
+  const int tx0 = (lid % tiles_x) * TW;
+  const int ty0 = ((lid / tiles_x) % tiles_y) * TH;
+  const int img = lid / (tiles_x * tiles_y);
+  const int n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  float scA = 1.f, iscA = 1.f;
+  if constexpr (F16) {
+    const float bound = __uint_as_float(*g.amax_in) * g.in_mul + g.in_add;
+    f16x2_scales(__float_as_uint(bound), scA, iscA);
+  }
+
+  unsigned abase[UR];
+  int awr[UR];
+#pragma unroll
+  for (int r = 0; r < UR; ++r) {
+    const int u = tid + r * 256;
+    const int hp = u >> 1, half = u & 1;
+    const int y = ty0 - DIL + hp / HWD, x = tx0 - DIL + hp % HWD;
+    const bool ok = hp < HPIX && y >= 0 && y < g.H && x >= 0 && x < g.W;
+    abase[r] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)g.Cin + half * 8) * 4u : OOB;
+    awr[r] = hp < HPIX ? hp * 32 + ((half ^ ((hp >> 3) & 1)) * 16) : -1;
+  }
+  u32x4 ra[UR][2];
+  auto loadA = [&](int slab) {
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      const unsigned off = abase[r] != OOB ? abase[r] + (unsigned)slab * 64u : OOB;
+      ra[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
+      ra[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, abase[r] != OOB ? (int)(off + 16) : (int)OOB, 0, 0);
+    }
+  };
+  auto storeA = [&](int st) {
+    unsigned char* base = smA + st * A_STAGE;
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      if (awr[r] < 0) continue;
+      unsigned short q[3][8];
+      const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
+                             ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if constexpr (F16) {
+          const float t = __uint_as_float(w[e]) * scA;
+          const _Float16 hi = (_Float16)t;
+          float rr = t - (float)hi;
+          if (!(fabsf(t) <= 65504.f)) rr = 0.f;
+          const _Float16 lo = (_Float16)rr;
+          q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+          q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+        } else {
+          split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        u32x4 v;
+        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[r]) = v;
+      }
+    }
+  };
+  const int bslot = ((lane & 1) ^ ((lane >> 4) & 1)) * 8;
+  auto issueB = [&](int kslab, int st) {
+    unsigned char* base = smB + st * B_STAGE;
+#pragma unroll
+    for (int r = 0; r < (BPIECES + 3) / 4; ++r) {
+      const int piece = wid + r * 4;
+      if (piece < BPIECES) {
+        const int pl = piece / (BN / 32), rb = piece % (BN / 32);
+        const int wrow = min(n0 + rb * 32 + (lane >> 1), g.Cout - 1);
+        __builtin_amdgcn_global_load_lds(
+            NAWS_GLB_PTR(g.B + pl * g.planeB + (long long)kslab * g.slabB + (long long)wrow * 16 + bslot),
+            NAWS_LDS_PTR(base + pl * B_PLANE + rb * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int S = g.Cin / 16, T = 9 * S;
+  const int rd_b = l31 * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+  issueB(0, 0);                  // (tap 0, slab 0)
+  loadA(0);
+  storeA(0);
+  for (int kk = 0; kk < T; ++kk) {
+    const int slab = kk / 9, tap = kk - slab * 9;
+    __syncthreads();             // halo stage + weight stage of this step are complete
+    if (kk + 1 < T) {
+      const int s1 = (kk + 1) / 9, t1 = (kk + 1) - s1 * 9;
+      issueB(t1 * S + s1, (kk + 1) & 1);
+    }
+    if (tap == 0 && slab + 1 < S) loadA(slab + 1);
+    const unsigned char* sa = smA + (slab & (ASTAGES - 1)) * A_STAGE;
+    const unsigned char* sb = smB + (kk & 1) * B_STAGE;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    vec_t a[NPL][TI], b[NPL][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int hp = (2 * wid + i + DIL + dy * DIL) * HWD + (l31 + DIL + dx * DIL);
+      const int off = hp * 32 + ((h ^ ((hp >> 3) & 1)) * 16);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        a[pl][i] = *reinterpret_cast<const vec_t*>(sa + pl * A_PLANE + off);
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        b[pl][j] = *reinterpret_cast<const vec_t*>(sb + pl * B_PLANE + rd_b + j * 1024);
+#define NAWS_X3_TERM(P, Q)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
+      acc[i][j] = mfma16(a[P][i], b[Q][j], acc[i][j]);
+    NAWS_X3_TERM(0, 0)
+    NAWS_X3_TERM(0, 1)
+    NAWS_X3_TERM(1, 0)
+    if constexpr (!F16) {
+      NAWS_X3_TERM(1, 1)
+      NAWS_X3_TERM(0, 2)
+      NAWS_X3_TERM(2, 0)
+    }
+#undef NAWS_X3_TERM
+    if (tap == 8 && slab + 1 < S) {
+      if (ASTAGES == 1) __syncthreads();   // every wave is done with the only halo stage
+      storeA((slab + 1) & (ASTAGES - 1));
+    }
+  }
+
+  halo_epilogue<BN, F16>(g, acc, img, ty0, tx0, n0, wid, lane, iscA, smx);
+}
+
+// ---- the fp16x2 halo-tile kernel with a deep weight ring --------------------------------------
+// Same tile, LDS images, MFMA order and epilogue as conv_x3_halo_kernel<BN, true, DIL> (results
+// are bit-identical), different pipeline.  There a (tap, slab) weight stage is requested one step
+// (24 MFMAs = 0.35 us of matrix time) before it is read and __syncthreads() drains vmcnt to 0
+// every step, so each step waits out an L2 round trip: 36-41 % MFMA busy at full clock with half
+// of all wave cycles in s_waitcnt (profiles/r02_default_plan_pmc.md).  Here the weight stages
+// form a ring of NB, the LDS-DMA runs NB-1 steps ahead, and a step retires only its own pieces
+// with a counted s_waitcnt before a raw s_barrier (the pipeline of gemm_x3_m16_kernel).  The nine
+// taps of a slab are unrolled, so tap offsets are immediates and the position of the halo loads
+// (issued at tap 0, consumed after tap 8) in the in-order vmcnt queue is static.
+template <int BN, int DIL, int NB, bool STAMP = false>
+__global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_h2_ring_kernel(CArgs g) {
+  constexpr int NPL = 2;
+  typedef f16x8 vec_t;
+  constexpr int ASTAGES = (BN <= 64 || DIL == 2) ? 1 : 2;
+  constexpr int TH = 8, TW = 32, HWD = TW + 2 * DIL, HPIX = (TH + 2 * DIL) * HWD;
+  constexpr int A_ROWS = (HPIX + 7) / 8 * 8;
+  constexpr int A_PLANE = A_ROWS * 32, A_STAGE = NPL * A_PLANE;
+  constexpr int B_PLANE = BN * 32, B_STAGE = NPL * B_PLANE;
+  constexpr int TJ = BN / 32, TI = 2;
+  constexpr int UR = (HPIX * 2 + 255) / 256;
+  constexpr int BPIECES = NPL * BN / 32;
+  constexpr int NBL = BPIECES / 4;                 // DMA instructions per wave per step
+  static_assert(BPIECES % 4 == 0, "every wave issues the same number of pieces");
+  static_assert(NB >= 2 && NB <= 9, "ring depth");
+  static_assert((NB - 2) * NBL + 2 * UR <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  unsigned char* smA = smx;
+  unsigned char* smB = smx + ASTAGES * A_STAGE;
+
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  int lid = blockIdx.x;
+  const int tn = lid % g.tiles_n;
+  lid /= g.tiles_n;
+  const int tx0 = (lid % tiles_x) * TW;
+  const int ty0 = ((lid / tiles_x) % tiles_y) * TH;
+  const int img = lid / (tiles_x * tiles_y);
+  const int n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  float scA, iscA;
+  {
+    const float bound = __uint_as_float(*g.amax_in) * g.in_mul + g.in_add;
+    f16x2_scales(__float_as_uint(bound), scA, iscA);
+  }
+
+  unsigned abase[UR];
+  int awr[UR];
+#pragma unroll
+  for (int r = 0; r < UR; ++r) {
+    const int u = tid + r * 256;
+    const int hp = u >> 1, half = u & 1;
+    const int y = ty0 - DIL + hp / HWD, x = tx0 - DIL + hp % HWD;
+    const bool ok = hp < HPIX && y >= 0 && y < g.H && x >= 0 && x < g.W;
+    abase[r] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)g.Cin + half * 8) * 4u : OOB;
+    awr[r] = hp < HPIX ? hp * 32 + ((half ^ ((hp >> 3) & 1)) * 16) : -1;
+  }
+  u32x4 ra[UR][2];
+  auto loadA = [&](int slab) {
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      const unsigned off = abase[r] != OOB ? abase[r] + (unsigned)slab * 64u : OOB;
+      ra[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
+      ra[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, abase[r] != OOB ? (int)(off + 16) : (int)OOB, 0, 0);
+    }
+  };
+  auto storeA = [&](int st) {
+    unsigned char* base = smA + st * A_STAGE;
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      if (awr[r] < 0) continue;
+      unsigned short q[2][8];
+      const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
+                             ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = __uint_as_float(w[e]) * scA;
+        const _Float16 hi = (_Float16)t;
+        float rr = t - (float)hi;
+        if (!(fabsf(t) <= 65504.f)) rr = 0.f;
+        const _Float16 lo = (_Float16)rr;
+        q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+        q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        u32x4 v;
+        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[r]) = v;
+      }
+    }
+  };
+  const int bslot = ((lane & 1) ^ ((lane >> 4) & 1)) * 8;
+  // this wave's pieces of a weight stage: piece = wid + 4 r -> (plane, 32-row block)
+  const unsigned short* srcB[NBL];
+  int dstB[NBL];
+#pragma unroll
+  for (int r = 0; r < NBL; ++r) {
+    const int piece = wid + r * 4;
+    const int pl = piece / (BN / 32), rb = piece % (BN / 32);
+    const int wrow = min(n0 + rb * 32 + (lane >> 1), g.Cout - 1);
+    srcB[r] = g.B + pl * g.planeB + (long long)wrow * 16 + bslot;
+    dstB[r] = pl * B_PLANE + rb * 1024;
+  }
+  auto issueB = [&](int kslab, int st) {
+    unsigned char* base = smB + st * B_STAGE;
+#pragma unroll
+    for (int r = 0; r < NBL; ++r)
+      __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(srcB[r] + (long long)kslab * g.slabB),
+                                       NAWS_LDS_PTR(base + dstB[r]), 16, 0, 0);
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int S = g.Cin / 16, T = 9 * S;       // step kk = slab * 9 + tap reads weight slab tap * S + slab
+  const int rd_b = l31 * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
+  const int hp_w = 2 * wid * HWD + l31;      // halo pixel of (tile row 2 wid, column l31), tap (-1, -1)
+#pragma unroll
+  for (int s = 0; s < NB - 1; ++s) issueB(s * S, s);      // T >= 9 > NB - 1: taps s of slab 0
+  loadA(0);
+  storeA(0);
+  int st_cur = 0, st_fill = NB - 1, kk = 0;
+  // STAMP (diagnostic build, tools/ab_conv.py --stamp): cycle sums of the step's phases
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tA = 0, tB = 0;
+#define NAWS_STAMP(K)                                                        \
+  if constexpr (STAMP) {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    if (K >= 0) ph[K < 0 ? 0 : K] += tB - tA;                                \
+    tA = tB;                                                                 \
+  }
+  NAWS_STAMP(-1)
+  for (int slab = 0; slab < S; ++slab) {
+    const bool more = slab + 1 < S;
+    const unsigned char* sa = smA + (slab & (ASTAGES - 1)) * A_STAGE;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++kk) {
+      // retire this wave's pieces of step kk: younger in the queue are the NB-2 later weight
+      // stages and, for taps 1..NB-1, the halo loads of the next slab issued at tap 0
+      if (kk + NB - 2 < T) {
+        if (tap >= 1 && tap <= NB - 1 && more) wait_vm_lgkm0<(NB - 2) * NBL + 2 * UR>();
+        else wait_vm_lgkm0<(NB - 2) * NBL>();
+      } else {
+        wait_vm_lgkm0<0>();
+      }
+      NAWS_STAMP(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      NAWS_STAMP(1)
+      if (kk + NB - 1 < T) {
+        const int t2 = (tap + NB - 1) % 9, ds = (tap + NB - 1) / 9;
+        issueB(t2 * S + slab + ds, st_fill);
+      }
+      if (tap == 0 && more) loadA(slab + 1);
+      NAWS_STAMP(2)
+      const unsigned char* sb = smB + st_cur * B_STAGE;
+      const int dy = tap / 3, dx = tap % 3;
+      vec_t a[NPL][TI], b[NPL][TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int hp = hp_w + (i + dy * DIL) * HWD + dx * DIL;
+        const int off = hp * 32 + ((h ^ ((hp >> 3) & 1)) * 16);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          a[pl][i] = *reinterpret_cast<const vec_t*>(sa + pl * A_PLANE + off);
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          b[pl][j] = *reinterpret_cast<const vec_t*>(sb + pl * B_PLANE + rd_b + j * 1024);
+      NAWS_STAMP(3)
+#define NAWS_X3_TERM(P, Q)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
+      acc[i][j] = mfma16(a[P][i], b[Q][j], acc[i][j]);
+      NAWS_X3_TERM(0, 0)
+      NAWS_X3_TERM(0, 1)
+      NAWS_X3_TERM(1, 0)
+#undef NAWS_X3_TERM
+      NAWS_STAMP(4)
+      if (tap == 8 && more) {
+        if (ASTAGES == 1) __builtin_amdgcn_s_barrier();   // every wave is done with the only halo stage
+        storeA((slab + 1) & (ASTAGES - 1));
+        NAWS_STAMP(5)
+      }
+      st_cur = (st_cur + 1 == NB) ? 0 : st_cur + 1;
+      st_fill = (st_fill + 1 == NB) ? 0 : st_fill + 1;
+    }
+  }
+#undef NAWS_STAMP
+  if constexpr (STAMP) {
+    if (g.dbg && lane == 0)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) g.dbg[((long long)blockIdx.x * 4 + wid) * 8 + k] = ph[k];
+  }
+  halo_epilogue<BN, true>(g, acc, img, ty0, tx0, n0, wid, lane, iscA, smx);
+}
+
+template <int BN, int DIL, int NB, bool STAMP = false>
+int launch_conv_h2_ring(CArgs& g, int N, hipStream_t s) {
+  g.tiles_n = (int)naws_cdiv(g.Cout, BN);
+  const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
+  if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  constexpr int A_ROWS = ((8 + 2 * DIL) * (32 + 2 * DIL) + 7) / 8 * 8;
+  constexpr int ASTAGES = (BN <= 64 || DIL == 2) ? 1 : 2;
+  const size_t lds = (size_t)ASTAGES * 2 * A_ROWS * 32 + (size_t)NB * 2 * BN * 32;
+  auto kern = conv_h2_ring_kernel<BN, DIL, NB, STAMP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
+  return naws_check_launch();
+}
+
+template <int BN, bool F16 = false, int DIL = 1>
+int launch_conv_x3_halo(CArgs& g, int N, hipStream_t s) {
+  g.tiles_n = (int)naws_cdiv(g.Cout, BN);
+  const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
+  if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  constexpr int A_ROWS = ((8 + 2 * DIL) * (32 + 2 * DIL) + 7) / 8 * 8;
+  constexpr int NPL = F16 ? 2 : 3;
+  const size_t lds = (size_t)(BN <= 64 ? 1 : 2) * NPL * A_ROWS * 32 + (size_t)2 * NPL * BN * 32;
+  auto kern = conv_x3_halo_kernel<BN, F16, DIL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
+  return naws_check_launch();
+}
+
+}  // namespace
+
+extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const float* bias,
+                                           int N, int H, int W, int Cin, int Cout, int dilation,
+                                           int relu, float* Y, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (dilation < 1) return NAWS_ERR_ARG;
+  if (Cin % 16 != 0 || Cout % 4 != 0) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W3); NAWS_REQUIRE_PTR(Y);
+  if (!bias && relu) return NAWS_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)W3) & 15) != 0) return NAWS_ERR_ARG;
+  const long long pix = (long long)N * H * W;
+  if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
+  CArgs g{};
+  g.X = X; g.B = (const unsigned short*)W3; g.bias = bias; g.Y = Y;
+  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = dilation; g.relu = relu;
+  g.slabB = (long long)Cout * 16;
+  g.planeB = (long long)9 * Cin * Cout;
+  g.bytesX = (unsigned)(pix * Cin * 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_x3_variant < 0) {
+    const char* e = getenv("NAWS_X3_VARIANT");
+    g_x3_variant = e ? atoi(e) : 0;
+  }
+  // wide shallow layers: the halo-tile kernel (input gathered once per channel slab, not per tap)
+  if (dilation == 1 && Cout <= 128 && Cout % 32 == 0 && g_x3_variant != 6) {
+    if (Cout <= 64) return launch_conv_x3_halo<64>(g, N, s);
+    return launch_conv_x3_halo<128>(g, N, s);
+  }
+  if (Cout <= 64) return launch_conv_x3<256, 64, 4, 1>(g, s);
+  if (Cout <= 128 || naws_cdiv(pix, 256) * naws_cdiv(Cout, 256) < 256) {
+    if (naws_cdiv(pix, 256) * naws_cdiv(Cout, 128) < 512) return launch_conv_x3<128, 128, 2, 2>(g, s);
+    return launch_conv_x3<256, 128, 2, 2>(g, s);
+  }
+  return launch_conv_x3<256, 256, 2, 4>(g, s);
+}
+
+namespace {
+// ---- the fp16x2 halo-tile kernel with wave-private weight fragments ----------------------------
+// In-kernel stamps of the ring kernel above (tools/ab_conv.py --stamp) put a quarter of a wave's
+// cycles into ISSUING its one or two weight LDS-DMA pieces per step and another quarter into the
+// step's counted wait and barrier, against 30-40 % in the MFMAs.  Here the weights never pass
+// through LDS: the four waves are a WR x WC grid - wave (wr, wc) owns tile rows wr * 8/WR ... and
+// the 32 output channels wc - and a wave's MFMA B operand (32 channels x 16 deep x 2 planes) is
+// exactly one 16-byte buffer load per lane and plane, straight from the slab-major weight planes
+// (a 1 KB contiguous run per wave instruction), prefetched two steps ahead in a static register
+// ring.  No weight stage, no DMA, no per-step barrier: the waves only meet once per 16-channel
+// slab, when the halo image (still LDS, two stages) changes.  Same MFMA order per accumulator as
+// conv_x3_halo_kernel<., true, .>: results are bit-identical.
+template <int DIL> struct NawsWpGeom {
+  static constexpr int HPIX = (8 + 2 * DIL) * (32 + 2 * DIL);
+  static constexpr int RAW = (HPIX + 7) / 8 * 8 * 16;
+  static constexpr int A_HALF = ((RAW / 4) % 64 == 32 && RAW > HPIX * 16) ? RAW : RAW + 128;   // bytes per k-half (+ a spare slot)
+};
+template <int WR, int WC, int DIL, bool PIPE = true>
+__global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArgs g) {
+  static_assert(WR * WC == 4, "four waves");
+  constexpr int NPL = 2, BN = 32 * WC, TI = 8 / WR;
+  typedef f16x8 vec_t;
+  constexpr int TH = 8, TW = 32, HWD = TW + 2 * DIL, HPIX = (TH + 2 * DIL) * HWD;
+  // halo image per plane: [k-half][halo pixel][16 B] - a wave's fragment read (32 consecutive
+  // pixels of one k-half per 32 lanes) is a contiguous 512-byte run, conflict-free without a
+  // swizzle, so a tap is an IMMEDIATE offset; the two k-halves sit 32 banks apart for the stores
+  constexpr int A_HALF = NawsWpGeom<DIL>::A_HALF;
+  constexpr int A_PLANE = 2 * A_HALF, A_STAGE = NPL * A_PLANE;
+  constexpr int UR = (HPIX * 2 + 255) / 256;
+  // A fragments are read TIH rows at a time; PIPE: double-buffered, one group ahead of the MFMAs
+  constexpr int TIH = PIPE ? TI / 2 : (TI > 4 ? 4 : TI), IH = TI / TIH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  unsigned char* smA = smx;
+
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  int lid = blockIdx.x;
+  const int tn = lid % g.tiles_n;
+  lid /= g.tiles_n;
+  const int tx0 = (lid % tiles_x) * TW;
+  const int ty0 = ((lid / tiles_x) % tiles_y) * TH;
+  const int img = lid / (tiles_x * tiles_y);
+  const int n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid / WC, wc = wid % WC;
+  const int l31 = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)g.B, 0, (int)(2 * g.planeB * 2), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  float scA, iscA;
+  {
+    const float bound = __uint_as_float(*g.amax_in) * g.in_mul + g.in_add;
+    f16x2_scales(__float_as_uint(bound), scA, iscA);
+  }
+
+  unsigned abase[UR];
+  int awr[UR];
+#pragma unroll
+  for (int r = 0; r < UR; ++r) {
+    const int u = tid + r * 256;
+    const int hp = u >> 1, half = u & 1;
+    const int y = ty0 - DIL + hp / HWD, x = tx0 - DIL + hp % HWD;
+    const bool ok = hp < HPIX && y >= 0 && y < g.H && x >= 0 && x < g.W;
+    abase[r] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)g.Cin + half * 8) * 4u : OOB;
+    // (units past the halo store into the spare slot behind it: no divergent branch)
+    awr[r] = half * A_HALF + min(hp, HPIX) * 16;
+  }
+  u32x4 ra[UR][2];
+  auto loadA = [&](int slab) {
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      const unsigned off = abase[r] != OOB ? abase[r] + (unsigned)slab * 64u : OOB;
+      ra[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
+      ra[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, abase[r] != OOB ? (int)(off + 16) : (int)OOB, 0, 0);
+    }
+  };
+  auto storeA = [&](int st) {
+    unsigned char* base = smA + st * A_STAGE;
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      unsigned short q[2][8];
+      const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
+                             ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = __uint_as_float(w[e]) * scA;
+        const _Float16 hi = (_Float16)t;
+        float rr = t - (float)hi;
+        if (!(fabsf(t) <= 65504.f)) rr = 0.f;
+        const _Float16 lo = (_Float16)rr;
+        q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+        q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        u32x4 v;
+        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[r]) = v;
+      }
+    }
+  };
+  // weight fragment of (tap, slab): lane (l31, h) holds k-half h of channel n0 + 32 wc + l31
+  const int S = g.Cin / 16;
+  const int voffB = (min(n0 + wc * 32 + l31, g.Cout - 1) * 16 + h * 8) * 2;
+  const int slabBytes = (int)g.slabB * 2, planeBytes = (int)(g.planeB * 2);
+  vec_t bq[3][NPL];
+  auto loadB = [&](int ring, int kslab) {
+    const int so = kslab * slabBytes;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, voffB, so + pl * planeBytes, 0);
+      bq[ring][pl] = *reinterpret_cast<const vec_t*>(&v);
+    }
+  };
+
+  f32x16 acc[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int rd_a = h * A_HALF + (wr * TI * HWD + l31) * 16;   // (first tile row of the wave, column l31), tap (-1, -1)
+  if constexpr (!PIPE) {
+    loadB(0, 0);                               // (tap 0, slab 0)
+    loadB(1, S);                               // (tap 1, slab 0)
+    loadA(0);
+    storeA(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int slab = 0; slab < S; ++slab) {
+      const bool more = slab + 1 < S;
+      const unsigned char* sa = smA + (slab & 1) * A_STAGE;
+      const int slab_n = more ? slab + 1 : slab;        // the last slab re-reads its own (unused) pieces
+  #pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        __builtin_amdgcn_sched_barrier(0);     // keep a tap's fragment reads with its MFMAs (registers)
+        {
+          const int t2 = (tap + 2) % 9;
+          loadB((tap + 2) % 3, t2 * S + (tap + 2 >= 9 ? slab_n : slab));
+        }
+        if (tap == 0 && more) loadA(slab + 1);
+        const int dy = tap / 3, dx = tap % 3;
+  #pragma unroll
+        for (int ih = 0; ih < IH; ++ih) {
+          vec_t a[NPL][TIH];
+  #pragma unroll
+          for (int i = 0; i < TIH; ++i) {
+  #pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+              a[pl][i] = *reinterpret_cast<const vec_t*>(
+                  sa + rd_a + pl * A_PLANE + ((ih * TIH + i + dy * DIL) * HWD + dx * DIL) * 16);
+          }
+  #pragma unroll
+          for (int i = 0; i < TIH; ++i)
+            acc[ih * TIH + i] = mfma16(a[0][i], bq[tap % 3][0], acc[ih * TIH + i]);
+  #pragma unroll
+          for (int i = 0; i < TIH; ++i)
+            acc[ih * TIH + i] = mfma16(a[0][i], bq[tap % 3][1], acc[ih * TIH + i]);
+  #pragma unroll
+          for (int i = 0; i < TIH; ++i)
+            acc[ih * TIH + i] = mfma16(a[1][i], bq[tap % 3][0], acc[ih * TIH + i]);
+        }
+        if (tap == 8 && more) storeA((slab + 1) & 1);
+      }
+      if (more) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+  } else {
+    // Software pipeline inside a wave: group = (tap, TIH rows); the fragment reads of group g + 1
+    // are issued before the MFMAs of group g (counted lgkmcnt by the compiler: static order), the
+    // weight fragments run two taps ahead, and the next slab's halo comes in one 256-unit round at
+    // a time (load at tap 2 r, convert + store after tap 2 r + 1) so only 8 registers stage it.
+    // Beyond the last slab every prefetch address is out of range: zero fill, no traffic.
+    constexpr int G = 9 * IH;
+    auto loadA1 = [&](int r, int slab, bool live) {
+      const unsigned off = (live && abase[r] != OOB) ? abase[r] + (unsigned)slab * 64u : OOB;
+      ra[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
+      ra[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off != OOB ? (int)(off + 16) : (int)OOB, 0, 0);
+    };
+    auto storeA1 = [&](int r, int st) {
+      unsigned char* base = smA + st * A_STAGE;
+      unsigned short q[2][8];
+      const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
+                             ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = __uint_as_float(w[e]) * scA;
+        const _Float16 hi = (_Float16)t;
+        float rr = t - (float)hi;
+        if (!(fabsf(t) <= 65504.f)) rr = 0.f;
+        const _Float16 lo = (_Float16)rr;
+        q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+        q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        u32x4 v;
+        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
+        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
+        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
+        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
+        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[r]) = v;
+      }
+    };
+    static_assert(2 * (UR - 1) + 1 <= 8, "halo rounds fit the taps of a slab");
+    vec_t a[2][NPL][TIH];
+    auto readA = [&](int buf, const unsigned char* sa, int grp) {
+      const int tap = grp / IH, ih = grp % IH;
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int i = 0; i < TIH; ++i)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          a[buf][pl][i] = *reinterpret_cast<const vec_t*>(
+              sa + rd_a + pl * A_PLANE + ((ih * TIH + i + dy * DIL) * HWD + dx * DIL) * 16);
+    };
+    const unsigned oobB = 0x7FFFFFF0u;
+    auto loadBp = [&](int ring, int kslab, bool live) {
+      const int so = kslab * slabBytes;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, live ? voffB : (int)oobB,
+                                                              live ? so + pl * planeBytes : 0, 0);
+        bq[ring][pl] = *reinterpret_cast<const vec_t*>(&v);
+      }
+    };
+    loadBp(0, 0, true);
+    loadBp(1, S, true);
+    loadA(0);
+    storeA(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int slab = 0; slab < S; ++slab) {
+      const bool more = slab + 1 < S;
+      const unsigned char* sa = smA + (slab & 1) * A_STAGE;
+      readA(0, sa, 0);
+#pragma unroll
+      for (int grp = 0; grp < G; ++grp) {
+        const int tap = grp / IH, ih = grp % IH;
+        if (ih == 0) {
+          const int t2 = (tap + 2) % 9;
+          loadBp((tap + 2) % 3, t2 * S + (tap + 2 >= 9 ? slab + 1 : slab), tap + 2 < 9 || more);
+          if (tap % 2 == 0 && tap / 2 < UR) loadA1(tap / 2, slab + 1, more);
+        }
+        if (grp + 1 < G) readA((grp + 1) & 1, sa, grp + 1);
+#pragma unroll
+        for (int i = 0; i < TIH; ++i)
+          acc[ih * TIH + i] = mfma16(a[grp & 1][0][i], bq[tap % 3][0], acc[ih * TIH + i]);
+#pragma unroll
+        for (int i = 0; i < TIH; ++i)
+          acc[ih * TIH + i] = mfma16(a[grp & 1][0][i], bq[tap % 3][1], acc[ih * TIH + i]);
+#pragma unroll
+        for (int i = 0; i < TIH; ++i)
+          acc[ih * TIH + i] = mfma16(a[grp & 1][1][i], bq[tap % 3][0], acc[ih * TIH + i]);
+        if (ih == IH - 1 && tap % 2 == 1 && tap / 2 < UR) storeA1(tap / 2, (slab + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+
+  // epilogue: acc[i] = tile row wr * TI + i, channel n0 + 32 wc + l31
+  float vmax = 0.f;
+  const int col = n0 + wc * 32 + l31;
+  const int ty = ty0 + wr * TI;
+  if (col < g.Cout) {
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    const float un = iscA * g.scaleB[col];               // powers of two: exact
+    if (g.pool) {
+      const int Ho = g.H / 2, Wo = g.W / 2;
+#pragma unroll
+      for (int i = 0; i < TI; i += 2) {
+        const int yo = (ty + i) >> 1;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const int xo = (tx0 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1;
+          if (yo >= Ho || xo >= Wo) continue;
+          float v = -3.4028234e38f;
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              float t = acc[i + ii][e + d] * un + bv;
+              if (g.relu) t = fmaxf(t, 0.f);
+              v = fmaxf(v, t);
+            }
+          g.Y[((long long)(img * Ho + yo) * Wo + xo) * g.Cout + col] = v;
+          vmax = fmaxf(vmax, fabsf(v));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int y = ty + i;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int x = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (y >= g.H || x >= g.W) continue;
+          float v = acc[i][e] * un + bv;
+          if (g.relu) v = fmaxf(v, 0.f);
+          g.Y[((long long)(img * g.H + y) * g.W + x) * g.Cout + col] = v;
+          vmax = fmaxf(vmax, fabsf(v));
+        }
+      }
+    }
+  }
+  if (g.amax_out) {
+    float* red = reinterpret_cast<float*>(smx);     // the halo stages are no longer read
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+    __syncthreads();
+    if (lane == 0) red[wid] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+      if (v > __hip_atomic_load(g.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(g.amax_out, v);
+    }
+  }
+}
+
+template <int WR, int WC, int DIL, bool PIPE = true>
+int launch_conv_h2_wp(CArgs& g, int N, hipStream_t s) {
+  constexpr int BN = 32 * WC;
+  g.tiles_n = (int)naws_cdiv(g.Cout, BN);
+  const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
+  if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)2 * 2 * 2 * NawsWpGeom<DIL>::A_HALF;
+  auto kern = conv_h2_wp_kernel<WR, WC, DIL, PIPE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
+  return naws_check_launch();
+}
+}  // namespace
+
+// Diagnostics (tools/ab_conv.py --stamp): with a buffer of 8 x 4 x workgroups u64 words set, the
+// ring-4 / dilation-1 launches run the stamped build and leave per-wave cycle sums of the step
+// phases {counted wait, barrier, DMA issue, LDS fragment reads, MFMAs, halo refill} there.
+static unsigned long long* g_conv_stamp_buf = nullptr;
+extern "C" int naws_debug_conv_stamp_buffer(void* buf) {
+  g_conv_stamp_buf = (unsigned long long*)buf;
+  return NAWS_OK;
+}
+
+// fp16x2 form of the shallow-layer convolution (the halo-tile kernel): W2 / scaleW =
+// naws_split_f16x2 of the packed weight viewed [Cout][9*Cin]; the activation scale comes from
+// *amax_in * in_mul + in_add (an upper bound of max|X|); dilation 1, Cout <= 128, Cout % 32 == 0.
+extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,
+                                           const float* bias, int N, int H, int W, int Cin,
+                                           int Cout, int dilation, int relu, float* Y,
+                                           const uint32_t* amax_in, float in_mul, float in_add,
+                                           uint32_t* amax_out, int amax_out_zeroed, int pool2,
+                                           void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (dilation != 1 && dilation != 2) return NAWS_ERR_UNSUPPORTED;
+  if (dilation == 2 && pool2) return NAWS_ERR_ARG;
+  if (Cin % 16 != 0 || (9 * Cin) % 32 != 0 || Cout % 32 != 0 || (Cout > 128 && Cout % 128 != 0))
+    return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W2); NAWS_REQUIRE_PTR(scaleW); NAWS_REQUIRE_PTR(Y);
+  NAWS_REQUIRE_PTR(amax_in);
+  if (!bias && relu) return NAWS_ERR_ARG;
+  if (!(in_mul > 0.f) || !(in_add >= 0.f) || amax_in == amax_out) return NAWS_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)W2) & 15) != 0) return NAWS_ERR_ARG;
+  const long long pix = (long long)N * H * W;
+  if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
+  CArgs g{};
+  g.X = X; g.B = (const unsigned short*)W2; g.bias = bias; g.Y = Y;
+  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = dilation; g.relu = relu;
+  g.slabB = (long long)Cout * 16;
+  g.planeB = (long long)9 * Cin * Cout;
+  g.bytesX = (unsigned)(pix * Cin * 4);
+  g.scaleB = scaleW; g.amax_in = (const unsigned*)amax_in; g.in_mul = in_mul; g.in_add = in_add;
+  g.amax_out = (unsigned*)amax_out;
+  g.pool = pool2 ? 1 : 0;
+  if (pool2 && (H < 2 || W < 2)) return NAWS_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  // (a chain of layers zeroes all its words with one fill and passes amax_out_zeroed = 1: a
+  // memset per layer is a 6 us kernel plus a launch gap in a dependent chain)
+  if (amax_out && !amax_out_zeroed && hipMemsetAsync(amax_out, 0, sizeof(uint32_t), s) != hipSuccess)
+    return NAWS_ERR_LAUNCH;
+  // 64-wide channel tiles (3 workgroups per CU) where 128-wide ones leave CUs idle or the layer is
+  // deep: measured per layer at 2 images (tools/kernel_bench.py --what x3): conv3_x 0.137 / 0.259
+  // vs 0.156 / 0.289 ms, conv4_2 0.282 vs 0.297; conv2_2 (608 tiles of 128) keeps 128
+  bool bn64 = Cout <= 64;
+  if (!bn64 && Cout % 64 == 0) {
+    const long long t128 = (long long)N * naws_cdiv(H, 8) * naws_cdiv(W, 32) * naws_cdiv(Cout, 128);
+    bn64 = Cin >= 128 && Cout >= 256 && t128 < 4 * 512;
+    const char* e = getenv("NAWS_CONV_BN");            // A/B knob (tools/kernel_bench.py)
+    if (e) bn64 = atoi(e) == 64;
+  }
+  static int ring = -2;                                 // NAWS_CONV_RING: 0 = the one-step pipeline
+  {
+    const char* e = getenv("NAWS_CONV_RING");           // read per call: in-process A/B
+    ring = e ? atoi(e) : 11;
+  }
+  if (ring == 10 || ring == 11) {                         // wave-private weight fragments
+    if (2 * g.planeB * 2 > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+    // 2 x 2 waves (64-channel tiles, 3 workgroups per CU) up to 256 output channels, 1 x 4 waves
+    // (128-channel tiles, half the weight traffic) for the 512-channel layers: per layer at one
+    // image, tools/ab_conv.py --rings 11 --bn 64 128
+    if (Cout > 64 && Cout % 128 == 0 && !getenv("NAWS_CONV_BN")) bn64 = Cout < 512;
+    if (ring == 10) {
+      if (dilation == 2)
+        return bn64 ? launch_conv_h2_wp<2, 2, 2, false>(g, N, s) : launch_conv_h2_wp<1, 4, 2, false>(g, N, s);
+      return bn64 ? launch_conv_h2_wp<2, 2, 1, false>(g, N, s) : launch_conv_h2_wp<1, 4, 1, false>(g, N, s);
+    }
+    if (dilation == 2)
+      return bn64 ? launch_conv_h2_wp<2, 2, 2>(g, N, s) : launch_conv_h2_wp<1, 4, 2>(g, N, s);
+    return bn64 ? launch_conv_h2_wp<2, 2, 1>(g, N, s) : launch_conv_h2_wp<1, 4, 1>(g, N, s);
+  }
+  if (g_conv_stamp_buf && ring == 4 && dilation == 1) {   // diagnostic build
+    g.dbg = g_conv_stamp_buf;
+    return bn64 ? launch_conv_h2_ring<64, 1, 4, true>(g, N, s) : launch_conv_h2_ring<128, 1, 4, true>(g, N, s);
+  }
+  if (ring == 4) {
+    if (dilation == 2)
+      return bn64 ? launch_conv_h2_ring<64, 2, 4>(g, N, s) : launch_conv_h2_ring<128, 2, 4>(g, N, s);
+    return bn64 ? launch_conv_h2_ring<64, 1, 4>(g, N, s) : launch_conv_h2_ring<128, 1, 4>(g, N, s);
+  }
+  if (ring == 3) {
+    if (dilation == 2)
+      return bn64 ? launch_conv_h2_ring<64, 2, 3>(g, N, s) : launch_conv_h2_ring<128, 2, 3>(g, N, s);
+    return bn64 ? launch_conv_h2_ring<64, 1, 3>(g, N, s) : launch_conv_h2_ring<128, 1, 3>(g, N, s);
+  }
+  if (ring == 6) {
+    if (dilation == 2)
+      return bn64 ? launch_conv_h2_ring<64, 2, 6>(g, N, s) : launch_conv_h2_ring<128, 2, 6>(g, N, s);
+    return bn64 ? launch_conv_h2_ring<64, 1, 6>(g, N, s) : launch_conv_h2_ring<128, 1, 6>(g, N, s);
+  }
+  if (dilation == 2)
+    return bn64 ? launch_conv_x3_halo<64, true, 2>(g, N, s) : launch_conv_x3_halo<128, true, 2>(g, N, s);
+  return bn64 ? launch_conv_x3_halo<64, true>(g, N, s) : launch_conv_x3_halo<128, true>(g, N, s);
+}
+

@@ -26,17 +26,11 @@
 //
 // replaces: Caffe2 FC / FCGradient for fc6 / fc7 (reference detectron/modeling/wsl_heads.py:
 // 674-679, webly_heads.py:490-498), same as gemm_f32.hip.
-#include <stdlib.h>
-#include "naws_common.h"
+#include "x3_common.h"
 
 static int g_x3_variant = -1;
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct XArgs {
   const unsigned short* A;   // planes [3][K/16][rowsA][16]
@@ -61,23 +55,6 @@ struct XArgs {
   long long sRs, sCs;
   NawsAmax am;               // |C| maxima for the consumer's operand split (naws_common.h)
 };
-
-__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-template <bool F16> struct OperandVec { typedef bf16x8 type; };
-template <> struct OperandVec<true> { typedef f16x8 type; };
-
-#define NAWS_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#define NAWS_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // Operand planes are stored K-slab-major, P[plane][k/16][row][k%16]: the 16-deep K-step of a
 // BM-row tile is ONE contiguous BM*32-byte run per plane, so every LDS-DMA wave-instruction
@@ -505,18 +482,6 @@ int launch_x3_m16(XArgs& g, int batch, hipStream_t s) {
   return naws_check_launch();
 }
 
-__device__ __forceinline__ void split3(float a, unsigned short& p1, unsigned short& p2,
-                                       unsigned short& p3) {
-  const __bf16 h1 = (__bf16)a;
-  float r = a - (float)h1;
-  if (!(fabsf(a) <= 3.4028234e38f)) r = 0.f;        // inf / NaN live in plane 1 only
-  const __bf16 h2 = (__bf16)r;
-  const __bf16 h3 = (__bf16)(r - (float)h2);
-  p1 = *reinterpret_cast<const unsigned short*>(&h1);
-  p2 = *reinterpret_cast<const unsigned short*>(&h2);
-  p3 = *reinterpret_cast<const unsigned short*>(&h3);
-}
-
 // X fp32 [rows][ld] -> P[3][slabs][outer][16] through 64 x 64 LDS tiles.
 //   TRANS == false: outer = rows, K = cols;  TRANS == true: outer = cols, K = rows.
 // Each workgroup writes, per plane, 4 runs of 64 * 32 contiguous bytes.
@@ -621,10 +586,6 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ X, 
       if (tc == 0 && r < rows && v > 0.f) atomicMax(out + r, __float_as_uint(v));
     }
   }
-}
-
-__device__ __forceinline__ void f16x2_scales(unsigned amax_bits, float& s, float& inv) {
-  naws_f16x2_scales(amax_bits, s, inv);      // naws_common.h
 }
 
 template <bool TRANS>
@@ -760,488 +721,6 @@ __global__ __launch_bounds__(256) void split2h_dual_kernel(
   }
 }
 
-// ---- 3x3 convolution (NHWC fp32 activations) as an fp32x3 implicit GEMM -------------------------
-// A = activations gathered straight from the fp32 NHWC tensor (branch-free buffer loads, halo ->
-// 0), split into the three bf16 planes in registers (8 VALU ops per element, < 5 % of the MFMA
-// time of a step) and written into the same swizzled LDS image the DMA path uses; B = weight
-// planes [3][9*Cin/16][Cout][16] (naws_split_bf16x3 of the packed [Cout][3][3][Cin] weight) by
-// LDS-DMA.  A K-step is 16 channels of one tap.  Two LDS stages: step t+1's activations are
-// loaded at the top of step t and split/written after its MFMAs.
-struct CArgs {
-  const float* X;            // NHWC
-  const unsigned short* B;   // weight planes
-  const float* bias;
-  float* Y;                  // NHWC
-  int M, Cout, Cin, H, W, dil, relu;
-  long long planeB, slabB;
-  unsigned bytesX;
-  int tiles_m, tiles_n;
-  // fp16x2 form of the halo kernel
-  const float* scaleB;       // 1/scale per output channel (naws_split_f16x2 of the weight)
-  const unsigned* amax_in;   // bit pattern of an upper bound b of max|X| ...
-  float in_mul, in_add;      // ... the bound used is b * in_mul + in_add
-  unsigned* amax_out;        // receives the bit pattern of max|Y| (nullable)
-  int pool;                  // 1: write maxpool2x2/stride 2 of the output instead of the output
-};
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void conv_x3_kernel(CArgs g) {
-  constexpr int NT = 64 * WM * WN, NW = WM * WN;
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int TI = WTM / 32, TJ = WTN / 32;
-  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;
-  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
-  constexpr int UA = BM * 2 / NT;                 // (row, 8-channel half) units per thread
-  constexpr int BPIECES = 3 * BN / 32;            // 1 KB DMA pieces of the weight stage
-  static_assert(BM * 2 % NT == 0, "tile vs workgroup");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
-
-  const int ntiles = g.tiles_m * g.tiles_n;
-  int lid = blockIdx.x;
-  {
-    const int q = ntiles >> 3, rem = ntiles & 7, xcd = lid & 7, within = lid >> 3;
-    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
-  }
-  // all Cout tiles of one pixel tile are neighbours: the gathered activations are shared in L2
-  const int tm = lid / g.tiles_n, tn = lid % g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;
-  const int l31 = lane & 31, h = lane >> 5;
-
-  const __amdgpu_buffer_rsrc_t rsX =
-      __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  int py[UA], px[UA];
-  unsigned abase[UA];
-  int awr[UA];
-#pragma unroll
-  for (int i = 0; i < UA; ++i) {
-    const int u = tid + i * NT;
-    const int row = u >> 1, half = u & 1;
-    const int gm = m0 + row;
-    if (gm < g.M) {
-      px[i] = gm % g.W; py[i] = (gm / g.W) % g.H;
-      abase[i] = ((unsigned)gm * (unsigned)g.Cin + half * 8) * 4u;
-    } else { px[i] = 0; py[i] = 0; abase[i] = OOB; }
-    awr[i] = row * 32 + ((half ^ ((row >> 3) & 1)) * 16);
-  }
-  const int bslot = ((lane & 1) ^ ((lane >> 4) & 1)) * 8;
-
-  u32x4 ra[UA][2];
-  auto loadA = [&](int t) {
-    const int k0 = t * 16;
-    const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
-    const int dy = (tap / 3 - 1) * g.dil, dx = (tap % 3 - 1) * g.dil;
-    const int delta = ((dy * g.W + dx) * g.Cin + c0) * 4;
-#pragma unroll
-    for (int i = 0; i < UA; ++i) {
-      const int yy = py[i] + dy, xx = px[i] + dx;
-      const bool ok = (abase[i] != OOB) && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-      const unsigned off = ok ? (unsigned)((int)abase[i] + delta) : OOB;
-      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
-      ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? (int)(off + 16) : (int)OOB, 0, 0);
-    }
-  };
-  auto storeA = [&](int st) {
-    unsigned char* base = smx + st * STAGE;
-#pragma unroll
-    for (int i = 0; i < UA; ++i) {
-      unsigned short q[3][8];
-      const unsigned w[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w,
-                             ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        u32x4 v;
-        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
-        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
-        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
-        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
-        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[i]) = v;
-      }
-    }
-  };
-  auto issueB = [&](int t, int st) {
-    unsigned char* base = smx + st * STAGE + 3 * A_PLANE;
-#pragma unroll
-    for (int r = 0; r < (BPIECES + NW - 1) / NW; ++r) {
-      const int piece = wid + r * NW;             // wave-uniform
-      if (piece < BPIECES) {
-        const int pl = piece / (BN / 32), rb = piece % (BN / 32);
-        // weight rows past Cout re-read the last row (their columns are never stored)
-        const int wrow = min(n0 + rb * 32 + (lane >> 1), g.Cout - 1);
-        __builtin_amdgcn_global_load_lds(
-            NAWS_GLB_PTR(g.B + pl * g.planeB + t * g.slabB + (long long)wrow * 16 + bslot),
-            NAWS_LDS_PTR(base + pl * B_PLANE + rb * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int rd_a = (wm * WTM + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
-  const int rd_b = 3 * A_PLANE + (wn * WTN + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
-
-  const int T = 9 * g.Cin / 16;
-  issueB(0, 0);
-  loadA(0);
-  storeA(0);
-  for (int t = 0; t < T; ++t) {
-    __syncthreads();                     // stage t&1 complete (DMA drained + LDS writes visible)
-    const bool more = t + 1 < T;
-    if (more) { issueB(t + 1, (t + 1) & 1); loadA(t + 1); }
-    const unsigned char* st = smx + (t & 1) * STAGE;
-    bf16x8 a[3][TI], b[3][TJ];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-        a[pl][i] = *reinterpret_cast<const bf16x8*>(st + rd_a + pl * A_PLANE + i * 1024);
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-        b[pl][j] = *reinterpret_cast<const bf16x8*>(st + rd_b + pl * B_PLANE + j * 1024);
-    }
-#define NAWS_X3_TERM(P, Q)                                                                      \
-  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P][i], b[Q][j], acc[i][j], 0, 0, 0);
-    NAWS_X3_TERM(0, 0)
-    NAWS_X3_TERM(0, 1)
-    NAWS_X3_TERM(1, 0)
-    NAWS_X3_TERM(1, 1)
-    NAWS_X3_TERM(0, 2)
-    NAWS_X3_TERM(2, 0)
-#undef NAWS_X3_TERM
-    if (more) storeA((t + 1) & 1);
-  }
-
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const int col = n0 + wn * WTN + j * 32 + l31;
-    if (col >= g.Cout) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row >= g.M) continue;
-        float v = acc[i][j][e] + bv;
-        if (g.relu) v = fmaxf(v, 0.f);
-        g.Y[(long long)row * g.Cout + col] = v;
-      }
-    }
-  }
-}
-
-template <int BM, int BN, int WM, int WN>
-int launch_conv_x3(CArgs& g, hipStream_t s) {
-  g.tiles_m = (int)naws_cdiv(g.M, BM);
-  g.tiles_n = (int)naws_cdiv(g.Cout, BN);
-  const size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
-  auto kern = conv_x3_kernel<BM, BN, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * WM * WN), lds, s, g);
-  return naws_check_launch();
-}
-
-
-// Epilogue of the halo-tile kernels: un-scale, bias, ReLU, optional fused 2x2 max pool, store, and
-// the workgroup's max|Y| for the next layer's operand scale.  acc[i][j]: tile row 2 * wid + i,
-// channel block j (32x32x16 MFMA accumulator layout).
-template <int BN, bool F16>
-__device__ __forceinline__ void halo_epilogue(const CArgs& g, f32x16 (&acc)[2][BN / 32], int img,
-                                              int ty0, int tx0, int n0, int wid, int lane,
-                                              float iscA, unsigned char* smx) {
-  constexpr int TJ = BN / 32, TI = 2;
-  const int tid = threadIdx.x, l31 = lane & 31, h = lane >> 5;
-  float vmax = 0.f;
-  bool pooled = false;
-  if constexpr (F16) pooled = g.pool != 0;
-  if (pooled) {
-    // max-pool 2x2 / stride 2 fused: a lane's accumulators hold the four pixels of a window
-    // (rows 2*wid, 2*wid + 1 of the tile = i; register pairs (e, e+1) = adjacent columns), and
-    // max commutes exactly with the monotone epilogue (x * 2^k + b, ReLU)
-    const int Ho = g.H / 2, Wo = g.W / 2;
-    const int yo = (ty0 + 2 * wid) >> 1;
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int col = n0 + j * 32 + l31;
-      if (col >= g.Cout) continue;
-      const float bv = g.bias ? g.bias[col] : 0.f;
-      const float un = iscA * g.scaleB[col];
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const int xo = (tx0 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1;
-        if (yo >= Ho || xo >= Wo) continue;
-        float v = -3.4028234e38f;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            float t = acc[i][j][e + d] * un + bv;
-            if (g.relu) t = fmaxf(t, 0.f);
-            v = fmaxf(v, t);
-          }
-        g.Y[((long long)(img * Ho + yo) * Wo + xo) * g.Cout + col] = v;
-        vmax = fmaxf(vmax, fabsf(v));
-      }
-    }
-  } else {
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const int col = n0 + j * 32 + l31;
-    if (col >= g.Cout) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-    float un = 1.f;
-    if constexpr (F16) un = iscA * g.scaleB[col];        // powers of two: exact
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      const int y = ty0 + 2 * wid + i;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int x = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (y >= g.H || x >= g.W) continue;
-        float v = acc[i][j][e];
-        if constexpr (F16) v *= un;
-        v += bv;
-        if (g.relu) v = fmaxf(v, 0.f);
-        g.Y[((long long)(img * g.H + y) * g.W + x) * g.Cout + col] = v;
-        if constexpr (F16) vmax = fmaxf(vmax, fabsf(v));
-      }
-    }
-  }
-  }
-  if constexpr (F16) {
-    if (g.amax_out) {
-      float* red = reinterpret_cast<float*>(smx);     // the operand stages are no longer read
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
-      __syncthreads();
-      if (lane == 0) red[wid] = vmax;
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-        if (v > __hip_atomic_load(g.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-          atomicMax(g.amax_out, v);
-      }
-    }
-  }
-}
-
-// ---- 3x3 conv, fp32x3, with the input halo tile staged once per channel slab -------------------
-// The linear-pixel kernel above gathers every tap's activations again: 9 x 64 B per output pixel
-// per 16-channel slab.  For the wide shallow layers (Cout <= 128: conv1_2, conv2_1, conv2_2) that
-// gather, not the MFMA, sets the pace.  Here a workgroup owns an 8-row x 32-column pixel tile:
-// for each 16-channel slab the (8+2) x (32+2) halo is gathered, split and written to LDS ONCE
-// (340 pixels instead of 9 x 256), and the nine taps read their A fragments from it at shifted
-// rows - a wave's 32-lane fragment is one image row of the tile, so a tap is just a row offset
-// (dy * 34 + dx) into the halo image.  Same LDS row format and bank swizzle as everywhere else;
-// weights per (tap, slab) by LDS-DMA, double buffered.  dilation 1, stride 1.
-// F16: the fp16x2 form - activations scaled by one power of two per tensor (from an upper bound
-// of max|X| handed in by the producer of X), split into f16 hi / lo planes in registers; weight
-// planes from naws_split_f16x2 (per-output-channel scales); 3 MFMA terms instead of 6; the
-// accumulator is un-scaled in the epilogue, which also reports max|Y| for the next layer.
-template <int BN, bool F16 = false, int DIL = 1>
-__global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(CArgs g) {
-  constexpr int NPL = F16 ? 2 : 3;
-  typedef typename OperandVec<F16>::type vec_t;
-  // BN = 64: one halo stage (refilled behind an extra barrier every 9th step) keeps the
-  // workgroup at 45 KB of LDS, so three of them share a CU; BN = 128: two halo stages
-  constexpr int ASTAGES = BN <= 64 ? 1 : 2;
-  // DIL = 2 (conv5_x): the taps sit 2 pixels apart, the halo is (8+4) x (32+4) = 432 pixels
-  constexpr int TH = 8, TW = 32, HWD = TW + 2 * DIL, HPIX = (TH + 2 * DIL) * HWD;   // 340 halo pixels
-  constexpr int A_ROWS = (HPIX + 7) / 8 * 8;
-  constexpr int A_PLANE = A_ROWS * 32, A_STAGE = NPL * A_PLANE;
-  constexpr int B_PLANE = BN * 32, B_STAGE = NPL * B_PLANE;
-  constexpr int TJ = BN / 32, TI = 2;
-  constexpr int UR = (HPIX * 2 + 255) / 256;                                // staging rounds (3)
-  constexpr int BPIECES = NPL * BN / 32;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
-  unsigned char* smA = smx;
-  unsigned char* smB = smx + ASTAGES * A_STAGE;
-
-  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-  int lid = blockIdx.x;
-  const int tn = lid % g.tiles_n;
-  lid /= g.tiles_n;
-  const int tx0 = (lid % tiles_x) * TW;
-  const int ty0 = ((lid / tiles_x) % tiles_y) * TH;
-  const int img = lid / (tiles_x * tiles_y);
-  const int n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, h = lane >> 5;
-  const __amdgpu_buffer_rsrc_t rsX =
-      __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  float scA = 1.f, iscA = 1.f;
-  if constexpr (F16) {
-    const float bound = __uint_as_float(*g.amax_in) * g.in_mul + g.in_add;
-    f16x2_scales(__float_as_uint(bound), scA, iscA);
-  }
-
-  unsigned abase[UR];
-  int awr[UR];
-#pragma unroll
-  for (int r = 0; r < UR; ++r) {
-    const int u = tid + r * 256;
-    const int hp = u >> 1, half = u & 1;
-    const int y = ty0 - DIL + hp / HWD, x = tx0 - DIL + hp % HWD;
-    const bool ok = hp < HPIX && y >= 0 && y < g.H && x >= 0 && x < g.W;
-    abase[r] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)g.Cin + half * 8) * 4u : OOB;
-    awr[r] = hp < HPIX ? hp * 32 + ((half ^ ((hp >> 3) & 1)) * 16) : -1;
-  }
-  u32x4 ra[UR][2];
-  auto loadA = [&](int slab) {
-#pragma unroll
-    for (int r = 0; r < UR; ++r) {
-      const unsigned off = abase[r] != OOB ? abase[r] + (unsigned)slab * 64u : OOB;
-      ra[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
-      ra[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, abase[r] != OOB ? (int)(off + 16) : (int)OOB, 0, 0);
-    }
-  };
-  auto storeA = [&](int st) {
-    unsigned char* base = smA + st * A_STAGE;
-#pragma unroll
-    for (int r = 0; r < UR; ++r) {
-      if (awr[r] < 0) continue;
-      unsigned short q[3][8];
-      const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
-                             ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if constexpr (F16) {
-          const float t = __uint_as_float(w[e]) * scA;
-          const _Float16 hi = (_Float16)t;
-          float rr = t - (float)hi;
-          if (!(fabsf(t) <= 65504.f)) rr = 0.f;
-          const _Float16 lo = (_Float16)rr;
-          q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
-          q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
-        } else {
-          split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
-        }
-      }
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        u32x4 v;
-        v.x = q[pl][0] | ((unsigned)q[pl][1] << 16);
-        v.y = q[pl][2] | ((unsigned)q[pl][3] << 16);
-        v.z = q[pl][4] | ((unsigned)q[pl][5] << 16);
-        v.w = q[pl][6] | ((unsigned)q[pl][7] << 16);
-        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + awr[r]) = v;
-      }
-    }
-  };
-  const int bslot = ((lane & 1) ^ ((lane >> 4) & 1)) * 8;
-  auto issueB = [&](int kslab, int st) {
-    unsigned char* base = smB + st * B_STAGE;
-#pragma unroll
-    for (int r = 0; r < (BPIECES + 3) / 4; ++r) {
-      const int piece = wid + r * 4;
-      if (piece < BPIECES) {
-        const int pl = piece / (BN / 32), rb = piece % (BN / 32);
-        const int wrow = min(n0 + rb * 32 + (lane >> 1), g.Cout - 1);
-        __builtin_amdgcn_global_load_lds(
-            NAWS_GLB_PTR(g.B + pl * g.planeB + (long long)kslab * g.slabB + (long long)wrow * 16 + bslot),
-            NAWS_LDS_PTR(base + pl * B_PLANE + rb * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int S = g.Cin / 16, T = 9 * S;
-  const int rd_b = l31 * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
-  issueB(0, 0);                  // (tap 0, slab 0)
-  loadA(0);
-  storeA(0);
-  for (int kk = 0; kk < T; ++kk) {
-    const int slab = kk / 9, tap = kk - slab * 9;
-    __syncthreads();             // halo stage + weight stage of this step are complete
-    if (kk + 1 < T) {
-      const int s1 = (kk + 1) / 9, t1 = (kk + 1) - s1 * 9;
-      issueB(t1 * S + s1, (kk + 1) & 1);
-    }
-    if (tap == 0 && slab + 1 < S) loadA(slab + 1);
-    const unsigned char* sa = smA + (slab & (ASTAGES - 1)) * A_STAGE;
-    const unsigned char* sb = smB + (kk & 1) * B_STAGE;
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    vec_t a[NPL][TI], b[NPL][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      const int hp = (2 * wid + i + DIL + dy * DIL) * HWD + (l31 + DIL + dx * DIL);
-      const int off = hp * 32 + ((h ^ ((hp >> 3) & 1)) * 16);
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl)
-        a[pl][i] = *reinterpret_cast<const vec_t*>(sa + pl * A_PLANE + off);
-    }
-#pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-        b[pl][j] = *reinterpret_cast<const vec_t*>(sb + pl * B_PLANE + rd_b + j * 1024);
-#define NAWS_X3_TERM(P, Q)                                                                      \
-  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
-      acc[i][j] = mfma16(a[P][i], b[Q][j], acc[i][j]);
-    NAWS_X3_TERM(0, 0)
-    NAWS_X3_TERM(0, 1)
-    NAWS_X3_TERM(1, 0)
-    if constexpr (!F16) {
-      NAWS_X3_TERM(1, 1)
-      NAWS_X3_TERM(0, 2)
-      NAWS_X3_TERM(2, 0)
-    }
-#undef NAWS_X3_TERM
-    if (tap == 8 && slab + 1 < S) {
-      if (ASTAGES == 1) __syncthreads();   // every wave is done with the only halo stage
-      storeA((slab + 1) & (ASTAGES - 1));
-    }
-  }
-
-  halo_epilogue<BN, F16>(g, acc, img, ty0, tx0, n0, wid, lane, iscA, smx);
-}
-
-template <int BN, bool F16 = false, int DIL = 1>
-int launch_conv_x3_halo(CArgs& g, int N, hipStream_t s) {
-  g.tiles_n = (int)naws_cdiv(g.Cout, BN);
-  const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
-  if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
-  constexpr int A_ROWS = ((8 + 2 * DIL) * (32 + 2 * DIL) + 7) / 8 * 8;
-  constexpr int NPL = F16 ? 2 : 3;
-  const size_t lds = (size_t)(BN <= 64 ? 1 : 2) * NPL * A_ROWS * 32 + (size_t)2 * NPL * BN * 32;
-  auto kern = conv_x3_halo_kernel<BN, F16, DIL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
-  return naws_check_launch();
-}
 
 }  // namespace
 
@@ -1511,41 +990,6 @@ extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64
                                      stream);
 }
 
-extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const float* bias,
-                                           int N, int H, int W, int Cin, int Cout, int dilation,
-                                           int relu, float* Y, void* stream) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
-  if (dilation < 1) return NAWS_ERR_ARG;
-  if (Cin % 16 != 0 || Cout % 4 != 0) return NAWS_ERR_UNSUPPORTED;
-  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W3); NAWS_REQUIRE_PTR(Y);
-  if (!bias && relu) return NAWS_ERR_ARG;
-  if ((((uintptr_t)X | (uintptr_t)W3) & 15) != 0) return NAWS_ERR_ARG;
-  const long long pix = (long long)N * H * W;
-  if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
-  CArgs g{};
-  g.X = X; g.B = (const unsigned short*)W3; g.bias = bias; g.Y = Y;
-  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = dilation; g.relu = relu;
-  g.slabB = (long long)Cout * 16;
-  g.planeB = (long long)9 * Cin * Cout;
-  g.bytesX = (unsigned)(pix * Cin * 4);
-  hipStream_t s = (hipStream_t)stream;
-  if (g_x3_variant < 0) {
-    const char* e = getenv("NAWS_X3_VARIANT");
-    g_x3_variant = e ? atoi(e) : 0;
-  }
-  // wide shallow layers: the halo-tile kernel (input gathered once per channel slab, not per tap)
-  if (dilation == 1 && Cout <= 128 && Cout % 32 == 0 && g_x3_variant != 6) {
-    if (Cout <= 64) return launch_conv_x3_halo<64>(g, N, s);
-    return launch_conv_x3_halo<128>(g, N, s);
-  }
-  if (Cout <= 64) return launch_conv_x3<256, 64, 4, 1>(g, s);
-  if (Cout <= 128 || naws_cdiv(pix, 256) * naws_cdiv(Cout, 256) < 256) {
-    if (naws_cdiv(pix, 256) * naws_cdiv(Cout, 128) < 512) return launch_conv_x3<128, 128, 2, 2>(g, s);
-    return launch_conv_x3<256, 128, 2, 2>(g, s);
-  }
-  return launch_conv_x3<256, 256, 2, 4>(g, s);
-}
-
 // |x| maximum of a tensor, as a bit pattern (non-negative floats order like unsigned words).
 namespace {
 __global__ __launch_bounds__(256) void amax_word_kernel(const float* __restrict__ X, long long n,
@@ -1585,57 +1029,6 @@ extern "C" int naws_amax_f32(const float* X, int64_t n, uint32_t* out, void* str
   hipLaunchKernelGGL(amax_word_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(n / 4 + 1, 256 * 8), 2048)),
                      dim3(256), 0, s, X, (long long)n, (unsigned*)out);
   return naws_check_launch();
-}
-
-// fp16x2 form of the shallow-layer convolution (the halo-tile kernel): W2 / scaleW =
-// naws_split_f16x2 of the packed weight viewed [Cout][9*Cin]; the activation scale comes from
-// *amax_in * in_mul + in_add (an upper bound of max|X|); dilation 1, Cout <= 128, Cout % 32 == 0.
-extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,
-                                           const float* bias, int N, int H, int W, int Cin,
-                                           int Cout, int dilation, int relu, float* Y,
-                                           const uint32_t* amax_in, float in_mul, float in_add,
-                                           uint32_t* amax_out, int amax_out_zeroed, int pool2,
-                                           void* stream) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
-  if (dilation != 1 && dilation != 2) return NAWS_ERR_UNSUPPORTED;
-  if (dilation == 2 && pool2) return NAWS_ERR_ARG;
-  if (Cin % 16 != 0 || (9 * Cin) % 32 != 0 || Cout % 32 != 0 || (Cout > 128 && Cout % 128 != 0))
-    return NAWS_ERR_UNSUPPORTED;
-  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W2); NAWS_REQUIRE_PTR(scaleW); NAWS_REQUIRE_PTR(Y);
-  NAWS_REQUIRE_PTR(amax_in);
-  if (!bias && relu) return NAWS_ERR_ARG;
-  if (!(in_mul > 0.f) || !(in_add >= 0.f) || amax_in == amax_out) return NAWS_ERR_ARG;
-  if ((((uintptr_t)X | (uintptr_t)W2) & 15) != 0) return NAWS_ERR_ARG;
-  const long long pix = (long long)N * H * W;
-  if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
-  CArgs g{};
-  g.X = X; g.B = (const unsigned short*)W2; g.bias = bias; g.Y = Y;
-  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = dilation; g.relu = relu;
-  g.slabB = (long long)Cout * 16;
-  g.planeB = (long long)9 * Cin * Cout;
-  g.bytesX = (unsigned)(pix * Cin * 4);
-  g.scaleB = scaleW; g.amax_in = (const unsigned*)amax_in; g.in_mul = in_mul; g.in_add = in_add;
-  g.amax_out = (unsigned*)amax_out;
-  g.pool = pool2 ? 1 : 0;
-  if (pool2 && (H < 2 || W < 2)) return NAWS_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
-  // (a chain of layers zeroes all its words with one fill and passes amax_out_zeroed = 1: a
-  // memset per layer is a 6 us kernel plus a launch gap in a dependent chain)
-  if (amax_out && !amax_out_zeroed && hipMemsetAsync(amax_out, 0, sizeof(uint32_t), s) != hipSuccess)
-    return NAWS_ERR_LAUNCH;
-  // 64-wide channel tiles (3 workgroups per CU) where 128-wide ones leave CUs idle or the layer is
-  // deep: measured per layer at 2 images (tools/kernel_bench.py --what x3): conv3_x 0.137 / 0.259
-  // vs 0.156 / 0.289 ms, conv4_2 0.282 vs 0.297; conv2_2 (608 tiles of 128) keeps 128
-  bool bn64 = Cout <= 64;
-  if (!bn64 && Cout % 64 == 0) {
-    const long long t128 = (long long)N * naws_cdiv(H, 8) * naws_cdiv(W, 32) * naws_cdiv(Cout, 128);
-    bn64 = Cin >= 128 && Cout >= 256 && t128 < 4 * 512;
-    const char* e = getenv("NAWS_CONV_BN");            // A/B knob (tools/kernel_bench.py)
-    if (e) bn64 = atoi(e) == 64;
-  }
-  if (dilation == 2)
-    return bn64 ? launch_conv_x3_halo<64, true, 2>(g, N, s) : launch_conv_x3_halo<128, true, 2>(g, N, s);
-  return bn64 ? launch_conv_x3_halo<64, true>(g, N, s) : launch_conv_x3_halo<128, true>(g, N, s);
 }
 
 extern "C" int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_t slabA,

@@ -21,7 +21,8 @@ from naws_hip.engine import WsddnEngine  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--attr', required=True)
+    ap.add_argument('--attr', default='')
+    ap.add_argument('--env', default='', help='environment knob read per call instead of an attribute')
     ap.add_argument('--values', nargs='+', required=True)
     ap.add_argument('--rounds', type=int, default=6)
     ap.add_argument('--steps', type=int, default=10)
@@ -59,14 +60,17 @@ def main():
     run(5)
     for _ in range(a.rounds):
         for v in vals:
-            setattr(eng, a.attr, v)
+            if a.env:
+                os.environ[a.env] = str(v)
+            else:
+                setattr(eng, a.attr, v)
             run(3)
             t0 = time.perf_counter()
             run(a.steps)
             times[v].append((time.perf_counter() - t0) / a.steps * 1e3)
     for v in vals:
         ts = sorted(times[v])
-        print('%s=%r: median %.3f ms/step (min %.3f, max %.3f)' % (a.attr, v, ts[len(ts) // 2], ts[0], ts[-1]))
+        print('%s=%r: median %.3f ms/step (min %.3f, max %.3f)' % (a.env or a.attr, v, ts[len(ts) // 2], ts[0], ts[-1]))
 
 
 if __name__ == '__main__':
