@@ -311,6 +311,22 @@ def main():
         dt = float(td.item())
     loss = float(out['loss_cls'].sum().item() + out['loss_cls_noise'].sum().item())
 
+    # after the timed steps: the conv body alone (nothing else on the device).  Inside a step it
+    # shares the chip with the previous step's parameter update (side stream), so its stage time
+    # there reads longer than the stack itself takes.
+    conv_alone_ms = None
+    if rank == 0:
+        eng.timing_events = eng.phase_events = eng.update_events = None
+        eng.conv_body(t['data'])
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            eng.conv_body(t['data'])
+        c1.record()
+        torch.cuda.synchronize()
+        conv_alone_ms = c0.elapsed_time(c1) / 10
+
     if rank == 0:
         rt = mb['rois'].shape[0]
         k6 = 512 * 49
@@ -376,6 +392,11 @@ def main():
             tf = conv_gflop / stage_ms['conv_body']
             roof.update(conv_stack_ms=stage_ms['conv_body'], conv_stack_tflops=round(tf, 1),
                         conv_stack_frac_vs_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 3))
+            if conv_alone_ms:
+                roof.update(conv_stack_alone_ms=round(conv_alone_ms, 3),
+                            conv_stack_alone_tflops=round(conv_gflop / conv_alone_ms, 1),
+                            conv_stack_alone_frac_vs_fp32_mfma_peak=round(
+                                conv_gflop / conv_alone_ms / FP32_MFMA_PEAK_TFLOPS, 3))
         if roipool_bytes and stage_ms.get('roi_pool'):
             gbs = roipool_bytes / stage_ms['roi_pool'] / 1e6
             roof.update(roipool_ms=stage_ms['roi_pool'], roipool_GBps=round(gbs, 1),
