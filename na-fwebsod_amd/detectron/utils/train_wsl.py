@@ -47,17 +47,24 @@ def train_model(roidb=None, max_iter=None, printer=print):
     # Software pipeline: the batch of iteration i+1 is staged (one pinned copy + the device-side
     # image preparation, on the loader's copy stream) right after iteration i has been enqueued
     # and before its losses are fetched, so the host-side staging hides behind the GPU's work.
-    batch = loader.next_device_batch(device, cfg.NAWS.IMS_PER_GPU) if start_iter < last else None
+    # A loader failure on one rank must stop every rank before the next collective, or the others
+    # block in it until the watchdog fires: each rank's "my next batch is staged" flag travels with
+    # the per-iteration loss all-reduce (no extra collective, no extra sync), and once before the
+    # first iteration.
+    batch, ok = stage_batch(loader, device) if start_iter < last else (None, True)
+    if not agree_ok(ok, pg, world, device):
+        handle_critical_error(model, 'roi_data_loader failed' if not ok else
+                              'roi_data_loader failed on another rank')
     for cur_iter in range(start_iter, last):
-        if loader.has_stopped():
-            handle_critical_error(model, 'roi_data_loader failed')
         stats.IterTic()
         lr = model.UpdateWorkspaceLr(cur_iter, lr_policy.get_lr_at_iter(cur_iter))
         executor.feed(batch)
         executor.run()
-        batch = (loader.next_device_batch(device, cfg.NAWS.IMS_PER_GPU)
-                 if cur_iter + 1 < last else None)
-        vals = iteration_values(executor, model, pg, world)
+        batch, ok = stage_batch(loader, device) if cur_iter + 1 < last else (None, True)
+        vals, all_ok = iteration_values(executor, model, pg, world, ok=ok)
+        if not all_ok:
+            handle_critical_error(model, 'roi_data_loader failed' if not ok else
+                                  'roi_data_loader failed on another rank')
         stats.IterToc()
         stats.UpdateIterStats(vals)
         if rank == 0:
@@ -79,25 +86,50 @@ def train_model(roidb=None, max_iter=None, printer=print):
     return checkpoints
 
 
-def iteration_values(executor, model, pg, world):
-    """Scalar losses / metrics of this iteration, averaged over this process's images and over
-    ranks (the reference averages the per-GPU scalars on the host, net_wsl.py:210-220)."""
+def stage_batch(loader, device):
+    """(next per-GPU batch, True), or (None, False) when this rank's loader has failed."""
+    try:
+        if loader.has_stopped():
+            return None, False
+        return loader.next_device_batch(device, cfg.NAWS.IMS_PER_GPU), True
+    except Exception:  # the loader thread's error is logged where it happened (loader_wsl.py)
+        logger.exception('staging the next batch failed')
+        return None, False
+
+
+def agree_ok(ok, pg, world, device):
+    """True when every rank passed ok=True."""
+    if pg is None or world <= 1:
+        return bool(ok)
+    import torch.distributed as dist
+    t = torch.tensor([0.0 if ok else 1.0], device=device)
+    dist.all_reduce(t, group=pg)
+    return float(t.item()) == 0.0
+
+
+def iteration_values(executor, model, pg, world, ok=True):
+    """-> (scalar losses / metrics of this iteration, averaged over this process's images and over
+    ranks - the reference averages the per-GPU scalars on the host, net_wsl.py:210-220 -, and
+    whether every rank passed ok=True: the flag rides in the same all-reduce)."""
     ws = executor.ws
     vals = []
     for k in model.losses:
         vals.append(ws[k].reshape(-1).float().mean())
+    vals.append(torch.full((), 0.0 if ok else float(world), device=vals[0].device if vals else None))
     t = torch.stack(vals)
     if pg is not None and world > 1:
         import torch.distributed as dist
         dist.all_reduce(t, group=pg)
         t = t / world
-    out = {k: float(v) for k, v in zip(model.losses, t.cpu().tolist())}
+    host = t.cpu().tolist()
+    all_ok = host[-1] == 0.0
+    out = {k: float(v) for k, v in zip(model.losses, host[:-1])}
     labels = ws['labels_int32'].reshape(-1).cpu().numpy()
     for k, blob in (('accuracy_cls', 'cls_prob'), ('accuracy_cls_noise', 'cls_prob_noise')):
         if k in model.metrics and blob in ws:
             p = ws[blob].reshape(len(labels), -1).cpu().numpy()
             out[k] = float((p.argmax(1) == labels).mean())
-    return out
+    return out, all_ok
 
 
 def handle_critical_error(model, msg):

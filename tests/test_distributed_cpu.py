@@ -153,3 +153,58 @@ def test_row_chunks_cover():
         assert ch[0][0] == 0 and ch[-1][1] == rows
         assert all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
         assert all((b - a) % 128 == 0 for a, b in ch[:-1]) and len(ch) <= n
+
+
+def _health_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+    import types
+    from detectron.utils import train_wsl
+    pg = dist.group.WORLD
+    cpu = torch.device('cpu')
+    res = {}
+    # before the first iteration: one rank without a batch stops both
+    res['pre_all_good'] = train_wsl.agree_ok(True, pg, world, cpu)
+    res['pre_rank1_bad'] = train_wsl.agree_ok(rank != 1, pg, world, cpu)
+    # inside an iteration: the flag rides in the loss all-reduce, the losses still average
+    ex = types.SimpleNamespace(ws={'loss_cls': torch.tensor([1.0 + rank, 3.0 + rank]),
+                                   'labels_int32': torch.zeros((1,), dtype=torch.int32)})
+    model = types.SimpleNamespace(losses=['loss_cls'], metrics=[])
+    vals, ok = train_wsl.iteration_values(ex, model, pg, world, ok=True)
+    res['it_good'] = (vals['loss_cls'], ok)
+    vals, ok = train_wsl.iteration_values(ex, model, pg, world, ok=(rank != 0))
+    res['it_rank0_bad'] = (vals['loss_cls'], ok)
+
+    class DeadLoader:
+        def has_stopped(self):
+            return False
+
+        def next_device_batch(self, device, n):
+            raise RuntimeError('roi_data_loader failed')
+    res['stage'] = train_wsl.stage_batch(DeadLoader(), cpu)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_loader_failure_on_one_rank_reaches_every_rank_gloo_world2():
+    """a loader failure on one rank used to raise there only and leave the others in
+    the next collective.  Both ranks must see it at the same point (detectron/utils/train_wsl.py)."""
+    world = 2
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_health_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        r = out[rank]
+        assert r['pre_all_good'] is True and r['pre_rank1_bad'] is False
+        assert r['it_good'] == (2.5, True)              # mean over both ranks' images
+        assert r['it_rank0_bad'] == (2.5, False)
+        assert r['stage'] == (None, False)
