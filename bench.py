@@ -147,7 +147,7 @@ def infer_main(args):
                      'frac': round(tf / peak, 4), 'traffic': None,
                      'algorithmic_gflop_per_image': round((conv + head) / 1e9, 1)},
     }
-    print(json.dumps(res))
+    emit(res)
 
 
 def cpu_baseline(args, num_fg):
@@ -214,6 +214,18 @@ def alt_plan(args, dev, num_fg, B, t, seg, mode):
             'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warm,
             'final_loss': round(float(out['loss_cls'].sum().item() +
                                       out['loss_cls_noise'].sum().item()), 5)}
+
+
+def emit(res):
+    """The ONE JSON line, as the LAST line of stdout: RCCL writes its version banner through C
+    stdio, which would otherwise be flushed at exit, after Python's own line."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(res), flush=True)
 
 
 def main():
@@ -450,9 +462,10 @@ def main():
                 cfg[key + '_ms_per_step'] = res[key]['ms_per_step']
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, num_fg)
-        print(json.dumps(res))
     if pg is not None:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        emit(res)
 
 
 if __name__ == '__main__':
