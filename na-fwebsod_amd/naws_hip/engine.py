@@ -24,6 +24,8 @@ Blob names, shapes and update rule follow the reference:
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -215,6 +217,7 @@ class WsddnEngine(object):
         # step.  Off by default; the direct kernel still takes any deep layer whose single launch
         # has >= 256 tiles (the larger TTA scales).
         self.deep_direct = False
+        self._seg_ring = None
         self._amax5 = None
         self.conv_direct_h2 = {}
         self._streams = []
@@ -488,6 +491,26 @@ class WsddnEngine(object):
         self._pool_done = True              # pool3 was taken (fused or not) inside the chains
         return self._conv_chain(None, amax_final=self._amax5, first=cut, x=mid, bound_in=shared)
 
+    def _seg_to_device(self, seg):
+        """Per-image row offsets -> int32 device tensor WITHOUT stalling the host: a copy from
+        pageable memory (torch.tensor(list, device=...)) is synchronous and waits for everything
+        queued on the stream before it, i.e. once per step the host stopped running ahead of the GPU
+        and queued the next conv body just in time (the second image's chain started 1.5 ms after
+        the first one's in the kernel trace).  Here: a small ring of pinned slots, async copies."""
+        n = len(seg)
+        if self._seg_ring is None or self._seg_ring[0][0].numel() < n:
+            self._seg_ring = [[torch.empty((max(n, 64),), dtype=torch.int32).pin_memory(), None]
+                              for _ in range(8)]
+            self._seg_next = 0
+        slot = self._seg_ring[self._seg_next]
+        self._seg_next = (self._seg_next + 1) % len(self._seg_ring)
+        if slot[1] is not None:
+            slot[1].synchronize()          # eight copies ago: long done
+        slot[0][:n] = torch.tensor(seg, dtype=torch.int32)
+        out = slot[0][:n].to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.current_stream(self.device).record_event()
+        return out
+
     @staticmethod
     def segments(rois, n_img):
         """seg_off (host list) from rois[:,0]; rows must be grouped by image in order."""
@@ -633,7 +656,7 @@ class WsddnEngine(object):
             seg = self.segments(rois, n_img)
         rt = rois.shape[0]
         max_seg = max(seg[i + 1] - seg[i] for i in range(n_img))
-        seg_off = torch.tensor(seg, dtype=torch.int32, device=self.device)
+        seg_off = self._seg_to_device(seg)
         pev = getattr(self, 'phase_events', None)   # bench.py: per-stage HIP events (main stream)
 
         def mark(name):
@@ -897,7 +920,7 @@ class WsddnEngine(object):
         n_img = data.shape[0]
         if seg is None:
             seg = self.segments(rois, n_img)
-        seg_off = torch.tensor(seg, dtype=torch.int32, device=self.device)
+        seg_off = self._seg_to_device(seg)
         conv5 = self.conv_body(data)
         x = self._roi_features(conv5, rois, obn_scores)
         _h6, _h7, lg = self.head_forward(x, train=False, both_branches=False)

@@ -48,11 +48,15 @@ def main():
         except ValueError:
             return v
 
+    host = []
+
     def run(n):
+        h0 = time.perf_counter()
         for _ in range(n):
             eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
             eng.sgd_step()
         eng.flush()
+        host.append((time.perf_counter() - h0) / n * 1e3)     # enqueue time, before the GPU is done
         torch.cuda.synchronize()
 
     vals = [conv(v) for v in a.values]
@@ -68,6 +72,7 @@ def main():
             t0 = time.perf_counter()
             run(a.steps)
             times[v].append((time.perf_counter() - t0) / a.steps * 1e3)
+    print('host enqueue time per step: median %.3f ms' % sorted(host)[len(host) // 2])
     for v in vals:
         ts = sorted(times[v])
         print('%s=%r: median %.3f ms/step (min %.3f, max %.3f)' % (a.env or a.attr, v, ts[len(ts) // 2], ts[0], ts[-1]))

@@ -1,0 +1,19 @@
+import csv,glob,sys
+f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
+rows=[r for r in csv.DictReader(open(f))]
+for r in rows:
+    r['s']=int(r['Start_Timestamp']); r['e']=int(r['End_Timestamp'])
+rows.sort(key=lambda r:r['s'])
+fc6=[r for r in rows if 'gemm_x3_m16' in r['Kernel_Name'] and r['Grid_Size_X']=='262144' and (r['e']-r['s'])>3e6]
+t0=fc6[-3]['s']; t1=fc6[-2]['s']
+win=[r for r in rows if r['s']>=t0 and r['s']<t1]
+def nm(r): return r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').split('(')[0][:50]
+print('step wall %.3f ms'%((t1-t0)/1e6))
+qs={}
+for r in win:
+    q=r['Queue_Id']; qs.setdefault(q,[]).append(r)
+for q,v in sorted(qs.items()):
+    print('queue',q,'kernels',len(v),'first %.3f last end %.3f busy %.3f ms'%((v[0]['s']-t0)/1e6,(v[-1]['e']-t0)/1e6,sum(r['e']-r['s'] for r in v)/1e6))
+if len(sys.argv)>2:
+    for r in win:
+        print('q%s %8.3f +%7.1f us  %-50s grid %s'%(r['Queue_Id'],(r['s']-t0)/1e6,(r['e']-r['s'])/1e3,nm(r),r['Grid_Size_X']))
