@@ -227,6 +227,8 @@ class WsddnEngine(object):
         # streams (before the head, checkpoints, lr changes, end of run).
         self.defer_update = None     # None/True -> side stream; False -> inline on the main stream
         self._update_pending = False
+        self._update_waiting = False
+        self.update_after_conv1 = 1
         self._upd_stream = None
         self._upd_event = None
         self._wplanes = None         # split planes of fc6_w / fc7_w / fc7_w^T (16-bit MFMA plans)
@@ -340,7 +342,7 @@ class WsddnEngine(object):
     DEEP_FIRST = 10                      # index of conv4_1 in VGG16_CONVS
 
     def _conv_chain(self, data, out=None, amax_final=None, first=0, end=None, x=None,
-                    bound_in=None, amax_last=None):
+                    bound_in=None, amax_last=None, affine_in=None):
         """data NCHW [b,3,H,W] -> conv5_3 NHWC, on the current stream.  amax_final (int32 [1],
         fp16x2 plan): receives the bit pattern of max|conv5_3| for the RoIPool operand scale.
         first / end: run only VGG16_CONVS[first:end] (x = the input of layer `first`, bound_in = the
@@ -352,9 +354,12 @@ class WsddnEngine(object):
         # bound of max|x|; a max-pool in between only lowers it), saving that layer's own pass
         amax = torch.zeros((len(VGG16_CONVS) + 1,), device=self.device, dtype=torch.int32)   # one fill
         prev, affine = None, (1.0, 0.0)  # slot holding the bound for the current x, if any
-        if bound_in is not None:
+        if bound_in is not None:         # (affine_in: the bound is bound_in * mul + add, once)
             amax[-1:].copy_(bound_in)
             prev = len(VGG16_CONVS)
+            if affine_in is not None:
+                affine = affine_in
+        affine_slot = 0 if affine_in is None else len(VGG16_CONVS)
         fused_pool = False               # the previous layer's epilogue already pooled
         last_conv = max(i for i in range(first, end) if not VGG16_CONVS[i][0].startswith('pool'))
         for li, item in enumerate(VGG16_CONVS):
@@ -396,7 +401,7 @@ class WsddnEngine(object):
                         if li == last_conv and amax_last is not None:
                             word, zeroed = amax_last, True
                         if wp.planes.dim() == 4:         # direct halo-tile kernel
-                            mul, add = affine if prev == 0 else (1.0, 0.0)
+                            mul, add = affine if prev == affine_slot else (1.0, 0.0)
                             # a 2x2 / stride-2 max-pool that follows is taken in the epilogue
                             fused_pool = (self.fuse_pool and li + 1 < len(VGG16_CONVS)
                                           and VGG16_CONVS[li + 1][0] == 'pool')
@@ -440,6 +445,9 @@ class WsddnEngine(object):
                 and all(k in self.conv_direct_h2 for k in ('conv4_1', 'conv5_3')))
         self._amax5 = (torch.empty((n if per_image and not deep else 1,), device=self.device,
                                    dtype=torch.int32) if planes else None)
+        if self._update_waiting and (not per_image or deep or self.mfma_dtype != 'fp16x2'
+                                     or not self.conv_h2):
+            self._launch_update(())        # no per-image conv1_1 head to put it behind
         if not per_image:
             return self._conv_chain(data, amax_final=self._amax5)
         if deep:
@@ -456,12 +464,41 @@ class WsddnEngine(object):
         start = main.record_event()
         while len(self._streams) < n:
             self._streams.append(torch.cuda.Stream(device=self.device))
+        split = (self._update_waiting and self.mfma_dtype == 'fp16x2' and self.conv_h2)
+        k = int(self.update_after_conv1)          # leading VGG16_CONVS entries queued before the update
+        if split:
+            # the head of every image's chain first (conv1_1: HBM-bound, 0.06 ms alone), THEN the
+            # deferred parameter update, then the rest of the chains: started together, the SGD
+            # kernel's workgroups fill the CUs and the two conv1_1 launches at the head of the
+            # dependent chains took 0.7 ms each (kernel trace)
+            heads, evs = [], []
+            for i in range(n):
+                st = self._streams[i]
+                st.wait_event(start)
+                with torch.cuda.stream(st):
+                    if k == 1:
+                        wp, b, _w = self.conv['conv1_1']
+                        y = ops.conv3x3_c3_nchw_to_nhwc(data[i:i + 1], wp, b, True)
+                        bound, aff = ops.amax_word(data[i:i + 1]), self._c11_bound
+                    else:
+                        bound, aff = torch.zeros((1,), device=self.device, dtype=torch.int32), None
+                        y = self._conv_chain(data[i:i + 1], first=0, end=k, amax_last=bound)
+                    heads.append((y, bound, aff))
+                    evs.append(st.record_event())
+            pool_done = self._pool_done
+            self._launch_update(evs)
         for i in range(n):
             st = self._streams[i]
-            st.wait_event(start)
+            if not split:
+                st.wait_event(start)
             with torch.cuda.stream(st):
-                self._conv_chain(data[i:i + 1], out=out[i:i + 1],
-                                 amax_final=None if self._amax5 is None else self._amax5[i:i + 1])
+                af = None if self._amax5 is None else self._amax5[i:i + 1]
+                if split:
+                    self._pool_done = pool_done
+                    self._conv_chain(None, out=out[i:i + 1], amax_final=af, first=k, x=heads[i][0],
+                                     bound_in=heads[i][1], affine_in=heads[i][2])
+                else:
+                    self._conv_chain(data[i:i + 1], out=out[i:i + 1], amax_final=af)
                 done = st.record_event()
             main.wait_event(done)
         return out
@@ -863,16 +900,27 @@ class WsddnEngine(object):
         main = torch.cuda.current_stream(self.device)
         if self._upd_stream is None:
             self._upd_stream = torch.cuda.Stream(device=self.device)
-        # (starting it only after conv1_1 / conv1_2 / conv2_2 / conv3_3 of the next conv body, to keep
-        # it off the HBM-bound first layers, was measured twice: +0.3...0.6 ms per step)
-        self._upd_stream.wait_event(main.record_event())
+        self._grads_ready = main.record_event()
+        if self.update_after_conv1 > 0:
+            self._update_waiting = True      # launched by the next conv body (or by flush)
+        else:
+            self._launch_update(())
+        self._update_pending = True
+
+    def _launch_update(self, after):
+        """Queue the update on its side stream, behind the gradients and the events in `after`."""
+        self._update_waiting = False
+        self._upd_stream.wait_event(self._grads_ready)
+        for e in after:
+            self._upd_stream.wait_event(e)
         with torch.cuda.stream(self._upd_stream):
             self._apply_update()
             self._upd_event = self._upd_stream.record_event()
-        self._update_pending = True
 
     def flush(self):
         if self._update_pending:
+            if self._update_waiting:
+                self._launch_update(())
             self._update_pending = False
             torch.cuda.current_stream(self.device).wait_event(self._upd_event)
 
