@@ -499,9 +499,11 @@ extern "C" int naws_wsddn_outputs_bwd(const float* alpha_cls, const float* alpha
   return naws_check_launch();
 }
 
+// j-chunks per row block: the pair loop is a serial chain per wave (~80 instructions per j), so
+// the launch is sized for >= one wave per SIMD at 2 x 2000 proposals (64 rows x 128 j per wave)
 static int gate_chunks(int max_seg_len) {
-  int q = (max_seg_len + 255) / 256;
-  return q < 1 ? 1 : (q > 16 ? 16 : q);
+  int q = (max_seg_len + 127) / 128;
+  return q < 1 ? 1 : (q > 32 ? 32 : q);
 }
 
 extern "C" int64_t naws_entropy_gate_workspace_floats(int Rt, int C, int nseg, int max_seg_len) {
