@@ -372,7 +372,7 @@ void gemm_f32_kernel(GemmArgs g) {
 // With K = 2C = 40 the product has 80 flops per output element: the 128x128 MFMA tile form spends
 // its life in the epilogue (dependent aux loads, 244 us for 131 MB out + 131 MB aux).  Here a
 // workgroup owns 128 rows x 1024 columns (one guarded column atomic per 128 rows); a thread keeps its four columns of B - K float4s - in
-// registers for all 32 rows, A's row (K floats, workgroup-uniform) comes through the scalar cache,
+// registers for all its rows, A's row (K floats, workgroup-uniform) comes through the scalar cache,
 // and every output float4 is one coalesced aux load + one coalesced store: HBM-bound.  Sums run in
 // k order like the MFMA chain.  Also reports |C| row / column maxima (NawsAmax).
 constexpr int SK_ROWS = 128, SK_MAXK = 64, SK_RG = 4;
