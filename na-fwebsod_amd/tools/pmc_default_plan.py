@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""profiles/rNN_default_plan_pmc.md from the SQ counter pass of tools/profile_bench.sh
+(`<dir>/fp16x2_sq`): per hot kernel and problem shape - clock, MFMA busy, wait shares.
+
+    python tools/pmc_default_plan.py gpurun_out/prof_r02b/fp16x2_sq profiles/r02_default_plan_pmc.md"""
+import collections
+import csv
+import glob
+import sys
+
+HOT = ('gemm_x3', 'conv_h2', 'conv_x3', 'roi_pool', 'acm_sgd', 'split2h_dual', 'gemm_smallk', 'wino_',
+       'conv_c3')
+LABEL = {('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>', '262144', 493): 'fc6 fwd (M=4000 N=8192 K=25088)',
+         ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>', '1572864', 472): 'fc6 wgrad (M=8192 N=24576 K=4000)'}
+
+
+def main():
+    d, out = sys.argv[1:3]
+    cc = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    kt = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
+    dur = {r['Dispatch_Id']: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
+           for r in csv.DictReader(open(kt))}
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(cc)):
+        e = per[r['Dispatch_Id']]
+        e[r['Counter_Name']] = e.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+        e['_k'] = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        e['_g'] = r['Grid_Size']
+    groups = collections.defaultdict(list)
+    for did, v in per.items():
+        if not any(x in v['_k'] for x in HOT):
+            continue
+        cyc = v['GRBM_GUI_ACTIVE'] / 8
+        key = (v['_k'], v['_g'], round(v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1e7))
+        groups[key].append((dur[did], cyc / (dur[did] * 1e-3) / 1e9,
+                            v['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024),
+                            v['SQ_WAIT_INST_ANY'] / v['SQ_WAVE_CYCLES'],
+                            v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES'], v['SQ_LDS_BANK_CONFLICT']))
+    lines = ["# PMC reading of the default plan's kernels inside `bench.py`", '',
+             '`rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES '
+             'SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- python '
+             'bench.py --no-cpu-baseline --no-alt-plan --steps 3 --warmup 1`',
+             '(one counter pass, `na-fwebsod_amd/tools/profile_bench.sh`; under counter collection kernels are '
+             'serialised, so durations are 5-12 % above the un-profiled ones and concurrent streams do not '
+             'overlap).', '',
+             'clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x '
+             '1024 SIMDs); waits are fractions of SQ_WAVE_CYCLES.  Rows are grouped by (kernel, grid, MFMA '
+             'work), so one template appears once per distinct problem shape; "clock" above 2.4 GHz on '
+             'the 30 us kernels is GRBM_GUI_ACTIVE counting the dispatch ramp around a launch shorter than '
+             "the counter's window, not a real clock.", '',
+             '| kernel (grid threads) | launches | avg ms | clock GHz | MFMA busy | issue-stalled '
+             '(WAIT_INST_ANY) | parked (WAIT_ANY) | LDS bank conflict cycles |',
+             '|---|---|---|---|---|---|---|---|']
+    for key, v in sorted(groups.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
+        n = len(v)
+        avg = [sum(x[i] for x in v) / n for i in range(6)]
+        name = key[0] + ' (' + key[1] + ')'
+        if key in LABEL:
+            name += ' = ' + LABEL[key]
+        lines.append('| %s | %d | %.3f | %.2f | %.0f %% | %.0f %% | %.0f %% | %d |' % (
+            name, n, avg[0], avg[1], 100 * avg[2], 100 * avg[3], 100 * avg[4], avg[5]))
+    tail = sys.argv[3] if len(sys.argv) > 3 else None
+    if tail:
+        lines += ['', open(tail).read().rstrip()]
+    open(out, 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[8:40]))
+
+
+if __name__ == '__main__':
+    main()
