@@ -590,6 +590,18 @@ int naws_det_limit_fwd(const float* scores, const uint8_t* keep, int C, int R, i
                        int cap, int32_t* out_count, int32_t* out_cls, int32_t* out_row,
                        float* out_score, void* stream);
 
+/* fc6 weight gradient reading the pooled features in their FORWARD operand layout (no
+ * naws_f16_planes_transpose copy): C [M x N] (ld ldc) = sum_k A[k][m] X[k][n], A2 = planes
+ * [2][K/16][M][16] (a transposing naws_split_f16x2* of the output gradient, K % 32 == 0, zero
+ * beyond the xrows valid rows) with per-row factors scaleA; X2 = planes [2][N/16][xrows][16] as
+ * naws_roi_pool_f_f16x2_fwd / naws_split_f16x2 write them, slabX = elements between 16-column
+ * blocks, scaleX per column (NULL: ones).  Replaces: Caffe2 FCGradient's dW for fc6 (reference
+ * detectron/modeling/wsl_heads.py:674-679); same accumulation order as naws_gemm_f32_f16x2_nt on
+ * the transposed copy - bit-identical results. */
+int naws_gemm_f32_f16x2_nt_xk(int M, int N, int K, const void* A2, int64_t slabA, int64_t planeA,
+                              const float* scaleA, const void* X2, int64_t slabX, int64_t planeX,
+                              int xrows, const float* scaleX, float* C, int ldc, void* stream);
+
 /* ---- diagnostics (no reference counterpart) ------------------------------------------------- */
 /* With a device buffer of 8 x 4 x workgroups uint64 words set (NULL: off), the fp16x2 halo-tile
  * conv launches that take the ring-4 / dilation-1 route run a stamped build and leave per-wave

@@ -217,6 +217,7 @@ class WsddnEngine(object):
         # step.  Off by default; the direct kernel still takes any deep layer whose single launch
         # has >= 256 tiles (the larger TTA scales).
         self.deep_direct = False
+        self.wgrad_xk = True
         self._seg_ring = None
         self._amax5 = None
         self.conv_direct_h2 = {}
@@ -805,8 +806,11 @@ class WsddnEngine(object):
             # transposed as they are, or a transposing split of the fp32 features
             dz6t = ops.split_f16x2_dual(dz6, None, sc6t.view(2, 2 * HIDDEN),
                                         rowmul=x.inv_scale if planes_x else None)[1]
-            xt = (ops.f16_planes_transpose(x) if planes_x           # planes [2, Rt/16, 25088, 16]
-                  else ops.split_f16x2(x, transpose=True))
+            # x^T: with the pooling kernel's planes the wgrad GEMM reads them as they are through
+            # transposing LDS reads (csrc/gemm_btr.hip); otherwise a transposing split of the features
+            xk = planes_x and self.wgrad_xk
+            xt = None if xk else (ops.f16_planes_transpose(x) if planes_x   # [2, Rt/16, 25088, 16]
+                                  else ops.split_f16x2(x, transpose=True))
         elif x3:
             dz6t = ops.split_bf16x3(dz6, transpose=True)       # [3, Rt/16, 8192, 16]
             xt = ops.split_bf16x3(x, transpose=True)           # [3, Rt/16, 25088, 16]
@@ -820,7 +824,11 @@ class WsddnEngine(object):
                 # 25088 = 98 column tiles of 256: 32 x 98 = 12.25 waves of 256 CUs.  96 column
                 # tiles make 12 full waves; the last 512 columns go out as one wave of 128x128 tiles
                 ncut = self._wgrad_column_cut(r1 - r0)
-                if ncut:
+                if xk:
+                    for c0, c1 in (((0, ncut), (ncut, self.k6)) if ncut else ((0, self.k6),)):
+                        ops.gemm_f32_f16x2_nt_xk(dz6t.rows(r0, r1), x, ncols=(c0, c1),
+                                                 out=gw6[r0:r1, c0:c1])
+                elif ncut:
                     ops.gemm_f32_f16x2_nt(dz6t.rows(r0, r1), xt.rows(0, ncut), out=gw6[r0:r1, :ncut])
                     ops.gemm_f32_f16x2_nt(dz6t.rows(r0, r1), xt.rows(ncut, self.k6),
                                           out=gw6[r0:r1, ncut:])

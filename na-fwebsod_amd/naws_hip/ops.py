@@ -663,6 +663,33 @@ def gemm_f32_f16x2_nt(a, b, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, 
     return out
 
 
+def gemm_f32_f16x2_nt_xk(a, x, out=None, ncols=None, scale_x=None):
+    """C[M, N] = sum_k A[k][m] X[k][n]: a = F16x2 with planes [2, K/16, M, 16] (a transposing split:
+    K = the source's rows, zero beyond x's row count), x = F16x2 with planes [2, N/16, R, 16] - the
+    FORWARD operand of an [R, N] matrix (roi_pool_f_f16x2 / split_f16x2), read K(=row)-wise by the
+    kernel's transposing LDS reads, so no transposed copy of x is made.  x's per-row scales are
+    NOT applied (the caller folds them into a, as the fc6 wgrad does with rowmul); scale_x:
+    optional per-column factors.  ncols: (c0, c1) restricts to x's columns c0..c1 (multiples of 16)."""
+    a3, x3 = a.planes, x.planes
+    for t in (a3, x3):
+        if (not t.is_cuda or t.dtype != torch.float16 or t.dim() != 4 or t.shape[0] != 2
+                or t.shape[-1] != 16 or t.stride(-1) != 1 or t.stride(-2) != 16):
+            raise TypeError('operands must be unbatched f16 split planes [2, K/16, rows, 16]')
+    mm, k = a3.shape[-2], a3.shape[-3] * 16
+    r, n_all = x3.shape[-2], x3.shape[-3] * 16
+    c0, c1 = (0, n_all) if ncols is None else ncols
+    if c0 % 16 or c1 % 16 or not 0 <= c0 < c1 <= n_all or r > k:
+        raise L.NawsError('naws_gemm_f32_f16x2_nt_xk', L.ERR_SHAPE)
+    nn = c1 - c0
+    if out is None:
+        out = torch.empty((mm, nn), device=a3.device, dtype=_f32)
+    xs = x3[:, c0 // 16:]
+    L.call('naws_gemm_f32_f16x2_nt_xk', mm, nn, k, a3.data_ptr(), a3.stride(-3), a3.stride(0),
+           a.inv_scale.data_ptr(), xs.data_ptr(), x3.stride(-3), x3.stride(0), r,
+           _ptr(scale_x), out.data_ptr(), out.stride(0), _stream())
+    return out
+
+
 def amax_scales(batch, outer, device):
     """Zeroed scale block [2, (batch,) outer] of an F16x2 whose maxima a GEMM epilogue will report:
     [0] (viewed as int32 bit patterns: `amax_words`) is the rowmax / colmax accumulator, [1]

@@ -376,6 +376,44 @@ def test_roi_pool_planes_transpose_and_kscaled_split(dev):
     assert (np.abs(fwd - want2) <= 2e-6 * (np.abs(ref) @ np.abs(wgt).astype(np.float64).T) + 1e-30).all()
 
 
+@pytest.mark.parametrize('r,m,n', [
+    (203, 96, 6272),        # ragged proposals (zero-padded K), few tiles: 128 x 128 form
+    (1100, 2048, 25088),    # fc6 feature count, K > 1024: 256 x 256 form on both routes, 98 column tiles
+    (4000, 512, 1024),      # the engine's proposal count
+])
+def test_gemm_h2_xk_reads_forward_planes_bit_identically(dev, r, m, n):
+    """dW = dY^T X with X in its forward operand layout (transposing LDS reads, csrc/gemm_btr.hip)
+    against float64 and against the same product through naws_f16_planes_transpose + the NT
+    kernel - bit for bit where both run 256 x 256 tiles -, and over a column range of X (the
+    engine's column cut)."""
+    from naws_hip import ops
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn((r, n), device=dev, generator=g).relu_() * 3.0
+    x[: r // 2] *= 0.01                                          # rows with different scales
+    dy = torch.randn((r, m), device=dev, generator=g)
+    dy[torch.rand((r, m), device=dev, generator=g) < 0.5] = 0.0
+    xp = ops.split_f16x2(x)                                      # planes [2, n/16, r, 16], per-row scales
+    a2 = ops.split_f16x2(dy, transpose=True, rowmul=xp.inv_scale)
+    want = ops.gemm_f32_f16x2_nt(a2, ops.f16_planes_transpose(xp))
+    got = ops.gemm_f32_f16x2_nt_xk(a2, xp)
+    assert got.shape == (m, n)
+    ref = dy.double().t() @ x.double()
+    bnd = dy.double().abs().t() @ x.double().abs()
+    assert bool(((got.double() - ref).abs() <= 2e-6 * bnd + 1e-30).all())
+    big = ((m + 255) // 256) * ((n + 255) // 256) >= 256
+    if big:     # both routes on 256 x 256 tiles of the 16x16x32 MFMA: the same accumulation order
+        assert torch.equal(got, want)
+    else:       # the NT route's small-problem form sums k in groups of 16 (32x32x16 MFMA), this one of 32
+        assert bool(((got.double() - want.double()).abs() <= 2.0 ** -21 * bnd + 1e-30).all())
+    c0, c1 = n // 2, n // 2 + 512
+    part = ops.gemm_f32_f16x2_nt_xk(a2, xp, ncols=(c0, c1))           # few tiles: the 128 x 128 form
+    assert bool(((part.double() - ref[:, c0:c1]).abs() <= 2e-6 * bnd[:, c0:c1] + 1e-30).all())
+    if not big:
+        assert torch.equal(part, got[:, c0:c1])
+    with pytest.raises(ops.L.NawsError):
+        ops.gemm_f32_f16x2_nt_xk(a2, xp, ncols=(8, 24))
+
+
 @pytest.mark.parametrize('m,n,k,seg,kind', [
     (300, 512, 96, 256, 'h2'),          # 128x128 tiles (32x32 MFMA layout), two rowmax segments
     (4096, 4096, 1056, 0, 'h2'),        # 256x256 tiles on the 16x16x32 MFMA layout, one segment
