@@ -217,6 +217,7 @@ class WsddnEngine(object):
         # step.  Off by default; the direct kernel still takes any deep layer whose single launch
         # has >= 256 tiles (the larger TTA scales).
         self.deep_direct = False
+        self.direct_min_tiles = 256          # (512 / 1024 / never: TTA inference 45.3 / 47.5 / 47.4 vs 44.6 ms per image)
         self.wgrad_xk = True
         self._seg_ring = None
         self._amax5 = None
@@ -392,7 +393,7 @@ class WsddnEngine(object):
                         tiles = x.shape[0] * ((x.shape[1] + 7) // 8) * ((x.shape[2] + 31) // 32)
                         if (self.deep_direct and li >= self.DEEP_FIRST
                                 and tiles * (wd.planes.shape[-2] // 64) >= 512) or \
-                                tiles * (wd.planes.shape[-2] // 128) >= 256:
+                                tiles * (wd.planes.shape[-2] // 128) >= self.direct_min_tiles:
                             wp = wd
                     if isinstance(wp, ops.F16x2):
                         bound = None if prev is None else amax[prev:prev + 1]
