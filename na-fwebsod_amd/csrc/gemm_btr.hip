@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_h2_
 #define NAWS_BTR_TERM(P, Q)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TI / 2; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
       acc[ih * (TI / 2) + i][j] =                                                                 \
-          __builtin_amdgcn_mfma_f32_16x16x32_f16(a[P][i], b[Q][j], acc[ih * (TI / 2) + i][j], 0, 0, 0);
+          __builtin_amdgcn_mfma_f32_16x16x32_f16(b[Q][j], a[P][i], acc[ih * (TI / 2) + i][j], 0, 0, 0);
       NAWS_BTR_TERM(0, 0)
       NAWS_BTR_TERM(0, 1)
       NAWS_BTR_TERM(1, 0)
@@ -178,23 +178,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_h2_
     st_cur ^= 1;
   }
 
+  // the MFMAs ran with the operands swapped (B fragment first): the accumulator block is C^T, so a
+  // lane holds FOUR CONSECUTIVE COLUMNS of one row - row l15, columns kg * 4 + e - and the
+  // epilogue moves 16 bytes per lane (the products and their k order are the same: bit-identical
+  // to the un-swapped form, which holds four rows of one column and stores 4 bytes at a time)
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
-    const int row0 = m0 + wm * WTM + i * 16 + kg * 4;
-    float rsv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) rsv[e] = g.rs[min(row0 + e, g.M - 1)];
+    const int row = m0 + wm * WTM + i * 16 + l15;
+    if (row >= g.M) continue;
+    const float rsv = g.rs[row];
+    float* crow = g.C + (long long)row * g.ldc;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-      const int col = n0 + wn * WTN + j * 16 + l15;
-      if (col >= g.N) continue;
-      const float cscale = g.cs ? g.cs[col] : 1.f;
+      const int col = n0 + wn * WTN + j * 16 + kg * 4;
+      if (col >= g.N) continue;                      // N % 16 == 0: the four columns are all in or out
+      f32x4 v = acc[i][j];
+      if (g.cs) {
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(g.cs + col);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = row0 + e;
-        if (row >= g.M) continue;
-        g.C[(long long)row * g.ldc + col] = acc[i][j][e] * rsv[e] * cscale;   // powers of two: exact
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * rsv * c4[e];        // powers of two: exact
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * rsv;
       }
+      *reinterpret_cast<f32x4*>(crow + col) = v;
     }
   }
 }
@@ -226,9 +233,10 @@ extern "C" int naws_gemm_f32_f16x2_nt_xk(int M, int N, int K, const void* A2, in
                                          int64_t slabX, int64_t planeX, int xrows,
                                          const float* scaleX, float* C, int ldc, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || xrows <= 0 || xrows > K) return NAWS_ERR_SHAPE;
-  if (K % 32 != 0 || N % 16 != 0 || ldc < N) return NAWS_ERR_UNSUPPORTED;
+  if (K % 32 != 0 || N % 16 != 0 || ldc < N || ldc % 4 != 0) return NAWS_ERR_UNSUPPORTED;
   NAWS_REQUIRE_PTR(A2); NAWS_REQUIRE_PTR(X2); NAWS_REQUIRE_PTR(scaleA); NAWS_REQUIRE_PTR(C);
-  if ((((uintptr_t)A2 | (uintptr_t)X2) & 15) != 0) return NAWS_ERR_ARG;
+  if ((((uintptr_t)A2 | (uintptr_t)X2 | (uintptr_t)C) & 15) != 0) return NAWS_ERR_ARG;
+  if (scaleX && ((uintptr_t)scaleX & 15) != 0) return NAWS_ERR_ARG;
   if (slabA < (int64_t)M * 16 || slabX < (int64_t)xrows * 16) return NAWS_ERR_ARG;
   BArgs g{};
   g.A = (const unsigned short*)A2; g.X = (const unsigned short*)X2; g.C = C;
