@@ -50,6 +50,7 @@ struct XArgs {
   unsigned long long seed;
   int epilogue, accumulate;
   int tiles_m, tiles_n, batch;
+  int vec4;                  // every row of C / aux and bias / cs start 16-byte aligned: float4 epilogue
   const float* rs;           // fp16x2: per-row / per-column power-of-two factors undoing the
   const float* cs;           //         operand scaling (null otherwise)
   long long sRs, sCs;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
                                                        (ih * TIH + i) * 512);
 #define NAWS_M16_TERM(P, Q)                                                                      \
   _Pragma("unroll") for (int i = 0; i < TIH; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
-      acc[ih * TIH + i][j] = mfma32(a[P][i], b[Q][j], acc[ih * TIH + i][j]);
+      acc[ih * TIH + i][j] = mfma32(b[Q][j], a[P][i], acc[ih * TIH + i][j]);
         NAWS_M16_TERM(0, 0)
         if constexpr (NPL == 2) {
           NAWS_M16_TERM(0, 1)
@@ -436,53 +437,84 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
     st_fill = (st_fill + 1 == STAGES) ? 0 : st_fill + 1;
   }
 
+  // The MFMAs above ran with the operands swapped (B fragment first): an accumulator block is the
+  // TRANSPOSED 16x16 block of C, i.e. lane (l15, kg) holds row l15, columns kg * 4 + e - four
+  // consecutive columns of one row (same products, same k order: bit-identical to the un-swapped
+  // form, which holds four rows of one column).  The epilogue therefore moves 16 bytes per lane
+  // (C, aux, bias, column factors) wherever the layout allows (g.vec4), 4x fewer memory
+  // instructions than the 4-byte form: the aux-reading fc7 dgrad 0.72 -> see DESIGN 0a.
   const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
   const int epi = g.epilogue;
+  const bool has_bias = bias && epi >= NAWS_EPI_BIAS && epi <= NAWS_EPI_BIAS_RELU_DROP;
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
-    const int row0 = m0 + wm * WTM + i * 16 + kg * 4;
-    float rsv[4] = {1.f, 1.f, 1.f, 1.f};
-    if constexpr (F16) {
-      const float* rs = g.rs + bz * g.sRs;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rsv[e] = rs[min(row0 + e, g.M - 1)];
-    }
+    const int row = m0 + wm * WTM + i * 16 + l15;
+    float rsv = 1.f;
+    if constexpr (F16) rsv = (g.rs + bz * g.sRs)[min(row, g.M - 1)];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-      const int col = n0 + wn * WTN + j * 16 + l15;
-      if (col >= g.N) continue;
-      const float bv = (bias && epi >= NAWS_EPI_BIAS && epi <= NAWS_EPI_BIAS_RELU_DROP) ? bias[col] : 0.f;
-      float cscale = 1.f;
-      if constexpr (F16) cscale = g.cs[bz * g.sCs + col];
+      const int col = n0 + wn * WTN + j * 16 + kg * 4;
+      f32x4 v = acc[i][j];
+      if (row < g.M && col < g.N) {
+        const bool full = g.vec4 && col + 3 < g.N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {1.f, 1.f, 1.f, 1.f}, ax = {0.f, 0.f, 0.f, 0.f},
+              old = {0.f, 0.f, 0.f, 0.f};
+        float* cp = C + (long long)row * g.ldc + col;
+        const float* ap = aux ? aux + (long long)row * g.ldaux + col : nullptr;
+        if (full) {
+          if (has_bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+          if constexpr (F16) cs = *reinterpret_cast<const f32x4*>(g.cs + bz * g.sCs + col);
+          if (epi == NAWS_EPI_GATE_POS) ax = *reinterpret_cast<const f32x4*>(ap);
+          if (g.accumulate) old = *reinterpret_cast<const f32x4*>(cp);
+        } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = row0 + e;
-        if (row >= g.M) continue;
-        float v = acc[i][j][e];
-        if constexpr (F16) v = v * rsv[e] * cscale;       // powers of two: exact, in this order
-        v += bv;
-        if (epi == NAWS_EPI_BIAS_RELU || epi == NAWS_EPI_BIAS_RELU_DROP) v = fmaxf(v, 0.f);
-        if (epi == NAWS_EPI_BIAS_RELU_DROP) {
-          const unsigned long long idx =
-              (unsigned long long)bz * g.M * g.N + (unsigned long long)row * g.N + col;
-          v = naws_keep(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
-        } else if (epi == NAWS_EPI_GATE_POS) {
-          v = (aux[row * g.ldaux + col] > 0.f) ? v * g.alpha : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            if (col + e >= g.N) continue;
+            if (has_bias) bv[e] = bias[col + e];
+            if constexpr (F16) cs[e] = g.cs[bz * g.sCs + col + e];
+            if (epi == NAWS_EPI_GATE_POS) ax[e] = ap[e];
+            if (g.accumulate) old[e] = cp[e];
+          }
         }
-        const int idx = row * g.ldc + col;
-        if (g.accumulate) v += C[idx];
-        C[idx] = v;
-        acc[i][j][e] = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = v[e];
+          if constexpr (F16) t = t * rsv * cs[e];          // powers of two: exact, in this order
+          t += bv[e];
+          if (epi == NAWS_EPI_BIAS_RELU || epi == NAWS_EPI_BIAS_RELU_DROP) t = fmaxf(t, 0.f);
+          if (epi == NAWS_EPI_BIAS_RELU_DROP) {
+            const unsigned long long idx =
+                (unsigned long long)bz * g.M * g.N + (unsigned long long)row * g.N + (col + e);
+            t = naws_keep(g.seed, idx, g.drop_thr) ? t * g.drop_scale : 0.f;
+          } else if (epi == NAWS_EPI_GATE_POS) {
+            t = (ax[e] > 0.f) ? t * g.alpha : 0.f;
+          }
+          if (g.accumulate) t += old[e];
+          v[e] = t;
+        }
+        if (full) {
+          *reinterpret_cast<f32x4*>(cp) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < g.N) cp[e] = v[e];
+        }
       }
+      acc[i][j] = v;
     }
   }
   if (g.am.rowmax || g.am.colmax)
-    naws_tile_amax_16<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
+    naws_tile_amax_16t<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int NPL, int KS, bool F16>
 int launch_x3_m16(XArgs& g, int batch, hipStream_t s) {
+  auto a16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  g.vec4 = g.ldc % 4 == 0 && a16(g.C) && g.sC % 4 == 0 &&
+           (!g.aux || (g.ldaux % 4 == 0 && a16(g.aux))) &&
+           (!g.bias || (a16(g.bias) && g.sBias % 4 == 0)) &&
+           (!g.cs || (a16(g.cs) && g.sCs % 4 == 0));
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;

@@ -132,6 +132,55 @@ __device__ __forceinline__ void naws_tile_amax_32(const V16 (&acc)[TI][TJ], int 
   }
 }
 
+// acc[i][j] = TRANSPOSED 16x16 blocks (MFMA issued with the operands swapped): row = lane & 15,
+// col = (lane >> 4) * 4 + e.
+template <int TI, int TJ, typename V4>
+__device__ __forceinline__ void naws_tile_amax_16t(const V4 (&acc)[TI][TJ], int row_base, int col_base,
+                                                   int M, int N, int lane, const NawsAmax& a,
+                                                   long long bz) {
+  const int l15 = lane & 15, kg = lane >> 4;
+  float colm[TJ][4];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) colm[j][e] = 0.f;
+  unsigned* rowmax = a.rowmax ? a.rowmax + bz * a.sRow + (long long)(col_base / a.seg_cols) * M : nullptr;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int row = row_base + i * 16 + l15;
+    const float cmul = (a.colmul && row < M) ? fabsf(a.colmul[row]) : 1.f;
+    float rm = 0.f;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = col_base + j * 16 + kg * 4 + e;
+        if (row < M && col < N) {
+          const float av = fabsf(acc[i][j][e]);
+          rm = fmaxf(rm, av);
+          colm[j][e] = fmaxf(colm[j][e], av * cmul);
+        }
+      }
+    if (rowmax) {
+      rm = fmaxf(rm, __shfl_xor(rm, 16));
+      rm = fmaxf(rm, __shfl_xor(rm, 32));
+      if (kg == 0 && row < M && rm > 0.f) naws_atomic_max_bits(rowmax + row, rm);
+    }
+  }
+  if (a.colmax) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float cm = colm[j][e];
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) cm = fmaxf(cm, __shfl_xor(cm, d));
+        const int col = col_base + j * 16 + kg * 4 + e;
+        if (l15 == 0 && col < N && cm > 0.f) naws_atomic_max_bits(a.colmax + bz * a.sCol + col, cm);
+      }
+  }
+}
+
 // acc[i][j] = 16x16 blocks in the v_mfma_f32_16x16x* C/D layout (col = lane & 15,
 // row = (lane >> 4) * 4 + e).
 template <int TI, int TJ, typename V4>
