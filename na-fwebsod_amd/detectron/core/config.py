@@ -140,6 +140,9 @@ def _defaults():
                                      # of the images on the GPU (naws_prep_image_fwd); threads only decode
             'HOST_NMS': False,       # True: per-class NMS with the numpy loop instead of the HIP kernel
             'TTA_PAIR_FLIPS': True,  # inference TTA: a scale's plain + mirrored pass as one batch of 2
+            'LAGGED_STATS': False,   # training loop: read iteration i's scalars while i+1 runs (no per-iteration host sync;
+                                     # the NaN / failed-loader stop then comes one iteration late).  Measured on the
+                                     # synthetic roidb at 2 images per GPU: 19.3-19.8 ms per iteration either way
             'DEVICE_POST': True,     # inference: roi projection / dedup hash / scatter-back / TTA mean /
                                      # DETECTIONS_PER_IM cut on the GPU (csrc/infer_ops.hip): one result
                                      # download per image; False = the numpy path of the reference

@@ -55,28 +55,52 @@ def train_model(roidb=None, max_iter=None, printer=print):
     if not agree_ok(ok, pg, world, device):
         handle_critical_error(model, 'roi_data_loader failed' if not ok else
                               'roi_data_loader failed on another rank')
+    # The scalars of iteration i are read while iteration i+1 runs (cfg.NAWS.LAGGED_STATS): fetched
+    # right away, the read is a host sync per iteration - the GPU idles until the host has queued
+    # the next step, and the deferred parameter update cannot hide under the next conv body.  The
+    # values, the log lines and their iteration numbers are unchanged; the NaN / failed-loader stop
+    # comes one iteration later.
+    lag = bool(cfg.NAWS.LAGGED_STATS)
+    pending = None
+
+    def account(it, it_lr, handle, my_ok):
+        vals, all_ok = finish_iteration_values(handle)
+        if not all_ok:
+            handle_critical_error(model, 'roi_data_loader failed' if not my_ok else
+                                  'roi_data_loader failed on another rank')
+        stats.UpdateIterStats(vals)
+        if rank == 0:
+            if it == last - 1 and last != cfg.SOLVER.MAX_ITER:      # a shortened run: log its last iteration too
+                from detectron.utils.training_stats_wsl import log_json_stats
+                log_json_stats(stats.GetStats(it, it_lr, loader.queue_size(),
+                                              torch.cuda.max_memory_allocated(device) // (1 << 20)),
+                               stats.printer)
+            else:
+                stats.LogIterStats(it, it_lr, loader.queue_size(),
+                                   torch.cuda.max_memory_allocated(device) // (1 << 20))
+        if np.isnan(stats.iter_total_loss):
+            handle_critical_error(model, 'Loss is NaN')
+
     for cur_iter in range(start_iter, last):
         stats.IterTic()
         lr = model.UpdateWorkspaceLr(cur_iter, lr_policy.get_lr_at_iter(cur_iter))
         executor.feed(batch)
         executor.run()
         batch, ok = stage_batch(loader, device) if cur_iter + 1 < last else (None, True)
-        vals, all_ok = iteration_values(executor, model, pg, world, ok=ok)
-        if not all_ok:
-            handle_critical_error(model, 'roi_data_loader failed' if not ok else
-                                  'roi_data_loader failed on another rank')
+        handle = begin_iteration_values(executor, model, pg, world, ok=ok)
+        if pending is not None:
+            account(*pending)
+            pending = None
+        if lag and cur_iter + 1 < last and (cur_iter + 1) % period != 0:
+            pending = (cur_iter, lr, handle, ok)
+        else:
+            account(cur_iter, lr, handle, ok)
         stats.IterToc()
-        stats.UpdateIterStats(vals)
-        if rank == 0:
-            stats.LogIterStats(cur_iter, lr, loader.queue_size(),
-                               torch.cuda.max_memory_allocated(device) // (1 << 20))
         if (cur_iter + 1) % period == 0 and cur_iter > start_iter and rank == 0:
             checkpoints[cur_iter] = os.path.join(output_dir, 'model_iter{}.pkl'.format(cur_iter))
             nu.save_model_to_weights_file(checkpoints[cur_iter], model, executor)
         if cur_iter == start_iter + stats.LOG_PERIOD:
             stats.ResetIterTimer()
-        if np.isnan(stats.iter_total_loss):
-            handle_critical_error(model, 'Loss is NaN')
     if executor.engine is not None:
         executor.engine.flush()
     if rank == 0:
@@ -107,29 +131,72 @@ def agree_ok(ok, pg, world, device):
     return float(t.item()) == 0.0
 
 
-def iteration_values(executor, model, pg, world, ok=True):
-    """-> (scalar losses / metrics of this iteration, averaged over this process's images and over
-    ranks - the reference averages the per-GPU scalars on the host, net_wsl.py:210-220 -, and
-    whether every rank passed ok=True: the flag rides in the same all-reduce)."""
+def begin_iteration_values(executor, model, pg, world, ok=True):
+    """Queue what an iteration reports - its scalar losses averaged over this process's images and
+    over ranks (the reference averages the per-GPU scalars on the host, net_wsl.py:210-220), the
+    "every rank passed ok=True" flag riding in the same all-reduce, and this process's accuracies -
+    as ONE small device tensor copied to pinned host memory without blocking.  Returns a handle
+    for finish_iteration_values."""
     ws = executor.ws
-    vals = []
-    for k in model.losses:
-        vals.append(ws[k].reshape(-1).float().mean())
-    vals.append(torch.full((), 0.0 if ok else float(world), device=vals[0].device if vals else None))
+    vals = [ws[k].reshape(-1).float().mean() for k in model.losses]
+    dev = vals[0].device
+    vals.append(torch.full((), 0.0 if ok else float(world), device=dev))
     t = torch.stack(vals)
     if pg is not None and world > 1:
         import torch.distributed as dist
         dist.all_reduce(t, group=pg)
         t = t / world
-    host = t.cpu().tolist()
-    all_ok = host[-1] == 0.0
-    out = {k: float(v) for k, v in zip(model.losses, host[:-1])}
-    labels = ws['labels_int32'].reshape(-1).cpu().numpy()
+    names = []
+    labels = ws['labels_int32'].reshape(-1).to(torch.int64)
+    accs = []
     for k, blob in (('accuracy_cls', 'cls_prob'), ('accuracy_cls_noise', 'cls_prob_noise')):
         if k in model.metrics and blob in ws:
-            p = ws[blob].reshape(len(labels), -1).cpu().numpy()
-            out[k] = float((p.argmax(1) == labels).mean())
+            p = ws[blob].reshape(labels.numel(), -1)
+            accs.append((p.argmax(1) == labels.to(p.device)).float().mean())
+            names.append(k)
+    if accs:
+        t = torch.cat([t, torch.stack(accs).to(t.dtype)])
+    if dev.type == 'cuda':
+        host = _stats_slot(t.numel())
+        host.copy_(t, non_blocking=True)
+        done = torch.cuda.current_stream(dev).record_event()
+    else:
+        host, done = t.clone(), None
+    return list(model.losses), names, host, done
+
+
+_STATS_RING = {'slots': None, 'next': 0}
+
+
+def _stats_slot(n):
+    """One of a few reusable pinned host vectors (a fresh pinned allocation per iteration costs a
+    hipHostMalloc, which synchronises the device; at most two handles are alive at a time)."""
+    r = _STATS_RING
+    if r['slots'] is None or r['slots'][0].numel() < n:
+        r['slots'] = [torch.empty((max(n, 16),), dtype=torch.float32).pin_memory() for _ in range(4)]
+        r['next'] = 0
+    slot = r['slots'][r['next']]
+    r['next'] = (r['next'] + 1) % len(r['slots'])
+    return slot[:n]
+
+
+def finish_iteration_values(handle):
+    """-> ({name: float}, all ranks ok) of a begin_iteration_values handle (waits for its copy)."""
+    losses, names, host, done = handle
+    if done is not None:
+        done.synchronize()
+    v = host.tolist()
+    nl = len(losses)
+    out = {k: float(x) for k, x in zip(losses, v[:nl])}
+    all_ok = v[nl] == 0.0
+    for k, x in zip(names, v[nl + 1:]):
+        out[k] = float(x)
     return out, all_ok
+
+
+def iteration_values(executor, model, pg, world, ok=True):
+    """begin + finish in one call (blocking)."""
+    return finish_iteration_values(begin_iteration_values(executor, model, pg, world, ok=ok))
 
 
 def handle_critical_error(model, msg):

@@ -174,7 +174,8 @@ def _health_worker(rank, world, port, q):
     model = types.SimpleNamespace(losses=['loss_cls'], metrics=[])
     vals, ok = train_wsl.iteration_values(ex, model, pg, world, ok=True)
     res['it_good'] = (vals['loss_cls'], ok)
-    vals, ok = train_wsl.iteration_values(ex, model, pg, world, ok=(rank != 0))
+    h = train_wsl.begin_iteration_values(ex, model, pg, world, ok=(rank != 0))     # the lagged form
+    vals, ok = train_wsl.finish_iteration_values(h)
     res['it_rank0_bad'] = (vals['loss_cls'], ok)
 
     class DeadLoader:
