@@ -26,7 +26,9 @@ HBM_ACHIEVABLE_GBPS = 6300.0    # same guide: ~6.3 TB/s achievable of the 8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--steps', type=int, default=150,
+                    help='150 x ~14 ms: a timed region of >= 2 s (the clock of the power-limited '
+                         'GEMMs settles over hundreds of ms)')
     ap.add_argument('--warmup', type=int, default=20,
                     help='SURVEY.md 8(d): discard the first 20 iterations')
     ap.add_argument('--images-per-gpu', type=int, default=2)
@@ -41,11 +43,21 @@ def parse():
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and run the all-reduce schedule even with one rank '
                          '(exercises the N>1 code path on a 1-GPU box)')
+    ap.add_argument('--self-launch', action='store_true',
+                    help='start the ranks as children through torch.distributed.run even for '
+                         '--gpus 1 (the path a bare `python bench.py --gpus N`, N > 1, always takes)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no GPU work: the ranks rendezvous over gloo and run the barrier / '
+                         'max-over-ranks / one-JSON-line skeleton with a 1 ms sleep as the step '
+                         '(checks the launcher and the multi-rank plumbing on a CPU box; the line '
+                         'is labelled dry-run and carries no throughput claim)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=2,
+                    help='timed iterations of the CPU restatement (after one warm-up iteration)')
     ap.add_argument('--no-alt-plan', action='store_true',
                     help='skip the extra measurements of the same workload under the exact-split '
                          '(fp32x3) and the fp32-MFMA-only plans')
-    ap.add_argument('--alt-steps', type=int, default=20)
+    ap.add_argument('--alt-steps', type=int, default=40)
     ap.add_argument('--allreduce-chunks', type=int, default=0, help='0 = auto (engine.py)')
     ap.add_argument('--no-conv-x3', action='store_true',
                     help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
@@ -152,7 +164,8 @@ def infer_main(args):
 
 def cpu_baseline(args, num_fg):
     """CPU restatement of the reference path (oracle/, torch-CPU + C ops) on BASELINE
-    configs[0]: 2 synthetic 600x1000 images x 500 proposals, one fwd+bwd+SGD iteration."""
+    configs[0]: 2 synthetic 600x1000 images x 500 proposals; one warm-up iteration, then
+    --cpu-iters timed fwd+bwd+SGD iterations with per-stage wall times."""
     import numpy as np
     import torch
     from detectron.datasets import synthetic
@@ -166,24 +179,42 @@ def cpu_baseline(args, num_fg):
     rng = np.random.default_rng(0)
     masks = {k: (rng.uniform(size=(rt, 4096)) > 0.5).astype(np.float32)
              for k in ('drop6', 'drop7', '_[noisy]_drop6', '_[noisy]_drop7')}
-    t0 = time.time()
-    ref = oracle.full_forward_backward(blobs, mb, masks, num_fg)
     lr = np.array([1e-3], np.float32)
-    for name, g in ref['grads'].items():
-        p = blobs[name].numpy().reshape(-1)
-        m = np.zeros_like(p)
-        a = np.zeros_like(p)
-        bias = name.endswith('_b')
-        oracle.acm_sgd(np.ascontiguousarray(g.reshape(-1)), m, lr, p, a, 0.9, 0,
-                       0.0 if bias else 5e-4, 1, 2, 2.0 if bias else 1.0, 0)
-    dt = time.time() - t0
-    return {'value': round(2.0 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '1 iteration (fwd+bwd+SGD) of 2 images %dx%d x %d proposals, fp32, '
-                      'torch-CPU conv/fc + C oracle ops, %.1f s' % (args.height, args.width,
-                                                                    args.cpu_rois, dt)}
+    state = {}
+
+    def iteration(stages):
+        ref = oracle.full_forward_backward(blobs, mb, masks, num_fg, timings=stages)
+        t0 = time.perf_counter()
+        for name, g in ref['grads'].items():
+            p = blobs[name].numpy().reshape(-1)
+            if name not in state:
+                state[name] = (np.zeros_like(p), np.zeros_like(p))
+            m, a = state[name]
+            bias = name.endswith('_b')
+            oracle.acm_sgd(np.ascontiguousarray(g.reshape(-1)), m, lr, p, a, 0.9, 0,
+                           0.0 if bias else 5e-4, 1, 2, 2.0 if bias else 1.0, 1)
+        stages['sgd'] = stages.get('sgd', 0.0) + time.perf_counter() - t0
+
+    iteration({})                                   # warm-up: thread pool, oneDNN primitives, pages
+    iters = max(1, args.cpu_iters)
+    stages = {}
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration(stages)
+    dt = (time.perf_counter() - t0) / iters
+    res = {'value': round(2.0 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+           'sample': '1 warm-up + %d timed iterations (fwd+bwd+SGD) of 2 images %dx%d x %d '
+                     'proposals, fp32, torch-CPU conv/fc + C oracle ops, %.1f s per iteration'
+                     % (iters, args.height, args.width, args.cpu_rois, dt),
+           'ms_per_iteration': round(dt * 1e3, 1)}
+    for k, v in stages.items():
+        res['stage_ms_' + k] = round(v / iters * 1e3, 1)
+    return res
 
 
 def alt_plan(args, dev, num_fg, B, t, seg, mode):
+    """The same workload under another arithmetic plan, with its own roofline block for the
+    fc6-forward launch (HIP events on the launch stream, as for the headline plan)."""
     import torch
     from detectron.datasets import synthetic
     from naws_hip.engine import WsddnEngine
@@ -196,24 +227,123 @@ def alt_plan(args, dev, num_fg, B, t, seg, mode):
     eng.set_lr(args.lr)
     steps = max(1, args.alt_steps)
     warm = 3
+    ev = []
 
-    def run(n):
+    def run(n, timed):
+        eng.timing_events = ev if timed else None
         for _ in range(n):
             out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
             eng.sgd_step()
         eng.flush()
         torch.cuda.synchronize()
         return out
-    run(warm)
+    run(warm, False)
     t0 = time.perf_counter()
-    out = run(steps)
+    out = run(steps, True)
     dt = time.perf_counter() - t0
+    rt = t['rois'].shape[0]
+    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+    flops = 2.0 * rt * 8192 * 25088
+    achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
+    peak, kname = plan_peak_and_kernel(mode)
+    roof = {'bound': 'mfma', 'kernel': 'fc6 fwd (both branches, M=%d N=8192 K=25088): %s' % (rt, kname),
+            'kernel_ms': round(kern_ms, 4), 'achieved': round(achieved, 2) if achieved else None,
+            'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4) if achieved else None,
+            'traffic': None}
     del eng
     torch.cuda.empty_cache()
     return {'mfma_dtype': mode, 'value': round(B * steps / dt, 3), 'unit': 'images/sec',
             'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warm,
             'final_loss': round(float(out['loss_cls'].sum().item() +
-                                      out['loss_cls_noise'].sum().item()), 5)}
+                                      out['loss_cls_noise'].sum().item()), 5),
+            'roofline': roof}
+
+
+def plan_peak_and_kernel(mode):
+    """(ceiling in ALGORITHMIC TFLOP/s, name) of a plan's fc6-forward kernel.  The split plans
+    execute 3 (fp16x2) / 6 (fp32x3) 16-bit MFMA flops per algorithmic fp32 flop, so their
+    ceiling is the dense 16-bit peak divided by the pass count - a derived figure, not a
+    hardware number; fp32 = the v_mfma_f32_32x32x2_f32 datasheet peak."""
+    if mode == 'bf16':
+        return BF16_MFMA_PEAK_TFLOPS, ('gemm_x3_m16_kernel<256,256,4x2 waves,2 stages,1 plane x 4 '
+                                       'K-slabs> (bf16 slab operands, v_mfma_f32_16x16x32_bf16)')
+    if mode == 'fp32x3':
+        return round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), X3_KERNEL_NAME
+    if mode == 'fp16x2':
+        return round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1), ('gemm_x3_m16_kernel<256,256,4x2 waves,2 stages,2 '
+                                                       'planes x 2 K-slabs,f16> = 3 x '
+                                                       'v_mfma_f32_16x16x32_f16 per fp32 product')
+    return FP32_MFMA_PEAK_TFLOPS, 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves> (v_mfma_f32_32x32x2_f32)'
+
+
+X3_KERNEL_NAME = ('gemm_x3_kernel<256,256,2x4 waves,3 stages> = 6 x v_mfma_f32_32x32x16_bf16 per '
+                  'fp32 product')
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n, port, argv, python=None, script=None):
+    """argv of the child job for a bare `python bench.py --gpus N`: one process per GPU through
+    torch.distributed.run on this node (the driver's own N > 1 command line), rendezvous on
+    127.0.0.1.  `argv` = this process's arguments after the script name; --self-launch is
+    dropped (the children are ranks, not launchers)."""
+    rest = [a for a in argv if a != '--self-launch']
+    return [python or sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+            '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+            script or os.path.abspath(__file__)] + rest
+
+
+def launcher_env(environ):
+    """Environment of the children: the parent's, minus any rank variables (a stale RANK /
+    WORLD_SIZE would be trusted by the ranks), plus the dmabuf-IPC switch RCCL needs here."""
+    env = {k: v for k, v in environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK',
+                        'MASTER_ADDR', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    env['NAWS_BENCH_CHILD'] = '1'
+    return env
+
+
+def is_result_line(line):
+    line = line.strip()
+    if not (line.startswith('{') and line.endswith('}')):
+        return False
+    try:
+        return 'metric' in json.loads(line)
+    except ValueError:
+        return False
+
+
+def self_launch(args, argv):
+    """Parent of a bare `python bench.py --gpus N`: it never touches the GPU (a process that has
+    initialised HIP must not be replaced, and need not be: the ranks are children).  The
+    children's output is passed through as it comes; rank 0's JSON line is held back and printed
+    as the LAST line of stdout.  Exit code: the job's."""
+    import subprocess
+    cmd = launcher_command(args.gpus, free_port(), argv)
+    print('bench.py: launching %d rank(s): %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=launcher_env(os.environ), stdout=subprocess.PIPE,
+                            stderr=None, text=True, bufsize=1)
+    held = None
+    for line in proc.stdout:
+        if is_result_line(line):
+            held = line.strip()
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if held is not None:
+        print(held, flush=True)
+    if rc != 0:
+        sys.exit(rc if rc > 0 else 1)
+    if held is None:
+        sys.exit('bench.py: the ranks exited 0 without a result line')
 
 
 def emit(res):
@@ -228,20 +358,66 @@ def emit(res):
     print(json.dumps(res), flush=True)
 
 
+def dry_run(args, rank, world):
+    """The rank skeleton of main() without a GPU (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get('NAWS_DRY_RUN_FAIL_RANK') == str(rank):
+        sys.exit(3)                      # the launcher test's failing rank
+    if world > 1 or args.force_dist:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if dist.is_initialized():
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    rank_dt = [dt]
+    if dist.is_initialized():
+        td = torch.zeros((world,), dtype=torch.float64)
+        td[rank] = dt
+        dist.all_reduce(td)
+        rank_dt = td.tolist()
+        dt = max(rank_dt)
+        dist.destroy_process_group()
+    if rank == 0:
+        print('rank 0: some library banner after which the line must still come last')
+        emit({'metric': 'dry-run (no GPU work; launcher / rendezvous check only)', 'value': None,
+              'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+              'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+              'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'none',
+              'config': {'workload': 'dry-run', 'parallelism': 'dp%d' % world,
+                         'rccl_world_size': world,
+                         'ms_per_step_rank_min': round(min(rank_dt) / args.steps * 1e3, 3),
+                         'ms_per_step_rank_max': round(max(rank_dt) / args.steps * 1e3, 3),
+                         'launched_by_bench': os.environ.get('NAWS_BENCH_CHILD') == '1'}})
+    else:
+        print('rank %d: noise on stdout' % rank, flush=True)
+
+
 def main():
     args = parse()
     if args.infer:
         return infer_main(args)
+    under_launcher = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if not under_launcher and (args.gpus > 1 or args.self_launch):
+        # a bare `python bench.py --gpus N`: this process becomes the launcher (before anything
+        # here has touched the GPU) and the ranks run as its children
+        return self_launch(args, sys.argv[1:])
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world:
-        # one process per GPU: N > 1 is launched through torch.distributed.run (which sets
-        # WORLD_SIZE); a bare `python bench.py --gpus 8` would silently measure one GPU
-        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python -m '
-                 'torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 '
-                 'bench.py --gpus %d ...`' % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit('bench.py: --gpus %d inside a %d-rank job (WORLD_SIZE=%d): launch it with '
+                 '--nproc-per-node %d, or run `python bench.py --gpus %d` bare and it starts its '
+                 'own ranks' % (args.gpus, world, world, args.gpus, args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
@@ -289,16 +465,19 @@ def main():
     ev = []
     pev = []
     uev = []     # the fused SGD kernel, on the update stream
+    cev = []     # update stream: from "gradients complete" to "all-reduce complete"
 
     def step(timed):
         if timed:
             eng.timing_events = ev
             eng.phase_events = pev
             eng.update_events = uev
+            eng.comm_events = cev
         else:
             eng.timing_events = None
             eng.phase_events = None
             eng.update_events = None
+            eng.comm_events = None
         out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
         eng.sgd_step()
         return out
@@ -317,10 +496,13 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        td = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(td, op=torch.distributed.ReduceOp.MAX)
-        dt = float(td.item())
+    rank_dt = [dt]
+    if pg is not None:
+        td = torch.zeros((world,), device=dev, dtype=torch.float64)
+        td[rank] = dt
+        torch.distributed.all_reduce(td, op=torch.distributed.ReduceOp.SUM)
+        rank_dt = td.cpu().tolist()
+        dt = max(rank_dt)               # the job's time is its slowest rank's
     loss = float(out['loss_cls'].sum().item() + out['loss_cls_noise'].sum().item())
 
     # after the timed steps: the conv body alone (nothing else on the device).  Inside a step it
@@ -328,7 +510,7 @@ def main():
     # there reads longer than the stack itself takes.
     conv_alone_ms = None
     if rank == 0:
-        eng.timing_events = eng.phase_events = eng.update_events = None
+        eng.timing_events = eng.phase_events = eng.update_events = eng.comm_events = None
         eng.conv_body(t['data'])
         torch.cuda.synchronize()
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -358,17 +540,7 @@ def main():
         bf = args.mfma_dtype == 'bf16'
         x3 = args.mfma_dtype == 'fp32x3'
         h2 = args.mfma_dtype == 'fp16x2'
-        # fp32x3 executes 6 bf16 MFMA flops per algorithmic fp32 flop: its ceiling in algorithmic
-        # TFLOP/s is the bf16 dense peak / 6 (frac = executed MFMA flops / bf16 peak)
-        peak = (BF16_MFMA_PEAK_TFLOPS if bf else
-                round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if x3 else
-                round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1) if h2 else FP32_MFMA_PEAK_TFLOPS)
-        kname = ('gemm_x3_m16_kernel<256,256,4x2 waves,2 stages,1 plane x 4 K-slabs> (bf16 slab operands, v_mfma_f32_16x16x32_bf16)' if bf else
-                 'gemm_x3_kernel<256,256,2x4 waves,3 stages> = 6 x v_mfma_f32_32x32x16_bf16 per '
-                 'fp32 product' if x3 else
-                 'gemm_x3_m16_kernel<256,256,4x2 waves,2 stages,2 planes x 2 K-slabs,f16> = 3 x '
-                 'v_mfma_f32_16x16x32_f16 per fp32 product' if h2 else
-                 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves>')
+        peak, kname = plan_peak_and_kernel(args.mfma_dtype)
         dtype = ('bf16 (bf16 MFMA operands, fp32 accumulate/storage/loss)' if bf else
                  'f32 (exact 3xbf16 operand split, 6-pass bf16 MFMA, fp32 accumulate)' if x3 else
                  'f32 (2xf16 split, 3-pass f16 MFMA, fp32 accumulate)' if h2 else
@@ -438,9 +610,21 @@ def main():
                'lr': args.lr, 'final_loss': round(loss, 5),
                'rccl_backend': (torch.distributed.get_backend() if pg is not None else 'none'),
                'rccl_world_size': (torch.distributed.get_world_size() if pg is not None else 1),
-               'allreduce_chunks': eng.allreduce_chunks if eng.reducer.active else 0}
+               'allreduce_chunks': eng.allreduce_chunks if eng.reducer.active else 0,
+               # per-rank wall time of the timed region (value uses the max); the time the main
+               # stream stood waiting for the deferred all-reduce + SGD + weight re-split before
+               # the head could read the parameters (HIP events around engine.flush(): the
+               # exposed part of the exchange and update - everything else was hidden under the
+               # conv body); the time the update stream waited for the collective after this
+               # rank's gradients were complete
+               'ms_per_step_rank_min': round(min(rank_dt) / args.steps * 1e3, 3),
+               'ms_per_step_rank_max': round(max(rank_dt) / args.steps * 1e3, 3),
+               'exposed_comm_ms': None,
+               'allreduce_wait_ms': (round(sum(s.elapsed_time(e) for s, e in cev) / len(cev), 3)
+                                     if cev else None)}
         for k, v in stage_ms.items():                 # flat: the driver's parser drops nested dicts
             cfg['stage_ms_' + k] = v
+        cfg['exposed_comm_ms'] = stage_ms.get('join_update')
         res = {
             'metric': 'images/sec (600px, 2000 proposals) VGG16-C5 WSDDN fwd+bwd',
             'value': round(world * B * args.steps / dt, 3),
@@ -460,6 +644,11 @@ def main():
                 res[key] = alt_plan(args, dev, num_fg, B, t, seg, mode)
                 cfg[key + '_images_per_sec'] = res[key]['value']
                 cfg[key + '_ms_per_step'] = res[key]['ms_per_step']
+                # flat copies of the plan's own roofline block (nested dicts may be dropped)
+                roof[key + '_fc6_fwd_kernel_ms'] = res[key]['roofline']['kernel_ms']
+                roof[key + '_fc6_fwd_tflops'] = res[key]['roofline']['achieved']
+                roof[key + '_fc6_fwd_peak'] = res[key]['roofline']['peak']
+                roof[key + '_fc6_fwd_frac'] = res[key]['roofline']['frac']
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, num_fg)
     if pg is not None:

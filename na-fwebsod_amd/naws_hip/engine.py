@@ -934,7 +934,15 @@ class WsddnEngine(object):
             torch.cuda.current_stream(self.device).wait_event(self._upd_event)
 
     def _apply_update(self):
-        self.wait_allreduce()
+        cev = getattr(self, 'comm_events', None)   # bench.py: how long this stream, with this
+        if cev is not None and self.reducer.active:  # rank's gradients complete, waits for the exchange
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            self.wait_allreduce()
+            c1.record()
+            cev.append((c0, c1))
+        else:
+            self.wait_allreduce()
         uev = getattr(self, 'update_events', None)   # bench.py: HIP events on the update stream
         if uev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -490,7 +490,8 @@ def loss_tail(fc8, rois, labels_oh, is_mean=True):
 
 
 def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatial_scale=0.125,
-                          roi_size=7, train=True, conv5=None, roi_feat=None, backward=True):
+                          roi_size=7, train=True, conv5=None, roi_feat=None, backward=True,
+                          timings=None):
     """Whole hot path on the CPU for a minibatch of B images (each image is one reference
     'GPU': per-image softmax-over-proposals / ReduceSum / gate / loss; gradients summed over
     images, exactly what the all-reduce does).
@@ -498,18 +499,29 @@ def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatia
     masks: dict of 0/1 keep masks [Rt,4096] for drop6, drop7, _[noisy]_drop6, _[noisy]_drop7.
     conv5 / roi_feat: results of an earlier call on the same images / proposals (they do not
     depend on the head parameters), to skip recomputing them; backward=False stops after the
-    per-image loss tails.
+    per-image loss tails.  timings: a dict that receives the wall seconds of each stage
+    (conv / roi_pool / head_fwd / loss / head_bwd), accumulated - bench.py's cpu_baseline.
     Returns dict(losses per image, grads per trainable blob, intermediates)."""
+    import time
     import torch
+    clock = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + now - clock[0]
+        clock[0] = now
     rois = mb['rois']
     argmax = None
     if conv5 is None:
         data = torch.from_numpy(mb['data'])
         with torch.no_grad():
             conv5 = vgg16_conv5_body(data, blobs).numpy()    # StopGradient: forward only
+    lap('conv')
     if roi_feat is None:
         pooled, argmax = roi_pool_f(conv5, rois, roi_size, roi_size, spatial_scale)
         roi_feat = roi_feature_boost(pooled, mb['obn_scores'].reshape(-1))
+    lap('roi_pool')
     x = torch.from_numpy(roi_feat.reshape(rois.shape[0], -1))
     names = ['fc6_w', 'fc6_b', 'fc7_w', 'fc7_b', '_[noisy]_fc6_w', '_[noisy]_fc6_b',
              '_[noisy]_fc7_w', '_[noisy]_fc7_b', 'fc8c_w', 'fc8c_b', 'fc8d_w', 'fc8d_b',
@@ -517,6 +529,7 @@ def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatia
     params = {n: blobs[n].clone().requires_grad_(True) for n in names}
     tmasks = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in (masks or {}).items()}
     act = head_forward(x, params, tmasks, train=train)
+    lap('head_fwd')
     fc8 = {k: act[k].detach().numpy() for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')}
     b = rois[:, 0].astype(np.int64)
     n_img = mb['data'].shape[0]
@@ -527,6 +540,7 @@ def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatia
         tails.append(t)
         for k in dl:
             dl[k][sel] = t['d_' + k]
+    lap('loss')
     res = dict(conv5_3=conv5, roi_feat=roi_feat, roi_argmax=argmax,
                act={k: v.detach().numpy() for k, v in act.items()}, tails=tails, d_logits=dl)
     if backward:
@@ -534,6 +548,7 @@ def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatia
         gouts = [torch.from_numpy(dl[k]) for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
         grads = torch.autograd.grad(outs, [params[n] for n in names], gouts)
         res['grads'] = {n: g.numpy() for n, g in zip(names, grads)}
+        lap('head_bwd')
     return res
 
 
