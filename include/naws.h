@@ -6,9 +6,17 @@
  * launches asynchronously on that stream and returns 0 (NAWS_OK) or a
  * negative NAWS_ERR_* code.  Shape / argument violations return an error
  * where the reference op's CAFFE_ENFORCE* would throw (sites cited per
- * function).  There is no global state: the two stateful reference ops
- * (Stat: cur_iter_/init_; ACMWeightDecayMomentumSGDUpdate: iter_count_) take
- * the state as explicit caller-owned arguments.
+ * function).  The two stateful reference ops (Stat: cur_iter_/init_;
+ * ACMWeightDecayMomentumSGDUpdate: iter_count_) take the state as explicit
+ * caller-owned arguments.  Entry points are re-entrant across host threads,
+ * streams and devices (the kernels run on the calling thread's current
+ * device, which must own the pointers).  What the library keeps process-wide,
+ * all of it listed here: (1) the per-thread error code behind
+ * naws_last_hip_error(); (2) a per-(kernel, device) record of which kernels
+ * have had their dynamic-LDS limit raised - a cache of an idempotent driver
+ * call, see naws_launch_state_reset(); (3) the A/B knobs of
+ * naws_set_variant(), which never change a result.  It reads no environment
+ * variables.
  *
  * All tensors are dense fp32 unless noted.  "ref:" citations are relative to
  * the upstream repository root (shenyunhang/NA-fWebSOD).
@@ -602,12 +610,15 @@ int naws_gemm_f32_f16x2_nt_xk(int M, int N, int K, const void* A2, int64_t slabA
                               const float* scaleA, const void* X2, int64_t slabX, int64_t planeX,
                               int xrows, const float* scaleX, float* C, int ldc, void* stream);
 
-/* ---- diagnostics (no reference counterpart) ------------------------------------------------- */
-/* With a device buffer of 8 x 4 x workgroups uint64 words set (NULL: off), the fp16x2 halo-tile
- * conv launches that take the ring-4 / dilation-1 route run a stamped build and leave per-wave
- * cycle sums of the step phases {counted wait, barrier, DMA issue, LDS fragment reads, MFMAs,
- * halo refill} there (na-fwebsod_amd/tools/ab_conv.py --stamp).  Outputs are unchanged. */
-int naws_debug_conv_stamp_buffer(void* buf);
+/* ---- process-wide state and tuning (no reference counterpart) ------------------------------ */
+/* Kernels that need more than 64 KB of dynamic LDS have that limit raised once per (kernel,
+ * device) pair; the library remembers which pairs are done.  After hipDeviceReset() - which
+ * drops the attribute - call this to make it forget.  Always safe to call. */
+int naws_launch_state_reset(void);
+/* Select a tile / pipeline form for the A/B tools (na-fwebsod_amd/tools/ab_*.py): knob in
+ * {"gemm", "x3", "h2", "conv_ring", "conv_bn", "roi_nw", "wino"}; no form changes a result.
+ * Unknown knob: NAWS_ERR_ARG.  The library never reads the environment. */
+int naws_set_variant(const char* knob, int value);
 
 #ifdef __cplusplus
 }

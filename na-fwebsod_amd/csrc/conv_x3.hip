@@ -4,7 +4,7 @@
 // /root/reference/detectron/modeling/VGG16.py:9-48 (Conv 3x3 pad = dilation, bias, Relu).
 #include "x3_common.h"
 
-static int g_x3_variant = -1;
+#define g_x3_variant naws_knob(NAWS_KNOB_X3)
 
 namespace {
 // ---- 3x3 convolution (NHWC fp32 activations) as an fp32x3 implicit GEMM -------------------------
@@ -197,12 +197,7 @@ int launch_conv_x3(CArgs& g, hipStream_t s) {
   g.tiles_n = (int)naws_cdiv(g.Cout, BN);
   const size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
   auto kern = conv_x3_kernel<BM, BN, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * WM * WN), lds, s, g);
   return naws_check_launch();
 }
@@ -472,6 +467,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 3 : 2)) void conv_x3_halo_kernel(C
   halo_epilogue<BN, F16>(g, acc, img, ty0, tx0, n0, wid, lane, iscA, smx);
 }
 
+#ifdef NAWS_AB   // superseded by conv_h2_wp_kernel; kept for tools/ab_conv.py (make AB=1)
 // ---- the fp16x2 halo-tile kernel with a deep weight ring --------------------------------------
 // Same tile, LDS images, MFMA order and epilogue as conv_x3_halo_kernel<BN, true, DIL> (results
 // are bit-identical), different pipeline.  There a (tap, slab) weight stage is requested one step
@@ -694,15 +690,12 @@ int launch_conv_h2_ring(CArgs& g, int N, hipStream_t s) {
   constexpr int ASTAGES = (BN <= 64 || DIL == 2) ? 1 : 2;
   const size_t lds = (size_t)ASTAGES * 2 * A_ROWS * 32 + (size_t)NB * 2 * BN * 32;
   auto kern = conv_h2_ring_kernel<BN, DIL, NB, STAMP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
   return naws_check_launch();
 }
+
+#endif  // NAWS_AB
 
 template <int BN, bool F16 = false, int DIL = 1>
 int launch_conv_x3_halo(CArgs& g, int N, hipStream_t s) {
@@ -713,12 +706,7 @@ int launch_conv_x3_halo(CArgs& g, int N, hipStream_t s) {
   constexpr int NPL = F16 ? 2 : 3;
   const size_t lds = (size_t)(BN <= 64 ? 1 : 2) * NPL * A_ROWS * 32 + (size_t)2 * NPL * BN * 32;
   auto kern = conv_x3_halo_kernel<BN, F16, DIL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
   return naws_check_launch();
 }
@@ -743,10 +731,6 @@ extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const
   g.planeB = (long long)9 * Cin * Cout;
   g.bytesX = (unsigned)(pix * Cin * 4);
   hipStream_t s = (hipStream_t)stream;
-  if (g_x3_variant < 0) {
-    const char* e = getenv("NAWS_X3_VARIANT");
-    g_x3_variant = e ? atoi(e) : 0;
-  }
   // wide shallow layers: the halo-tile kernel (input gathered once per channel slab, not per tap)
   if (dilation == 1 && Cout <= 128 && Cout % 32 == 0 && g_x3_variant != 6) {
     if (Cout <= 64) return launch_conv_x3_halo<64>(g, N, s);
@@ -1102,17 +1086,13 @@ int launch_conv_h2_wp(CArgs& g, int N, hipStream_t s) {
   if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
   const size_t lds = (size_t)2 * 2 * 2 * NawsWpGeom<DIL>::A_HALF;
   auto kern = conv_h2_wp_kernel<WR, WC, DIL, PIPE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
   return naws_check_launch();
 }
 }  // namespace
 
+#ifdef NAWS_AB
 // Diagnostics (tools/ab_conv.py --stamp): with a buffer of 8 x 4 x workgroups u64 words set, the
 // ring-4 / dilation-1 launches run the stamped build and leave per-wave cycle sums of the step
 // phases {counted wait, barrier, DMA issue, LDS fragment reads, MFMAs, halo refill} there.
@@ -1121,6 +1101,7 @@ extern "C" int naws_debug_conv_stamp_buffer(void* buf) {
   g_conv_stamp_buf = (unsigned long long*)buf;
   return NAWS_OK;
 }
+#endif
 
 // fp16x2 form of the shallow-layer convolution (the halo-tile kernel): W2 / scaleW =
 // naws_split_f16x2 of the packed weight viewed [Cout][9*Cin]; the activation scale comes from
@@ -1161,54 +1142,48 @@ extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const
   // 64-wide channel tiles (3 workgroups per CU) where 128-wide ones leave CUs idle or the layer is
   // deep: measured per layer at 2 images (tools/kernel_bench.py --what x3): conv3_x 0.137 / 0.259
   // vs 0.156 / 0.289 ms, conv4_2 0.282 vs 0.297; conv2_2 (608 tiles of 128) keeps 128
-  bool bn64 = Cout <= 64;
-  if (!bn64 && Cout % 64 == 0) {
-    const long long t128 = (long long)N * naws_cdiv(H, 8) * naws_cdiv(W, 32) * naws_cdiv(Cout, 128);
-    bn64 = Cin >= 128 && Cout >= 256 && t128 < 4 * 512;
-    const char* e = getenv("NAWS_CONV_BN");            // A/B knob (tools/kernel_bench.py)
-    if (e) bn64 = atoi(e) == 64;
+  if (2 * g.planeB * 2 > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  // wave-private weight fragments (conv_h2_wp_kernel): 2 x 2 waves (64-channel tiles, 3 workgroups
+  // per CU) up to 256 output channels, 1 x 4 waves (128-channel tiles, half the weight traffic) for
+  // the 512-channel layers: per layer at one image, tools/ab_conv.py --rings 11 --bn 64 128
+  bool bn64 = Cout <= 64 || (Cout % 128 == 0 && Cout < 512);
+  const int force_bn = naws_knob(NAWS_KNOB_CONV_BN);      // A/B knob: 64 / 128, 0 = the rule above
+  if (force_bn && Cout > 64 && Cout % 128 == 0) bn64 = force_bn == 64;
+#ifdef NAWS_AB
+  // the superseded pipelines (results bit-identical): knob "conv_ring" = 0 one-step halo kernel,
+  // 3 / 4 / 6 weight ring of that depth, 10 wave-private without the software pipeline
+  const int ring = naws_knob(NAWS_KNOB_CONV_RING);
+  if (ring == 10) {
+    if (dilation == 2)
+      return bn64 ? launch_conv_h2_wp<2, 2, 2, false>(g, N, s) : launch_conv_h2_wp<1, 4, 2, false>(g, N, s);
+    return bn64 ? launch_conv_h2_wp<2, 2, 1, false>(g, N, s) : launch_conv_h2_wp<1, 4, 1, false>(g, N, s);
   }
-  static int ring = -2;                                 // NAWS_CONV_RING: 0 = the one-step pipeline
-  {
-    const char* e = getenv("NAWS_CONV_RING");           // read per call: in-process A/B
-    ring = e ? atoi(e) : 11;
-  }
-  if (ring == 10 || ring == 11) {                         // wave-private weight fragments
-    if (2 * g.planeB * 2 > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
-    // 2 x 2 waves (64-channel tiles, 3 workgroups per CU) up to 256 output channels, 1 x 4 waves
-    // (128-channel tiles, half the weight traffic) for the 512-channel layers: per layer at one
-    // image, tools/ab_conv.py --rings 11 --bn 64 128
-    if (Cout > 64 && Cout % 128 == 0 && !getenv("NAWS_CONV_BN")) bn64 = Cout < 512;
-    if (ring == 10) {
-      if (dilation == 2)
-        return bn64 ? launch_conv_h2_wp<2, 2, 2, false>(g, N, s) : launch_conv_h2_wp<1, 4, 2, false>(g, N, s);
-      return bn64 ? launch_conv_h2_wp<2, 2, 1, false>(g, N, s) : launch_conv_h2_wp<1, 4, 1, false>(g, N, s);
+  if (ring != 11) {
+    bn64 = Cout <= 64;
+    if (!bn64 && Cout % 64 == 0) {
+      const long long t128 = (long long)N * naws_cdiv(H, 8) * naws_cdiv(W, 32) * naws_cdiv(Cout, 128);
+      bn64 = Cin >= 128 && Cout >= 256 && t128 < 4 * 512;
+      if (force_bn) bn64 = force_bn == 64;
     }
+    if (g_conv_stamp_buf && ring == 4 && dilation == 1) {   // diagnostic build
+      g.dbg = g_conv_stamp_buf;
+      return bn64 ? launch_conv_h2_ring<64, 1, 4, true>(g, N, s) : launch_conv_h2_ring<128, 1, 4, true>(g, N, s);
+    }
+#define NAWS_RING_CASE(NBV)                                                                          \
+    if (ring == NBV) {                                                                               \
+      if (dilation == 2)                                                                             \
+        return bn64 ? launch_conv_h2_ring<64, 2, NBV>(g, N, s) : launch_conv_h2_ring<128, 2, NBV>(g, N, s); \
+      return bn64 ? launch_conv_h2_ring<64, 1, NBV>(g, N, s) : launch_conv_h2_ring<128, 1, NBV>(g, N, s);   \
+    }
+    NAWS_RING_CASE(3) NAWS_RING_CASE(4) NAWS_RING_CASE(6)
+#undef NAWS_RING_CASE
     if (dilation == 2)
-      return bn64 ? launch_conv_h2_wp<2, 2, 2>(g, N, s) : launch_conv_h2_wp<1, 4, 2>(g, N, s);
-    return bn64 ? launch_conv_h2_wp<2, 2, 1>(g, N, s) : launch_conv_h2_wp<1, 4, 1>(g, N, s);
+      return bn64 ? launch_conv_x3_halo<64, true, 2>(g, N, s) : launch_conv_x3_halo<128, true, 2>(g, N, s);
+    return bn64 ? launch_conv_x3_halo<64, true>(g, N, s) : launch_conv_x3_halo<128, true>(g, N, s);
   }
-  if (g_conv_stamp_buf && ring == 4 && dilation == 1) {   // diagnostic build
-    g.dbg = g_conv_stamp_buf;
-    return bn64 ? launch_conv_h2_ring<64, 1, 4, true>(g, N, s) : launch_conv_h2_ring<128, 1, 4, true>(g, N, s);
-  }
-  if (ring == 4) {
-    if (dilation == 2)
-      return bn64 ? launch_conv_h2_ring<64, 2, 4>(g, N, s) : launch_conv_h2_ring<128, 2, 4>(g, N, s);
-    return bn64 ? launch_conv_h2_ring<64, 1, 4>(g, N, s) : launch_conv_h2_ring<128, 1, 4>(g, N, s);
-  }
-  if (ring == 3) {
-    if (dilation == 2)
-      return bn64 ? launch_conv_h2_ring<64, 2, 3>(g, N, s) : launch_conv_h2_ring<128, 2, 3>(g, N, s);
-    return bn64 ? launch_conv_h2_ring<64, 1, 3>(g, N, s) : launch_conv_h2_ring<128, 1, 3>(g, N, s);
-  }
-  if (ring == 6) {
-    if (dilation == 2)
-      return bn64 ? launch_conv_h2_ring<64, 2, 6>(g, N, s) : launch_conv_h2_ring<128, 2, 6>(g, N, s);
-    return bn64 ? launch_conv_h2_ring<64, 1, 6>(g, N, s) : launch_conv_h2_ring<128, 1, 6>(g, N, s);
-  }
+#endif
   if (dilation == 2)
-    return bn64 ? launch_conv_x3_halo<64, true, 2>(g, N, s) : launch_conv_x3_halo<128, true, 2>(g, N, s);
-  return bn64 ? launch_conv_x3_halo<64, true>(g, N, s) : launch_conv_x3_halo<128, true>(g, N, s);
+    return bn64 ? launch_conv_h2_wp<2, 2, 2>(g, N, s) : launch_conv_h2_wp<1, 4, 2>(g, N, s);
+  return bn64 ? launch_conv_h2_wp<2, 2, 1>(g, N, s) : launch_conv_h2_wp<1, 4, 1>(g, N, s);
 }
 

@@ -299,12 +299,7 @@ int launch(BArgs& g, int batch, hipStream_t s) {
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(unsigned short);
   auto kern = gemm_bf16_kernel<BM, BN, WM, WN, A_BF16, B_BF16, CONV>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, batch);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
   return naws_check_launch();

@@ -211,12 +211,7 @@ int launch_btr(BArgs& g, hipStream_t s) {
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   auto kern = gemm_h2_btr_kernel<BM, BN, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * WM * WN),
                      (size_t)STAGES * NQ * (BM + BN) * 32, s, g);
   return naws_check_launch();

@@ -474,16 +474,9 @@ __global__ __launch_bounds__(256) void gemm_smallk_nn_kernel(GemmArgs g) {
   }
 }
 
-// Tuning knob for A/B experiments (tools/kernel_bench.py): NAWS_GEMM_VARIANT
+// Tuning knob for A/B experiments (tools/kernel_bench.py): naws_set_variant("gemm", v)
 //   0 default, 2: pad LDS so only 1 workgroup fits a CU, 4: BK=32 tile forms
-int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("NAWS_GEMM_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+int gemm_variant() { return naws_knob(NAWS_KNOB_GEMM); }
 
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool CONV, int WM = 2, int WN = 2>
 int launch(GemmArgs& g, int batch, hipStream_t s) {
@@ -495,12 +488,7 @@ int launch(GemmArgs& g, int batch, hipStream_t s) {
   size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float);
   if (gemm_variant() == 2) lds = std::max<size_t>(lds, 84 * 1024);
   auto kern = gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, CONV, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, batch);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, g);
   return naws_check_launch();

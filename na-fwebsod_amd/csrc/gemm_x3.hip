@@ -28,7 +28,7 @@
 // 674-679, webly_heads.py:490-498), same as gemm_f32.hip.
 #include "x3_common.h"
 
-static int g_x3_variant = -1;
+#define g_x3_variant naws_knob(NAWS_KNOB_X3)
 
 namespace {
 
@@ -270,12 +270,7 @@ int launch_x3(XArgs& g, int batch, hipStream_t s) {
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;
   auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   g.batch = batch;
   if ((long long)g.tiles_m * g.tiles_n * batch > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * batch), 1, 1);
@@ -519,12 +514,7 @@ int launch_x3_m16(XArgs& g, int batch, hipStream_t s) {
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;
   auto kern = gemm_x3_m16_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   g.batch = batch;
   if ((long long)g.tiles_m * g.tiles_n * batch > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * batch), 1, 1);
@@ -841,10 +831,6 @@ extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t s
   g.drop_scale = (float)(1.0 / (1.0 - (double)drop_ratio));
   g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
   hipStream_t s = (hipStream_t)stream;
-  if (g_x3_variant < 0) {
-    const char* e = getenv("NAWS_X3_VARIANT");
-    g_x3_variant = e ? atoi(e) : 0;
-  }
   if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2>(g, batch, s);
   // short K (the Winograd batch GEMMs): prologue and epilogue are a large share of a tile's life,
   // two 4-wave workgroups per CU overlap one's epilogue with the other's K loop
@@ -941,7 +927,7 @@ extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, i
                                   nullptr, stream);
 }
 
-static int g_h2_variant = -1;
+#define g_h2_variant naws_knob(NAWS_KNOB_H2)
 
 extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, int64_t slabA,
                                            int64_t planeA, const float* scaleA, const void* B2,
@@ -989,10 +975,6 @@ extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, 
     g.am.sRow = (long long)nseg * M; g.am.sCol = N;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (g_h2_variant < 0) {
-    const char* e = getenv("NAWS_H2_VARIANT");
-    g_h2_variant = e ? atoi(e) : 0;
-  }
   if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
   // fewer 256x256 tiles than CUs (the column remainder of a wgrad split into whole waves)
   if (naws_cdiv(M, 256) * naws_cdiv(N, 256) * batch < 256 && g_h2_variant != 5)
@@ -1111,10 +1093,6 @@ extern "C" int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_
   g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
   hipStream_t s = (hipStream_t)stream;
   if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 1, 4>(g, batch, s);
-  if (g_h2_variant < 0) {
-    const char* e = getenv("NAWS_H2_VARIANT");
-    g_h2_variant = e ? atoi(e) : 0;
-  }
   if (g_h2_variant == 9) return launch_x3<256, 256, 2, 4, 2, 1, 4>(g, batch, s);
   return launch_x3_m16<256, 256, 4, 2, 2, 1, 4, false>(g, batch, s);
 }

@@ -236,12 +236,7 @@ extern "C" int naws_roi_dedup_fwd(const float* boxes, const float* obn_scores, i
   int np2 = DT;                                        // >= one element per thread
   while (np2 < n) np2 <<= 1;
   const size_t lds = (size_t)np2 * 8 + DT * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_dedup_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (naws_allow_lds(roi_dedup_kernel) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(roi_dedup_kernel, dim3(npass), dim3(DT), lds, (hipStream_t)stream, boxes,
                      obn_scores, n, np2, (const DedupPass*)passes, dedup_boxes, rois_out, obn_out,
                      index_out, inv_out, count_out);

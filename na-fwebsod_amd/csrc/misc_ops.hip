@@ -14,6 +14,61 @@ thread_local int g_naws_last_hip_error = 0;
 extern "C" const char* naws_version(void) { return "naws-hip 0.1 (gfx950)"; }
 extern "C" int naws_last_hip_error(void) { return g_naws_last_hip_error; }
 
+// ---- the library's only process-wide state ------------------------------------------------------
+// (1) which (kernel, device) pairs have had their dynamic-LDS limit raised: a cache of an
+// idempotent driver call, correct for any number of devices and host threads; (2) the A/B knobs.
+#include <atomic>
+#include <mutex>
+#include <string.h>
+namespace {
+constexpr int LDS_SLOTS = 512;           // > the number of big-LDS kernel instantiations
+constexpr int MAX_DEV = 256;
+struct LdsSlot { const void* kernel; unsigned long long dev[MAX_DEV / 64]; };
+LdsSlot g_lds_slots[LDS_SLOTS];
+std::mutex g_lds_mutex;
+std::atomic<int> g_knobs[NAWS_KNOB_COUNT] = {{0}, {0}, {0}, {11}, {0}, {42}, {0}};
+const char* const g_knob_names[NAWS_KNOB_COUNT] = {"gemm", "x3", "h2", "conv_ring", "conv_bn",
+                                                    "roi_nw", "wino"};
+}  // namespace
+
+int naws_allow_lds_impl(const void* kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return naws_check_launch();
+  std::lock_guard<std::mutex> lock(g_lds_mutex);
+  LdsSlot* slot = nullptr;
+  if (dev >= 0 && dev < MAX_DEV) {
+    size_t h = ((uintptr_t)kernel >> 4) % LDS_SLOTS;
+    for (int probe = 0; probe < LDS_SLOTS; ++probe, h = (h + 1) % LDS_SLOTS) {
+      if (g_lds_slots[h].kernel == kernel) { slot = &g_lds_slots[h]; break; }
+      if (g_lds_slots[h].kernel == nullptr) { slot = &g_lds_slots[h]; slot->kernel = kernel; break; }
+    }
+    if (slot && (slot->dev[dev >> 6] >> (dev & 63)) & 1ULL) return NAWS_OK;
+  }
+  // (a full table or an out-of-range ordinal just means: set it on every launch)
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return naws_check_launch();
+  if (slot) slot->dev[dev >> 6] |= 1ULL << (dev & 63);
+  return NAWS_OK;
+}
+
+extern "C" int naws_launch_state_reset(void) {
+  std::lock_guard<std::mutex> lock(g_lds_mutex);
+  memset(g_lds_slots, 0, sizeof(g_lds_slots));
+  return NAWS_OK;
+}
+
+int naws_knob(int knob) { return g_knobs[knob].load(std::memory_order_relaxed); }
+
+extern "C" int naws_set_variant(const char* knob, int value) {
+  NAWS_REQUIRE_PTR(knob);
+  for (int i = 0; i < NAWS_KNOB_COUNT; ++i)
+    if (strcmp(knob, g_knob_names[i]) == 0) {
+      g_knobs[i].store(value, std::memory_order_relaxed);
+      return NAWS_OK;
+    }
+  return NAWS_ERR_ARG;
+}
+
 namespace {
 
 constexpr int TB = 256;

@@ -18,6 +18,21 @@ static inline int naws_check_launch() {
   return NAWS_OK;
 }
 
+// Launch attributes are per (kernel, device): a kernel that needs more than 64 KB of dynamic LDS
+// has hipFuncAttributeMaxDynamicSharedMemorySize raised once on EVERY device it is launched on
+// (table in misc_ops.hip, keyed by the kernel's host pointer, one bit per device ordinal;
+// naws_launch_state_reset() forgets it).  Returns NAWS_OK or NAWS_ERR_LAUNCH.
+int naws_allow_lds_impl(const void* kernel, int bytes);
+template <typename K>
+static inline int naws_allow_lds(K kernel, int bytes = 160 * 1024) {
+  return naws_allow_lds_impl(reinterpret_cast<const void*>(kernel), bytes);
+}
+
+// Tuning knobs of the A/B tools (naws_set_variant; defaults below).  None changes a result.
+enum NawsKnob { NAWS_KNOB_GEMM = 0, NAWS_KNOB_X3, NAWS_KNOB_H2, NAWS_KNOB_CONV_RING,
+                NAWS_KNOB_CONV_BN, NAWS_KNOB_ROI_NW, NAWS_KNOB_WINO, NAWS_KNOB_COUNT };
+int naws_knob(int knob);
+
 #define NAWS_REQUIRE_PTR(p) \
   do {                      \
     if ((p) == nullptr) return NAWS_ERR_NULL; \

@@ -652,8 +652,7 @@ extern "C" int naws_roi_pool_f_f16x2_hier_fwd(const float* X, int N, int C, int 
   RoiPlaneOut po;
   po.P = (unsigned short*)planes; po.inv_scale = scales + R; po.amax_words = (const unsigned*)amax_words;
   po.n_words = n_words; po.plane = K * R; po.R = R;
-  const char* env = getenv("NAWS_ROI_NW");          // A/B knob (tools/bench_roi.py): NW * 10 + RG
-  const int nw = env ? atoi(env) : 42;
+  const int nw = naws_knob(NAWS_KNOB_ROI_NW);       // A/B knob (tools/bench_roi.py): NW * 10 + RG
 #define NAWS_ROI_LAUNCH(NWV, RGV)                                                                    \
   hipLaunchKernelGGL((roi_pool_nhwc_xcd_kernel<true, true, NWV, RGV>),                               \
                      dim3((unsigned)(naws_cdiv(R, RGV) * (C / 64))), dim3(64 * NWV),                  \

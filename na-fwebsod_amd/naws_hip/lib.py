@@ -9,7 +9,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libnaws_hip.so')
+# NAWS_LIB: another build of the same ABI (tools/ab_*.py load `make AB=1`'s libnaws_hip_ab.so,
+# which also carries the superseded kernel generations)
+LIB_PATH = os.environ.get('NAWS_LIB') or os.path.join(os.path.dirname(_HERE), 'lib',
+                                                       'libnaws_hip.so')
+# host-side spelling of the library's A/B knobs (the library itself never reads the environment)
+_ENV_KNOBS = {'NAWS_GEMM_VARIANT': 'gemm', 'NAWS_X3_VARIANT': 'x3', 'NAWS_H2_VARIANT': 'h2',
+              'NAWS_CONV_RING': 'conv_ring', 'NAWS_CONV_BN': 'conv_bn', 'NAWS_ROI_NW': 'roi_nw',
+              'NAWS_WINO_VARIANT': 'wino'}
 
 OK, ERR_SHAPE, ERR_ARG, ERR_NULL, ERR_LAUNCH, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 _ERR_NAMES = {
@@ -91,7 +98,8 @@ PROTOTYPES = {
     'naws_conv3x3_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, f32, f32, p, i32,
                                     i32, p],
     'naws_amax_f32': [p, i64, p, p],
-    'naws_debug_conv_stamp_buffer': [p],
+    'naws_launch_state_reset': [],
+    'naws_set_variant': [C.c_char_p, i32],
     'naws_gemm_f32_f16x2_nt_xk': [i32, i32, i32, p, i64, i64, p, p, i64, i64, i32, p, p, i32, p],
     'naws_conv3x3_winograd_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p],
     'naws_gemm_f32_f16x2_nt_amax': [i32, i32, i32, p, i64, i64, p, p, i64, i64, p, p, i32, i32,
@@ -149,7 +157,15 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = argtypes, restype
     _lib = lib
+    for env, knob in _ENV_KNOBS.items():
+        if os.environ.get(env):
+            set_variant(knob, int(os.environ[env]))
     return lib
+
+
+def set_variant(knob, value):
+    """naws_set_variant: choose a kernel form for an A/B run (results never change)."""
+    return call('naws_set_variant', knob.encode(), int(value))
 
 
 def call(name, *args):

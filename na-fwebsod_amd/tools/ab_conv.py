@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Interleaved in-process A/B of the fp16x2 halo-tile conv pipelines (NAWS_CONV_RING: 0 = one-step
+"""(Needs the A/B build: `make -C na-fwebsod_amd/csrc AB=1`, run with
+NAWS_LIB=na-fwebsod_amd/lib/libnaws_hip_ab.so.)  Interleaved in-process A/B of the fp16x2 halo-tile conv pipelines (knob conv_ring: 0 = one-step
 weight prefetch, 3 / 4 / 6 = weight ring of that depth) and channel-tile widths (NAWS_CONV_BN) on
 the VGG-16 layer shapes of a 600 x 1000 image.  Both knobs are read per call, so all variants run
 round-robin in ONE process on the same operands; every variant's output must be bit-identical to
@@ -47,11 +48,8 @@ def main():
         times = [[] for _ in variants]
         for r in range(a.rounds + 1):
             for i, (ring, bn) in enumerate(variants):
-                os.environ['NAWS_CONV_RING'] = str(ring)
-                if bn:
-                    os.environ['NAWS_CONV_BN'] = str(bn)
-                else:
-                    os.environ.pop('NAWS_CONV_BN', None)
+                L.set_variant('conv_ring', ring)
+                L.set_variant('conv_bn', bn or 0)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 ops.conv3x3_nhwc_f16x2(x, w2, b, True, out=outs[i], amax_in=am, dilation=dil)
@@ -85,12 +83,14 @@ def main():
         if a.stamp and dil == 1:
             nwg = a.images * ((h + 7) // 8) * ((w + 31) // 32) * (cout // 64)
             dbg = torch.zeros((nwg * 4, 8), device=dev, dtype=torch.int64)
-            os.environ['NAWS_CONV_RING'] = '4'
-            os.environ.pop('NAWS_CONV_BN', None)
-            L.call('naws_debug_conv_stamp_buffer', dbg.data_ptr())
+            L.set_variant('conv_ring', 4)
+            L.set_variant('conv_bn', 0)
+            stamp = L.load().naws_debug_conv_stamp_buffer      # only in the AB build
+            stamp.argtypes, stamp.restype = [L.p], L.i32
+            stamp(dbg.data_ptr())
             ops.conv3x3_nhwc_f16x2(x, w2, b, True, out=outs[0], amax_in=am, dilation=dil)
             torch.cuda.synchronize()
-            L.call('naws_debug_conv_stamp_buffer', None)
+            stamp(None)
             d = dbg[dbg[:, 4] > 0].double()
             tot = d[:, :6].sum(1, keepdim=True)
             sh = (d[:, :6] / tot).mean(0).tolist()
@@ -100,8 +100,8 @@ def main():
                   'LDS reads %.1f %%  MFMA %.1f %%  halo refill %.1f %%   cycles/wave %.0f (MFMA floor %d)'
                   % (d.shape[0], bn, *[100 * v for v in sh], float(tot.mean()), floor), flush=True)
         del x, wt, w2, outs
-    os.environ.pop('NAWS_CONV_RING', None)
-    os.environ.pop('NAWS_CONV_BN', None)
+    L.set_variant('conv_ring', 11)
+    L.set_variant('conv_bn', 0)
 
 
 if __name__ == '__main__':

@@ -12,6 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from detectron.datasets import synthetic  # noqa: E402
+from naws_hip import lib as L  # noqa: E402
 from naws_hip.engine import WsddnEngine  # noqa: E402
 
 
@@ -41,10 +42,10 @@ def main():
         for k, v in base.items():
             setattr(eng, k, v)
         for k in [k for c in cases for k in c if k.isupper()]:
-            os.environ.pop(k, None)
+            L.set_variant(L._ENV_KNOBS[k], {'NAWS_CONV_RING': 11, 'NAWS_ROI_NW': 42}.get(k, 0))
         for k, v in kv.items():
             if k.isupper():
-                os.environ[k] = v
+                L.set_variant(L._ENV_KNOBS[k], int(v))
             else:
                 setattr(eng, k, type(base[k])(int(v)))
 

@@ -67,13 +67,9 @@ def main():
         for r in range(a.rounds + 1):
             for i, l in enumerate(libs):
                 if first[i] and i < len(a.env) and a.env[i] != '-':
-                    k, v = a.env[i].split('=')
-                    os.environ[k] = v
-                    g0 = cases[0][2]   # a tiny launch on the first case's buffers latches the knob
-                    rc = l.naws_gemm_f32(0, 1, 256, 256, 32, g0[5], 32, g0[7], 32, g0[9], 256, 1,
-                                         0, 0, 0, 0, None, 0, None, 0, 1.0, 0.0, 0, 0, st)
-                    assert rc == 0, rc
-                    del os.environ[k]
+                    k, v = a.env[i].split('=')      # NAWS_GEMM_VARIANT=4 -> this build's knob
+                    l.naws_set_variant.argtypes = [C.c_char_p, C.c_int]
+                    assert l.naws_set_variant(L._ENV_KNOBS[k].encode(), int(v)) == 0
                 first[i] = False
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()

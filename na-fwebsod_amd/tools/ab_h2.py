@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved in-process A/B of the fp16x2 GEMM kernel variants (NAWS_H2_VARIANT) on the fc6 / fc7
-shapes: the library is loaded once per variant (copies under /tmp, so each has its own latched
-knob), all variants run round-robin in ONE process on the same random operands, and every
+shapes: the form is selected per call
+with naws_set_variant("h2", v), all variants run round-robin in ONE process on the same random operands, and every
 variant's result is checked against a float64 product of the split operands on a sample of
 output entries.  (Perf deltas between separate runs or boxes are not comparable: DVFS, device
 spread - cdna_hip_programming.md rule 24.)
@@ -59,17 +59,15 @@ def main():
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     st = torch.cuda.current_stream().cuda_stream
-    tmp = tempfile.mkdtemp(prefix='naws_ab_')
-    libs = []
-    for v in a.variants:
-        os.environ['NAWS_H2_VARIANT'] = str(v)
-        lib = bind(v, tmp)
-        # latch the knob with a tiny launch
-        x = ops.split_f16x2(torch.randn(256, 64, device=dev))
-        call(lib, x, x, torch.empty(256, 256, device=dev), st)
-        torch.cuda.synchronize()
-        libs.append(lib)
-    del os.environ['NAWS_H2_VARIANT']
+    # one library; the form is chosen per call through naws_set_variant("h2", v)
+    class _Variant(object):
+        def __init__(self, v):
+            self.v = v
+
+        def __getattr__(self, name):
+            L.set_variant('h2', self.v)
+            return getattr(L.load(), name)
+    libs = [_Variant(v) for v in a.variants]
     R = a.rows
     kr = (R + 31) // 32 * 32
     cases = [('fc6 fwd  ', (R, 25088), (8192, 25088), None),

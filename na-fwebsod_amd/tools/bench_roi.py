@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from detectron.datasets import synthetic  # noqa: E402
-from naws_hip import ops  # noqa: E402
+from naws_hip import lib as L, ops  # noqa: E402
 
 
 def main():
@@ -26,7 +26,7 @@ def main():
     for r in range(8):
         for name, kw, nw in variants:
             if nw is not None:
-                os.environ['NAWS_ROI_NW'] = nw
+                L.set_variant('roi_nw', int(nw))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             out = ops.roi_pool_f_f16x2(x, rois, amax, 7, 7, 0.125, boost=boost, **kw)

@@ -97,3 +97,21 @@ def test_argument_validation_happens_before_any_launch():
     # MinEntropyLoss
     assert L.naws_min_entropy_loss_fwd(a, a, 0, 4, a, none) == lib.ERR_SHAPE
     assert L.naws_min_entropy_loss_bwd(a, a, none, 2, 4, a, none) == lib.ERR_NULL
+
+
+def test_process_wide_state_entry_points():
+    """include/naws.h lists the library's only process-wide state: the per-(kernel, device)
+    launch-attribute record (resettable) and the A/B knobs (unknown knob = NAWS_ERR_ARG);
+    neither needs a GPU to be exercised, and the library reads no environment variables."""
+    from naws_hip import lib
+    L = lib.load()
+    assert L.naws_launch_state_reset() == lib.OK
+    for knob in ('gemm', 'x3', 'h2', 'conv_ring', 'conv_bn', 'roi_nw', 'wino'):
+        assert L.naws_set_variant(knob.encode(), 0 if knob not in ('conv_ring', 'roi_nw')
+                                  else {'conv_ring': 11, 'roi_nw': 42}[knob]) == lib.OK
+    assert L.naws_set_variant(b'no_such_knob', 1) == lib.ERR_ARG
+    assert L.naws_set_variant(None, 1) == lib.ERR_NULL
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--undefined-only', lib.LIB_PATH], stdout=subprocess.PIPE,
+                         text=True).stdout
+    assert 'getenv' not in out
