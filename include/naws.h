@@ -15,7 +15,7 @@
  * naws_last_hip_error(); (2) a per-(kernel, device) record of which kernels
  * have had their dynamic-LDS limit raised - a cache of an idempotent driver
  * call, see naws_launch_state_reset(); (3) the A/B knobs of
- * naws_set_variant(), which never change a result.  It reads no environment
+ * naws_set_variant() (accumulation order at most).  It reads no environment
  * variables.
  *
  * All tensors are dense fp32 unless noted.  "ref:" citations are relative to
@@ -572,7 +572,12 @@ int naws_roi_entropy_fwd(const float* S, const float* C, int n, int num_classes,
  *   naws_dedup_pass records.  Outputs per pass (stride n): rois_out fp32 [npass][n][5] (the unique
  *   rois in np.unique's ascending-hash order, column 0 = batch_index), obn_out fp32 [npass][n],
  *   index_out int32 [npass][n] (first occurrence of each unique roi), inv_out int32 [npass][n]
- *   (scores_unique[inv] = scores in proposal order), count_out int32 [npass].  n <= 16384.
+ *   (scores_unique[inv] = scores in proposal order), count_out int32 [npass].  n <= 16384
+ *   (NAWS_ERR_UNSUPPORTED beyond).  Caller's contract (the pass records live on the device, the
+ *   entry cannot check it): every projected coordinate c satisfies |c| * dedup_boxes < 562, so
+ *   that the hash stays below 2^49 inside the 64-bit sort key (hash << 14 | index); the reference
+ *   default 1/16 allows 8992 px.  naws_hip.ops / core/test_wsl.py fall back to the host path
+ *   otherwise.
  * naws_tta_accumulate — acc[n][k] (=, when first) += scores[inv_index[r]][:] (inv_index nullable =
  *   identity): the scatter-back of :173-176 fused with the running sum of np.mean (:260-261).
  * naws_tta_finish — acc = float32(double(acc) / npass) (numpy's mean division).
@@ -616,7 +621,8 @@ int naws_gemm_f32_f16x2_nt_xk(int M, int N, int K, const void* A2, int64_t slabA
  * drops the attribute - call this to make it forget.  Always safe to call. */
 int naws_launch_state_reset(void);
 /* Select a tile / pipeline form for the A/B tools (na-fwebsod_amd/tools/ab_*.py): knob in
- * {"gemm", "x3", "h2", "conv_ring", "conv_bn", "roi_nw", "wino"}; no form changes a result.
+ * {"gemm", "x3", "h2", "conv_ring", "conv_bn", "roi_nw", "wino"}; a form may change the
+ * fp32 accumulation order (last bits), never the arithmetic.
  * Unknown knob: NAWS_ERR_ARG.  The library never reads the environment. */
 int naws_set_variant(const char* knob, int value);
 

@@ -85,6 +85,10 @@ def _defaults():
                 'AREA_TH_LO': 50 ** 2, 'AREA_TH_HI': 180 ** 2, 'ASPECT_RATIOS': (),
                 'ASPECT_RATIO_H_FLIP': False,
             },
+            # core/config.py:408-435: soft NMS (overlap threshold = TEST.NMS) and box voting
+            'SOFT_NMS': {'ENABLED': False, 'METHOD': 'linear', 'SIGMA': 0.5},
+            'BBOX_VOTE': {'ENABLED': False, 'VOTE_TH': 0.8, 'SCORING_METHOD': 'ID',
+                          'SCORING_METHOD_BETA': 1.0},
         },
         'SOLVER': {
             'BASE_LR': 0.001, 'LR_POLICY': 'step', 'GAMMA': 0.1, 'STEP_SIZE': 30000,

@@ -6,6 +6,8 @@ import torch
 
 from detectron.core.config import cfg
 from detectron.roi_data.minibatch_wsl import get_im_scale, im_list_to_blob, prep_im_for_blob
+from detectron.utils import boxes as box_utils
+from detectron.utils import image as image_utils
 
 
 def dedup_rois(rois, dedup_boxes):
@@ -45,7 +47,8 @@ def _device_image_blob(dev, im, im_scale, flip):
 
 def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_scores, flip=False):
     """im: HxWx3 BGR float/uint8; boxes [n,4] in image pixels (already mirrored when `flip`)
-    -> (scores [n, C+1], boxes).  `flip` mirrors the image horizontally."""
+    -> (scores [n, K], pred_boxes [n, 4K]: with TEST.BBOX_REG False the proposals repeated once
+    per class, core/test_wsl.py:166-168).  `flip` mirrors the image horizontally."""
     dev = executor.device
     im_scale = get_im_scale(im.shape[:2], target_scale, target_max_size)
     data = _device_image_blob(dev, im, im_scale, flip)
@@ -66,7 +69,7 @@ def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_score
     scores = scores.reshape([-1, scores.shape[-1]])
     if inv_index is not None:
         scores = scores[inv_index, :]
-    return scores, boxes
+    return scores, np.tile(boxes, (1, scores.shape[1]))
 
 
 # ---------------------------------------------------------------------------------------
@@ -76,24 +79,33 @@ def im_detect_bbox(executor, im, target_scale, target_max_size, boxes, obn_score
 # an image runs on the GPU in one launch pair (naws_nms_sorted_fwd, same arithmetic as the
 # reference's cython loop), with the numpy `nms` below as the host form.
 # ---------------------------------------------------------------------------------------
-def flip_boxes(boxes, im_width):
-    """Horizontal flip of [n,4] boxes (utils/boxes.py `flip_boxes`)."""
-    out = boxes.copy()
-    out[:, 0::4] = im_width - boxes[:, 2::4] - 1
-    out[:, 2::4] = im_width - boxes[:, 0::4] - 1
-    return out
+flip_boxes = box_utils.flip_boxes
 
 
 def im_detect_bbox_hflip(executor, im, target_scale, target_max_size, boxes, obn_scores):
-    scores_hf, _ = im_detect_bbox(executor, im, target_scale, target_max_size,
-                                  flip_boxes(boxes, im.shape[1]), obn_scores, flip=True)
-    return scores_hf, boxes        # scores refer to the un-flipped proposals, in order
+    """Detection on the mirrored image (:284-310): the proposals are mirrored, and the returned
+    boxes are the mirrored predictions mirrored back (in float32: equal to the proposals for
+    integer-valued boxes, which is what the 'ID' coordinate heuristic asserts)."""
+    im_width = im.shape[1]
+    scores_hf, boxes_hf = im_detect_bbox(executor, im, target_scale, target_max_size,
+                                         flip_boxes(boxes, im_width), obn_scores, flip=True)
+    return scores_hf, flip_boxes(boxes_hf, im_width)
 
 
 def im_detect_bbox_scale(executor, im, target_scale, target_max_size, boxes, obn_scores,
                          hflip=False):
     fn = im_detect_bbox_hflip if hflip else im_detect_bbox
     return fn(executor, im, target_scale, target_max_size, boxes, obn_scores)
+
+
+def im_detect_bbox_aspect_ratio(executor, im, aspect_ratio, boxes, obn_scores, hflip=False):
+    """Detection at a width-relative aspect ratio (:330-363): image and proposals are stretched,
+    the predictions are mapped back with 1 / aspect_ratio."""
+    im_ar = image_utils.aspect_ratio_rel(im, aspect_ratio)
+    boxes_ar = box_utils.aspect_ratio(boxes, aspect_ratio)
+    fn = im_detect_bbox_hflip if hflip else im_detect_bbox
+    scores_ar, pred_ar = fn(executor, im_ar, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes_ar, obn_scores)
+    return scores_ar, box_utils.aspect_ratio(pred_ar, 1.0 / aspect_ratio)
 
 
 def im_detect_bbox_pair(executor, im, target_scale, target_max_size, boxes, obn_scores):
@@ -133,14 +145,13 @@ def im_detect_bbox_pair(executor, im, target_scale, target_max_size, boxes, obn_
 
 
 def im_detect_bbox_aug(executor, im, boxes, obn_scores):
-    """hflip at TEST.SCALE, each BBOX_AUG.SCALES (+flip), identity last; scores combined by
-    BBOX_AUG.SCORE_HEUR ('ID' | 'AVG' | 'UNION'), boxes by COORD_HEUR."""
+    """hflip at TEST.SCALE, each BBOX_AUG.SCALES (+flip), each BBOX_AUG.ASPECT_RATIOS (+flip),
+    identity last (:181-281); scores combined by BBOX_AUG.SCORE_HEUR ('ID' | 'AVG' | 'UNION'),
+    boxes by COORD_HEUR.  -> (scores_c, boxes_c [., 4K])."""
     aug = cfg.TEST.BBOX_AUG
     assert not aug.SCALE_SIZE_DEP, 'Size dependent scaling not implemented'
     assert (aug.SCORE_HEUR == 'UNION') == (aug.COORD_HEUR == 'UNION'), \
         'Score and coord heuristics must be UNION together'
-    if aug.ASPECT_RATIOS:
-        raise NotImplementedError('aspect-ratio augmentation is not used by the na_wsddn configs')
     scores_ts, boxes_ts = [], []
 
     def add(s, b):
@@ -154,25 +165,32 @@ def im_detect_bbox_aug(executor, im, boxes, obn_scores):
     # reference's order: hflip at TEST.SCALE, each aug scale (+ its flip), identity last
     pair = bool(cfg.NAWS.TTA_PAIR_FLIPS)
     scores_i = None
+    k = cfg.MODEL.NUM_CLASSES
+    tiled = np.tile(boxes, (1, k))                               # what im_detect_bbox returns
+    tiled_hf = flip_boxes(flip_boxes(tiled, im.shape[1]), im.shape[1])      # ... and _hflip
     if aug.H_FLIP:
         if pair:
             scores_i, s_hf = im_detect_bbox_pair(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE,
                                                  boxes, obn_scores)
-            add(s_hf, boxes)
+            add(s_hf, tiled_hf)
         else:
             add(*im_detect_bbox_hflip(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes,
                                       obn_scores))
     for scale in aug.SCALES:
         if pair and aug.SCALE_H_FLIP:
             s0, s1 = im_detect_bbox_pair(executor, im, scale, aug.MAX_SIZE, boxes, obn_scores)
-            add(s0, boxes)
-            add(s1, boxes)
+            add(s0, tiled)
+            add(s1, tiled_hf)
             continue
         add(*im_detect_bbox_scale(executor, im, scale, aug.MAX_SIZE, boxes, obn_scores))
         if aug.SCALE_H_FLIP:
             add(*im_detect_bbox_scale(executor, im, scale, aug.MAX_SIZE, boxes, obn_scores,
                                       hflip=True))
-    boxes_i = boxes
+    for ar in aug.ASPECT_RATIOS:
+        add(*im_detect_bbox_aspect_ratio(executor, im, ar, boxes, obn_scores))
+        if aug.ASPECT_RATIO_H_FLIP:
+            add(*im_detect_bbox_aspect_ratio(executor, im, ar, boxes, obn_scores, hflip=True))
+    boxes_i = tiled
     if scores_i is None:
         scores_i, boxes_i = im_detect_bbox(executor, im, cfg.TEST.SCALE, cfg.TEST.MAX_SIZE, boxes,
                                            obn_scores)
@@ -234,6 +252,11 @@ def nms_all_classes(scores, boxes):
         from naws_hip import ops
         dev = torch.device('cuda', torch.cuda.current_device())
         sd = torch.as_tensor(np.ascontiguousarray(scores[:, 1:], np.float32), device=dev)
+        if boxes.shape[1] > 4:
+            # [n, 4K] class-tiled: without box regression (the only form this path has) every
+            # class holds the same box, and the launch takes one box set for all classes
+            assert np.array_equal(boxes[:, 4:8], boxes[:, -4:])
+            boxes = boxes[:, 4:8]
         bd = torch.as_tensor(np.ascontiguousarray(boxes, np.float32), device=dev)
         keep = ops.nms_per_class(bd, sd, cfg.TEST.SCORE_THRESH, cfg.TEST.NMS).cpu().numpy()
         return {j: np.where(keep[j - 1])[0] for j in range(1, num_classes)}
@@ -247,16 +270,33 @@ def nms_all_classes(scores, boxes):
 
 
 def box_results_with_nms_and_limit(scores, boxes):
-    """Per-class score threshold, NMS, then keep the DETECTIONS_PER_IM best over all classes.
+    """Per-class score threshold, NMS (greedy, or TEST.SOFT_NMS), optional TEST.BBOX_VOTE
+    refinement, then the DETECTIONS_PER_IM best over all classes (core/test_wsl.py:803-863).
     -> (scores, boxes, cls_boxes) with cls_boxes[j] = [n_j,5] for class j (0 = background)."""
     num_classes = cfg.MODEL.NUM_CLASSES
     cls_boxes = [np.zeros((0, 5), np.float32) for _ in range(num_classes)]
-    kept = nms_all_classes(scores, boxes)
-    for j in range(1, num_classes):
-        inds = kept[j]
+    soft, vote = cfg.TEST.SOFT_NMS.ENABLED, cfg.TEST.BBOX_VOTE.ENABLED
+    kept = None if soft else nms_all_classes(scores, boxes)
+
+    def dets_of(j, inds):
         bj = boxes[inds, j * 4:(j + 1) * 4] if boxes.shape[1] > 4 else boxes[inds, :]
-        cls_boxes[j] = np.hstack((bj, scores[inds, j][:, np.newaxis])).astype(np.float32,
-                                                                              copy=False)
+        return np.hstack((bj, scores[inds, j][:, np.newaxis])).astype(np.float32, copy=False)
+
+    for j in range(1, num_classes):
+        dets_j = None
+        if soft or vote:
+            dets_j = dets_of(j, np.where(scores[:, j] > cfg.TEST.SCORE_THRESH)[0])
+        if soft:
+            # the overlap threshold is TEST.NMS, the discard threshold the reference's literal 1e-4
+            nms_dets, _ = box_utils.soft_nms(dets_j, sigma=cfg.TEST.SOFT_NMS.SIGMA,
+                                             overlap_thresh=cfg.TEST.NMS, score_thresh=0.0001,
+                                             method=cfg.TEST.SOFT_NMS.METHOD)
+        else:
+            nms_dets = dets_of(j, kept[j])
+        if vote and nms_dets.shape[0] > 0:
+            nms_dets = box_utils.box_voting(nms_dets, dets_j, cfg.TEST.BBOX_VOTE.VOTE_TH,
+                                            scoring_method=cfg.TEST.BBOX_VOTE.SCORING_METHOD)
+        cls_boxes[j] = nms_dets
     if cfg.TEST.DETECTIONS_PER_IM > 0:
         all_scores = np.hstack([cls_boxes[j][:, -1] for j in range(1, num_classes)])
         if len(all_scores) > cfg.TEST.DETECTIONS_PER_IM:
@@ -285,13 +325,27 @@ def tta_passes():
     return out
 
 
-def device_post_supported(executor, im):
+DEDUP_MAX_N = 16384                 # naws_roi_dedup_fwd: the bitonic sort's LDS image
+DEDUP_MAX_HASH_COORD = 562.0        # |coord| * DEDUP_BOXES below this keeps the hash < 2^49
+
+
+def device_post_supported(executor, im, n_proposals=None):
+    """Whether im_detect_all_device can take this image: the cfg combination it implements, a
+    proposal count its sort holds (0 < n <= 16384) and projected coordinates whose dedup hash
+    fits the device key (include/naws.h, naws_roi_dedup_fwd); otherwise the numpy path runs."""
     aug = cfg.TEST.BBOX_AUG
-    return bool(cfg.NAWS.DEVICE_POST and cfg.NAWS.DEVICE_PREP and cfg.DEDUP_BOXES > 0
-                and not cfg.NAWS.HOST_NMS and getattr(executor, 'engine', None) is not None
-                and im.dtype == np.uint8
-                and (not aug.ENABLED or (aug.SCORE_HEUR in ('AVG', 'ID') and aug.COORD_HEUR == 'ID'
-                                         and not aug.ASPECT_RATIOS and not aug.SCALE_SIZE_DEP)))
+    if not (cfg.NAWS.DEVICE_POST and cfg.NAWS.DEVICE_PREP and cfg.DEDUP_BOXES > 0
+            and not cfg.NAWS.HOST_NMS and getattr(executor, 'engine', None) is not None
+            and im.dtype == np.uint8
+            and not cfg.TEST.SOFT_NMS.ENABLED and not cfg.TEST.BBOX_VOTE.ENABLED
+            and (not aug.ENABLED or (aug.SCORE_HEUR in ('AVG', 'ID') and aug.COORD_HEUR == 'ID'
+                                     and not aug.ASPECT_RATIOS and not aug.SCALE_SIZE_DEP))):
+        return False
+    if n_proposals is not None and not 0 < n_proposals <= DEDUP_MAX_N:
+        return False
+    h, w = im.shape[:2]
+    top = max(get_im_scale((h, w), s, m) for s, m, _f in tta_passes()) * max(h, w)
+    return top * cfg.DEDUP_BOXES < DEDUP_MAX_HASH_COORD
 
 
 def im_detect_all_device(executor, im, box_proposals, obn_scores):
@@ -386,7 +440,7 @@ def im_detect_all_device(executor, im, box_proposals, obn_scores):
 
 
 def im_detect_all(executor, im, box_proposals, obn_scores):
-    if device_post_supported(executor, im):
+    if device_post_supported(executor, im, len(box_proposals)):
         return im_detect_all_device(executor, im, box_proposals, obn_scores)
     if cfg.TEST.BBOX_AUG.ENABLED:
         scores, boxes = im_detect_bbox_aug(executor, im, box_proposals, obn_scores)

@@ -17,9 +17,11 @@ _DATASETS = {
     'flickr_voc': {_IM_DIR: _DATA_DIR + '/flickr_voc/images', _ANN_FN: _DATA_DIR + '/flickr_voc/images.json',
                    _DEVKIT_DIR: _DATA_DIR + '/VOC2007/VOCdevkit2007'},
     'flickr_coco': {_IM_DIR: _DATA_DIR + '/flickr_coco/images',
-                    _ANN_FN: _DATA_DIR + '/flickr_coco/images.json'},
-    'flickr_clean': {_IM_DIR: _DATA_DIR + '/flickr_clean/images',
-                     _ANN_FN: _DATA_DIR + '/flickr_clean/images.json',
+                    _ANN_FN: _DATA_DIR + '/flickr_coco/images.json',
+                    _DEVKIT_DIR: _DATA_DIR + '/VOC2007/VOCdevkit2007'},
+    # (upstream spells these two 'image', not 'images': dataset_catalog.py:253-260)
+    'flickr_clean': {_IM_DIR: _DATA_DIR + '/flickr_clean/image',
+                     _ANN_FN: _DATA_DIR + '/flickr_clean/image.json',
                      _DEVKIT_DIR: _DATA_DIR + '/VOC2007/VOCdevkit2007'},
     'coco_2014_train': {_IM_DIR: _DATA_DIR + '/coco/coco_train2014',
                         _ANN_FN: _DATA_DIR + '/coco/annotations/instances_train2014.json'},

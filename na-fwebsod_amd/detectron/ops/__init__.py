@@ -196,7 +196,8 @@ def BoxWithNMSLimit(scores, boxes, score_thresh=0.05, nms=0.3, detections_per_im
     [n, K] (column 0 = background), boxes [n, 4K] class-tiled -> (scores_nms [m], boxes_nms [m,4],
     classes_nms [m] float): per class 1..K-1 the candidates above score_thresh after greedy NMS
     (naws_nms_sorted_fwd: all classes in one launch pair), in descending score order, classes
-    concatenated; the image-wide detections_per_im cut keeps the highest scores."""
+    concatenated; the image-wide detections_per_im cut keeps exactly the detections_per_im highest
+    scores."""
     n, k = scores.shape
     fg = scores[:, 1:].contiguous()
     keep = _k.nms_per_class(boxes.contiguous(), fg, score_thresh, nms)            # [K-1, n] bool
@@ -211,8 +212,12 @@ def BoxWithNMSLimit(scores, boxes, score_thresh=0.05, nms=0.3, detections_per_im
     s = st[classes - 1, rows]
     b = boxes.view(n, k, 4)[rows, classes]
     if detections_per_im > 0 and s.numel() > detections_per_im:
-        th = torch.sort(s).values[-detections_per_im]
-        m = s >= th
+        # the op sorts all kept (class, row) entries by score and keeps exactly the first
+        # detections_per_im of them (ties beyond the limit are dropped; which of equal scores
+        # survives is unspecified upstream - std::sort - and is the earlier (class, row) here)
+        top = torch.sort(s, descending=True, stable=True).indices[:detections_per_im]
+        m = torch.zeros_like(s, dtype=torch.bool)
+        m[top] = True
         s, b, classes = s[m], b[m], classes[m]
     return s.contiguous(), b.contiguous(), classes.to(torch.float32)
 

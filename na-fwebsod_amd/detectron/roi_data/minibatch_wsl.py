@@ -128,6 +128,27 @@ def resize_linear(im, im_scale):
     return (rows[sy] * b0[:, None, None] + rows[sy1] * b1[:, None, None]).astype(np.float32)
 
 
+def resize_linear_xy(im, ow, oh):
+    """cv2.resize(im, dsize=(ow, oh)) on a float32 image: per-axis scale = source / destination
+    size (a double), otherwise the taps of resize_linear."""
+    im = np.asarray(im, np.float32)
+    h, w = im.shape[:2]
+
+    def taps(n_dst, n_src):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (float(n_src) / float(n_dst)) - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = f - s0.astype(np.float32)
+        f[s0 < 0] = 0.0
+        s0[s0 < 0] = 0
+        f[s0 >= n_src - 1] = 0.0
+        s0[s0 >= n_src - 1] = n_src - 1
+        return s0, np.minimum(s0 + 1, n_src - 1), np.float32(1) - f, f
+    sx, sx1, a0, a1 = taps(ow, w)
+    sy, sy1, b0, b1 = taps(oh, h)
+    rows = im[:, sx, :] * a0[None, :, None] + im[:, sx1, :] * a1[None, :, None]
+    return (rows[sy] * b0[:, None, None] + rows[sy1] * b1[:, None, None]).astype(np.float32)
+
+
 def get_im_scale(shape_hw, target_size, max_size):
     size_min, size_max = min(shape_hw), max(shape_hw)
     im_scale = float(target_size) / float(size_min)

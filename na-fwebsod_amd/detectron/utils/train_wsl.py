@@ -61,7 +61,6 @@ def train_model(roidb=None, max_iter=None, printer=print):
     # values, the log lines and their iteration numbers are unchanged; the NaN / failed-loader stop
     # comes one iteration later.
     lag = bool(cfg.NAWS.LAGGED_STATS)
-    pending = None
 
     def account(it, it_lr, handle, my_ok):
         vals, all_ok = finish_iteration_values(handle)
@@ -81,26 +80,25 @@ def train_model(roidb=None, max_iter=None, printer=print):
         if np.isnan(stats.iter_total_loss):
             handle_critical_error(model, 'Loss is NaN')
 
-    for cur_iter in range(start_iter, last):
+    def run(cur_iter, batch):
         stats.IterTic()
         lr = model.UpdateWorkspaceLr(cur_iter, lr_policy.get_lr_at_iter(cur_iter))
         executor.feed(batch)
         executor.run()
-        batch, ok = stage_batch(loader, device) if cur_iter + 1 < last else (None, True)
-        handle = begin_iteration_values(executor, model, pg, world, ok=ok)
-        if pending is not None:
-            account(*pending)
-            pending = None
-        if lag and cur_iter + 1 < last and (cur_iter + 1) % period != 0:
-            pending = (cur_iter, lr, handle, ok)
-        else:
-            account(cur_iter, lr, handle, ok)
+        return lr
+
+    def after(cur_iter):
         stats.IterToc()
         if (cur_iter + 1) % period == 0 and cur_iter > start_iter and rank == 0:
             checkpoints[cur_iter] = os.path.join(output_dir, 'model_iter{}.pkl'.format(cur_iter))
             nu.save_model_to_weights_file(checkpoints[cur_iter], model, executor)
         if cur_iter == start_iter + stats.LOG_PERIOD:
             stats.ResetIterTimer()
+
+    pipelined_iterations(start_iter, last, period, lag, (batch, ok), run,
+                         lambda: stage_batch(loader, device),
+                         lambda ok_: begin_iteration_values(executor, model, pg, world, ok=ok_),
+                         account, after)
     if executor.engine is not None:
         executor.engine.flush()
     if rank == 0:
@@ -108,6 +106,40 @@ def train_model(roidb=None, max_iter=None, printer=print):
         nu.save_model_to_weights_file(checkpoints['final'], model, executor)
     loader.shutdown()
     return checkpoints
+
+
+def pipelined_iterations(start_iter, last, period, lag, first, run, stage, begin, account,
+                         after=None):
+    """The loop of train_model over callables (so that tests/test_distributed_cpu.py can drive it
+    over gloo): run(i, batch) -> lr enqueues iteration i; stage() -> (batch, ok) stages the next
+    batch; begin(ok) -> handle queues the iteration's scalars + the ok flag (one all-reduce);
+    account(i, lr, handle, ok) reads them and raises on a failed loader / NaN.
+
+    With `lag` the scalars of iteration i are read after iteration i+1 has been enqueued.  A rank
+    whose loader fails while staging the batch of iteration i+1 therefore cannot stop at once:
+    the other ranks will enqueue iteration i+1's collectives before any of them reads the flag.
+    It runs iteration i+1 as well - on its previous batch, whose results nobody will use - so
+    that every rank has issued the same collectives when all of them raise in account()."""
+    batch, ok = first
+    pending, prev = None, None
+    for cur_iter in range(start_iter, last):
+        if batch is None:
+            if pending is None or prev is None:
+                raise RuntimeError('no batch for iteration %d' % cur_iter)
+            batch = prev
+        lr = run(cur_iter, batch)
+        prev = batch
+        batch, ok = stage() if cur_iter + 1 < last else (None, True)
+        handle = begin(ok)
+        if pending is not None:
+            account(*pending)
+            pending = None
+        if lag and cur_iter + 1 < last and (cur_iter + 1) % period != 0:
+            pending = (cur_iter, lr, handle, ok)
+        else:
+            account(cur_iter, lr, handle, ok)
+        if after is not None:
+            after(cur_iter)
 
 
 def stage_batch(loader, device):
@@ -149,9 +181,15 @@ def begin_iteration_values(executor, model, pg, world, ok=True):
     names = []
     labels = ws['labels_int32'].reshape(-1).to(torch.int64)
     accs = []
-    for k, blob in (('accuracy_cls', 'cls_prob'), ('accuracy_cls_noise', 'cls_prob_noise')):
-        if k in model.metrics and blob in ws:
-            p = ws[blob].reshape(labels.numel(), -1)
+    fused = {'accuracy_cls': 'cls_prob', 'accuracy_cls_noise': 'cls_prob_noise'}
+    for k in model.metrics:
+        if k in ws:
+            # the op-by-op plan ran the graph's own Accuracy op (OICR: accuracy_cls1..3 too)
+            accs.append(ws[k].reshape(-1).float().mean().to(dev))
+            names.append(k)
+        elif k in fused and fused[k] in ws:
+            # the fused engine keeps cls_prob only: top-1 against labels_int32 on the device
+            p = ws[fused[k]].reshape(labels.numel(), -1)
             accs.append((p.argmax(1) == labels.to(p.device)).float().mean())
             names.append(k)
     if accs:

@@ -514,7 +514,11 @@ class WsddnEngine(object):
         for _ in range(3):
             h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
         mid = torch.empty((n, h, w, 256), device=self.device, dtype=torch.float32)
-        shared = torch.zeros((1,), device=self.device, dtype=torch.int32)   # max|pool3| over images
+        # max|pool3| per image (bit patterns of non-negative floats: integer order = float order).
+        # One word per chain, reduced after the join: a chain whose last layer takes the Winograd
+        # route zeroes its word itself (winograd.hip), which would erase another chain's maximum
+        # in a shared word
+        words = torch.zeros((n,), device=self.device, dtype=torch.int32)
         main = torch.cuda.current_stream(self.device)
         start = main.record_event()
         while len(self._streams) < n:
@@ -523,11 +527,12 @@ class WsddnEngine(object):
             st = self._streams[i]
             st.wait_event(start)
             with torch.cuda.stream(st):
-                y = self._conv_chain(data[i:i + 1], first=0, end=cut, amax_last=shared)
+                y = self._conv_chain(data[i:i + 1], first=0, end=cut, amax_last=words[i:i + 1])
                 mid[i:i + 1].copy_(y)
                 done = st.record_event()
             main.wait_event(done)
         self._pool_done = True              # pool3 was taken (fused or not) inside the chains
+        shared = words.max().view(1)
         return self._conv_chain(None, amax_final=self._amax5, first=cut, x=mid, bound_in=shared)
 
     def _seg_to_device(self, seg):

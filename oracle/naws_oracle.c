@@ -369,6 +369,68 @@ int oracle_nms(const float* dets /* [n][5] x1 y1 x2 y2 score */, const int64_t* 
   return kept;
 }
 
+/* Soft-NMS.  ref: detectron/utils/cython_nms.pyx:98-203 (`soft_nms`), statement for statement:
+ * in place on a copy of the [n][5] detections; position i takes the first maximum of positions
+ * i..N-1 (swap), every later box overlapping it (iw > 0 and ih > 0, +1 pixel convention) has its
+ * score multiplied by weight (method 1 linear: 1 - ov if ov > Nt; 2 gaussian: exp(-ov*ov/sigma),
+ * np.exp = double exp of the float quotient stored back to float; else hard: 0 if ov > Nt) and,
+ * when the new score is below `threshold`, is overwritten by box N-1 (N shrinks, the position is
+ * examined again).  All cdef variables are C float; `ua = float(...)` is a double conversion of a
+ * float expression stored to a float.  Outputs boxes[:N] and inds[:N]; returns N. */
+int oracle_soft_nms(const float* boxes_in, int n, float sigma, float Nt, float threshold,
+                    int method, float* boxes /* [n][5] */, int64_t* inds /* [n] */) {
+  unsigned int N = (unsigned int)n;
+  for (int i = 0; i < n * 5; ++i) boxes[i] = boxes_in[i];
+  for (int i = 0; i < n; ++i) inds[i] = i;
+  const unsigned int N0 = N;                 /* `for i in range(N)`: the bound is taken once */
+  for (unsigned int i = 0; i < N0; ++i) {
+    float maxscore = boxes[i * 5 + 4];
+    unsigned int maxpos = i;
+    float tx1 = boxes[i * 5 + 0], ty1 = boxes[i * 5 + 1], tx2 = boxes[i * 5 + 2];
+    float ty2 = boxes[i * 5 + 3], ts = boxes[i * 5 + 4];
+    int64_t ti = inds[i];
+    unsigned int pos = i + 1;
+    while (pos < N) {                        /* get max box */
+      if (maxscore < boxes[pos * 5 + 4]) { maxscore = boxes[pos * 5 + 4]; maxpos = pos; }
+      pos = pos + 1;
+    }
+    for (int c = 0; c < 5; ++c) boxes[i * 5 + c] = boxes[maxpos * 5 + c];
+    inds[i] = inds[maxpos];
+    boxes[maxpos * 5 + 0] = tx1; boxes[maxpos * 5 + 1] = ty1; boxes[maxpos * 5 + 2] = tx2;
+    boxes[maxpos * 5 + 3] = ty2; boxes[maxpos * 5 + 4] = ts;
+    inds[maxpos] = ti;
+    tx1 = boxes[i * 5 + 0]; ty1 = boxes[i * 5 + 1]; tx2 = boxes[i * 5 + 2];
+    ty2 = boxes[i * 5 + 3]; ts = boxes[i * 5 + 4];
+    pos = i + 1;
+    while (pos < N) {
+      const float x1 = boxes[pos * 5 + 0], y1 = boxes[pos * 5 + 1];
+      const float x2 = boxes[pos * 5 + 2], y2 = boxes[pos * 5 + 3];
+      const float area = (x2 - x1 + 1) * (y2 - y1 + 1);
+      const float iw = ((tx2 < x2 ? tx2 : x2) - (tx1 > x1 ? tx1 : x1) + 1);
+      if (iw > 0) {
+        const float ih = ((ty2 < y2 ? ty2 : y2) - (ty1 > y1 ? ty1 : y1) + 1);
+        if (ih > 0) {
+          const float ua = (float)(double)((tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih);
+          const float ov = iw * ih / ua;
+          float weight;
+          if (method == 1) weight = ov > Nt ? 1 - ov : 1;
+          else if (method == 2) weight = (float)exp((double)(-(ov * ov) / sigma));
+          else weight = ov > Nt ? 0 : 1;
+          boxes[pos * 5 + 4] = weight * boxes[pos * 5 + 4];
+          if (boxes[pos * 5 + 4] < threshold) {
+            for (int c = 0; c < 5; ++c) boxes[pos * 5 + c] = boxes[(N - 1) * 5 + c];
+            inds[pos] = inds[N - 1];
+            N = N - 1;
+            pos = pos - 1;                   /* (unsigned wrap at pos = 0 cannot happen: pos > i) */
+          }
+        }
+      }
+      pos = pos + 1;
+    }
+  }
+  return (int)N;
+}
+
 /* MinEntropyLoss.  ref: detectron/ops/min_entropy_loss_op.cc:7-45 (forward), :47-98 (gradient).
  * X [N,C] probabilities, L [1,C] image labels: over rows n and the classes with L[c] >= 0.5,
  * loss = -sum p log p / norm, p = max(X, 1e-20), norm = number of terms (fp32 serial sum in

@@ -222,6 +222,21 @@ def nms(dets, thresh):
     return np.where(sup == 0)[0]
 
 
+def soft_nms(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method='linear'):
+    """Soft-NMS (ref: detectron/utils/boxes.py:321-338 -> cython_nms.pyx:98-203): [n,5] float32 ->
+    (dets_out [m,5], keep [m] original indices), in the reference's output order."""
+    dets, dp = _f(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return dets, []
+    out = np.empty((n, 5), np.float32)
+    inds = np.empty((n,), np.int64)
+    m = L().oracle_soft_nms(dp, n, C.c_float(sigma), C.c_float(overlap_thresh),
+                            C.c_float(score_thresh), {'hard': 0, 'linear': 1, 'gaussian': 2}[method],
+                            out.ctypes.data_as(_fp), inds.ctypes.data_as(C.c_void_p))
+    return out[:m].copy(), inds[:m].tolist()
+
+
 def roi_label(S, U, L_, CW=None, fg_thresh=0.5, bg_thresh_hi=0.5, bg_thresh_lo=-1.0, top_k=1,
               num_pos=9999, num_neg=9999, stats=None):
     """ref: detectron/ops/roi_label_op.cc:10-123 (see naws_oracle.c).  -> (RL int32 [n], RW [n])."""
@@ -290,8 +305,8 @@ def box_with_nms_limit(scores, boxes, score_thresh=0.05, nms_thresh=0.3, detecti
     image): scores [n, K] (column 0 = background, skipped), boxes [n, 4K] class-tiled.  For
     j = 1..K-1: candidates scores[:, j] > score_thresh, greedy NMS (utils/cython_nms.pyx
     arithmetic), kept in descending score order; the per-class results are concatenated in class
-    order; when more than detections_per_im remain, the lowest-scored are dropped per the
-    image-wide threshold.  Third-party (pytorch v1.3.0 caffe2/operators/box_with_nms_limit_op.cc,
+    order; when more than detections_per_im remain, exactly the detections_per_im highest-scored
+    entries are kept.  Third-party (pytorch v1.3.0 caffe2/operators/box_with_nms_limit_op.cc,
     un-vendored): restated from its published algorithm, PARITY UNPINNED.
     -> (scores_nms [m], boxes_nms [m,4], classes_nms [m] float)."""
     scores = np.asarray(scores, np.float32)
@@ -307,8 +322,12 @@ def box_with_nms_limit(scores, boxes, score_thresh=0.05, nms_thresh=0.3, detecti
         out_c.append(np.full((keep.size,), j, np.float32))
     s, b, c = np.concatenate(out_s), np.concatenate(out_b), np.concatenate(out_c)
     if detections_per_im > 0 and s.size > detections_per_im:
-        th = np.sort(s)[-detections_per_im]
-        m = s >= th
+        # the op sorts every kept (class, index) entry by score and keeps exactly the first
+        # detections_per_im; among equal scores its std::sort is unspecified - first (class, row)
+        # wins here
+        top = np.argsort(-s, kind='stable')[:detections_per_im]
+        m = np.zeros(s.shape, bool)
+        m[top] = True
         s, b, c = s[m], b[m], c[m]
     return s, b.reshape(-1, 4), c
 

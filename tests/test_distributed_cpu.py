@@ -209,3 +209,91 @@ def test_loader_failure_on_one_rank_reaches_every_rank_gloo_world2():
         assert r['it_good'] == (2.5, True)              # mean over both ranks' images
         assert r['it_rank0_bad'] == (2.5, False)
         assert r['stage'] == (None, False)
+
+
+def _lag_worker(rank, world, port, q, lag):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+    import types
+    from detectron.utils import train_wsl
+    pg = dist.group.WORLD
+    log = dict(ran=[], collectives=0, accounted=[], error=None)
+    FAIL_AT = 3            # rank 1's loader dies while staging the batch of iteration 3
+    staged = [0]
+
+    def stage():
+        staged[0] += 1
+        if rank == 1 and staged[0] >= FAIL_AT:
+            return None, False
+        return {'id': staged[0]}, True
+
+    def run(it, batch):
+        assert batch is not None                       # feed(None) was the r2 bug
+        log['ran'].append((it, batch['id']))
+        g = torch.ones(4)
+        dist.all_reduce(g, group=pg)                   # the iteration's gradient exchange
+        log['collectives'] += 1
+        return 1e-3
+
+    def begin(ok):
+        ex = types.SimpleNamespace(ws={'loss_cls': torch.tensor([1.0]),
+                                       'labels_int32': torch.zeros((1,), dtype=torch.int32)})
+        model = types.SimpleNamespace(losses=['loss_cls'], metrics=[])
+        log['collectives'] += 1
+        return train_wsl.begin_iteration_values(ex, model, pg, world, ok=ok)
+
+    def account(it, lr, handle, my_ok):
+        vals, all_ok = train_wsl.finish_iteration_values(handle)
+        if not all_ok:
+            raise RuntimeError('roi_data_loader failed' if not my_ok else
+                               'roi_data_loader failed on another rank')
+        log['accounted'].append(it)
+
+    try:
+        train_wsl.pipelined_iterations(0, 10, 1000, lag, ({'id': 0}, True), run, stage, begin,
+                                       account)
+    except RuntimeError as e:
+        log['error'] = str(e)
+    dist.barrier()                   # no collective is left hanging: both ranks get here
+    q.put((rank, log))
+    dist.destroy_process_group()
+
+
+def _run_lag(lag):
+    world = 2
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lag_worker, args=(r, world, port, q, lag)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def test_lagged_stats_loader_failure_stops_both_ranks_with_matched_collectives():
+    """with NAWS.LAGGED_STATS the failing rank used to die in executor.feed(None) while
+    the other had already enqueued the next iteration's all-reduce.  Now both ranks issue the
+    same collectives and raise at the same iteration."""
+    out = _run_lag(True)
+    a, b = out[0], out[1]
+    assert a['error'] == 'roi_data_loader failed on another rank'
+    assert b['error'] == 'roi_data_loader failed'
+    assert a['collectives'] == b['collectives']
+    assert [i for i, _ in a['ran']] == [i for i, _ in b['ran']] == [0, 1, 2, 3]
+    # rank 1 ran iteration 3 on its previous batch (its results are never accounted)
+    assert b['ran'][-1][1] == b['ran'][-2][1]
+    assert a['accounted'] == b['accounted'] == [0, 1]
+
+
+def test_unlagged_loader_failure_stops_both_ranks_in_the_same_iteration():
+    out = _run_lag(False)
+    a, b = out[0], out[1]
+    assert a['error'] == 'roi_data_loader failed on another rank'
+    assert b['error'] == 'roi_data_loader failed'
+    assert a['collectives'] == b['collectives']
+    assert [i for i, _ in a['ran']] == [i for i, _ in b['ran']] == [0, 1, 2]

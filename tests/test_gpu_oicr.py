@@ -90,6 +90,15 @@ def test_roi_entropy_and_box_with_nms_limit(dev):
                                 detections_per_im=999999)
     assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(c.cpu().numpy(), c_ref)
     assert np.array_equal(b.cpu().numpy(), b_ref)
+    # the image-wide cut: exactly detections_per_im rows, also with ties at the threshold
+    tied = np.round(scores * 8) / 8
+    for lim in (100, 37):
+        sr, br, cr = oracle.box_with_nms_limit(tied, boxes, 1e-11, 0.9, lim)
+        sl, bl, cl = O.BoxWithNMSLimit(_t(tied, dev), _t(boxes, dev), score_thresh=1e-11, nms=0.9,
+                                       detections_per_im=lim)
+        assert sl.numel() == lim == sr.size
+        assert np.array_equal(sl.cpu().numpy(), sr) and np.array_equal(cl.cpu().numpy(), cr)
+        assert np.array_equal(bl.cpu().numpy(), br)
     lines = []
     op = O.RoIEntropy(display=2, num_classes=k - 1, printer=lines.append)
     e = op(s, c)

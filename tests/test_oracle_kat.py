@@ -271,3 +271,9 @@ def test_roi_entropy_and_box_with_nms_limit_known_answers():
     # class 1: boxes 0 and 1 overlap (IoU 81/119 > .5): keep 0 (.9) and 2 (.5); class 2: .7 then .6
     assert np.allclose(s, [.9, .5, .7, .6]) and c.tolist() == [1, 1, 2, 2]
     assert np.array_equal(b, boxes[[0, 2, 2, 1]])
+    # the image-wide cut keeps EXACTLY detections_per_im entries, ties at the cut included
+    # (ADVICE r2): two .7s compete for the second slot, the earlier (class, row) stays
+    scores2 = np.array([[.1, .9, .0], [.1, .8, .7], [.1, .7, .7]], np.float32)
+    s, b, c = oracle.box_with_nms_limit(scores2, np.tile(boxes, (1, 3)), score_thresh=1e-11,
+                                        nms_thresh=0.5, detections_per_im=2)
+    assert np.allclose(s, [.9, .7]) and c.tolist() == [1, 1]
