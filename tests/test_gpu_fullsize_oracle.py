@@ -186,7 +186,8 @@ def test_full_size_bf16_c80_matches_oracle(dev, ref20):
     activations of the oracle are class-count independent (same seeded weights), so its C = 80
     run re-uses conv5_3 / roi_feat and adds the head forward + loss tails.  bf16 operands carry
     8 significant bits: conv5_3 / activations to 1e-2 normwise, logits to 3e-2 of max, losses to
-    5e-2 (the tight check of the bf16 kernels is tests/test_gpu_bf16.py)."""
+    5e-2, weight-gradient direction cosine >= 0.99 (the tight check of the bf16 kernels is
+    tests/test_gpu_bf16.py)."""
     from detectron.datasets import synthetic
     from oracle import oracle
     c = 80
@@ -198,7 +199,7 @@ def test_full_size_bf16_c80_matches_oracle(dev, ref20):
     mb['labels_oh'] = np.zeros((1, c), np.float32)
     mb['labels_oh'][0, cls] = 1
     mb['labels_int32'] = np.array([cls], np.int32)
-    ref = oracle.full_forward_backward(blobs, mb, None, c, train=False, backward=False,
+    ref = oracle.full_forward_backward(blobs, mb, None, c, train=False, backward=True,
                                        conv5=ref20['ref']['conv5_3'],
                                        roi_feat=ref20['ref']['roi_feat'])
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
@@ -213,6 +214,19 @@ def test_full_size_bf16_c80_matches_oracle(dev, ref20):
         assert np.isfinite(a) and abs(a - b) <= 5e-2 * abs(b), (k, a, b)
     cp, cpr = out['cls_prob'][0].cpu().numpy(), tl['cls_prob'][0]
     assert np.abs(cp - cpr).max() <= 5e-2 * cpr.max()
-    # gradients exist for every blob and are finite; their direction is checked on the small
-    # case against the fp32 oracle (test_engine_bf16_mode)
+    # backward at size: every gradient finite, and the direction of each
+    # weight gradient against the fp32 oracle's (dropout off on both sides; bf16 operands leave
+    # ~1e-2 of noise per GEMM, so the measure is the cosine, as in test_engine_bf16_mode)
     assert torch.isfinite(eng.grads).all() and float(eng.grads.abs().max()) > 0
+    cosines = {}
+    for name in ('fc6_w', '_[noisy]_fc6_w', 'fc7_w', '_[noisy]_fc7_w', 'fc8c_w', 'fc8d_w',
+                 'noisy_fc8c_w', 'noisy_fc8d_w', 'fc6_b', 'fc7_b'):
+        g = eng.grad_blob(name).cpu().numpy().astype(np.float64).reshape(-1)
+        r = ref['grads'][name].astype(np.float64).reshape(-1)
+        cosines[name] = float(g.dot(r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-300))
+        ratio = np.linalg.norm(g) / (np.linalg.norm(r) + 1e-300)
+        assert 0.9 <= ratio <= 1.1, (name, ratio)
+    print('\n[bf16, C=80] gradient cosine vs fp32 oracle: ' +
+          ', '.join('%s %.4f' % kv for kv in cosines.items()))
+    for name, cs in cosines.items():
+        assert cs >= 0.99, (name, cs)

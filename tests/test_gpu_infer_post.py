@@ -133,3 +133,120 @@ def test_im_detect_all_device_equals_host_path(dev, cfgmod, aug):
     assert len(got) == len(want) == 21 and sum(len(b) for b in want[1:]) > 0
     for j in range(1, 21):
         assert np.array_equal(got[j], want[j]), j
+
+
+# ---- the device kernels against values captured from the IMPORTED reference -------------------
+HOST = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_host_paths.npz'))
+TTA = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_tta.npz'))
+
+
+def _net(rois, obn, k, scale):
+    """The fixtures' deterministic stand-in network, on the device: scores are a function of the
+    fed roi / obn rows only (make_golden_host_paths.py / make_golden_tta.py `fetch`)."""
+    b = (rois[:, 1:5].sum(1, keepdim=True) * np.float32(0.001) + obn.reshape(-1, 1)).float()
+    j = torch.arange(k, device=rois.device, dtype=torch.float32)[None, :]
+    if scale:                                     # make_golden_tta.py
+        return (b * (1.0 + j * 0.03125)).float()
+    return (b + j * np.float32(0.01)).float()      # make_golden_host_paths.py
+
+
+def test_roi_dedup_kernel_matches_reference_im_detect_bbox(dev):
+    """naws_roi_dedup_fwd + naws_tta_accumulate against the reference's own im_detect_bbox
+    (core/test_wsl.py:102-178, run with a recording workspace: reference_host_paths.npz): the
+    rois / obn scores it feeds after the float64 projection + dedup hash + np.unique, and the
+    scores it returns after the scatter-back - bit for bit."""
+    from naws_hip import ops
+    boxes, obn = HOST['dedup_boxes'], HOST['dedup_obn']
+    dd = ops.roi_dedup(torch.from_numpy(boxes).to(dev), torch.from_numpy(obn.reshape(-1)).to(dev),
+                       [(float(HOST['dedup_im_scale']), 8, False, 0.0)], float(HOST['dedup_factor']))
+    m = int(dd['count'][0])
+    want = HOST['dedup_fed_rois']
+    assert m == want.shape[0] < boxes.shape[0]
+    assert np.array_equal(dd['rois'][0, :m].cpu().numpy(), want)
+    assert np.array_equal(dd['obn'][0, :m].cpu().numpy(), HOST['dedup_fed_obn'].reshape(-1))
+    k = HOST['dedup_scores'].shape[1]
+    sc = _net(dd['rois'][0, :m], dd['obn'][0, :m], k, scale=False)
+    acc = torch.empty((boxes.shape[0], k), device=dev)
+    ops.tta_accumulate(sc.contiguous(), dd['inv'][0], acc, first=True)
+    assert np.array_equal(acc.cpu().numpy(), HOST['dedup_scores'])
+
+
+def test_roi_dedup_kernel_matches_every_pass_of_the_reference_tta(dev, cfgmod):
+    """All ten passes of the yaml's TTA in ONE launch: the unique rois of every pass equal what
+    the reference's im_detect_bbox_aug fed, in its pass order (reference_tta.npz, case avg)."""
+    from detectron.core import test_wsl
+    from detectron.roi_data.minibatch_wsl import get_im_scale
+    from naws_hip import ops
+    c = cfgmod
+    c.merge_cfg_from_list(['TEST.BBOX_AUG.ENABLED', True])
+    h, w = [int(v) for v in TTA['aug_im_shape']]
+    passes = test_wsl.tta_passes()
+    specs = [(get_im_scale((h, w), s, m), w, f, 0.0) for s, m, f in passes]
+    dd = ops.roi_dedup(torch.from_numpy(TTA['aug_boxes']).to(dev),
+                       torch.from_numpy(TTA['aug_obn'].reshape(-1)).to(dev), specs, c.cfg.DEDUP_BOXES)
+    counts = dd['count'].cpu().tolist()
+    assert len(passes) == int(TTA['aug_avg_npass'])
+    for i in range(len(passes)):
+        want = TTA['aug_avg_fed%02d' % i]
+        assert counts[i] == want.shape[0], i
+        assert np.array_equal(dd['rois'][i, :counts[i]].cpu().numpy(), want), i
+
+
+class _FixtureExecutor(object):
+    """feed / run / fetch of the graph executor with the fixtures' stand-in network in place of
+    the forward pass: what remains under test is everything im_detect_all_device does around it
+    (projection, mirror, dedup, pairing of flipped passes, scatter-back, TTA mean, NMS, cut)."""
+
+    def __init__(self, dev, k):
+        self.device, self.k = dev, k
+        self.engine = object()
+
+    def feed(self, blobs):
+        self.blobs = blobs
+
+    def run(self):
+        pass
+
+    def fetch(self, name):
+        assert name == 'cls_prob'
+        return _net(self.blobs['rois'], self.blobs['obn_scores'], self.k, scale=True)
+
+
+@pytest.mark.parametrize('pair', [True, False])
+def test_im_detect_all_device_reproduces_the_reference_tta_combination(dev, cfgmod, pair):
+    """VERDICT r2 #7b: the reference's im_detect_bbox_aug (10 passes, AVG / ID) produced
+    reference_tta.npz's combined scores; the device path, fed the same stand-in network, must end
+    in the detections that box_results_with_nms_and_limit makes of those scores."""
+    from detectron.core import test_wsl
+    c = cfgmod
+    c.merge_cfg_from_list(['TEST.BBOX_AUG.ENABLED', True, 'NAWS.TTA_PAIR_FLIPS', pair,
+                           'TEST.DETECTIONS_PER_IM', 25])
+    h, w = [int(v) for v in TTA['aug_im_shape']]
+    im = np.zeros((h, w, 3), np.uint8)
+    k = c.cfg.MODEL.NUM_CLASSES
+    ex = _FixtureExecutor(dev, k)
+    assert test_wsl.device_post_supported(ex, im, TTA['aug_boxes'].shape[0])
+    got = test_wsl.im_detect_all(ex, im, TTA['aug_boxes'], TTA['aug_obn'])
+    c.cfg.NAWS.HOST_NMS = True
+    _s, _b, want = test_wsl.box_results_with_nms_and_limit(TTA['aug_avg_scores'],
+                                                          TTA['aug_avg_boxes'])
+    c.cfg.NAWS.HOST_NMS = False
+    assert sum(len(x) for x in want[1:]) >= 25
+    for j in range(1, k):
+        assert np.array_equal(got[j], want[j]), j
+
+
+def test_device_post_falls_back_outside_the_dedup_key_range(dev, cfgmod):
+    """proposal counts the sort cannot hold, and coordinates whose hash would leave
+    the 49 bits of the device key, go to the numpy path instead of raising / mis-sorting."""
+    from detectron.core import test_wsl
+    c = cfgmod
+    im = np.zeros((64, 96, 3), np.uint8)
+    ex = _FixtureExecutor(dev, 21)
+    assert test_wsl.device_post_supported(ex, im, 300)
+    assert not test_wsl.device_post_supported(ex, im, 0)
+    assert not test_wsl.device_post_supported(ex, im, test_wsl.DEDUP_MAX_N + 1)
+    c.merge_cfg_from_list(['DEDUP_BOXES', 1.0])       # 96 px * 688/64 * 1.0 = 1032 > 562
+    assert not test_wsl.device_post_supported(ex, im, 300)
+    c.merge_cfg_from_list(['DEDUP_BOXES', 0.125, 'TEST.SOFT_NMS.ENABLED', True])
+    assert not test_wsl.device_post_supported(ex, im, 300)
