@@ -256,6 +256,42 @@ int naws_acm_sgd_update_rowmax(const float* grad, float* momentum_buf, const flo
                                int64_t iter_count, uint32_t* rowmax, const int64_t* rm_table_host,
                                int n_rm, void* stream);
 
+/* The same update for iter_size == 1 (acmgrad NULL), additionally writing the fp16x2 operand planes
+ * of up to 4 weight matrices of the arena itself (the head GEMMs read fc6_w / fc7_w as row-scaled
+ * f16 hi / lo planes, naws_split_f16x2): no re-split pass over the weights after the update.
+ * A row's scale is taken from 2 x bound[row], bound = max|w| of the row BEFORE this update (what
+ * the previous call reported in rowmax, or naws_split_f16x2's maxima) - an upper bound is all a
+ * scale needs.  rowmax (zeroed by the caller, != bound) receives max|w| AFTER the update,
+ * inv_scale the 1/scale of the planes just written.  If any |w_new| exceeds its 2 x bound (or is
+ * NaN), *overflow = max(*overflow, overflow_tag): queue naws_split_f16x2_rows_if(...,
+ * overflow, overflow_tag) behind this call and the planes are redone from the exact maxima, on
+ * the device's own decision.  regions: HOST array, ascending and disjoint; rows and
+ * rows_per_batch multiples of 32, cols of 256, one (lr_mult, weight decay) run per region.
+ * Parameters, momentum: bit-identical to naws_acm_sgd_update.
+ *   ref: detectron/ops/acm_weightdecay_momentum_sgd_op.h:72-109. */
+typedef struct naws_sgd_plane_region {
+  int64_t start;           /* first arena element of the matrix */
+  int32_t rows, cols;      /* row-major, contiguous (ld = cols) */
+  int32_t rows_per_batch;  /* planes: f16 [2][rows / rows_per_batch][cols / 16][rows_per_batch][16] */
+  int32_t reserved;
+  void* planes;
+  int64_t plane_stride;    /* elements between the hi and the lo plane */
+  const uint32_t* bound;   /* [rows] */
+  uint32_t* rowmax;        /* [rows] */
+  float* inv_scale;        /* [rows] */
+} naws_sgd_plane_region;
+int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf, const float* lr, float* param,
+                              int64_t total, const int64_t* seg_end, const float* seg_lr_mult,
+                              const float* seg_wd, int nseg, float momentum, int nesterov,
+                              int gpu_num, int64_t iter_count, const naws_sgd_plane_region* regions,
+                              int n_regions, int32_t* overflow, int32_t overflow_tag, void* stream);
+/* naws_split_f16x2's row-scaled form from given maxima (rowmax [batch][rows] bit patterns ->
+ * planes [2][batch][kpad/16][rows][16], inv_scale [batch][rows]), run only if *cond == cond_value
+ * when the kernel executes (cond NULL: always): the fallback of naws_acm_sgd_update_f16x2. */
+int naws_split_f16x2_rows_if(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
+                             const uint32_t* rowmax, void* P, float* inv_scale, int kpad,
+                             const int32_t* cond, int32_t cond_value, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * a-14  Stat accumulate   ref: detectron/ops/stat_op.cu:14-20, :24-78
  * AI += I*L; AL += L  (n elements).  init != 0 zeroes AI/AL first (the op's

@@ -711,8 +711,10 @@ __global__ __launch_bounds__(256) void split2h_dual_kernel(
     const float* __restrict__ X, int rows, int cols, int ld, long long sx,
     const unsigned* __restrict__ rowmax, const unsigned* __restrict__ colmax,
     const float* __restrict__ rowmul, unsigned short* __restrict__ Pn, float* __restrict__ inv_n,
-    int slabs_n, unsigned short* __restrict__ Pt, float* __restrict__ inv_t, int slabs_t, int batch) {
+    int slabs_n, unsigned short* __restrict__ Pt, float* __restrict__ inv_t, int slabs_t, int batch,
+    const int* __restrict__ cond, int cond_value) {
   __shared__ float tile[64][65];
+  if (cond && *cond != cond_value) return;          // (naws_split_f16x2_rows_if)
   const int bz = blockIdx.z;
   const float* Xb = X + bz * sx;
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
@@ -916,7 +918,26 @@ extern "C" int naws_split_f16x2_dual(const float* X, int batch, int rows, int co
                      (long long)strideX, (const unsigned*)rowmax, (const unsigned*)colmax, rowmul,
                      (unsigned short*)Pn, Pn ? scales_n + (long long)batch * rows : nullptr,
                      kpad_n / 16, (unsigned short*)Pt, Pt ? scales_t + (long long)batch * cols : nullptr,
-                     kpad_t / 16, batch);
+                     kpad_t / 16, batch, (const int*)nullptr, 0);
+  return naws_check_launch();
+}
+
+// The row-scaled planes from given maxima, conditionally: every workgroup leaves at once unless
+// *cond == cond_value (the device-side fallback of naws_acm_sgd_update_f16x2).
+extern "C" int naws_split_f16x2_rows_if(const float* X, int batch, int rows, int cols, int ld,
+                                        int64_t strideX, const uint32_t* rowmax, void* P,
+                                        float* inv_scale, int kpad, const int32_t* cond,
+                                        int32_t cond_value, void* stream) {
+  if (batch <= 0 || rows <= 0 || cols <= 0 || ld < cols) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(rowmax); NAWS_REQUIRE_PTR(P); NAWS_REQUIRE_PTR(inv_scale);
+  if (kpad != (cols + 31) / 32 * 32 || ((uintptr_t)P & 15) != 0) return NAWS_ERR_ARG;
+  const long long gy = naws_cdiv(rows, 64);
+  if (batch > 65535 || gy > 65535) return NAWS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, batch);
+  hipLaunchKernelGGL(split2h_dual_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, rows, cols, ld,
+                     (long long)strideX, (const unsigned*)rowmax, (const unsigned*)nullptr,
+                     (const float*)nullptr, (unsigned short*)P, inv_scale, kpad / 16,
+                     (unsigned short*)nullptr, (float*)nullptr, 0, batch, (const int*)cond, cond_value);
   return naws_check_launch();
 }
 

@@ -333,6 +333,34 @@ __global__ void stat_kernel(const float* __restrict__ I, const float* __restrict
 }
 
 // ---- fused ACM weight-decay momentum SGD over a parameter arena ------------
+// One element of the update, every product and sum rounded on its own (no FMA contraction): the
+// reference's CPU operator is scalar C++ built for generic x86-64 (math::Scale, math::Axpy, then
+// `lr * g + momentum * m`, acm_weightdecay_momentum_sgd_op.h:79-109), and the oracle restates it
+// with -ffp-contract=off; both SGD kernels below go through this one function, so they agree
+// with each other bit for bit.  a = the accumulated gradient (acm + g).
+__device__ __forceinline__ void sgd_elem(float a, float& m, float& p, float scale, float wd, float LR,
+                                         float momentum, int nesterov) {
+  float t = __fmul_rn(a, scale);                       // Normalize
+  t = __fadd_rn(t, __fmul_rn(wd, p));                  // Regularize (Axpy)
+  if (!nesterov) {
+    const float adj = __fadd_rn(__fmul_rn(LR, t), __fmul_rn(momentum, m));
+    m = adj;
+    p = __fsub_rn(p, adj);
+  } else {
+    const float mi = m;
+    const float mi_new = __fadd_rn(__fmul_rn(momentum, mi), __fmul_rn(LR, t));
+    m = mi_new;
+    p = __fsub_rn(p, __fsub_rn(__fmul_rn(__fadd_rn(1.0f, momentum), mi_new), __fmul_rn(momentum, mi)));
+  }
+}
+__device__ __forceinline__ void sgd_update4(const float4& g, float4& m, float4& p, float scale,
+                                            float wd, float LR, float momentum, int nesterov) {
+  sgd_elem(g.x, m.x, p.x, scale, wd, LR, momentum, nesterov);
+  sgd_elem(g.y, m.y, p.y, scale, wd, LR, momentum, nesterov);
+  sgd_elem(g.z, m.z, p.z, scale, wd, LR, momentum, nesterov);
+  sgd_elem(g.w, m.w, p.w, scale, wd, LR, momentum, nesterov);
+}
+
 struct SgdRowmaxRegions {      // rows whose max|updated parameter| is reported (fp16x2 re-split)
   long long start[4], end[4], rowlen[4], out[4];
   int n;
@@ -361,23 +389,10 @@ __global__ __launch_bounds__(TB) void acm_sgd_kernel(
     if (!do_update) { acm[i] = a; if (first) mom[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
     float4 p = param[i];
     float4 m = first ? make_float4(0.f, 0.f, 0.f, 0.f) : mom[i];
-    float av[4] = {a.x, a.y, a.z, a.w}, pv[4] = {p.x, p.y, p.z, p.w};
+    float pv[4] = {p.x, p.y, p.z, p.w};
+    sgd_update4(a, m, p, scale, wd, LR, momentum, nesterov);
     float mv[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float t = av[k] * scale;  // Normalize
-      t = t + wd * pv[k];       // Regularize (Axpy)
-      if (!nesterov) {
-        const float adj = LR * t + momentum * mv[k];
-        mv[k] = adj;
-        pv[k] -= adj;
-      } else {
-        const float mi = mv[k];
-        const float mi_new = momentum * mi + LR * t;
-        mv[k] = mi_new;
-        pv[k] -= (1.0f + momentum) * mi_new - momentum * mi;
-      }
-    }
+    pv[0] = p.x; pv[1] = p.y; pv[2] = p.z; pv[3] = p.w;
     // the update value goes to the acmgrad OUTPUT, which is then cleared; the
     // grad blob itself is not written (acm_weightdecay_momentum_sgd_op.h:94-108)
     mom[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
@@ -404,6 +419,187 @@ __global__ __launch_bounds__(TB) void acm_sgd_kernel(
             atomicMax(rowmax + rm.out[r] + row, __float_as_uint(m));
         }
       }
+    }
+  }
+}
+
+
+// ---- the same update, writing the fp16x2 operand planes of the weight matrices itself -----------
+// (VERDICT r2 #5.)  fc6_w / fc7_w are consumed by the head GEMMs as row-scaled f16 hi / lo planes
+// P[2][batch][cols/16][rows][16] (naws_split_f16x2).  Re-splitting them after every update is a
+// 0.96 GB read + 0.96 GB write on the update stream, beside the HBM-bound first conv layers of the
+// next iteration.  A row's scale only needs an UPPER BOUND of its max|w|, and one SGD
+// step moves a weight by a tiny fraction of itself: with bound = 2 x (the row maximum BEFORE the
+// update, reported by the previous call) this kernel converts each updated value on the way out.
+// Should any |w_new| exceed its bound, *overflow = overflow_tag is raised and the caller's
+// conditional re-split (naws_split_f16x2_rows_if, queued behind this launch) redoes the planes
+// from the exact maxima this kernel reports - the device decides, the host never looks.
+//
+// Geometry: a workgroup owns a 32-row x 256-column tile.  Pass 1: wave w, step j holds row
+// 4 j + w: its 64 lanes read three 1 KB runs (grad, momentum, param: float4 per lane), update,
+// write two back, fold max|w_new| over the wave, and park the scaled hi / lo halves in LDS as
+// [slab][row][16 f16] (slab stride 1056 B: the four slabs a 16-lane ds_write_b64 group touches
+// land on disjoint 8-bank windows).  Pass 2: the LDS image leaves as 16 x 1 KB runs per plane,
+// each one (slab, 32 rows) block of the K-slab-major plane.
+struct SgdPlaneRegion {
+  long long start;                 // first arena element
+  int rows, cols, rows_per_batch;  // rows x cols row-major; planes [2][rows / rows_per_batch][cols/16][rows_per_batch][16]
+  int tile0;                       // first workgroup of this region
+  unsigned short* planes;
+  long long plane_stride;          // elements between the hi and the lo plane
+  const unsigned* bound;           // [rows] max|w| per row before the update (bit patterns)
+  unsigned* rowmax;                // [rows] max|w| per row after it (atomic max; caller zeroes)
+  float* inv_scale;                // [rows]
+};
+struct SgdPlaneArgs {
+  SgdPlaneRegion r[4];
+  int n, tiles;                    // regions, tile workgroups
+  long long lin_start[4], lin_end[4];   // the arena outside the regions, in float4 units
+  int lin_block0[5];               // first linear workgroup of each range (prefix), relative to `tiles`
+  int n_lin;
+};
+constexpr int SGP_SLAB = 1056;     // bytes per slab in the LDS image (32 rows x 32 B + 32)
+constexpr int SGP_PLANE = 16 * SGP_SLAB;
+
+__device__ __forceinline__ int sgd_segment(const int64_t* __restrict__ seg_end, int nseg, int64_t e) {
+  int lo = 0, hi = nseg - 1;    // first segment with seg_end > e
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_end[mid] > e) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
+    const float4* __restrict__ grad, float4* __restrict__ mom, const float* __restrict__ lr,
+    float4* __restrict__ param, const int64_t* __restrict__ seg_end,
+    const float* __restrict__ seg_lr_mult, const float* __restrict__ seg_wd, int nseg,
+    float momentum, int nesterov, float scale, int first, SgdPlaneArgs a, int* __restrict__ overflow,
+    int overflow_tag) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[2 * SGP_PLANE];
+  const float base_lr = lr[0];
+  const int bid = blockIdx.x;
+  if (bid >= a.tiles) {
+    // ---- everything outside the matrix regions (biases, fc8): the plain float4 update
+    const int lb = bid - a.tiles;
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) q += (k < a.n_lin && lb >= a.lin_block0[k]) ? 1 : 0;
+    const int nb = a.lin_block0[q + 1] - a.lin_block0[q];
+    for (int64_t i = a.lin_start[q] + (int64_t)(lb - a.lin_block0[q]) * TB + threadIdx.x;
+         i < a.lin_end[q]; i += (int64_t)nb * TB) {
+      const int sg = sgd_segment(seg_end, nseg, i * 4);
+      float4 g = grad[i], p = param[i];
+      float4 m = first ? make_float4(0.f, 0.f, 0.f, 0.f) : mom[i];
+      sgd_update4(g, m, p, scale, seg_wd[sg], base_lr * seg_lr_mult[sg], momentum, nesterov);
+      mom[i] = m;
+      param[i] = p;
+    }
+    return;
+  }
+  int ri = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) ri += (k < a.n && bid >= a.r[k].tile0) ? 1 : 0;
+  const SgdPlaneRegion& R = a.r[ri];
+  const int ct = R.cols >> 8;                         // column tiles per row band
+  const int t = bid - R.tile0;
+  const int band = t / ct, ctile = t - band * ct;     // column tile fastest: neighbours stream on
+  const int r0 = band * 32, c0 = ctile * 256;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // one hyper-parameter run per region (a region lies inside one blob pair of equal settings;
+  // checked on the host)
+  const int sg = sgd_segment(seg_end, nseg, R.start);
+  const float LR = base_lr * seg_lr_mult[sg], wd = seg_wd[sg];
+  const int64_t base4 = (R.start + (int64_t)r0 * R.cols + c0) >> 2;
+  const int row4 = R.cols >> 2;
+  // the 32 rows' bounds in lanes 0..31, fetched once (a per-row load + wait inside the loop
+  // serialises the wave on a memory round trip per row)
+  const unsigned bound_lane = R.bound[r0 + (lane & 31)];
+  float rmax[8];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float4 g[4], m[4], p[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {                  // 12 x 1 KB wave-loads in flight
+      const int row = (half * 4 + jj) * 4 + wid;
+      const int64_t i = base4 + (int64_t)row * row4 + lane;
+      g[jj] = grad[i];
+      p[jj] = param[i];
+      m[jj] = first ? make_float4(0.f, 0.f, 0.f, 0.f) : mom[i];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int row = (half * 4 + jj) * 4 + wid;
+      const int64_t i = base4 + (int64_t)row * row4 + lane;
+      sgd_update4(g[jj], m[jj], p[jj], scale, wd, LR, momentum, nesterov);
+      mom[i] = m[jj];
+      param[i] = p[jj];
+      // the row's scale: from twice the maximum it had before this update (wave-uniform).
+      // 2 x bound = exponent + 1 (a zero / denormal / huge bound is left as it is: the overflow
+      // test below then sends the row to the exact re-split)
+      const unsigned bb = (unsigned)__builtin_amdgcn_readlane((int)bound_lane, row);
+      const unsigned b2 = ((bb >> 23) >= 1u && (bb >> 23) < 0xfeu) ? bb + (1u << 23) : bb;
+      float sc, isc;
+      naws_f16x2_scales(b2, sc, isc);
+      const float pv[4] = {p[jj].x, p[jj].y, p[jj].z, p[jj].w};
+      unsigned short hq[4], lq[4];
+      float mx = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mx = fmaxf(mx, fabsf(pv[k]));
+        const float v = pv[k] * sc;
+        const _Float16 hi = (_Float16)v;
+        float rr = v - (float)hi;
+        if (!(fabsf(v) <= 65504.f)) rr = 0.f;         // NaN / overflow live in the hi plane only
+        const _Float16 lo = (_Float16)rr;
+        hq[k] = *reinterpret_cast<const unsigned short*>(&hi);
+        lq[k] = *reinterpret_cast<const unsigned short*>(&lo);
+      }
+      const int off = (lane >> 2) * SGP_SLAB + row * 32 + (lane & 3) * 8;
+      *reinterpret_cast<uint2*>(img + off) =
+          make_uint2(hq[0] | ((unsigned)hq[1] << 16), hq[2] | ((unsigned)hq[3] << 16));
+      *reinterpret_cast<uint2*>(img + SGP_PLANE + off) =
+          make_uint2(lq[0] | ((unsigned)lq[1] << 16), lq[2] | ((unsigned)lq[3] << 16));
+      // NaN-aware fold (fmaxf drops NaNs; a NaN weight must reach the overflow test)
+      mx = wave_max((pv[0] != pv[0] || pv[1] != pv[1] || pv[2] != pv[2] || pv[3] != pv[3])
+                        ? __uint_as_float(0x7f800000u) : mx);
+      rmax[half * 4 + jj] = mx;
+    }
+  }
+  // the wave's eight rows report together: lane j < 8 owns row 4 j + wid (one memory round trip
+  // per wave instead of one per row)
+  {
+    float mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine = (lane == j) ? rmax[j] : mine;
+    const int row = (lane & 7) * 4 + wid;
+    const unsigned bb = (unsigned)__shfl((int)bound_lane, row);     // (all lanes take part)
+    if (lane < 8) {
+      const unsigned b2 = ((bb >> 23) >= 1u && (bb >> 23) < 0xfeu) ? bb + (1u << 23) : bb;
+      if (ctile == 0) {
+        float sc, isc;
+        naws_f16x2_scales(b2, sc, isc);
+        R.inv_scale[r0 + row] = isc;
+      }
+      const bool is_inf = __float_as_uint(mine) == 0x7f800000u;     // a NaN / inf weight in the row
+      if (mine > 0.f && !is_inf) naws_atomic_max_bits(R.rowmax + r0 + row, mine);
+      if (!(mine <= __uint_as_float(b2)) || is_inf) atomicMax(overflow, overflow_tag);
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: the image leaves as (slab, 32 rows) blocks: 1 KB contiguous per wave-store
+  const int batch = r0 / R.rows_per_batch, rb0 = r0 - batch * R.rows_per_batch;
+  const long long sp = (long long)R.cols * R.rows_per_batch;       // one batch item of one plane
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = k * TB + threadIdx.x;            // 16-byte chunk of the plane's image
+      const int slab = idx >> 6, rem = idx & 63;       // rem = row * 2 + half
+      const uint4 v = *reinterpret_cast<const uint4*>(img + pl * SGP_PLANE + slab * SGP_SLAB + rem * 16);
+      const long long dst = pl * R.plane_stride + batch * sp +
+                            ((long long)((c0 >> 4) + slab) * R.rows_per_batch + rb0) * 16 + rem * 8;
+      *reinterpret_cast<uint4*>(R.planes + dst) = v;
     }
   }
 }
@@ -612,6 +808,63 @@ extern "C" int naws_acm_sgd_update(const float* grad, float* momentum_buf, const
   return naws_acm_sgd_update_rowmax(grad, momentum_buf, lr, param, acmgrad, total, seg_end,
                                     seg_lr_mult, seg_wd, nseg, momentum, nesterov, iter_size,
                                     gpu_num, iter_count, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf, const float* lr,
+                                         float* param, int64_t total, const int64_t* seg_end,
+                                         const float* seg_lr_mult, const float* seg_wd, int nseg,
+                                         float momentum, int nesterov, int gpu_num,
+                                         int64_t iter_count, const naws_sgd_plane_region* regions,
+                                         int n_regions, int32_t* overflow, int32_t overflow_tag,
+                                         void* stream) {
+  if (total <= 0 || nseg <= 0 || gpu_num <= 0 || iter_count < 0) return NAWS_ERR_SHAPE;
+  if (total % 4 != 0 || n_regions <= 0 || n_regions > 4) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(grad); NAWS_REQUIRE_PTR(momentum_buf); NAWS_REQUIRE_PTR(lr);
+  NAWS_REQUIRE_PTR(param); NAWS_REQUIRE_PTR(seg_end); NAWS_REQUIRE_PTR(seg_lr_mult);
+  NAWS_REQUIRE_PTR(seg_wd); NAWS_REQUIRE_PTR(regions); NAWS_REQUIRE_PTR(overflow);
+  if ((((uintptr_t)grad | (uintptr_t)momentum_buf | (uintptr_t)param) % 16)) return NAWS_ERR_ARG;
+  SgdPlaneArgs a{};
+  long long tiles = 0, cursor = 0;
+  int n_lin = 0;
+  long long lin_blocks = 0;
+  a.lin_block0[0] = 0;
+  auto add_linear = [&](long long s4, long long e4) {       // float4 units
+    if (e4 <= s4) return true;
+    if (n_lin == 4) return false;
+    a.lin_start[n_lin] = s4; a.lin_end[n_lin] = e4;
+    lin_blocks += std::min<long long>(naws_cdiv(e4 - s4, TB), 1024);
+    a.lin_block0[++n_lin] = (int)lin_blocks;
+    return true;
+  };
+  for (int i = 0; i < n_regions; ++i) {
+    const naws_sgd_plane_region& g = regions[i];
+    if (g.rows <= 0 || g.cols <= 0 || g.rows_per_batch <= 0) return NAWS_ERR_SHAPE;
+    const long long n = (long long)g.rows * g.cols;
+    if (g.start < cursor || g.start + n > total) return NAWS_ERR_SHAPE;     // ascending, disjoint
+    if (g.rows % 32 != 0 || g.cols % 256 != 0 || g.rows % g.rows_per_batch != 0 ||
+        g.rows_per_batch % 32 != 0 || g.start % 4 != 0)
+      return NAWS_ERR_UNSUPPORTED;
+    NAWS_REQUIRE_PTR(g.planes); NAWS_REQUIRE_PTR(g.bound); NAWS_REQUIRE_PTR(g.rowmax);
+    NAWS_REQUIRE_PTR(g.inv_scale);
+    if (((uintptr_t)g.planes & 15) != 0 || g.bound == g.rowmax) return NAWS_ERR_ARG;
+    if (!add_linear(cursor / 4, g.start / 4)) return NAWS_ERR_UNSUPPORTED;
+    SgdPlaneRegion& r = a.r[i];
+    r.start = g.start; r.rows = g.rows; r.cols = g.cols; r.rows_per_batch = g.rows_per_batch;
+    r.tile0 = (int)tiles; r.planes = (unsigned short*)g.planes; r.plane_stride = g.plane_stride;
+    r.bound = g.bound; r.rowmax = g.rowmax; r.inv_scale = g.inv_scale;
+    tiles += (long long)(g.rows / 32) * (g.cols / 256);
+    cursor = g.start + n;
+  }
+  if (!add_linear(cursor / 4, total / 4)) return NAWS_ERR_UNSUPPORTED;
+  if (tiles + lin_blocks > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  a.n = n_regions; a.tiles = (int)tiles; a.n_lin = n_lin;
+  for (int k = n_lin + 1; k < 5; ++k) a.lin_block0[k] = (int)lin_blocks;
+  const float scale = (float)(1.0 / (double)gpu_num);
+  hipLaunchKernelGGL(acm_sgd_planes_kernel, dim3((unsigned)(tiles + lin_blocks)), dim3(TB), 0,
+                     (hipStream_t)stream, (const float4*)grad, (float4*)momentum_buf, lr,
+                     (float4*)param, seg_end, seg_lr_mult, seg_wd, nseg, momentum, nesterov, scale,
+                     iter_count == 0 ? 1 : 0, a, overflow, overflow_tag);
+  return naws_check_launch();
 }
 
 extern "C" int naws_min_entropy_loss_fwd(const float* X, const float* L, int N, int C, float* Y,

@@ -205,6 +205,11 @@ class WsddnEngine(object):
         # re-split that follows it on the update stream)
         self.fused_wmax = True
         self._rm_table = None
+        # fp16x2: the SGD kernel also WRITES the updated fc6_w / fc7_w operand planes (scale from
+        # twice the row maximum before the update; a device-side conditional re-split covers a row
+        # that outgrows it): no 0.96 GB read + 0.96 GB write re-split on the update stream
+        self.fused_planes = True
+        self._sgd_regions = None
         # RoIPoolF over 2x2 / 4x4 block maxima of conv5_3 (csrc/roi_ops.hip): same values, ~8x less
         # gather traffic
         self.roi_hier = True
@@ -267,6 +272,17 @@ class WsddnEngine(object):
             o6, o7 = self.arena.offsets['fc6_w'][0], self.arena.offsets['fc7_w'][0]
             self._rm_table = ops.RowmaxTable([(o6, o6 + n6 * self.k6, self.k6, 0),
                                               (o7, o7 + n6 * HIDDEN, HIDDEN, 2 * n6)], self.device)
+            if self.k6 % 256 == 0:
+                # [w6 rows | w7 rows]: the maxima before an update (the scale bounds of the planes
+                # the update writes) and the "a row outgrew its bound" word
+                self._wbound = torch.zeros((2 * n6,), device=self.device, dtype=torch.int32)
+                self._wovf = torch.zeros((1,), device=self.device, dtype=torch.int32)
+                sc = self._wscales.view(2, 2, n6)            # [operand][maxima | 1/scale][rows]
+                self._sgd_regions = ops.SgdPlaneRegions([
+                    (o6, n6, self.k6, n6, p6.planes, self._wbound[:n6], sc[0, 0].view(torch.int32),
+                     sc[0, 1]),
+                    (o7, n6, HIDDEN, HIDDEN, p7.planes, self._wbound[n6:], sc[1, 0].view(torch.int32),
+                     sc[1, 1])])
         elif self._wplanes is None:
             self._wplanes = dict(w6=cv(w6), w7=cv(w7), w7t=cv(w7, transpose=True))
         else:
@@ -957,19 +973,43 @@ class WsddnEngine(object):
         # wave's 256 floats stay in one row)
         fused = (self.fused_wmax and self.mfma_dtype == 'fp16x2' and self._wplanes is not None
                  and self.iter_size == 1 and self.k6 % 256 == 0)
+        # (planes marked dirty - a caller wrote through blob() - carry stale maxima: that update
+        # takes the exact route below)
+        planes = (fused and self.fused_planes and self._sgd_regions is not None
+                  and not self._planes_dirty)
         rowmax = None
         if fused:
-            self._wscales.view(2, 2, 2 * HIDDEN)[:, 0].zero_()
+            maxima = self._wscales.view(2, 2, 2 * HIDDEN)[:, 0]
+            if planes:
+                self._wbound.view(2, 2 * HIDDEN).copy_(maxima.view(torch.int32))
+            maxima.zero_()
             rowmax = self._wscales.view(torch.int32)
-        ops.acm_sgd_update(self.grads, self.momentum_buf, self.lr, self.params, self.acmgrad,
-                           self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
-                           self.iter_size, self.gpu_num, self.sgd_iter_count, rowmax=rowmax,
-                           rm_table=self._rm_table if fused else None)
+        if planes:
+            tag = self.sgd_iter_count + 1
+            ops.acm_sgd_update_f16x2(self.grads, self.momentum_buf, self.lr, self.params,
+                                     self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
+                                     self.gpu_num, self.sgd_iter_count, self._sgd_regions,
+                                     self._wovf, tag)
+        else:
+            ops.acm_sgd_update(self.grads, self.momentum_buf, self.lr, self.params, self.acmgrad,
+                               self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
+                               self.iter_size, self.gpu_num, self.sgd_iter_count, rowmax=rowmax,
+                               rm_table=self._rm_table if fused else None)
         if uev is not None:
             e1.record()
             uev.append((e0, e1))
         self.sgd_iter_count += 1
-        if fused:                              # same stream as the update: hidden with it
+        if planes:
+            # the planes are written; should a row have outgrown twice its old maximum, these two
+            # launches redo them from the exact maxima (otherwise their workgroups leave at once)
+            w6, w7 = self._weight_views()
+            wp = self._wplanes
+            sc = self._wscales.view(2, 2, 2 * HIDDEN).view(torch.int32)
+            ops.split_f16x2_rows_if(w6, sc[0, 0], wp['w6'], self._wovf, tag)
+            ops.split_f16x2_rows_if(w7, sc[1, 0], wp['w7'], self._wovf, tag)
+            ops.split_f16x2(w7, transpose=True, out=wp['w7t'])
+            self._planes_dirty = False
+        elif fused:                            # same stream as the update: hidden with it
             w6, w7 = self._weight_views()
             wp = self._wplanes
             q6 = ops.split_f16x2_dual(w6, wp['w6'].scales, None, out_n=wp['w6'])[0]

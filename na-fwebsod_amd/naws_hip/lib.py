@@ -56,6 +56,8 @@ PROTOTYPES = {
     'naws_acm_sgd_update': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p],
     'naws_acm_sgd_update_rowmax': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p, p,
                                    i32, p],
+    'naws_acm_sgd_update_f16x2': [p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i64, p, i32, p, i32, p],
+    'naws_split_f16x2_rows_if': [p, i32, i32, i32, i32, i64, p, p, p, i32, p, i32, p],
     'naws_roi_label_fwd': [p, p, p, p, i32, i32, i32, f32, f32, f32, i32, i32, i32, p, p, p, p, p],
     'naws_softmax_with_loss_n_fwd': [p, p, p, i32, i32, f32, p, p, p, p],
     'naws_softmax_with_loss_n_bwd': [p, p, p, p, i32, i32, f32, p, p, p],

@@ -4,6 +4,8 @@ torch is plumbing only: it owns device memory and the current HIP stream; every
 computation below is one or more hand-written gfx950 kernels in libnaws_hip.so.
 Inputs must be CUDA(HIP) fp32 tensors; anything else raises (no CPU fallback).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -858,6 +860,59 @@ def acm_sgd_update(grad, momentum_buf, lr, param, acmgrad, seg_end, seg_lr_mult,
            param.data_ptr(), _ptr(acmgrad), total, seg_end.data_ptr(), seg_lr_mult.data_ptr(),
            seg_wd.data_ptr(), seg_end.numel(), float(momentum), int(nesterov), int(iter_size),
            int(gpu_num), int(iter_count), _stream())
+
+
+class _SgdPlaneRegion(C.Structure):
+    """naws_sgd_plane_region (include/naws.h)."""
+    _fields_ = [('start', C.c_int64), ('rows', C.c_int32), ('cols', C.c_int32),
+                ('rows_per_batch', C.c_int32), ('reserved', C.c_int32), ('planes', C.c_void_p),
+                ('plane_stride', C.c_int64), ('bound', C.c_void_p), ('rowmax', C.c_void_p),
+                ('inv_scale', C.c_void_p)]
+
+
+class SgdPlaneRegions(object):
+    """The weight matrices whose fp16x2 operand planes `acm_sgd_update_f16x2` writes itself:
+    [(first arena element, rows, cols, rows_per_batch, F16x2 planes, bound int32 [rows],
+      rowmax int32 [rows], inv_scale fp32 [rows])], ascending."""
+
+    def __init__(self, regions):
+        self.keep = regions                       # the tensors stay alive with the table
+        self.n = len(regions)
+        self.host = (_SgdPlaneRegion * self.n)()
+        for i, (start, rows, cols, rpb, planes, bound, rowmax, inv) in enumerate(regions):
+            if planes.dtype != torch.float16 or not planes.is_contiguous() or planes.shape[0] != 2:
+                raise TypeError('planes must be contiguous f16 [2, ...]')
+            for t, dt in ((bound, torch.int32), (rowmax, torch.int32), (inv, _f32)):
+                if t.dtype != dt or t.numel() != rows or not t.is_contiguous():
+                    raise TypeError('bound / rowmax / inv_scale: contiguous [rows] int32 / int32 / fp32')
+            self.host[i] = _SgdPlaneRegion(int(start), int(rows), int(cols), int(rpb), 0,
+                                           planes.data_ptr(), planes.stride(0), bound.data_ptr(),
+                                           rowmax.data_ptr(), inv.data_ptr())
+
+
+def acm_sgd_update_f16x2(grad, momentum_buf, lr, param, seg_end, seg_lr_mult, seg_wd, momentum,
+                         nesterov, gpu_num, iter_count, regions, overflow, overflow_tag):
+    """ITER_SIZE 1.  The fused update that also emits the operand planes of `regions`
+    (SgdPlaneRegions); `overflow` (int32 [1]) receives overflow_tag when a row outgrew its bound."""
+    L.call('naws_acm_sgd_update_f16x2', grad.data_ptr(), momentum_buf.data_ptr(), lr.data_ptr(),
+           param.data_ptr(), param.numel(), seg_end.data_ptr(), seg_lr_mult.data_ptr(),
+           seg_wd.data_ptr(), seg_end.numel(), float(momentum), int(nesterov), int(gpu_num),
+           int(iter_count), C.addressof(regions.host), regions.n, overflow.data_ptr(),
+           int(overflow_tag), _stream())
+
+
+def split_f16x2_rows_if(x, rowmax, out, cond, cond_value):
+    """Redo the row-scaled planes of x (fp32 [rows, cols] or [b, rows, cols]) into the F16x2 `out`
+    from the maxima `rowmax` (int32 bit patterns, [b*rows]) - only if cond[0] == cond_value when
+    the kernel runs."""
+    batched = x.dim() == 3
+    x2 = x[0] if batched else x
+    batch = x.shape[0] if batched else 1
+    rows, cols = x2.shape
+    L.call('naws_split_f16x2_rows_if', x.data_ptr(), batch, rows, cols, x2.stride(0),
+           (x.stride(0) if batched else 0), rowmax.data_ptr(), out.planes.data_ptr(),
+           out.inv_scale.data_ptr(), (cols + 31) // 32 * 32, _ptr(cond), int(cond_value), _stream())
+    return out
 
 
 # ----------------------------------------------------------------------------

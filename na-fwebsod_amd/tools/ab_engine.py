@@ -65,7 +65,8 @@ def main():
     for _ in range(a.rounds):
         for v in vals:
             if a.env:
-                os.environ[a.env] = str(v)
+                from naws_hip import lib as _L
+                _L.set_variant(_L._ENV_KNOBS.get(a.env, a.env), int(v))
             else:
                 setattr(eng, a.attr, v)
             run(3)

@@ -41,7 +41,8 @@ def main():
         torch.cuda.synchronize()
         return s.elapsed_time(e) / n
 
-    for knob in ('',):
+    for knob, fp in (('fused_planes=1: ', True), ('fused_planes=0: ', False)):
+        eng.fused_planes = fp
         eng.update_events = []
         t_all = timed(eng._apply_update)
         ev = eng.update_events[1:]

@@ -233,21 +233,48 @@ def test_rccl_chunked_allreduce_single_rank(dev):
 
 
 def test_weight_planes_after_fused_update_match_fresh_split(dev):
-    """fp16x2: the SGD kernel reports the updated rows' maxima and the re-split reads the weights
-    once - the operand planes must equal a from-scratch split of the updated parameters."""
+    """fp16x2.  (1) fused_planes off: the SGD kernel reports the updated rows' maxima and the
+    re-split reads the weights once - the planes equal a from-scratch split bit for bit.
+    (2) fused_planes on (default): the SGD kernel writes the planes itself, scaled from twice the
+    row maximum before the update - scales may be one power of two smaller than a fresh split's,
+    the planes reconstruct the same fp32 weights to 2^-22 relative, and a training run gives the
+    same losses and parameters as (1) to fp32-accumulation level."""
     from naws_hip import ops
-    eng, mb, _blobs = _setup(dev, mfma_dtype='fp16x2')
-    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
-    eng.set_lr(1e-2)
-    for _ in range(2):
-        eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
-        eng.sgd_step()
-    eng.flush()
-    torch.cuda.synchronize()
-    assert eng._rm_table is not None and not eng._planes_dirty
-    w6, w7 = eng._weight_views()
-    for key, fresh in (('w6', ops.split_f16x2(w6)), ('w7', ops.split_f16x2(w7)),
-                       ('w7t', ops.split_f16x2(w7, transpose=True))):
-        got = eng._wplanes[key]
-        assert torch.equal(got.inv_scale, fresh.inv_scale), key
-        assert torch.equal(got.planes.view(torch.int16), fresh.planes.view(torch.int16)), key
+    runs = {}
+    for fused_planes in (False, True):
+        eng, mb, _blobs = _setup(dev, mfma_dtype='fp16x2')
+        eng.fused_planes = fused_planes
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        eng.set_lr(1e-2)
+        losses = []
+        for _ in range(3):
+            out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+            losses.append(float(out['loss_cls'].sum() + out['loss_cls_noise'].sum()))
+            eng.sgd_step()
+        eng.flush()
+        torch.cuda.synchronize()
+        assert eng._rm_table is not None and not eng._planes_dirty
+        assert (eng._sgd_regions is not None) and int(eng._wovf.item()) == 0
+        w6, w7 = eng._weight_views()
+        for key, fresh in (('w6', ops.split_f16x2(w6)), ('w7', ops.split_f16x2(w7)),
+                           ('w7t', ops.split_f16x2(w7, transpose=True))):
+            got = eng._wplanes[key]
+            if not fused_planes or key == 'w7t':
+                assert torch.equal(got.inv_scale, fresh.inv_scale), key
+                assert torch.equal(got.planes.view(torch.int16), fresh.planes.view(torch.int16)), key
+                continue
+            ratio = got.inv_scale / fresh.inv_scale
+            assert bool(((ratio == 1) | (ratio == 2)).all()), key
+            w = (w6 if key == 'w6' else w7).reshape(-1, got.planes.shape[-3] * 16).double()
+            p = got.planes.double()
+            d = (p[0] + p[1])
+            d = d.unsqueeze(0) if d.dim() == 3 else d
+            dense = d.permute(0, 2, 1, 3).reshape(w.shape) * got.inv_scale.reshape(-1).double()[:, None]
+            rowmax = w.abs().amax(dim=1, keepdim=True)
+            assert bool(((dense - w).abs() <= torch.maximum(w.abs() * 2.0 ** -22,
+                                                            rowmax * 2.0 ** -36)).all()), key
+        runs[fused_planes] = (losses, eng.params.clone())
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert abs(a - b) <= 1e-5 * abs(a), (runs[False][0], runs[True][0])
+    pa, pb = runs[False][1], runs[True][1]
+    assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max())

@@ -141,13 +141,16 @@ TTA = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_tta.npz'))
 
 
 def _net(rois, obn, k, scale):
-    """The fixtures' deterministic stand-in network, on the device: scores are a function of the
-    fed roi / obn rows only (make_golden_host_paths.py / make_golden_tta.py `fetch`)."""
-    b = (rois[:, 1:5].sum(1, keepdim=True) * np.float32(0.001) + obn.reshape(-1, 1)).float()
-    j = torch.arange(k, device=rois.device, dtype=torch.float32)[None, :]
-    if scale:                                     # make_golden_tta.py
-        return (b * (1.0 + j * 0.03125)).float()
-    return (b + j * np.float32(0.01)).float()      # make_golden_host_paths.py
+    """The fixtures' deterministic stand-in network: scores are a function of the fed roi / obn
+    rows only (make_golden_host_paths.py / make_golden_tta.py `fetch`).  Evaluated with the very
+    numpy expression the generator used (a device-side sum may associate differently), on the
+    rows downloaded from the device, and uploaded again."""
+    r = rois.cpu().numpy()
+    o = obn.reshape(-1, 1).cpu().numpy()
+    b = (r[:, 1:5].sum(1, keepdims=True) * 0.001 + o).astype(np.float32)
+    j = np.arange(k, dtype=np.float32)[None, :]
+    out = (b * (1.0 + j * 0.03125)) if scale else (b + j * 0.01)
+    return torch.from_numpy(out.astype(np.float32)).to(rois.device)
 
 
 def test_roi_dedup_kernel_matches_reference_im_detect_bbox(dev):

@@ -242,10 +242,104 @@ def test_acm_sgd(dev, iter_size, gpu_num, nesterov):
                                        gpu_num, lr_mult[k], it_ref[k])
             mr[sl], pr[sl], ar[sl] = mk, pk, ak
             lo += sz
-        _close(pd, pr, rtol=1e-6, atol=1e-7)
-        _close(md, mr, rtol=1e-5, atol=1e-8)
+        # every product and sum of the kernel is rounded on its own (no FMA contraction), as in
+        # the oracle's -ffp-contract=off restatement of the scalar CPU operator: bit for bit
+        assert np.array_equal(pd.cpu().numpy(), pr), it
+        assert np.array_equal(md.cpu().numpy(), mr), it
         if use_acm:
-            _close(ad, ar, rtol=1e-6, atol=1e-7)
+            assert np.array_equal(ad.cpu().numpy(), ar), it
+
+
+def _planes_to_dense(f16x2, rows_per_batch):
+    """F16x2 planes [2, (b,) K/16, rows, 16] -> the fp32 matrix they represent, [b*rows, K]."""
+    p = f16x2.planes.double()
+    d = p[0] + p[1]
+    if d.dim() == 3:
+        d = d.unsqueeze(0)
+    d = d.permute(0, 2, 1, 3).reshape(d.shape[0] * d.shape[2], -1)       # [b*rows, K]
+    return d * f16x2.inv_scale.reshape(-1).double()[:, None]
+
+
+@pytest.mark.parametrize('nesterov', [0, 1])
+def test_acm_sgd_update_f16x2_writes_the_operand_planes(dev, nesterov):
+    """naws_acm_sgd_update_f16x2: parameters and momentum bit-identical to the
+    plain fused update (which is held to the oracle in test_acm_sgd); rowmax = the exact row
+    maxima of the updated weights; the planes it writes, times the 1/scale it reports, reproduce
+    every updated weight to the documented 2^-22 relative / 2^-38 of twice the old row maximum;
+    the bias / fc8 elements between and behind the matrices are updated too."""
+    from naws_hip import ops
+    rng = np.random.default_rng(8 + nesterov)
+    # [W6-like 64 x 512 | bias 64 | W7-like 2 x (32 x 256) | bias 64 | tail 40]
+    r6, c6, r7, c7 = 64, 512, 32, 256
+    sizes = [r6 * c6, 64, 2 * r7 * c7, 64, 40]
+    lr_mult = [1.0, 2.0, 1.0, 2.0, 1.0]
+    wd = [5e-4, 0.0, 5e-4, 0.0, 5e-4]
+    total = sum(sizes)
+    o7 = sizes[0] + sizes[1]
+    ends = _t(np.cumsum(sizes).astype(np.int64), dev)
+    lm, wdd = _t(np.array(lr_mult, np.float32), dev), _t(np.array(wd, np.float32), dev)
+    p0 = rng.standard_normal(total).astype(np.float32)
+    p0[:r6 * c6].reshape(r6, c6)[5] *= 1e-6             # rows of very different magnitude
+    p0[:r6 * c6].reshape(r6, c6)[9] *= 3e4
+    lr = _t(np.array([1e-2], np.float32), dev)
+    pa, pb = _t(p0, dev), _t(p0, dev)
+    ma = _t(rng.standard_normal(total).astype(np.float32), dev)    # garbage: the first call zeroes it
+    mb = ma.clone()
+    w6 = pb[:r6 * c6].view(r6, c6)
+    w7 = pb[o7:o7 + 2 * r7 * c7].view(2, r7, c7)
+    q6, q7 = ops.split_f16x2(w6), ops.split_f16x2(w7)                     # initial planes + maxima
+    bound = torch.zeros((r6 + 2 * r7,), device=dev, dtype=torch.int32)
+    ovf = torch.zeros((1,), device=dev, dtype=torch.int32)
+    mx6, mx7 = q6.scales[0].view(torch.int32), q7.scales[0].view(torch.int32).reshape(-1)
+    regs = ops.SgdPlaneRegions([(0, r6, c6, r6, q6.planes, bound[:r6], mx6, q6.scales[1]),
+                                (o7, 2 * r7, c7, r7, q7.planes, bound[r6:], mx7,
+                                 q7.scales[1].reshape(-1))])
+    rowscale = np.ones((total,), np.float32)            # gradients in proportion to their rows
+    rowscale[:r6 * c6].reshape(r6, c6)[5] = 1e-6
+    rowscale[:r6 * c6].reshape(r6, c6)[9] = 3e4
+    for it in range(3):
+        g = _t(rng.standard_normal(total).astype(np.float32) * rowscale, dev)
+        ops.acm_sgd_update(g, ma, lr, pa, None, ends, lm, wdd, 0.9, nesterov, 1, 2, it)
+        bound[:r6].copy_(mx6); bound[r6:].copy_(mx7)
+        old = bound.clone()
+        mx6.zero_(); mx7.zero_()
+        ops.acm_sgd_update_f16x2(g, mb, lr, pb, ends, lm, wdd, 0.9, nesterov, 2, it, regs, ovf, it + 1)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb), it
+        assert int(ovf.item()) == 0
+        for w, q, mx, b in ((w6, q6, mx6, old[:r6]), (w7, q7, mx7, old[r6:])):
+            w2 = w.reshape(-1, w.shape[-1])
+            assert torch.equal(mx.view(torch.float32), w2.abs().amax(dim=1)), it
+            dense = _planes_to_dense(q, w.shape[-2])
+            err = (dense - w2.double()).abs()
+            floor = 2.0 * b.view(torch.float32).double() * 2.0 ** -38
+            tol = torch.maximum(w2.double().abs() * 2.0 ** -22, floor[:, None])
+            assert bool((err <= tol).all()), (it, float((err / tol).max()))
+            # 1/scale is the power of two that goes with twice the old maximum
+            e_old = torch.floor(torch.log2(b.view(torch.float32).double()))
+            assert torch.equal(q.inv_scale.reshape(-1).double(), 2.0 ** (e_old + 1 - 14)), it
+    # ---- a row that outgrows twice its old maximum raises the flag, and the conditional re-split
+    # then leaves exactly the planes of a from-scratch split
+    g = torch.zeros((total,), device=dev)
+    g[3 * c6:4 * c6] = -5e3                     # row 3 of W6 jumps by lr * 5e3 / gpu_num = 25
+    bound[:r6].copy_(mx6); bound[r6:].copy_(mx7)
+    mx6.zero_(); mx7.zero_()
+    ops.acm_sgd_update_f16x2(g, mb, lr, pb, ends, lm, wdd, 0.9, nesterov, 2, 3, regs, ovf, 77)
+    assert int(ovf.item()) == 77
+    ops.split_f16x2_rows_if(w6, mx6, q6, ovf, 76)                         # wrong tag: nothing happens
+    stale = q6.planes.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(stale, q6.planes)
+    ops.split_f16x2_rows_if(w6, mx6, q6, ovf, 77)
+    ops.split_f16x2_rows_if(w7, mx7, q7, ovf, 77)
+    for w, q in ((w6, q6), (w7, q7)):
+        fresh = ops.split_f16x2(w)
+        assert torch.equal(q.inv_scale, fresh.inv_scale)
+        assert torch.equal(q.planes.view(torch.int16), fresh.planes.view(torch.int16))
+    # argument checks (the ENFORCE-style codes)
+    from naws_hip import lib
+    bad = ops.SgdPlaneRegions([(0, r6, c6 - 256 + 64, r6, q6.planes, bound[:r6], mx6, q6.scales[1])])
+    with pytest.raises(lib.NawsError):
+        ops.acm_sgd_update_f16x2(g, mb, lr, pb, ends, lm, wdd, 0.9, 0, 2, 4, bad, ovf, 1)
 
 
 def test_stat(dev):
