@@ -11,7 +11,8 @@
 // Workspace layout: V [16][P*Cin + PAD] | M [16][P*Cout + PAD], P = N * d*d * ceil(Hs/2) *
 // ceil(Ws/2); PAD = 0 (spacing the 16 slabs apart was tried against HBM-channel aliasing: no effect).
 #include <stdlib.h>
-#include "naws_common.h"
+#include <type_traits>
+#include "x3_common.h"
 
 namespace {
 
@@ -259,6 +260,256 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   }
 }
 
+// ---- fp16x2: the 16 batched GEMMs AND the output transform in one kernel ------------------------
+// (VERDICT r2 #4.)  The three-kernel route writes M = V U (16 x P x Cout fp32, 78 MB per conv4/5
+// layer-image) and reads it back for A^T M A, and each of its 16 x tiles GEMM tiles has a K loop
+// of only Cin / 16 = 16..32 steps: prologue + epilogue dominated (18-28 % MFMA busy).  Here a
+// workgroup owns 64 Winograd tiles x 128 output channels for ALL 16 frequencies: one K loop of
+// 16 x Cin (the operand planes are laid out so that frequency xi's slabs follow xi-1's: global
+// slab index = xi * Cin/16 + s, for V and U alike), a per-frequency accumulator that is folded
+//      Y[i][j] += AT[i][a] AT[j][b] * (V_xi U_xi) * (1/scaleV * 1/scaleU[xi][col]),  xi = 4 a + b,
+//      AT = [[1, 1, 1, 0], [0, 1, -1, -1]]
+// into the four output-position accumulators at each frequency boundary (36 of the 64
+// coefficient pairs are non-zero: 2.25 fused multiply-adds per product element, on the VALU
+// beside the next frequency's MFMAs), and an epilogue that adds the bias, applies the ReLU,
+// writes the 2 x 2 output pixels of each tile straight into the NHWC tensor and reports max|y|.
+// M never exists.  Pipeline = gemm_x3_kernel's: 3-stage LDS ring of 32-deep K-steps filled by
+// LDS-DMA two steps ahead, counted s_waitcnt + one raw s_barrier per step, same swizzled LDS image.
+struct WinoFusedArgs {
+  const unsigned short* V;   // planes [2][16][Cin/16][P][16]
+  const unsigned short* U;   // planes [2][16][Cin/16][Cout][16]
+  const float* invV;         // [P], all equal: 1/scale of V
+  const float* scaleU;       // [16][Cout]: 1/scale of U's rows
+  const float* bias;
+  float* Y;
+  unsigned* amax_out;
+  WinoGeom g;
+  int Cin, Cout, relu;
+  long long planeV, planeU;
+  int tiles_m, tiles_n;
+};
+
+constexpr int WF_BM = 64, WF_BN = 128, WF_KS = 2, WF_STAGES = 3;
+constexpr int WF_A_PLANE = WF_BM * 32, WF_B_PLANE = WF_BN * 32, WF_NQ = 2 * WF_KS;
+constexpr int WF_STAGE = WF_NQ * (WF_A_PLANE + WF_B_PLANE);            // 24 KB
+constexpr int WF_PIECES = WF_NQ * (WF_BM / 32 + WF_BN / 32);           // 1 KB DMA pieces per step
+constexpr int WF_G = WF_PIECES / 4;                                    // per wave
+constexpr int WF_LDS = WF_STAGES * WF_STAGE + WF_BM * 8 + 16;   // ring | tile table | amax words
+
+template <int XI>
+__device__ __forceinline__ void wino_fold(f32x16 (&tmp)[2], f32x16 (&out)[4][2], const float (&c)[2]) {
+  constexpr int a = XI / 4, b = XI % 4;
+  constexpr int AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      constexpr int unused = 0; (void)unused;
+      const int sgn = AT[i][a] * AT[jj][b];
+      if (sgn == 0) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float cj = sgn > 0 ? c[j] : -c[j];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[i * 2 + jj][j][e] = fmaf(tmp[j][e], cj, out[i * 2 + jj][j][e]);
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tmp[j][e] = 0.f;
+}
+
+__global__ __launch_bounds__(256, 2) void wino_fused_h2_kernel(WinoFusedArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  // one contiguous tile range per XCD (as gemm_x3_kernel): the four channel tiles of a row of
+  // Winograd tiles sit on one L2
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int lid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, rem = ntiles & 7, xcd = lid & 7, within = lid >> 3;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+  }
+  const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+  const int m0 = tm * WF_BM, n0 = tn * WF_BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int P = (int)g.g.P;
+
+  // output addressing of the workgroup's 64 tiles: element offset of output pixel (0, 0) of
+  // the tile and which of its 2 x 2 pixels exist
+  int* tab_off = reinterpret_cast<int*>(smx + WF_STAGES * WF_STAGE);
+  int* tab_ok = tab_off + WF_BM;
+  if (tid < WF_BM) {
+    const int p = m0 + tid;
+    int off = 0, ok = 0;
+    if (p < P) {
+      int n, py, px, ty, tx;
+      tile_coords(g.g, p, n, py, px, ty, tx);
+      const int y0 = 2 * ty * g.g.d + py, x0 = 2 * tx * g.g.d + px;
+      off = ((n * g.g.H + y0) * g.g.W + x0) * g.Cout;
+      ok = (y0 < g.g.H && x0 < g.g.W ? 1 : 0) | (y0 + g.g.d < g.g.H ? 2 : 0) | (x0 + g.g.d < g.g.W ? 4 : 0);
+    }
+    tab_off[tid] = off;
+    tab_ok[tid] = ok;
+  }
+
+  // DMA pieces of this wave: q = wid + 4 k; q < 8: V piece (plane-slab q / 2, 32-row group q % 2),
+  // else U piece (plane-slab (q - 8) / 4, row group (q - 8) % 4)
+  const int lrow = lane >> 1;
+  const int kslot = ((lane & 1) ^ ((lrow >> 3) & 1)) * 8;
+  // k < 2: a V piece (q = wid + 4 k < 8), k >= 2: a U piece
+  const unsigned short* src[WF_G];
+  int dst[WF_G];
+  const long long slabV = (long long)P * 16, slabU = (long long)g.Cout * 16;
+#pragma unroll
+  for (int k = 0; k < WF_G; ++k) {
+    const int q = wid + 4 * k;
+    if (k < 2) {
+      const int pq = q / (WF_BM / 32), rg = q % (WF_BM / 32);
+      const int pl = pq / WF_KS, ks = pq % WF_KS;
+      src[k] = g.V + pl * g.planeV + ks * slabV + (long long)min(m0 + rg * 32 + lrow, P - 1) * 16 + kslot;
+      dst[k] = pq * WF_A_PLANE + rg * 1024;
+    } else {
+      const int q2 = q - WF_NQ * (WF_BM / 32);
+      const int pq = q2 / (WF_BN / 32), rg = q2 % (WF_BN / 32);
+      const int pl = pq / WF_KS, ks = pq % WF_KS;
+      src[k] = g.U + pl * g.planeU + ks * slabU +
+               (long long)min(n0 + rg * 32 + lrow, g.Cout - 1) * 16 + kslot;
+      dst[k] = WF_NQ * WF_A_PLANE + pq * WF_B_PLANE + rg * 1024;
+    }
+  }
+  const long long stepV = WF_KS * slabV, stepU = WF_KS * slabU;     // elements per K-step
+  auto issue = [&](int st) {                        // the next K-step of the stream, in order
+    unsigned char* base = smx + st * WF_STAGE;
+#pragma unroll
+    for (int k = 0; k < WF_G; ++k) {
+      __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(src[k]), NAWS_LDS_PTR(base + dst[k]), 16, 0, 0);
+      src[k] += (k < 2) ? stepV : stepU;
+    }
+  };
+
+  f32x16 tmp[2], out[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      tmp[j][e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[q][j][e] = 0.f;
+    }
+  const int swz = (h ^ ((l31 >> 3) & 1)) * 16;
+  const int rd_a = (wm * 32 + l31) * 32 + swz;
+  const int rd_b = WF_NQ * WF_A_PLANE + (wn * 64 + l31) * 32 + swz;
+  const int S2 = g.Cin / (16 * WF_KS);              // K-steps per frequency
+  const int T = 16 * S2;
+  const float isc = g.invV[0];
+  const int colj = n0 + wn * 64 + l31;              // this lane's column of block j = 0 (j = 1: + 32)
+  const int c0i = min(colj, g.Cout - 1), c1i = min(colj + 32, g.Cout - 1);
+
+#pragma unroll
+  for (int s = 0; s < WF_STAGES - 1; ++s)
+    if (s < T) issue(s);
+  int st_cur = 0, st_fill = WF_STAGES - 1;
+  int xi = 0, left = S2;
+  float cf[2] = {g.scaleU[c0i] * isc, g.scaleU[c1i] * isc};
+  for (int t = 0; t < T; ++t) {
+    if (t + WF_STAGES - 2 < T) wait_vmcnt<(WF_STAGES - 2) * WF_G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + WF_STAGES - 1 < T) issue(st_fill);
+    const unsigned char* st = smx + st_cur * WF_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < WF_KS; ++ks) {
+      f16x8 a[2], b[2][2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        a[pl] = *reinterpret_cast<const f16x8*>(st + rd_a + (pl * WF_KS + ks) * WF_A_PLANE);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[pl][j] = *reinterpret_cast<const f16x8*>(st + rd_b + (pl * WF_KS + ks) * WF_B_PLANE + j * 1024);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tmp[j] = mfma16(a[0], b[0][j], tmp[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tmp[j] = mfma16(a[0], b[1][j], tmp[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tmp[j] = mfma16(a[1], b[0][j], tmp[j]);
+    }
+    st_cur = (st_cur + 1 == WF_STAGES) ? 0 : st_cur + 1;
+    st_fill = (st_fill + 1 == WF_STAGES) ? 0 : st_fill + 1;
+    if (--left == 0) {
+      // frequency xi = 4 a + b is complete: Y[i][j] += AT[i][a] AT[j][b] * tmp * (1 / scales),
+      // AT = [[1, 1, 1, 0], [0, 1, -1, -1]].  The coefficients are wave-uniform run-time values
+      // (a zero coefficient still costs its multiply-add: 4 instead of 2.25 per element, in
+      // exchange for ONE copy of the loop - 16 specialised copies spilt half the accumulators)
+      const int a = xi >> 2, b = xi & 3;
+      const float ra[2] = {a == 3 ? 0.f : 1.f, a == 0 ? 0.f : (a == 1 ? 1.f : -1.f)};
+      const float rb[2] = {b == 3 ? 0.f : 1.f, b == 0 ? 0.f : (b == 1 ? 1.f : -1.f)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float cq = ra[q >> 1] * rb[q & 1];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float c = cq * cf[j];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) out[q][j][e] = fmaf(tmp[j][e], c, out[q][j][e]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tmp[j][e] = 0.f;
+      ++xi;
+      left = S2;
+      if (xi < 16) {
+        cf[0] = g.scaleU[(long long)xi * g.Cout + c0i] * isc;
+        cf[1] = g.scaleU[(long long)xi * g.Cout + c1i] * isc;
+      }
+    }
+  }
+
+  // ---- epilogue: bias, ReLU, the tile's 2 x 2 output pixels, max|y|
+  float vmax = 0.f;
+  const int dW = g.g.d * g.g.W * g.Cout, dX = g.g.d * g.Cout;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = colj + j * 32;
+    if (col >= g.Cout) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int ok = tab_ok[row];
+      if (!(ok & 1)) continue;
+      float* y00 = g.Y + tab_off[row] + col;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = q >> 1, jj = q & 1;
+        if ((i && !(ok & 2)) || (jj && !(ok & 4))) continue;
+        float v = out[q][j][e] + bv;
+        if (g.relu) v = fmaxf(v, 0.f);
+        y00[i * dW + jj * dX] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  }
+  if (g.amax_out) {
+    vmax = wave_max(vmax);
+    // (no static LDS in this kernel: its dynamic limit is raised to the full 160 KB)
+    float* red = reinterpret_cast<float*>(smx + WF_STAGES * WF_STAGE + WF_BM * 8);
+    if (lane == 0) red[wid] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+      if (v > __hip_atomic_load(g.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(g.amax_out, v);
+    }
+  }
+}
+
 // U[xi][o][c] = (G g G^T)[xi] from the reference blob layout [O][I][3][3]
 __global__ void wino_weight_kernel(const float* __restrict__ Wt, int Cout, int Cin,
                                    float* __restrict__ U) {
@@ -443,6 +694,19 @@ extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* 
                        dim3(256), 0, s, X, g, Cin, amax, invA, Vp, (unsigned*)amax_out);
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
+  }
+  // the fused GEMM + output-transform kernel (knob "wino" = 1: the three-kernel route)
+  if (naws_knob(NAWS_KNOB_WINO) != 1 && (long long)N * H * W * Cout < 0x7fffffffLL &&
+      16 * g.P * Cin < 0x7fffffffLL) {
+    WinoFusedArgs a{};
+    a.V = Vp; a.U = (const unsigned short*)U2; a.invV = invA; a.scaleU = scaleU; a.bias = bias;
+    a.Y = Y; a.amax_out = (unsigned*)amax_out; a.g = g; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+    a.planeV = 16 * g.P * Cin; a.planeU = (long long)16 * Cout * Cin;
+    a.tiles_m = (int)naws_cdiv(g.P, WF_BM); a.tiles_n = (int)naws_cdiv(Cout, WF_BN);
+    if (naws_allow_lds(wino_fused_h2_kernel) != NAWS_OK) return NAWS_ERR_LAUNCH;
+    hipLaunchKernelGGL(wino_fused_h2_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256),
+                       WF_LDS, s, a);
+    return naws_check_launch();
   }
   int rc = naws_gemm_f32_f16x2_nt((int)g.P, Cout, Cin, Vp, g.P * 16, 16 * g.P * Cin, invA, U2,
                                   (int64_t)Cout * 16, (int64_t)16 * Cout * Cin, scaleU, Mb, Cout, 16,
