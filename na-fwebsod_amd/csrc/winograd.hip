@@ -289,6 +289,7 @@ struct WinoFusedArgs {
   int tiles_m, tiles_n;
 };
 
+#ifdef NAWS_AB   // the LDS-DMA form of the fusion: measured, not faster (see below); A/B build only
 constexpr int WF_BM = 64, WF_BN = 128, WF_KS = 2, WF_STAGES = 3;
 constexpr int WF_A_PLANE = WF_BM * 32, WF_B_PLANE = WF_BN * 32, WF_NQ = 2 * WF_KS;
 constexpr int WF_STAGE = WF_NQ * (WF_A_PLANE + WF_B_PLANE);            // 24 KB
@@ -510,6 +511,224 @@ __global__ __launch_bounds__(256, 2) void wino_fused_h2_kernel(WinoFusedArgs g) 
   }
 }
 
+#endif  // NAWS_AB
+
+// ---- the same fusion with wave-private weight fragments ------------------------------------------
+// The form above moves 24 KB per K-step through LDS-DMA for 12 MFMAs per wave: 6 DMA issues per
+// wave and step (100+ cycles each beside MFMAs and LDS reads) cost more than the MFMAs they feed
+// (measured: 0.148 ms per conv4_2 image against 0.118 for the GEMM + transform pair it replaces).
+// Here the four waves are a 1 x 4 grid - wave wc owns ALL rows of the workgroup's 32 TI Winograd
+// tiles x the 32 output channels wc - so a wave's MFMA B operand (32 channels x 16 deep x 2 planes)
+// is exactly one 16-byte buffer load per lane and plane straight from U's slab-major planes (1 KB
+// contiguous per wave-instruction), used by no other wave: it skips LDS, is prefetched two K-steps
+// ahead in a static 4-deep register ring, and needs no barrier.  Only V's 32 TI rows go through
+// the (3-stage, LDS-DMA) ring: TI pieces per wave and step instead of 6.
+template <int TI, int KS>
+__global__ __launch_bounds__(256, 2) void wino_fused_wp_kernel(WinoFusedArgs g) {
+  constexpr int BM = 32 * TI, STAGES = 3;
+  constexpr int RING = KS >= 4 ? 2 : 4, AHEAD = KS >= 4 ? 1 : 2;    // U fragment ring / prefetch distance
+  constexpr int A_PLANE = BM * 32, NQ = 2 * KS, STAGE = NQ * A_PLANE;
+  constexpr int GA = NQ * TI / 4;                   // V pieces (1 KB) per wave per K-step
+  constexpr int G = GA + NQ;                        // + this wave's U fragments
+  static_assert(NQ * TI % 4 == 0, "pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int lid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, rem = ntiles & 7, xcd = lid & 7, within = lid >> 3;
+    lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+  }
+  const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int P = (int)g.g.P;
+
+  int* tab_off = reinterpret_cast<int*>(smx + STAGES * STAGE);
+  int* tab_ok = tab_off + BM;
+  if (tid < BM) {
+    const int p = m0 + tid;
+    int off = 0, ok = 0;
+    if (p < P) {
+      int n, py, px, ty, tx;
+      tile_coords(g.g, p, n, py, px, ty, tx);
+      const int y0 = 2 * ty * g.g.d + py, x0 = 2 * tx * g.g.d + px;
+      off = ((n * g.g.H + y0) * g.g.W + x0) * g.Cout;
+      ok = (y0 < g.g.H && x0 < g.g.W ? 1 : 0) | (y0 + g.g.d < g.g.H ? 2 : 0) | (x0 + g.g.d < g.g.W ? 4 : 0);
+    }
+    tab_off[tid] = off;
+    tab_ok[tid] = ok;
+  }
+
+  // V pieces of this wave: q = wc * GA + k -> (plane-slab q / TI, 32-row group q % TI)
+  const int lrow = lane >> 1;
+  const int kslot = ((lane & 1) ^ ((lrow >> 3) & 1)) * 8;
+  const long long slabV = (long long)P * 16;
+  const unsigned short* src[GA];
+  int dst[GA];
+#pragma unroll
+  for (int k = 0; k < GA; ++k) {
+    const int q = wc * GA + k;
+    const int pq = q / TI, rg = q % TI;
+    const int pl = pq / KS, ks = pq % KS;
+    src[k] = g.V + pl * g.planeV + ks * slabV + (long long)min(m0 + rg * 32 + lrow, P - 1) * 16 + kslot;
+    dst[k] = pq * A_PLANE + rg * 1024;
+  }
+  const long long stepV = KS * slabV;
+  auto issueA = [&](int st) {
+    unsigned char* base = smx + st * STAGE;
+#pragma unroll
+    for (int k = 0; k < GA; ++k) {
+      __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(src[k]), NAWS_LDS_PTR(base + dst[k]), 16, 0, 0);
+      src[k] += stepV;
+    }
+  };
+  // U fragments: lane (l31, h) holds k-half h of channel n0 + 32 wc + l31
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)g.U, 0, (int)(2 * g.planeU * 2), 0x00020000);
+  const int voffB = (min(n0 + wc * 32 + l31, g.Cout - 1) * 16 + h * 8) * 2;
+  const int slabBytes = g.Cout * 32, planeBytes = (int)(g.planeU * 2);
+  f16x8 bq[RING][KS][2];
+  auto loadB = [&](auto ring_tag, int step) {
+    constexpr int R = decltype(ring_tag)::value;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+            rsU, voffB, (step * KS + ks) * slabBytes + pl * planeBytes, 0);
+        bq[R][ks][pl] = *reinterpret_cast<const f16x8*>(&v);
+      }
+  };
+
+  f32x16 tmp[TI], out[4][TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      tmp[i][e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[q][i][e] = 0.f;
+    }
+  const int rd_a = l31 * 32 + (h ^ ((l31 >> 3) & 1)) * 16;
+  const int S2 = g.Cin / (16 * KS);
+  const int T = 16 * S2;                            // a multiple of 4 (host: Cin % (64 KS) == 0)
+  const float isc = g.invV[0];
+  const int col = n0 + wc * 32 + l31;
+  const int ci = min(col, g.Cout - 1);
+
+  issueA(0); loadB(std::integral_constant<int, 0>{}, 0);
+  issueA(1);
+  if constexpr (AHEAD == 2) loadB(std::integral_constant<int, 1>{}, 1);
+  int st_cur = 0, st_fill = STAGES - 1;
+  int xi = 0, left = S2;
+  float cf = g.scaleU[ci] * isc;
+  auto step = [&](auto u_tag, int t) {
+    constexpr int U = decltype(u_tag)::value;
+    // in flight behind step t's operands: V pieces of step t+1 (and, AHEAD 2, its U fragments)
+    if (t + 1 < T) wait_vmcnt<(AHEAD == 2 ? G : GA)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < T) issueA(st_fill);
+    if (t + AHEAD < T) loadB(std::integral_constant<int, (U + AHEAD) % RING>{}, t + AHEAD);
+    const unsigned char* st = smx + st_cur * STAGE;
+    // every fragment of the step is requested before its first MFMA: one LDS latency per step
+    f16x8 a[KS][2][TI];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          a[ks][pl][i] = *reinterpret_cast<const f16x8*>(st + rd_a + (pl * KS + ks) * A_PLANE + i * 1024);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) tmp[i] = mfma16(a[ks][0][i], bq[U % RING][ks][0], tmp[i]);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) tmp[i] = mfma16(a[ks][0][i], bq[U % RING][ks][1], tmp[i]);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) tmp[i] = mfma16(a[ks][1][i], bq[U % RING][ks][0], tmp[i]);
+    }
+    st_cur = (st_cur + 1 == STAGES) ? 0 : st_cur + 1;
+    st_fill = (st_fill + 1 == STAGES) ? 0 : st_fill + 1;
+    if (--left == 0) {
+      const int a = xi >> 2, b = xi & 3;
+      const float ra[2] = {a == 3 ? 0.f : 1.f, a == 0 ? 0.f : (a == 1 ? 1.f : -1.f)};
+      const float rb[2] = {b == 3 ? 0.f : 1.f, b == 0 ? 0.f : (b == 1 ? 1.f : -1.f)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float c = ra[q >> 1] * rb[q & 1] * cf;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) out[q][i][e] = fmaf(tmp[i][e], c, out[q][i][e]);
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tmp[i][e] = 0.f;
+      ++xi;
+      left = S2;
+      if (xi < 16) cf = g.scaleU[(long long)xi * g.Cout + ci] * isc;
+    }
+  };
+  for (int t = 0; t < T; t += 4) {
+    step(std::integral_constant<int, 0>{}, t);
+    step(std::integral_constant<int, 1>{}, t + 1);
+    step(std::integral_constant<int, 2>{}, t + 2);
+    step(std::integral_constant<int, 3>{}, t + 3);
+  }
+
+  float vmax = 0.f;
+  const int dW = g.g.d * g.g.W * g.Cout, dX = g.g.d * g.Cout;
+  if (col < g.Cout) {
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int ok = tab_ok[row];
+        if (!(ok & 1)) continue;
+        float* y00 = g.Y + tab_off[row] + col;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ii = q >> 1, jj = q & 1;
+          if ((ii && !(ok & 2)) || (jj && !(ok & 4))) continue;
+          float v = out[q][i][e] + bv;
+          if (g.relu) v = fmaxf(v, 0.f);
+          y00[ii * dW + jj * dX] = v;
+          vmax = fmaxf(vmax, fabsf(v));
+        }
+      }
+  }
+  if (g.amax_out) {
+    vmax = wave_max(vmax);
+    float* red = reinterpret_cast<float*>(smx + STAGES * STAGE + BM * 8);
+    if (lane == 0) red[wc] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+      if (v > __hip_atomic_load(g.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(g.amax_out, v);
+    }
+  }
+}
+
+template <int TI, int KS>
+int launch_wino_fused_wp(WinoFusedArgs& a, hipStream_t s) {
+  constexpr int BM = 32 * TI;
+  a.tiles_m = (int)naws_cdiv(a.g.P, BM);
+  a.tiles_n = (int)naws_cdiv(a.Cout, 128);
+  const size_t lds = (size_t)3 * (2 * KS * BM * 32) + BM * 8 + 16;
+  auto kern = wino_fused_wp_kernel<TI, KS>;
+  if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), lds, s, a);
+  return naws_check_launch();
+}
+
 // U[xi][o][c] = (G g G^T)[xi] from the reference blob layout [O][I][3][3]
 __global__ void wino_weight_kernel(const float* __restrict__ Wt, int Cout, int Cin,
                                    float* __restrict__ U) {
@@ -695,18 +914,38 @@ extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* 
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
   }
-  // the fused GEMM + output-transform kernel (knob "wino" = 1: the three-kernel route)
-  if (naws_knob(NAWS_KNOB_WINO) != 1 && (long long)N * H * W * Cout < 0x7fffffffLL &&
-      16 * g.P * Cin < 0x7fffffffLL) {
+  // The fused GEMM + output-transform kernel where it wins (tools/ab_wino.py, interleaved, one
+  // image per launch as the engine runs them; ms incl. the 0.035 ms input transform):
+  //     layer shape            three kernels   fused (32 tiles x 128 ch, 64-deep K-steps)
+  //     256 -> 256, 150x250        0.219           0.169
+  //     256 -> 512,  75x125        0.111           0.102
+  //     512 -> 512,  75x125        0.149           0.175     (every fused form: 0.17-0.21)
+  // A fused workgroup walks all 16 frequencies, so U's planes (16 Cin Cout 4 B) are streamed by
+  // every row of tiles: at 512 x 512 they are 16.8 MB, four times an XCD's L2, and come from the
+  // Infinity Cache each time - the three-kernel route keeps whole frequencies (1 MB of U) on one
+  // XCD.  Rule: fuse while U's planes stay within 8.4 MB.  Knob "wino": 0 = this rule, 1 = never
+  // fuse, 3 = always (A/B build: 2 / 4 / 5 / 6 select the other fused forms).
+  const int wv = naws_knob(NAWS_KNOB_WINO);
+  const bool fits = (long long)N * H * W * Cout < 0x7fffffffLL && 16 * g.P * Cin < 0x7fffffffLL &&
+                    (long long)64 * Cout * Cin < 0x7fffffffLL && Cin % 256 == 0;
+  if (wv != 1 && fits && (wv != 0 || (long long)Cin * Cout <= 256 * 512)) {
     WinoFusedArgs a{};
     a.V = Vp; a.U = (const unsigned short*)U2; a.invV = invA; a.scaleU = scaleU; a.bias = bias;
     a.Y = Y; a.amax_out = (unsigned*)amax_out; a.g = g; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.planeV = 16 * g.P * Cin; a.planeU = (long long)16 * Cout * Cin;
-    a.tiles_m = (int)naws_cdiv(g.P, WF_BM); a.tiles_n = (int)naws_cdiv(Cout, WF_BN);
-    if (naws_allow_lds(wino_fused_h2_kernel) != NAWS_OK) return NAWS_ERR_LAUNCH;
-    hipLaunchKernelGGL(wino_fused_h2_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256),
-                       WF_LDS, s, a);
-    return naws_check_launch();
+#ifdef NAWS_AB
+    if (wv == 2) {
+      a.tiles_m = (int)naws_cdiv(g.P, WF_BM); a.tiles_n = (int)naws_cdiv(Cout, WF_BN);
+      if (naws_allow_lds(wino_fused_h2_kernel) != NAWS_OK) return NAWS_ERR_LAUNCH;
+      hipLaunchKernelGGL(wino_fused_h2_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256),
+                         WF_LDS, s, a);
+      return naws_check_launch();
+    }
+    if (wv == 4) return launch_wino_fused_wp<1, 2>(a, s);
+    if (wv == 5) return launch_wino_fused_wp<2, 2>(a, s);
+    if (wv == 7) return launch_wino_fused_wp<2, 4>(a, s);
+#endif
+    return launch_wino_fused_wp<1, 4>(a, s);
   }
   int rc = naws_gemm_f32_f16x2_nt((int)g.P, Cout, Cin, Vp, g.P * 16, 16 * g.P * Cin, invA, U2,
                                   (int64_t)Cout * 16, (int64_t)16 * Cout * Cin, scaleU, Mb, Cout, 16,

@@ -29,9 +29,10 @@ def main():
         b = torch.randn((cout,), device=dev, generator=g)
         u2 = ops.split_f16x2(ops.winograd_weight_transform(wt))
         am = ops.amax_word(x)
-        outs, times = {}, {0: [], 1: []}
+        variants = (0, 1, 2, 4, 5, 6)
+        outs, times = {}, {v: [] for v in variants}
         for r in range(a.rounds + 1):
-            for v in (0, 1):
+            for v in variants:
                 L.set_variant('wino', v)
                 amo = torch.zeros((1,), device=dev, dtype=torch.int32)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,11 +45,11 @@ def main():
                 else:
                     times[v].append(s.elapsed_time(e))
         L.set_variant('wino', 0)
-        d = float((outs[0][0] - outs[1][0]).abs().max() / outs[1][0].abs().max())
+        d = max(float((outs[v][0] - outs[1][0]).abs().max() / outs[1][0].abs().max()) for v in variants)
         med = {v: sorted(t)[len(t) // 2] for v, t in times.items()}
-        print('%s %d->%d %dx%d d%d x%d: fused %.3f ms, three kernels %.3f ms; max |diff| / max %.1e; '
-              'amax words %s' % (name, cin, cout, h, w, dil, a.images, med[0], med[1], d,
-                                 'equal' if outs[0][1] == outs[1][1] else 'differ (%x %x)' % (outs[0][1], outs[1][1])),
+        print('%s %d->%d %dx%d d%d x%d: auto %.3f ms, three kernels %.3f, fused: LDS-DMA %.3f, '
+              'wave-private 32 tiles x K32 %.3f, 64 x K32 %.3f, 32 x K64 %.3f; max |diff| / max %.1e' % (
+                  name, cin, cout, h, w, dil, a.images, med[0], med[1], med[2], med[4], med[5], med[6], d),
               flush=True)
 
 
