@@ -340,17 +340,18 @@ __global__ void stat_kernel(const float* __restrict__ I, const float* __restrict
 // with each other bit for bit.  a = the accumulated gradient (acm + g).
 __device__ __forceinline__ void sgd_elem(float a, float& m, float& p, float scale, float wd, float LR,
                                          float momentum, int nesterov) {
-  float t = __fmul_rn(a, scale);                       // Normalize
-  t = __fadd_rn(t, __fmul_rn(wd, p));                  // Regularize (Axpy)
+#pragma clang fp contract(off)          // (the build's -ffp-contract=fast-honor-pragmas honours this)
+  float t = a * scale;                                 // Normalize
+  t = t + wd * p;                                      // Regularize (Axpy)
   if (!nesterov) {
-    const float adj = __fadd_rn(__fmul_rn(LR, t), __fmul_rn(momentum, m));
+    const float adj = LR * t + momentum * m;
     m = adj;
-    p = __fsub_rn(p, adj);
+    p = p - adj;
   } else {
     const float mi = m;
-    const float mi_new = __fadd_rn(__fmul_rn(momentum, mi), __fmul_rn(LR, t));
+    const float mi_new = momentum * mi + LR * t;
     m = mi_new;
-    p = __fsub_rn(p, __fsub_rn(__fmul_rn(__fadd_rn(1.0f, momentum), mi_new), __fmul_rn(momentum, mi)));
+    p = p - ((1.0f + momentum) * mi_new - momentum * mi);
   }
 }
 __device__ __forceinline__ void sgd_update4(const float4& g, float4& m, float4& p, float scale,

@@ -101,14 +101,32 @@ def main():
             if dom_sub in r['Kernel_Name']:
                 key = (r['Grid_Size_X'], r['Grid_Size_Z'])
                 by[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
-        lines += ['', '| %s launches by grid (x, z) | launches | avg ms | min ms | max ms |' % short(dom_sub),
-                  '|---|---|---|---|---|']
-        for key, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        lines += ['', '| %s launches by grid (x, z) and duration cluster | launches | avg ms | min ms | max ms |'
+                  % short(dom_sub), '|---|---|---|---|---|']
+        # launches of one template with one grid can still be different problems (fc6 forward
+        # K = 25088 and the batch-2 fc7 GEMMs K = 4096 share grid 262144 x 1): the trace has no K
+        # column, so a grid's launches are split where two neighbouring sorted durations differ by
+        # more than 1.8x - each cluster is one problem shape
+        clusters = []
+        for key, v in by.items():
+            v = sorted(v)
+            cur = [v[0]]
+            for a, b in zip(v, v[1:]):
+                if b > 1.8 * a:
+                    clusters.append((key, cur))
+                    cur = []
+                cur.append(b)
+            clusters.append((key, cur))
+        for key, v in sorted(clusters, key=lambda kv: -sum(kv[1]) / len(kv[1])):
             lines.append('| grid %s x %s | %d | %.3f | %.3f | %.3f |' % (key[0], key[1], len(v),
                                                                        sum(v) / len(v), min(v), max(v)))
-        lines += ['', 'bench.py times the fc6-forward launch (M=4000 N=8192 K=25088: grid 262144 x 1 for '
-                  'the fp16x2 / fp32x3 plans) live with HIP events on the launch stream; its `roofline.kernel_ms` '
-                  'is that row.']
+        if dom_grid is not None:
+            dom_c = [v for key, v in clusters if key[0] == dom_grid]
+            if dom_c:
+                v = max(dom_c, key=lambda c: sum(c) / len(c))
+                lines += ['', 'dominant launch (fc6 forward, M=4000 N=8192 K=25088): grid %s, %d launches, '
+                          'avg %.3f ms (min %.3f, max %.3f) - the launch `bench.py` times live with HIP '
+                          'events (`roofline.kernel_ms`)' % (dom_grid, len(v), sum(v) / len(v), min(v), max(v))]
     open(out + '.md', 'w').write('\n'.join(lines) + '\n')
     import shutil
     shutil.copy(_find(stats_dir, '*_kernel_stats.csv')[0], out + '_kernel_stats.csv')

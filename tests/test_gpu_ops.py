@@ -316,7 +316,8 @@ def test_acm_sgd_update_f16x2_writes_the_operand_planes(dev, nesterov):
             assert bool((err <= tol).all()), (it, float((err / tol).max()))
             # 1/scale is the power of two that goes with twice the old maximum
             e_old = torch.floor(torch.log2(b.view(torch.float32).double()))
-            assert torch.equal(q.inv_scale.reshape(-1).double(), 2.0 ** (e_old + 1 - 14)), it
+            want = torch.ldexp(torch.ones_like(e_old), (e_old + 1 - 14).to(torch.int32))   # exact 2^n
+            assert torch.equal(q.inv_scale.reshape(-1).double(), want), it
     # ---- a row that outgrows twice its old maximum raises the flag, and the conditional re-split
     # then leaves exactly the planes of a from-scratch split
     g = torch.zeros((total,), device=dev)
