@@ -300,7 +300,7 @@ __device__ __forceinline__ f32x4 mfma32(f16x8 a, f16x8 b, f32x4 c) {
 template <int BM, int BN, int WM, int WN, int STAGES, int NPL, int KS, bool F16>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_m16_kernel(XArgs g) {
   static_assert(KS % 2 == 0, "a 16x16x32 MFMA spans two 16-deep slabs");
-  static_assert(NPL <= 2, "one- or two-plane operands");
+  static_assert(!F16 || NPL <= 2, "f16 operands have one or two planes");
   typedef typename OperandVec<F16>::type vec_t;
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -310,9 +310,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   constexpr int NQ = NPL * KS;
   constexpr int STAGE = NQ * (A_PLANE + B_PLANE);
   constexpr int PIECE_ROWS = NT / 2;
-  constexpr int PA = BM / PIECE_ROWS, PB = BN / PIECE_ROWS;
-  constexpr int G = NQ * (PA + PB);
-  static_assert(BM % PIECE_ROWS == 0 && BN % PIECE_ROWS == 0, "tile vs workgroup");
+  // DMA pieces (1 KB = 32 rows of one plane-slab).  Tiles whose sides are multiples of the
+  // workgroup's PIECE_ROWS use the round form (wave w takes rows p * PIECE_ROWS + 32 w of every
+  // plane-slab); other tiles (256 x 128 on 8 waves) deal the flat piece list round-robin:
+  // piece q = wid + NW k, the first NQ BM / 32 of them A pieces.
+  constexpr bool ROUND = BM % PIECE_ROWS == 0 && BN % PIECE_ROWS == 0;
+  constexpr int NW = WM * WN;
+  constexpr int PA = ROUND ? BM / PIECE_ROWS : 1, PB = ROUND ? BN / PIECE_ROWS : 1;
+  constexpr int NPA = NQ * BM / 32, NPB = NQ * BN / 32;      // pieces per step
+  constexpr int G = ROUND ? NQ * (PA + PB) : (NPA + NPB) / NW;
+  static_assert(ROUND || (NPA % NW == 0 && NPB % NW == 0), "tile vs workgroup");
   static_assert((STAGES - 2) * G <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
 
@@ -359,7 +366,40 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   for (int p = 0; p < PB; ++p)
     srcB[p] = B + (long long)min(n0 + p * PIECE_ROWS + lrow, g.N - 1) * 16 + kslot;
 
+  // flat form: this wave's pieces
+  constexpr int GF = ROUND ? 1 : G;
+  const unsigned short* fsrc[GF];
+  int fdst[GF];
+  if constexpr (!ROUND) {
+    const int r32 = lane >> 1;
+#pragma unroll
+    for (int kq = 0; kq < GF; ++kq) {
+      const int q = wid + NW * kq;
+      if (kq < NPA / NW) {
+        const int pq = q / (BM / 32), rg = q % (BM / 32);
+        fsrc[kq] = A + (long long)(pq / KS) * g.planeA + (long long)(pq % KS) * g.slabA +
+                   (long long)min(m0 + rg * 32 + r32, g.M - 1) * 16 + (lane & 1) * 8;
+        fdst[kq] = pq * A_PLANE + rg * 1024;
+      } else {
+        const int q2 = q - NPA;
+        const int pq = q2 / (BN / 32), rg = q2 % (BN / 32);
+        fsrc[kq] = B + (long long)(pq / KS) * g.planeB + (long long)(pq % KS) * g.slabB +
+                   (long long)min(n0 + rg * 32 + r32, g.N - 1) * 16 + (lane & 1) * 8;
+        fdst[kq] = NQ * A_PLANE + pq * B_PLANE + rg * 1024;
+      }
+    }
+  }
   auto issue = [&](int t, int st) {
+    if constexpr (!ROUND) {
+      unsigned char* base = smx + st * STAGE;
+#pragma unroll
+      for (int kq = 0; kq < GF; ++kq) {
+        const long long adv = (long long)(t * KS) * (kq < NPA / NW ? g.slabA : g.slabB);
+        __builtin_amdgcn_global_load_lds(NAWS_GLB_PTR(fsrc[kq] + adv), NAWS_LDS_PTR(base + fdst[kq]),
+                                         16, 0, 0);
+      }
+      return;
+    }
     unsigned char* base = smx + st * STAGE + wid * 1024;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -421,9 +461,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   _Pragma("unroll") for (int i = 0; i < TIH; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
       acc[ih * TIH + i][j] = mfma32(b[Q][j], a[P][i], acc[ih * TIH + i][j]);
         NAWS_M16_TERM(0, 0)
-        if constexpr (NPL == 2) {
+        if constexpr (NPL >= 2) {
           NAWS_M16_TERM(0, 1)
           NAWS_M16_TERM(1, 0)
+        }
+        if constexpr (NPL == 3) {                     // the exact 3 x bf16 split: six terms
+          NAWS_M16_TERM(1, 1)
+          NAWS_M16_TERM(0, 2)
+          NAWS_M16_TERM(2, 0)
         }
 #undef NAWS_M16_TERM
       }
@@ -844,8 +889,17 @@ extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t s
     case 1: return launch_x3<256, 128, 2, 2, 2>(g, batch, s);
     case 2: return launch_x3<256, 256, 2, 4, 2>(g, batch, s);
     case 3: return launch_x3<256, 128, 2, 2, 3>(g, batch, s);
-    default: return launch_x3<256, 256, 2, 4, 3>(g, batch, s);
+    case 7: return launch_x3<256, 256, 2, 4, 3>(g, batch, s);
+    case 9: if (K % 32 == 0) return launch_x3_m16<128, 256, 2, 4, 2, 3, 2, false>(g, batch, s); break;
+    default: break;
   }
+  // round 3: the six-term product on v_mfma_f32_16x16x32_bf16 (256 x 128 tiles on 4 x 2 waves, two
+  // 72 KB LDS stages; 256 x 256 does not fit three planes of 32-deep steps).  tools/ab_x3.py,
+  // interleaved: fc6 fwd 7.08 vs 7.19 ms, fc6 wgrad 7.19 vs 7.59, fc7 1.17 / 1.20 vs 1.20 / 1.24 -
+  // +2...5 %, NOT the +25 % the f16 kernel got from this shape: the bf16 32x32x16 form already ran
+  // at 1.84 GHz (the f16 one had been throttled to 1.5 GHz), both land on the same power ceiling
+  if (K % 32 == 0) return launch_x3_m16<256, 128, 4, 2, 2, 3, 2, false>(g, batch, s);
+  return launch_x3<256, 256, 2, 4, 3>(g, batch, s);
 }
 
 // P[2][batch][kpad/16][outer][16] f16 + scales[2][batch][outer]: [0] = |x| maxima (bit patterns,
