@@ -276,8 +276,8 @@ def plan_peak_and_kernel(mode):
     return FP32_MFMA_PEAK_TFLOPS, 'gemm_f32_kernel<256,256,16,KC,KC,4x4 waves> (v_mfma_f32_32x32x2_f32)'
 
 
-X3_KERNEL_NAME = ('gemm_x3_kernel<256,256,2x4 waves,3 stages> = 6 x v_mfma_f32_32x32x16_bf16 per '
-                  'fp32 product')
+X3_KERNEL_NAME = ('gemm_x3_m16_kernel<256,128,4x2 waves,2 stages,3 planes x 2 K-slabs> = 6 x '
+                  'v_mfma_f32_16x16x32_bf16 per fp32 product')
 
 
 def free_port():
@@ -599,7 +599,7 @@ def main():
         if tj and headline and B == 2:
             roof['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
             roof['traffic_source'] = os.path.relpath(tj[-1], ROOT)
-        pmc = {'fp16x2': 'profiles/r02_default_plan_pmc.md', 'fp32x3': 'profiles/r01_x3_gemm_pmc.md'}
+        pmc = {'fp16x2': 'profiles/r03_default_plan_pmc.md', 'fp32x3': 'profiles/r01_x3_gemm_pmc.md'}
         if args.mfma_dtype in pmc:
             roof['profile_ref'] = pmc[args.mfma_dtype]
         cfg = {'workload': 'configs[1] flickr_voc na_wsddn_V-16-C5_1x C=%d: %d img %dx%d/GPU x %d '

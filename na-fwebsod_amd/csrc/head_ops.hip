@@ -561,30 +561,49 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
           make_uint2(hq[0] | ((unsigned)hq[1] << 16), hq[2] | ((unsigned)hq[3] << 16));
       *reinterpret_cast<uint2*>(img + SGP_PLANE + off) =
           make_uint2(lq[0] | ((unsigned)lq[1] << 16), lq[2] | ((unsigned)lq[3] << 16));
-      // NaN-aware fold (fmaxf drops NaNs; a NaN weight must reach the overflow test)
-      mx = wave_max((pv[0] != pv[0] || pv[1] != pv[1] || pv[2] != pv[2] || pv[3] != pv[3])
-                        ? __uint_as_float(0x7f800000u) : mx);
-      rmax[half * 4 + jj] = mx;
+      // (a NaN weight must reach the overflow test: fmaxf drops NaNs, so it is carried as +inf)
+      rmax[half * 4 + jj] = (pv[0] != pv[0] || pv[1] != pv[1] || pv[2] != pv[2] || pv[3] != pv[3])
+                                ? __uint_as_float(0x7f800000u) : mx;
     }
   }
-  // the wave's eight rows report together: lane j < 8 owns row 4 j + wid (one memory round trip
-  // per wave instead of one per row)
+  // Fold the wave's eight per-lane row maxima across the 64 lanes by a halving butterfly - each
+  // exchange keeps half of the rows on each side, 4 + 2 + 1 + 3 shuffles instead of 8 x 6 (the
+  // first version, one full wave reduction per row, was issue-bound on its ds_bpermute chains:
+  // 72 % SQ_WAIT_INST_ANY at 4.6 TB/s).  Afterwards lane l holds row (l >> 3) & 7, complete.
   {
-    float mine = 0.f;
+    float v4[4], v2[2], v1;
+    const bool up32 = (lane & 32) != 0, up16 = (lane & 16) != 0, up8 = (lane & 8) != 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) mine = (lane == j) ? rmax[j] : mine;
-    const int row = (lane & 7) * 4 + wid;
+    for (int i = 0; i < 4; ++i) {            // xor 32: lanes < 32 keep rows 0..3, the others 4..7
+      const float mine = up32 ? rmax[4 + i] : rmax[i], give = up32 ? rmax[i] : rmax[4 + i];
+      v4[i] = fmaxf(mine, __shfl_xor(give, 32));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {            // xor 16: keep rows {0,1} / {2,3} of the half
+      const float mine = up16 ? v4[2 + i] : v4[i], give = up16 ? v4[i] : v4[2 + i];
+      v2[i] = fmaxf(mine, __shfl_xor(give, 16));
+    }
+    {
+      const float mine = up8 ? v2[1] : v2[0], give = up8 ? v2[0] : v2[1];
+      v1 = fmaxf(mine, __shfl_xor(give, 8));
+    }
+    v1 = fmaxf(v1, __shfl_xor(v1, 4));
+    v1 = fmaxf(v1, __shfl_xor(v1, 2));
+    v1 = fmaxf(v1, __shfl_xor(v1, 1));
+    // lane l now holds step j = 4 (l >> 5) + 2 ((l >> 4) & 1) + ((l >> 3) & 1) = row 4 j + wid
+    const int j = ((lane >> 5) << 2) | (((lane >> 4) & 1) << 1) | ((lane >> 3) & 1);
+    const int row = j * 4 + wid;
     const unsigned bb = (unsigned)__shfl((int)bound_lane, row);     // (all lanes take part)
-    if (lane < 8) {
+    if ((lane & 7) == 0) {
       const unsigned b2 = ((bb >> 23) >= 1u && (bb >> 23) < 0xfeu) ? bb + (1u << 23) : bb;
       if (ctile == 0) {
         float sc, isc;
         naws_f16x2_scales(b2, sc, isc);
         R.inv_scale[r0 + row] = isc;
       }
-      const bool is_inf = __float_as_uint(mine) == 0x7f800000u;     // a NaN / inf weight in the row
-      if (mine > 0.f && !is_inf) naws_atomic_max_bits(R.rowmax + r0 + row, mine);
-      if (!(mine <= __uint_as_float(b2)) || is_inf) atomicMax(overflow, overflow_tag);
+      const bool is_inf = __float_as_uint(v1) == 0x7f800000u;       // a NaN / inf weight in the row
+      if (v1 > 0.f && !is_inf) naws_atomic_max_bits(R.rowmax + r0 + row, v1);
+      if (!(v1 <= __uint_as_float(b2)) || is_inf) atomicMax(overflow, overflow_tag);
     }
   }
   __syncthreads();

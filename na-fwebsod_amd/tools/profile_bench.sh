@@ -2,7 +2,7 @@
 # plans + the two PMC passes (FETCH_SIZE, WRITE_SIZE) and an SQ pass of the default plan;
 # summarise with tools/summarize_profile.py into profiles/.
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/prof_$R
 for P in fp16x2 fp32x3 fp32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${P}_stats -o st -- python bench.py --no-cpu-baseline --no-alt-plan --mfma-dtype $P --steps 20 --warmup 5 > $O.$P.log 2>&1

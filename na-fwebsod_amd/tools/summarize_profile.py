@@ -35,8 +35,8 @@ def main():
                  'gemm_f32_kernel<256,256,16,KC,KC,4x4> fc6 fwd', 1.354, None),
         'fp16x2': ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>',
                    'gemm_x3_m16_kernel<256,256,4x2,2 stages,2 planes x 2 slabs,f16> fc6 fwd', 1.354, '262144'),
-        'fp32x3': ('gemm_x3_kernel<256, 256, 2, 4, 3, 3, 1', 'gemm_x3_kernel<256,256,2x4,3 stages> fc6 fwd',
-                   1.966, '262144'),
+        'fp32x3': ('gemm_x3_m16_kernel<256, 128, 4, 2, 2, 3, 2, false>',
+                   'gemm_x3_m16_kernel<256,128,4x2,2 stages,3 planes x 2 slabs> fc6 fwd', 1.966, '524288'),
         'bf16': ('gemm_bf16_kernel<256, 128, 4, 2, false, false, false>',
                  'gemm_bf16_kernel<256,128,4x2,fp32 sources> fc6 fwd', 1.354, None),
     }[mode]

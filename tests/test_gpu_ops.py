@@ -315,9 +315,10 @@ def test_acm_sgd_update_f16x2_writes_the_operand_planes(dev, nesterov):
             tol = torch.maximum(w2.double().abs() * 2.0 ** -22, floor[:, None])
             assert bool((err <= tol).all()), (it, float((err / tol).max()))
             # 1/scale is the power of two that goes with twice the old maximum
-            e_old = torch.floor(torch.log2(b.view(torch.float32).double()))
-            want = torch.ldexp(torch.ones_like(e_old), (e_old + 1 - 14).to(torch.int32))   # exact 2^n
-            assert torch.equal(q.inv_scale.reshape(-1).double(), want), it
+            # (exact powers of two: evaluated on the host, a device pow is not exact)
+            e_old = np.floor(np.log2(b.view(torch.float32).cpu().numpy().astype(np.float64)))
+            want = np.ldexp(1.0, (e_old + 1 - 14).astype(np.int64))
+            assert np.array_equal(q.inv_scale.reshape(-1).cpu().numpy().astype(np.float64), want), it
     # ---- a row that outgrows twice its old maximum raises the flag, and the conditional re-split
     # then leaves exactly the planes of a from-scratch split
     g = torch.zeros((total,), device=dev)
