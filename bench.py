@@ -555,7 +555,11 @@ def main():
         headline = (args.height, args.width, args.rois, num_fg) == (600, 1000, 2000, 20)
         conv_gflop = 463.7 * B if headline else None
         roipool_bytes = B * (512 * 74 * 124 * 4 + args.rois * 25088 * 4 + args.rois * 24) if headline else None
+        # 3 reads + 2 writes of the arena; the fp16x2 plan's update also writes the hi / lo operand
+        # planes of fc6_w / fc7_w (4 B per weight) in the same kernel
         sgd_bytes = 5 * 4 * eng.arena.total
+        if h2 and eng.fused_planes and eng._sgd_regions is not None:
+            sgd_bytes += 4 * 2 * 4096 * (eng.k6 + 4096)
         sgd_ms = sum(s.elapsed_time(e) for s, e in uev) / max(len(uev), 1)
         roof = {'bound': 'mfma', 'kernel': 'fc6 fwd (both branches, M=%d N=8192 K=%d): %s' % (rt, k6, kname),
                 'achieved': round(achieved, 2) if achieved else None,
