@@ -886,11 +886,13 @@ extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t s
     return launch_x3<256, 128, 2, 2, 2>(g, batch, s);
   }
   switch (g_x3_variant) {
+    case 7: return launch_x3<256, 256, 2, 4, 3>(g, batch, s);      // round 1 / 2's form (tools/ab_x3.py)
+#ifdef NAWS_AB
     case 1: return launch_x3<256, 128, 2, 2, 2>(g, batch, s);
     case 2: return launch_x3<256, 256, 2, 4, 2>(g, batch, s);
     case 3: return launch_x3<256, 128, 2, 2, 3>(g, batch, s);
-    case 7: return launch_x3<256, 256, 2, 4, 3>(g, batch, s);
     case 9: if (K % 32 == 0) return launch_x3_m16<128, 256, 2, 4, 2, 3, 2, false>(g, batch, s); break;
+#endif
     default: break;
   }
   // round 3: the six-term product on v_mfma_f32_16x16x32_bf16 (256 x 128 tiles on 4 x 2 waves, two
@@ -1057,10 +1059,12 @@ extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, 
   // short K (the Winograd batch GEMMs): two 4-wave workgroups per CU overlap one's prologue /
   // epilogue with the other's K loop
   if (K <= 1024 && g_h2_variant != 5) {
+#ifdef NAWS_AB   // the forms measured against the default (tools/ab_h2.py): A/B build only
     if (g_h2_variant == 6) return launch_x3<256, 128, 2, 2, 2, 2, 1, true>(g, batch, s);
     if (g_h2_variant == 12) return launch_x3<128, 128, 2, 2, 4, 2, 1, true>(g, batch, s);
     if (g_h2_variant == 14) return launch_x3<128, 128, 2, 2, 3, 2, 2, true>(g, batch, s);
     if (g_h2_variant == 15) return launch_x3_m16<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+#endif
     if (g_h2_variant == 17) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
     // 16-deep K-steps on a ring of 3 stages (48 KB: still two workgroups per CU): the DMA runs two
     // steps ahead instead of one, which is what a 16..32-step tile needs (tools/ab_h2.py, the
@@ -1068,14 +1072,15 @@ extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, 
     return launch_x3<128, 128, 2, 2, 3, 2, 1, true>(g, batch, s);
   }
   switch (g_h2_variant) {
+#ifdef NAWS_AB   // superseded tile / stage / MFMA-shape forms: A/B build only
     case 1: return launch_x3<256, 256, 2, 4, 3, 2, 1, true>(g, batch, s);
     case 2: return launch_x3<256, 256, 2, 4, 4, 2, 1, true>(g, batch, s);
     case 3: return launch_x3<256, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
     case 4: return launch_x3<256, 128, 2, 2, 3, 2, 2, true>(g, batch, s);
     case 7: return launch_x3_m16<256, 256, 2, 4, 2, 2, 2, true>(g, batch, s);
-    case 10: return launch_x3_m16<256, 256, 4, 2, 2, 2, 2, true>(g, batch, s);
     case 11: return launch_x3_m16<256, 128, 2, 2, 3, 2, 2, true>(g, batch, s);
     case 9: return launch_x3<256, 256, 2, 4, 2, 2, 2, true>(g, batch, s);
+#endif
     // 16x16x32 MFMAs, 4 x 2 waves (64 x 128 per wave): the chip holds a higher clock on this shape
     // in the power-limited long-K GEMMs (tools/ab_h2.py, interleaved: fc6 fwd 3.62 vs 3.83 ms)
     default: return launch_x3_m16<256, 256, 4, 2, 2, 2, 2, true>(g, batch, s);

@@ -653,17 +653,21 @@ extern "C" int naws_roi_pool_f_f16x2_hier_fwd(const float* X, int N, int C, int 
   po.P = (unsigned short*)planes; po.inv_scale = scales + R; po.amax_words = (const unsigned*)amax_words;
   po.n_words = n_words; po.plane = K * R; po.R = R;
   const int nw = naws_knob(NAWS_KNOB_ROI_NW);       // A/B knob (tools/bench_roi.py): NW * 10 + RG
+  (void)nw;
 #define NAWS_ROI_LAUNCH(NWV, RGV)                                                                    \
   hipLaunchKernelGGL((roi_pool_nhwc_xcd_kernel<true, true, NWV, RGV>),                               \
                      dim3((unsigned)(naws_cdiv(R, RGV) * (C / 64))), dim3(64 * NWV),                  \
                      (size_t)(RGV * 64 * pooled_h * pooled_w + RGV) * sizeof(float), s, X, C, H, W,  \
                      rois, R, boost, pooled_h, pooled_w, spatial_scale, C / 64, (float*)nullptr, po, \
                      (const float*)workspace, (const float*)(workspace + (long long)N * H * W * C))
+#ifdef NAWS_AB   // the other (waves, rois per workgroup) forms: A/B build only (tools/bench_roi.py)
   if (nw == 41) NAWS_ROI_LAUNCH(4, 1);
   else if (nw == 44) NAWS_ROI_LAUNCH(4, 4);
   else if (nw == 82) NAWS_ROI_LAUNCH(8, 2);
   else if (nw == 84) NAWS_ROI_LAUNCH(8, 4);
-  else NAWS_ROI_LAUNCH(4, 2);     // measured best (tools/bench_roi.py): 0.35 ms incl. the maps vs 0.58 direct
+  else
+#endif
+  NAWS_ROI_LAUNCH(4, 2);     // measured best (tools/bench_roi.py): 0.35 ms incl. the maps vs 0.58 direct
 #undef NAWS_ROI_LAUNCH
   return naws_check_launch();
 }

@@ -43,7 +43,7 @@ def test_variant_knobs_do_not_change_results(dev):
     b = ops.split_f16x2(torch.randn((640, 512), device=dev, generator=g))
     ref = ops.gemm_f32_f16x2_nt(a, b).clone()
     try:
-        for v in (1, 5, 6):
+        for v in (5, 17):                  # forms present in the product library (K <= 1024)
             lib.set_variant('h2', v)
             out = ops.gemm_f32_f16x2_nt(a, b)
             # another tile form may accumulate K in another grouping: fp32-accumulation close
