@@ -285,6 +285,20 @@ int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf, const floa
                               const float* seg_wd, int nseg, float momentum, int nesterov,
                               int gpu_num, int64_t iter_count, const naws_sgd_plane_region* regions,
                               int n_regions, int32_t* overflow, int32_t overflow_tag, void* stream);
+/* The same with the plane format of the other 16-bit arithmetic plans: NAWS_PLANES_BF16X3 = the
+ * exact three-plane bf16 split (naws_split_bf16x3: planes [3][batch][cols/16][rows_per_batch][16]),
+ * NAWS_PLANES_BF16 = one plane of the weights rounded to bf16 (naws_to_bf16_slab; cols % 64 == 0).
+ * Neither carries a scale: bound / rowmax / inv_scale of the regions and the overflow word are
+ * unused (may be NULL).  NAWS_PLANES_F16X2 is naws_acm_sgd_update_f16x2. */
+#define NAWS_PLANES_F16X2 0
+#define NAWS_PLANES_BF16X3 1
+#define NAWS_PLANES_BF16 2
+int naws_acm_sgd_update_planes(int format, const float* grad, float* momentum_buf, const float* lr,
+                               float* param, int64_t total, const int64_t* seg_end,
+                               const float* seg_lr_mult, const float* seg_wd, int nseg,
+                               float momentum, int nesterov, int gpu_num, int64_t iter_count,
+                               const naws_sgd_plane_region* regions, int n_regions,
+                               int32_t* overflow, int32_t overflow_tag, void* stream);
 /* naws_split_f16x2's row-scaled form from given maxima (rowmax [batch][rows] bit patterns ->
  * planes [2][batch][kpad/16][rows][16], inv_scale [batch][rows]), run only if *cond == cond_value
  * when the kernel executes (cond NULL: always): the fallback of naws_acm_sgd_update_f16x2. */

@@ -471,13 +471,18 @@ __device__ __forceinline__ int sgd_segment(const int64_t* __restrict__ seg_end, 
   return lo;
 }
 
+// FMT: 0 = fp16x2 (row-scaled f16 hi / lo; bounds, maxima and the overflow word as described),
+// 1 = the exact 3 x bf16 split of the fp32x3 plan, 2 = the bf16 plan's single rounded plane
+// (neither has a scale: no bound, no maxima, nothing can overflow).
+template <int FMT>
 __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
     const float4* __restrict__ grad, float4* __restrict__ mom, const float* __restrict__ lr,
     float4* __restrict__ param, const int64_t* __restrict__ seg_end,
     const float* __restrict__ seg_lr_mult, const float* __restrict__ seg_wd, int nseg,
     float momentum, int nesterov, float scale, int first, SgdPlaneArgs a, int* __restrict__ overflow,
     int overflow_tag) {
-  __shared__ __attribute__((aligned(16))) unsigned char img[2 * SGP_PLANE];
+  constexpr int NPL = FMT == 0 ? 2 : (FMT == 1 ? 3 : 1);
+  __shared__ __attribute__((aligned(16))) unsigned char img[NPL * SGP_PLANE];
   const float base_lr = lr[0];
   const int bid = blockIdx.x;
   if (bid >= a.tiles) {
@@ -515,7 +520,8 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
   const int row4 = R.cols >> 2;
   // the 32 rows' bounds in lanes 0..31, fetched once (a per-row load + wait inside the loop
   // serialises the wave on a memory round trip per row)
-  const unsigned bound_lane = R.bound[r0 + (lane & 31)];
+  unsigned bound_lane = 0;
+  if constexpr (FMT == 0) bound_lane = R.bound[r0 + (lane & 31)];
   float rmax[8];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -535,37 +541,58 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
       sgd_update4(g[jj], m[jj], p[jj], scale, wd, LR, momentum, nesterov);
       mom[i] = m[jj];
       param[i] = p[jj];
-      // the row's scale: from twice the maximum it had before this update (wave-uniform).
-      // 2 x bound = exponent + 1 (a zero / denormal / huge bound is left as it is: the overflow
-      // test below then sends the row to the exact re-split)
-      const unsigned bb = (unsigned)__builtin_amdgcn_readlane((int)bound_lane, row);
-      const unsigned b2 = ((bb >> 23) >= 1u && (bb >> 23) < 0xfeu) ? bb + (1u << 23) : bb;
-      float sc, isc;
-      naws_f16x2_scales(b2, sc, isc);
       const float pv[4] = {p[jj].x, p[jj].y, p[jj].z, p[jj].w};
-      unsigned short hq[4], lq[4];
-      float mx = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        mx = fmaxf(mx, fabsf(pv[k]));
-        const float v = pv[k] * sc;
-        const _Float16 hi = (_Float16)v;
-        float rr = v - (float)hi;
-        if (!(fabsf(v) <= 65504.f)) rr = 0.f;         // NaN / overflow live in the hi plane only
-        const _Float16 lo = (_Float16)rr;
-        hq[k] = *reinterpret_cast<const unsigned short*>(&hi);
-        lq[k] = *reinterpret_cast<const unsigned short*>(&lo);
-      }
       const int off = (lane >> 2) * SGP_SLAB + row * 32 + (lane & 3) * 8;
-      *reinterpret_cast<uint2*>(img + off) =
-          make_uint2(hq[0] | ((unsigned)hq[1] << 16), hq[2] | ((unsigned)hq[3] << 16));
-      *reinterpret_cast<uint2*>(img + SGP_PLANE + off) =
-          make_uint2(lq[0] | ((unsigned)lq[1] << 16), lq[2] | ((unsigned)lq[3] << 16));
+      float mx = 0.f;
+      if constexpr (FMT == 0) {
+        // the row's scale: from twice the maximum it had before this update (wave-uniform).
+        // 2 x bound = exponent + 1 (a zero / denormal / huge bound is left as it is: the overflow
+        // test below then sends the row to the exact re-split)
+        const unsigned bb = (unsigned)__builtin_amdgcn_readlane((int)bound_lane, row);
+        const unsigned b2 = ((bb >> 23) >= 1u && (bb >> 23) < 0xfeu) ? bb + (1u << 23) : bb;
+        float sc, isc;
+        naws_f16x2_scales(b2, sc, isc);
+        unsigned short hq[4], lq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          mx = fmaxf(mx, fabsf(pv[k]));
+          const float v = pv[k] * sc;
+          const _Float16 hi = (_Float16)v;
+          float rr = v - (float)hi;
+          if (!(fabsf(v) <= 65504.f)) rr = 0.f;         // NaN / overflow live in the hi plane only
+          const _Float16 lo = (_Float16)rr;
+          hq[k] = *reinterpret_cast<const unsigned short*>(&hi);
+          lq[k] = *reinterpret_cast<const unsigned short*>(&lo);
+        }
+        *reinterpret_cast<uint2*>(img + off) =
+            make_uint2(hq[0] | ((unsigned)hq[1] << 16), hq[2] | ((unsigned)hq[3] << 16));
+        *reinterpret_cast<uint2*>(img + SGP_PLANE + off) =
+            make_uint2(lq[0] | ((unsigned)lq[1] << 16), lq[2] | ((unsigned)lq[3] << 16));
+      } else {
+        // bf16 planes: a = a1 + a2 + a3 exactly (the split3 of gemm_x3.hip), or a1 alone
+        unsigned short q[3][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const __bf16 h1 = (__bf16)pv[k];
+          float rr = pv[k] - (float)h1;
+          if (!(fabsf(pv[k]) <= 3.4028234e38f)) rr = 0.f;   // inf / NaN live in plane 1 only
+          const __bf16 h2 = (__bf16)rr;
+          const __bf16 h3 = (__bf16)(rr - (float)h2);
+          q[0][k] = *reinterpret_cast<const unsigned short*>(&h1);
+          q[1][k] = *reinterpret_cast<const unsigned short*>(&h2);
+          q[2][k] = *reinterpret_cast<const unsigned short*>(&h3);
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          *reinterpret_cast<uint2*>(img + pl * SGP_PLANE + off) = make_uint2(
+              q[pl][0] | ((unsigned)q[pl][1] << 16), q[pl][2] | ((unsigned)q[pl][3] << 16));
+      }
       // (a NaN weight must reach the overflow test: fmaxf drops NaNs, so it is carried as +inf)
       rmax[half * 4 + jj] = (pv[0] != pv[0] || pv[1] != pv[1] || pv[2] != pv[2] || pv[3] != pv[3])
                                 ? __uint_as_float(0x7f800000u) : mx;
     }
   }
+  if constexpr (FMT == 0)
   // Fold the wave's eight per-lane row maxima across the 64 lanes by a halving butterfly - each
   // exchange keeps half of the rows on each side, 4 + 2 + 1 + 3 shuffles instead of 8 x 6 (the
   // first version, one full wave reduction per row, was issue-bound on its ds_bpermute chains:
@@ -611,7 +638,7 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
   const int batch = r0 / R.rows_per_batch, rb0 = r0 - batch * R.rows_per_batch;
   const long long sp = (long long)R.cols * R.rows_per_batch;       // one batch item of one plane
 #pragma unroll
-  for (int pl = 0; pl < 2; ++pl) {
+  for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int idx = k * TB + threadIdx.x;            // 16-byte chunk of the plane's image
@@ -830,8 +857,9 @@ extern "C" int naws_acm_sgd_update(const float* grad, float* momentum_buf, const
                                     gpu_num, iter_count, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf, const float* lr,
-                                         float* param, int64_t total, const int64_t* seg_end,
+extern "C" int naws_acm_sgd_update_planes(int format, const float* grad, float* momentum_buf,
+                                          const float* lr, float* param, int64_t total,
+                                          const int64_t* seg_end,
                                          const float* seg_lr_mult, const float* seg_wd, int nseg,
                                          float momentum, int nesterov, int gpu_num,
                                          int64_t iter_count, const naws_sgd_plane_region* regions,
@@ -839,9 +867,12 @@ extern "C" int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf,
                                          void* stream) {
   if (total <= 0 || nseg <= 0 || gpu_num <= 0 || iter_count < 0) return NAWS_ERR_SHAPE;
   if (total % 4 != 0 || n_regions <= 0 || n_regions > 4) return NAWS_ERR_ARG;
+  if (format < NAWS_PLANES_F16X2 || format > NAWS_PLANES_BF16) return NAWS_ERR_ARG;
+  const bool scaled = format == NAWS_PLANES_F16X2;
   NAWS_REQUIRE_PTR(grad); NAWS_REQUIRE_PTR(momentum_buf); NAWS_REQUIRE_PTR(lr);
   NAWS_REQUIRE_PTR(param); NAWS_REQUIRE_PTR(seg_end); NAWS_REQUIRE_PTR(seg_lr_mult);
-  NAWS_REQUIRE_PTR(seg_wd); NAWS_REQUIRE_PTR(regions); NAWS_REQUIRE_PTR(overflow);
+  NAWS_REQUIRE_PTR(seg_wd); NAWS_REQUIRE_PTR(regions);
+  if (scaled) NAWS_REQUIRE_PTR(overflow);
   if ((((uintptr_t)grad | (uintptr_t)momentum_buf | (uintptr_t)param) % 16)) return NAWS_ERR_ARG;
   SgdPlaneArgs a{};
   long long tiles = 0, cursor = 0;
@@ -864,9 +895,13 @@ extern "C" int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf,
     if (g.rows % 32 != 0 || g.cols % 256 != 0 || g.rows % g.rows_per_batch != 0 ||
         g.rows_per_batch % 32 != 0 || g.start % 4 != 0)
       return NAWS_ERR_UNSUPPORTED;
-    NAWS_REQUIRE_PTR(g.planes); NAWS_REQUIRE_PTR(g.bound); NAWS_REQUIRE_PTR(g.rowmax);
-    NAWS_REQUIRE_PTR(g.inv_scale);
-    if (((uintptr_t)g.planes & 15) != 0 || g.bound == g.rowmax) return NAWS_ERR_ARG;
+    NAWS_REQUIRE_PTR(g.planes);
+    if (scaled) {
+      NAWS_REQUIRE_PTR(g.bound); NAWS_REQUIRE_PTR(g.rowmax); NAWS_REQUIRE_PTR(g.inv_scale);
+      if (g.bound == g.rowmax) return NAWS_ERR_ARG;
+    }
+    if (((uintptr_t)g.planes & 15) != 0) return NAWS_ERR_ARG;
+    if (format == NAWS_PLANES_BF16 && g.cols % 64 != 0) return NAWS_ERR_UNSUPPORTED;
     if (!add_linear(cursor / 4, g.start / 4)) return NAWS_ERR_UNSUPPORTED;
     SgdPlaneRegion& r = a.r[i];
     r.start = g.start; r.rows = g.rows; r.cols = g.cols; r.rows_per_batch = g.rows_per_batch;
@@ -880,11 +915,28 @@ extern "C" int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf,
   a.n = n_regions; a.tiles = (int)tiles; a.n_lin = n_lin;
   for (int k = n_lin + 1; k < 5; ++k) a.lin_block0[k] = (int)lin_blocks;
   const float scale = (float)(1.0 / (double)gpu_num);
-  hipLaunchKernelGGL(acm_sgd_planes_kernel, dim3((unsigned)(tiles + lin_blocks)), dim3(TB), 0,
-                     (hipStream_t)stream, (const float4*)grad, (float4*)momentum_buf, lr,
-                     (float4*)param, seg_end, seg_lr_mult, seg_wd, nseg, momentum, nesterov, scale,
-                     iter_count == 0 ? 1 : 0, a, overflow, overflow_tag);
+#define NAWS_SGD_PLANES(F)                                                                          \
+  hipLaunchKernelGGL(acm_sgd_planes_kernel<F>, dim3((unsigned)(tiles + lin_blocks)), dim3(TB), 0,    \
+                     (hipStream_t)stream, (const float4*)grad, (float4*)momentum_buf, lr,            \
+                     (float4*)param, seg_end, seg_lr_mult, seg_wd, nseg, momentum, nesterov, scale,  \
+                     iter_count == 0 ? 1 : 0, a, overflow, overflow_tag)
+  if (format == NAWS_PLANES_F16X2) NAWS_SGD_PLANES(0);
+  else if (format == NAWS_PLANES_BF16X3) NAWS_SGD_PLANES(1);
+  else NAWS_SGD_PLANES(2);
+#undef NAWS_SGD_PLANES
   return naws_check_launch();
+}
+
+extern "C" int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf, const float* lr,
+                                         float* param, int64_t total, const int64_t* seg_end,
+                                         const float* seg_lr_mult, const float* seg_wd, int nseg,
+                                         float momentum, int nesterov, int gpu_num,
+                                         int64_t iter_count, const naws_sgd_plane_region* regions,
+                                         int n_regions, int32_t* overflow, int32_t overflow_tag,
+                                         void* stream) {
+  return naws_acm_sgd_update_planes(NAWS_PLANES_F16X2, grad, momentum_buf, lr, param, total, seg_end,
+                                    seg_lr_mult, seg_wd, nseg, momentum, nesterov, gpu_num,
+                                    iter_count, regions, n_regions, overflow, overflow_tag, stream);
 }
 
 extern "C" int naws_min_entropy_loss_fwd(const float* X, const float* L, int N, int C, float* Y,

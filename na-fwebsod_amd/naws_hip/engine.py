@@ -285,6 +285,15 @@ class WsddnEngine(object):
                      sc[1, 1])])
         elif self._wplanes is None:
             self._wplanes = dict(w6=cv(w6), w7=cv(w7), w7t=cv(w7, transpose=True))
+            if self.k6 % 256 == 0:
+                # fp32x3 / bf16: the SGD kernel writes these planes too (exact / rounded bf16:
+                # no scales, nothing to bound)
+                n6 = 2 * HIDDEN
+                o6, o7 = self.arena.offsets['fc6_w'][0], self.arena.offsets['fc7_w'][0]
+                fmt = L.PLANES_BF16X3 if self.mfma_dtype == 'fp32x3' else L.PLANES_BF16
+                self._sgd_regions = ops.SgdPlaneRegions([
+                    (o6, n6, self.k6, n6, self._wplanes['w6'], None, None, None),
+                    (o7, n6, HIDDEN, HIDDEN, self._wplanes['w7'], None, None, None)], fmt)
         else:
             cv(w6, out=self._wplanes['w6'])
             cv(w7, out=self._wplanes['w7'])
@@ -977,6 +986,10 @@ class WsddnEngine(object):
         # takes the exact route below)
         planes = (fused and self.fused_planes and self._sgd_regions is not None
                   and not self._planes_dirty)
+        # fp32x3 / bf16: the same kernel with their plane formats (no maxima involved)
+        planes_bf = (self.mfma_dtype in ('fp32x3', 'bf16') and self.fused_planes
+                     and self._sgd_regions is not None and self.iter_size == 1
+                     and not self._planes_dirty and self._wplanes is not None)
         rowmax = None
         if fused:
             maxima = self._wscales.view(2, 2, 2 * HIDDEN)[:, 0]
@@ -990,6 +1003,10 @@ class WsddnEngine(object):
                                      self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
                                      self.gpu_num, self.sgd_iter_count, self._sgd_regions,
                                      self._wovf, tag)
+        elif planes_bf:
+            ops.acm_sgd_update_planes(self.grads, self.momentum_buf, self.lr, self.params,
+                                      self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
+                                      self.gpu_num, self.sgd_iter_count, self._sgd_regions)
         else:
             ops.acm_sgd_update(self.grads, self.momentum_buf, self.lr, self.params, self.acmgrad,
                                self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
@@ -1016,6 +1033,10 @@ class WsddnEngine(object):
             q7 = ops.split_f16x2_dual(w7, wp['w7'].scales, None, out_n=wp['w7'])[0]
             assert q6 is wp['w6'] and q7 is wp['w7']
             ops.split_f16x2(w7, transpose=True, out=wp['w7t'])
+            self._planes_dirty = False
+        elif planes_bf:
+            cv = ops.split_bf16x3 if self.mfma_dtype == 'fp32x3' else ops.to_bf16_slab
+            cv(self._weight_views()[1], transpose=True, out=self._wplanes['w7t'])
             self._planes_dirty = False
         elif self.mfma_dtype != 'fp32' and self._wplanes is not None:
             self._refresh_weight_planes()

@@ -27,6 +27,7 @@ LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_RELU_DROP, EPI_GATE_POS = range(5)
 UN_LOG, UN_SCALE, UN_REPLACE_NAN, UN_LEAKY_RELU, UN_CLIP, UN_RELU = range(6)
 BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV, BIN_GATE_POS = range(5)
+PLANES_F16X2, PLANES_BF16X3, PLANES_BF16 = range(3)
 
 p, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
 
@@ -56,6 +57,7 @@ PROTOTYPES = {
     'naws_acm_sgd_update': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p],
     'naws_acm_sgd_update_rowmax': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p, p,
                                    i32, p],
+    'naws_acm_sgd_update_planes': [i32, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i64, p, i32, p, i32, p],
     'naws_acm_sgd_update_f16x2': [p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i64, p, i32, p, i32, p],
     'naws_split_f16x2_rows_if': [p, i32, i32, i32, i32, i64, p, p, p, i32, p, i32, p],
     'naws_roi_label_fwd': [p, p, p, p, i32, i32, i32, f32, f32, f32, i32, i32, i32, p, p, p, p, p],

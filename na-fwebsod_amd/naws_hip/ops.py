@@ -871,34 +871,53 @@ class _SgdPlaneRegion(C.Structure):
 
 
 class SgdPlaneRegions(object):
-    """The weight matrices whose fp16x2 operand planes `acm_sgd_update_f16x2` writes itself:
-    [(first arena element, rows, cols, rows_per_batch, F16x2 planes, bound int32 [rows],
-      rowmax int32 [rows], inv_scale fp32 [rows])], ascending."""
+    """The weight matrices whose operand planes `acm_sgd_update_planes` writes itself:
+    [(first arena element, rows, cols, rows_per_batch, planes, bound int32 [rows], rowmax int32
+      [rows], inv_scale fp32 [rows])], ascending.  planes: contiguous f16 [2, ...] (fp16x2), bf16
+    [3, ...] (fp32x3) or bf16 [...] (bf16 plan); bound / rowmax / inv_scale only for fp16x2 (None
+    otherwise)."""
 
-    def __init__(self, regions):
+    def __init__(self, regions, fmt=L.PLANES_F16X2):
         self.keep = regions                       # the tensors stay alive with the table
+        self.fmt = fmt
         self.n = len(regions)
         self.host = (_SgdPlaneRegion * self.n)()
+        want = {L.PLANES_F16X2: (torch.float16, 2), L.PLANES_BF16X3: (torch.bfloat16, 3),
+                L.PLANES_BF16: (torch.bfloat16, None)}[fmt]
         for i, (start, rows, cols, rpb, planes, bound, rowmax, inv) in enumerate(regions):
-            if planes.dtype != torch.float16 or not planes.is_contiguous() or planes.shape[0] != 2:
-                raise TypeError('planes must be contiguous f16 [2, ...]')
-            for t, dt in ((bound, torch.int32), (rowmax, torch.int32), (inv, _f32)):
-                if t.dtype != dt or t.numel() != rows or not t.is_contiguous():
-                    raise TypeError('bound / rowmax / inv_scale: contiguous [rows] int32 / int32 / fp32')
+            if planes.dtype != want[0] or not planes.is_contiguous() or \
+                    (want[1] is not None and planes.shape[0] != want[1]) or \
+                    planes.numel() != (want[1] or 1) * rows * cols:
+                raise TypeError('planes must be the contiguous operand planes of a [rows, cols] matrix')
+            if fmt == L.PLANES_F16X2:
+                for t, dt in ((bound, torch.int32), (rowmax, torch.int32), (inv, _f32)):
+                    if t.dtype != dt or t.numel() != rows or not t.is_contiguous():
+                        raise TypeError('bound / rowmax / inv_scale: contiguous [rows] int32 / int32 / fp32')
             self.host[i] = _SgdPlaneRegion(int(start), int(rows), int(cols), int(rpb), 0,
-                                           planes.data_ptr(), planes.stride(0), bound.data_ptr(),
-                                           rowmax.data_ptr(), inv.data_ptr())
+                                           planes.data_ptr(),
+                                           planes.stride(0) if want[1] is not None else 0,
+                                           _ptr(bound), _ptr(rowmax), _ptr(inv))
 
 
 def acm_sgd_update_f16x2(grad, momentum_buf, lr, param, seg_end, seg_lr_mult, seg_wd, momentum,
                          nesterov, gpu_num, iter_count, regions, overflow, overflow_tag):
     """ITER_SIZE 1.  The fused update that also emits the operand planes of `regions`
-    (SgdPlaneRegions); `overflow` (int32 [1]) receives overflow_tag when a row outgrew its bound."""
-    L.call('naws_acm_sgd_update_f16x2', grad.data_ptr(), momentum_buf.data_ptr(), lr.data_ptr(),
-           param.data_ptr(), param.numel(), seg_end.data_ptr(), seg_lr_mult.data_ptr(),
-           seg_wd.data_ptr(), seg_end.numel(), float(momentum), int(nesterov), int(gpu_num),
-           int(iter_count), C.addressof(regions.host), regions.n, overflow.data_ptr(),
-           int(overflow_tag), _stream())
+    (SgdPlaneRegions, fp16x2); `overflow` (int32 [1]) receives overflow_tag when a row outgrew
+    its bound."""
+    assert regions.fmt == L.PLANES_F16X2
+    acm_sgd_update_planes(grad, momentum_buf, lr, param, seg_end, seg_lr_mult, seg_wd, momentum,
+                          nesterov, gpu_num, iter_count, regions, overflow, overflow_tag)
+
+
+def acm_sgd_update_planes(grad, momentum_buf, lr, param, seg_end, seg_lr_mult, seg_wd, momentum,
+                          nesterov, gpu_num, iter_count, regions, overflow=None, overflow_tag=0):
+    """The fused update writing the planes of `regions` in the regions' format (bf16x3 / bf16:
+    exact / rounded planes, no scales, no overflow word)."""
+    L.call('naws_acm_sgd_update_planes', regions.fmt, grad.data_ptr(), momentum_buf.data_ptr(),
+           lr.data_ptr(), param.data_ptr(), param.numel(), seg_end.data_ptr(),
+           seg_lr_mult.data_ptr(), seg_wd.data_ptr(), seg_end.numel(), float(momentum),
+           int(nesterov), int(gpu_num), int(iter_count), C.addressof(regions.host), regions.n,
+           _ptr(overflow), int(overflow_tag), _stream())
 
 
 def split_f16x2_rows_if(x, rowmax, out, cond, cond_value):

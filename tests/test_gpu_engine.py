@@ -278,3 +278,30 @@ def test_weight_planes_after_fused_update_match_fresh_split(dev):
         assert abs(a - b) <= 1e-5 * abs(a), (runs[False][0], runs[True][0])
     pa, pb = runs[False][1], runs[True][1]
     assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max())
+
+
+@pytest.mark.parametrize('mode', ['fp32x3', 'bf16'])
+def test_weight_planes_written_by_the_update_equal_a_fresh_split(dev, mode):
+    """fp32x3 / bf16 plans: the SGD kernel also writes the fc6_w / fc7_w operand planes (exact
+    3 x bf16 split / one rounded bf16 plane: no scales involved), so after training steps they
+    must equal a from-scratch split of the updated parameters bit for bit - and the run must be
+    bit-identical to the one that re-splits after every update."""
+    from naws_hip import ops
+    cv = ops.split_bf16x3 if mode == 'fp32x3' else ops.to_bf16_slab
+    runs = {}
+    for fused in (True, False):
+        eng, mb, _blobs = _setup(dev, mfma_dtype=mode)
+        eng.fused_planes = fused
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        eng.set_lr(1e-2)
+        for _ in range(3):
+            eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+            eng.sgd_step()
+        eng.flush()
+        torch.cuda.synchronize()
+        assert not eng._planes_dirty and (eng._sgd_regions is not None)
+        w6, w7 = eng._weight_views()
+        for key, fresh in (('w6', cv(w6)), ('w7', cv(w7)), ('w7t', cv(w7, transpose=True))):
+            assert torch.equal(eng._wplanes[key].view(torch.int16), fresh.view(torch.int16)), (fused, key)
+        runs[fused] = (eng.params.clone(), eng.momentum_buf.clone())
+    assert torch.equal(runs[True][0], runs[False][0]) and torch.equal(runs[True][1], runs[False][1])

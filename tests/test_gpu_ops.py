@@ -339,7 +339,8 @@ def test_acm_sgd_update_f16x2_writes_the_operand_planes(dev, nesterov):
         assert torch.equal(q.planes.view(torch.int16), fresh.planes.view(torch.int16))
     # argument checks (the ENFORCE-style codes)
     from naws_hip import lib
-    bad = ops.SgdPlaneRegions([(0, r6, c6 - 256 + 64, r6, q6.planes, bound[:r6], mx6, q6.scales[1])])
+    odd = torch.empty((2, 20, r6, 16), device=dev, dtype=torch.float16)       # 320 columns: not x 256
+    bad = ops.SgdPlaneRegions([(0, r6, 320, r6, odd, bound[:r6], mx6, q6.scales[1])])
     with pytest.raises(lib.NawsError):
         ops.acm_sgd_update_f16x2(g, mb, lr, pb, ends, lm, wdd, 0.9, 0, 2, 4, bad, ovf, 1)
 
