@@ -550,6 +550,17 @@ int naws_conv3x3_winograd_nhwc_f32x3_fwd(const float* X, const void* U3, const f
  * comparison (suppress when IoU >= thresh, +1 pixel areas) as the reference loop.
  * workspace: naws_nms_workspace_bytes(batch, n_max) bytes, 8-byte aligned.  n_max <= 16384. */
 int64_t naws_nms_workspace_bytes(int batch, int n_max);
+/* Soft-NMS for `batch` independent detection lists (= the classes of one image) in one call.
+ * replaces: detectron/utils/cython_nms.pyx:98-203 `soft_nms` (boxes.py:321-338), the
+ * TEST.SOFT_NMS branch of core/test_wsl.py:826-834.  dets[batch][n_max][5] = (x1,y1,x2,y2,score)
+ * in the caller's order (the reference passes them in proposal order), counts[batch].  method:
+ * 0 hard, 1 linear, 2 gaussian; overlap_thresh = Nt, score_thresh = the discard threshold.
+ * out_dets[batch][n_max][5] / keep[batch][n_max] (original indices) / out_counts[batch]: the
+ * surviving detections with their decayed scores IN THE REFERENCE'S OUTPUT ORDER (its in-place
+ * swap / overwrite-by-the-last-box sequence is replayed).  n_max <= 5111 (the list lives in LDS). */
+int naws_soft_nms_fwd(const float* dets, const int32_t* counts, int batch, int n_max, float sigma,
+                      float overlap_thresh, float score_thresh, int method, float* out_dets,
+                      int32_t* keep, int32_t* out_counts, void* stream);
 int naws_nms_sorted_fwd(const float* boxes, const int32_t* counts, int batch, int n_max,
                         float thresh, void* workspace, int32_t* keep, void* stream);
 /* ---- loader image preparation --------------------------------------------------

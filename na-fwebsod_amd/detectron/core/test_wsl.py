@@ -269,6 +269,28 @@ def nms_all_classes(scores, boxes):
     return out
 
 
+def soft_nms_all_classes(all_dets):
+    """{class: dets [n_j, 5]} -> {class: soft-NMS'd dets} through naws_soft_nms_fwd (one workgroup
+    per class, the reference's output order), or None when a class's list does not fit the
+    kernel's LDS image (the numpy form then runs)."""
+    from naws_hip import ops
+    classes = sorted(all_dets)
+    n_max = max([all_dets[j].shape[0] for j in classes] + [1])
+    if n_max > ops.SOFT_NMS_MAX or not torch.cuda.is_available():
+        return None
+    dev = torch.device('cuda', torch.cuda.current_device())
+    packed = np.zeros((len(classes), n_max, 5), np.float32)
+    counts = np.zeros((len(classes),), np.int32)
+    for k, j in enumerate(classes):
+        packed[k, :all_dets[j].shape[0]] = all_dets[j]
+        counts[k] = all_dets[j].shape[0]
+    out, _keep, oc = ops.soft_nms_per_class(
+        torch.from_numpy(packed).to(dev), torch.from_numpy(counts).to(dev), cfg.TEST.SOFT_NMS.SIGMA,
+        cfg.TEST.NMS, 0.0001, box_utils.SOFT_NMS_METHODS[cfg.TEST.SOFT_NMS.METHOD])
+    out, oc = out.cpu().numpy(), oc.cpu().numpy()
+    return {j: out[k, :oc[k]].copy() for k, j in enumerate(classes)}
+
+
 def box_results_with_nms_and_limit(scores, boxes):
     """Per-class score threshold, NMS (greedy, or TEST.SOFT_NMS), optional TEST.BBOX_VOTE
     refinement, then the DETECTIONS_PER_IM best over all classes (core/test_wsl.py:803-863).
@@ -282,11 +304,18 @@ def box_results_with_nms_and_limit(scores, boxes):
         bj = boxes[inds, j * 4:(j + 1) * 4] if boxes.shape[1] > 4 else boxes[inds, :]
         return np.hstack((bj, scores[inds, j][:, np.newaxis])).astype(np.float32, copy=False)
 
+    all_dets = {}
+    if soft or vote:
+        for j in range(1, num_classes):
+            all_dets[j] = dets_of(j, np.where(scores[:, j] > cfg.TEST.SCORE_THRESH)[0])
+    soft_dev = None
+    if soft and not cfg.NAWS.HOST_NMS:
+        soft_dev = soft_nms_all_classes(all_dets)        # every class in one launch (or None)
     for j in range(1, num_classes):
-        dets_j = None
-        if soft or vote:
-            dets_j = dets_of(j, np.where(scores[:, j] > cfg.TEST.SCORE_THRESH)[0])
-        if soft:
+        dets_j = all_dets.get(j)
+        if soft and soft_dev is not None:
+            nms_dets = soft_dev[j]
+        elif soft:
             # the overlap threshold is TEST.NMS, the discard threshold the reference's literal 1e-4
             nms_dets, _ = box_utils.soft_nms(dets_j, sigma=cfg.TEST.SOFT_NMS.SIGMA,
                                              overlap_thresh=cfg.TEST.NMS, score_thresh=0.0001,

@@ -81,6 +81,7 @@ PROTOTYPES = {
     'naws_transpose_to_bf16': [p, i32, i32, i32, i32, i32, p, p],
     'naws_conv3x3_nhwc_f32x3_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
     'naws_conv3x3_winograd_nhwc_f32x3_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p],
+    'naws_soft_nms_fwd': [p, p, i32, i32, f32, f32, f32, i32, p, p, p, p],
     'naws_nms_sorted_fwd': [p, p, i32, i32, f32, p, p, p],
     'naws_prep_image_fwd': [p, i32, i32, i32, i32, i32, i32, i32, p, p, C.c_double, i32, f32, f32, i32, i32,
                             i64, i32, p, p],

@@ -430,6 +430,26 @@ def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None, am
     return y
 
 
+SOFT_NMS_MAX = 5111         # naws_soft_nms_fwd keeps a class's list in LDS
+
+
+def soft_nms_per_class(dets, counts, sigma, overlap_thresh, score_thresh, method):
+    """dets fp32 [C, n_max, 5], counts int32 [C] (device) -> (out_dets [C, n_max, 5], keep int32
+    [C, n_max], out_counts int32 [C]): cython_nms.soft_nms of every class in one launch, results in
+    the reference's output order."""
+    _chk(dets, 'dets')
+    c, n_max, five = dets.shape
+    if five != 5 or counts.dtype != torch.int32 or counts.numel() != c:
+        raise L.NawsError('naws_soft_nms_fwd', L.ERR_SHAPE)
+    out = torch.empty_like(dets)
+    keep = torch.empty((c, n_max), device=dets.device, dtype=torch.int32)
+    oc = torch.empty((c,), device=dets.device, dtype=torch.int32)
+    L.call('naws_soft_nms_fwd', dets.data_ptr(), counts.data_ptr(), c, n_max, float(sigma),
+           float(overlap_thresh), float(score_thresh), int(method), out.data_ptr(), keep.data_ptr(),
+           oc.data_ptr(), _stream())
+    return out, keep, oc
+
+
 def nms_per_class(boxes, scores, score_thresh, nms_thresh):
     """Per-class greedy NMS of one image on the GPU (cython_nms.pyx `nms` semantics).
     boxes [R,4] (or [R,4*C] class-tiled, the reference's pred_boxes), scores [R,C] (fg classes).

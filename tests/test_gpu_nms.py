@@ -62,3 +62,61 @@ def test_nms_class_tiled_boxes_and_empty(dev):
     assert torch.equal(k1, k2)
     e = ops.nms_per_class(torch.zeros((0, 4), device=dev), torch.zeros((0, 4), device=dev), 0.1, 0.4)
     assert e.shape == (4, 0)
+
+
+@pytest.mark.parametrize('method', ['linear', 'gaussian', 'hard'])
+def test_soft_nms_kernel_matches_the_sequential_restatement(dev, method):
+    """naws_soft_nms_fwd (one workgroup per class, the list in LDS, the reference's swap /
+    overwrite-by-the-last-box order replayed by a two-pointer compaction) against the oracle's
+    statement-for-statement C loop of cython_nms.pyx:98-203: decayed scores bit-identical, kept
+    indices in the same ORDER, for lists of 1 ... 4000 boxes incl. ties and heavy discarding."""
+    import torch
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(70)
+    sizes = [1, 2, 3, 17, 64, 65, 333, 1024, 1025, 2500, 4000, 0]
+    n_max = max(sizes)
+    for thr in (0.0001, 0.05, 0.3):
+        packed = np.zeros((len(sizes), n_max, 5), np.float32)
+        for k, n in enumerate(sizes):
+            b = np.floor(rng.uniform(0, 300, (n, 4))).astype(np.float32)
+            b[:, 2:] = b[:, :2] + np.floor(rng.uniform(5, 150, (n, 2))).astype(np.float32)
+            sc = (rng.uniform(0, 1, (n, 1)) ** 3).astype(np.float32)
+            if n >= 5:
+                sc[rng.integers(0, n, n // 5)] = np.float32(0.25)           # ties
+            packed[k, :n] = np.hstack([b, sc])
+        out, keep, oc = ops.soft_nms_per_class(torch.from_numpy(packed).to(dev),
+                                               torch.tensor(sizes, dtype=torch.int32, device=dev),
+                                               0.5, 0.3, thr, {'hard': 0, 'linear': 1, 'gaussian': 2}[method])
+        out, keep, oc = out.cpu().numpy(), keep.cpu().numpy(), oc.cpu().numpy()
+        for k, n in enumerate(sizes):
+            want, wk = oracle.soft_nms(packed[k, :n], 0.5, 0.3, thr, method)
+            assert oc[k] == len(wk), (method, thr, n, oc[k], len(wk))
+            assert keep[k, :oc[k]].tolist() == wk, (method, thr, n)
+            assert np.array_equal(out[k, :oc[k]], want), (method, thr, n)
+
+
+def test_box_results_soft_nms_on_the_device_equals_the_host_form(dev):
+    """TEST.SOFT_NMS through box_results_with_nms_and_limit: the device kernel (default) and the
+    numpy form (NAWS.HOST_NMS) return identical detections."""
+    from detectron.core import config as c
+    from detectron.core import test_wsl
+    import os
+    c.reset_cfg()
+    try:
+        c.merge_cfg_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                           'na-fwebsod_amd', 'configs', 'flickr_voc', 'na_wsddn_V-16-C5_1x.yaml'))
+        c.merge_cfg_from_list(['TEST.SOFT_NMS.ENABLED', True, 'TEST.BBOX_VOTE.ENABLED', True,
+                               'TEST.DETECTIONS_PER_IM', 60])
+        rng = np.random.default_rng(71)
+        n, k = 500, 21
+        b = np.floor(rng.uniform(0, 300, (n, 4))).astype(np.float32)
+        b[:, 2:] = b[:, :2] + np.floor(rng.uniform(10, 120, (n, 2))).astype(np.float32)
+        scores = (rng.uniform(0, 1, (n, k)) ** 5).astype(np.float32)
+        got = test_wsl.box_results_with_nms_and_limit(scores, np.tile(b, (1, k)))[2]
+        c.cfg.NAWS.HOST_NMS = True
+        want = test_wsl.box_results_with_nms_and_limit(scores, np.tile(b, (1, k)))[2]
+        for j in range(1, k):
+            assert np.array_equal(got[j], want[j]), j
+    finally:
+        c.reset_cfg()
