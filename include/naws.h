@@ -686,6 +686,14 @@ int naws_launch_state_reset(void);
  * fp32 accumulation order (last bits), never the arithmetic.
  * Unknown knob: NAWS_ERR_ARG.  The library never reads the environment. */
 int naws_set_variant(const char* knob, int value);
+/* A stream for background work (the parameter update that runs beside the next iteration's conv
+ * body): priority 0 = normal, > 0 = lower than normal, < 0 = higher (clamped to the device's
+ * range); cu_mask (mask_words 32-bit words, bit i = compute unit i in the runtime's numbering;
+ * NULL / 0 = all) confines its kernels to those compute units so an HBM-bound kernel does not take
+ * wave slots from an MFMA-bound one.  The handle is a hipStream_t; release it with
+ * naws_stream_destroy.  No reference counterpart (Caffe2 runs one stream per GPU). */
+int naws_stream_create(int priority, const uint32_t* cu_mask, int mask_words, void** stream);
+int naws_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,44 @@ extern "C" int naws_set_variant(const char* knob, int value) {
   return NAWS_ERR_ARG;
 }
 
+extern "C" int naws_stream_create(int priority, const uint32_t* cu_mask, int mask_words,
+                                  void** stream) {
+  NAWS_REQUIRE_PTR(stream);
+  if (mask_words < 0 || (mask_words > 0 && !cu_mask)) return NAWS_ERR_ARG;
+  hipStream_t s = nullptr;
+  if (mask_words > 0) {
+    // (a masked stream takes the default priority: the runtime has no call that sets both)
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask) != hipSuccess) {
+      (void)hipGetLastError();
+      return NAWS_ERR_LAUNCH;
+    }
+  } else {
+    int least = 0, greatest = 0;   // numerically: least >= greatest
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+      (void)hipGetLastError();
+      return NAWS_ERR_LAUNCH;
+    }
+    int pr = priority > 0 ? least : (priority < 0 ? greatest : 0);
+    if (pr > least) pr = least;
+    if (pr < greatest) pr = greatest;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr) != hipSuccess) {
+      (void)hipGetLastError();
+      return NAWS_ERR_LAUNCH;
+    }
+  }
+  *stream = s;
+  return NAWS_OK;
+}
+
+extern "C" int naws_stream_destroy(void* stream) {
+  if (!stream) return NAWS_OK;
+  if (hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return NAWS_ERR_LAUNCH;
+  }
+  return NAWS_OK;
+}
+
 namespace {
 
 constexpr int TB = 256;

@@ -237,6 +237,10 @@ class WsddnEngine(object):
         self._update_waiting = False
         self.update_after_conv1 = 1
         self._upd_stream = None
+        self._upd_stream_kind = None
+        self.update_stream = 'torch'
+        self._bg_streams = []
+        self._upd_streams = {}
         self._upd_event = None
         self._wplanes = None         # split planes of fc6_w / fc7_w / fc7_w^T (16-bit MFMA plans)
         self._planes_dirty = True
@@ -937,14 +941,38 @@ class WsddnEngine(object):
             self._apply_update()
             return
         main = torch.cuda.current_stream(self.device)
-        if self._upd_stream is None:
-            self._upd_stream = torch.cuda.Stream(device=self.device)
+        if self._upd_stream is None or self._upd_stream_kind != self.update_stream:
+            kind = self.update_stream
+            if kind not in self._upd_streams:
+                self._upd_streams[kind] = self._make_update_stream(kind)
+            self._upd_stream, self._upd_stream_kind = self._upd_streams[kind], kind
         self._grads_ready = main.record_event()
         if self.update_after_conv1 > 0:
             self._update_waiting = True      # launched by the next conv body (or by flush)
         else:
             self._launch_update(())
         self._update_pending = True
+
+    def _make_update_stream(self, kind):
+        """'torch': a plain stream; 'low': lowest priority; 'cu<stride>' / 'cu<stride>+<offset>':
+        every stride-th compute unit only; 'first<n>': compute units 0..n-1."""
+        if kind in (None, '', 'torch'):
+            return torch.cuda.Stream(device=self.device)
+        if kind == 'low':
+            bs = ops.BackgroundStream(self.device, priority=1)
+        else:
+            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            if kind.startswith('first'):
+                n = int(kind[5:])
+                mask = [((1 << min(32, max(0, n - 32 * w))) - 1) for w in range((n_cu + 31) // 32)]
+            elif kind.startswith('cu'):
+                stride, _, off = kind[2:].partition('+')
+                mask = ops.cu_mask_every(n_cu, int(stride), int(off or 0))
+            else:
+                raise ValueError('update_stream: %r' % (kind,))
+            bs = ops.BackgroundStream(self.device, cu_mask=mask)
+        self._bg_streams.append(bs)         # keeps the handle alive as long as the engine
+        return bs.stream
 
     def _launch_update(self, after):
         """Queue the update on its side stream, behind the gradients and the events in `after`."""

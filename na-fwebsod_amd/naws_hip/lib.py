@@ -105,6 +105,8 @@ PROTOTYPES = {
     'naws_amax_f32': [p, i64, p, p],
     'naws_launch_state_reset': [],
     'naws_set_variant': [C.c_char_p, i32],
+    'naws_stream_create': [i32, p, i32, p],
+    'naws_stream_destroy': [p],
     'naws_gemm_f32_f16x2_nt_xk': [i32, i32, i32, p, i64, i64, p, p, i64, i64, i32, p, p, i32, p],
     'naws_conv3x3_winograd_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p],
     'naws_gemm_f32_f16x2_nt_amax': [i32, i32, i32, p, i64, i64, p, p, i64, i64, p, p, i32, i32,

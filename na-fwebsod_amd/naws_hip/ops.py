@@ -1145,3 +1145,32 @@ def reduce_sum_axis0(x):
     y = torch.empty((1, x.shape[1]), device=x.device, dtype=_f32)
     L.call('naws_reduce_sum_axis0', x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), _stream())
     return y
+
+
+class BackgroundStream(object):
+    """naws_stream_create: a HIP stream with a priority or a compute-unit mask, usable wherever
+    torch takes a stream (`.stream` is a torch.cuda.ExternalStream over the same handle)."""
+
+    def __init__(self, device, priority=0, cu_mask=None):
+        handle = C.c_void_p()
+        words = None
+        if cu_mask is not None:
+            words = (C.c_uint32 * len(cu_mask))(*[int(w) & 0xFFFFFFFF for w in cu_mask])
+        with torch.cuda.device(device):
+            L.call('naws_stream_create', int(priority), words, 0 if words is None else len(words),
+                   C.byref(handle))
+        self.handle = handle
+        self.stream = torch.cuda.ExternalStream(handle.value, device=device)
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            L.call('naws_stream_destroy', self.handle)
+        self.handle = None
+
+
+def cu_mask_every(n_cu, stride, offset=0):
+    """32-bit mask words selecting compute units offset, offset + stride, ... below n_cu."""
+    words = [0] * ((n_cu + 31) // 32)
+    for i in range(offset, n_cu, stride):
+        words[i // 32] |= 1 << (i % 32)
+    return words

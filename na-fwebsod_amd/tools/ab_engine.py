@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--rois', type=int, default=2000)
     ap.add_argument('--mfma-dtype', default='fp16x2')
+    ap.add_argument('--stages', action='store_true', help='per-stage times (HIP events on the main stream)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     c, B = 20, 2
@@ -60,6 +61,7 @@ def main():
         torch.cuda.synchronize()
 
     vals = [conv(v) for v in a.values]
+    stages = {}
     times = {v: [] for v in vals}
     run(5)
     for _ in range(a.rounds):
@@ -70,13 +72,22 @@ def main():
             else:
                 setattr(eng, a.attr, v)
             run(3)
+            if a.stages:
+                eng.phase_events = []
             t0 = time.perf_counter()
             run(a.steps)
             times[v].append((time.perf_counter() - t0) / a.steps * 1e3)
+            if a.stages:
+                ev, eng.phase_events = eng.phase_events, None
+                for (_n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+                    if n1 != 'start':
+                        stages.setdefault(v, {}).setdefault(n1, []).append(e0.elapsed_time(e1))
     print('host enqueue time per step: median %.3f ms' % sorted(host)[len(host) // 2])
     for v in vals:
         ts = sorted(times[v])
         print('%s=%r: median %.3f ms/step (min %.3f, max %.3f)' % (a.env or a.attr, v, ts[len(ts) // 2], ts[0], ts[-1]))
+        if v in stages:
+            print('    ' + '  '.join('%s %.3f' % (n, float(np.median(x))) for n, x in stages[v].items()))
 
 
 if __name__ == '__main__':
