@@ -43,6 +43,11 @@ def parse():
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL and run the all-reduce schedule even with one rank '
                          '(exercises the N>1 code path on a 1-GPU box)')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='DIAGNOSTIC: every rank uses cuda:0 and the gradients travel over gloo '
+                         '(RCCL refuses two ranks on one device): runs the real N > 1 schedule - '
+                         'chunked fc6_w exchange, deferred update behind it - on a 1-GPU box.  The '
+                         'line says shared_gpu: true; its value is NOT a throughput claim')
     ap.add_argument('--self-launch', action='store_true',
                     help='start the ranks as children through torch.distributed.run even for '
                          '--gpus 1 (the path a bare `python bench.py --gpus N`, N > 1, always takes)')
@@ -418,6 +423,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.dry_run:
         return dry_run(args, rank, world)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
@@ -425,7 +432,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
     from detectron.datasets import synthetic
     from naws_hip.engine import WsddnEngine
@@ -615,6 +625,7 @@ def main():
                'rccl_backend': (torch.distributed.get_backend() if pg is not None else 'none'),
                'rccl_world_size': (torch.distributed.get_world_size() if pg is not None else 1),
                'allreduce_chunks': eng.allreduce_chunks if eng.reducer.active else 0,
+               'shared_gpu': bool(args.share_gpu),
                # per-rank wall time of the timed region (value uses the max); the time the main
                # stream stood waiting for the deferred all-reduce + SGD + weight re-split before
                # the head could read the parameters (HIP events around engine.flush(): the
