@@ -274,7 +274,8 @@ typedef struct naws_sgd_plane_region {
   int32_t rows, cols;      /* row-major, contiguous (ld = cols) */
   int32_t rows_per_batch;  /* planes: f16 [2][rows / rows_per_batch][cols / 16][rows_per_batch][16] */
   int32_t reserved;
-  void* planes;
+  void* planes;            /* NULL: the matrix is left untouched - parameters, momentum and planes
+                            * were already updated by naws_gemm_f32_f16x2_nt_xk_sgd */
   int64_t plane_stride;    /* elements between the hi and the lo plane */
   const uint32_t* bound;   /* [rows] */
   uint32_t* rowmax;        /* [rows] */
@@ -675,6 +676,28 @@ int naws_det_limit_fwd(const float* scores, const uint8_t* keep, int C, int R, i
 int naws_gemm_f32_f16x2_nt_xk(int M, int N, int K, const void* A2, int64_t slabA, int64_t planeA,
                               const float* scaleA, const void* X2, int64_t slabX, int64_t planeX,
                               int xrows, const float* scaleX, float* C, int ldc, void* stream);
+
+/* naws_gemm_f32_f16x2_nt_xk with the ACM SGD update of the [M x N] parameter block `param`
+ * (ld ldp; `momentum_buf` its momentum, same indexing) in the epilogue INSTEAD of the store: the
+ * gradient never reaches memory.  For a run without a gradient exchange - one process; the
+ * reference adds its all-reduce ops only for NUM_GPUS > 1 (detectron/modeling/
+ * optimizer_wsl.py:52-72) - and ITER_SIZE 1.  Element arithmetic (lr[0] * lr_mult, weight_decay,
+ * 1 / gpu_num, iter_count == 0 starts the momentum at zero), the block's fp16x2 operand planes
+ * (`planes`: hi at planes, lo at planes + plane_stride, [N/16][plane_rows][16], plane_rows >= M),
+ * bound / rowmax / inv_scale / overflow exactly as naws_acm_sgd_update_f16x2 treats a region:
+ * bit-identical parameters, momentum and planes.  Hand that call the same region with planes =
+ * NULL for the rest of the arena.
+ *   ref: Caffe2 FCGradient dW (detectron/modeling/wsl_heads.py:674-679) +
+ *        detectron/ops/acm_weightdecay_momentum_sgd_op.h:72-109. */
+int naws_gemm_f32_f16x2_nt_xk_sgd(int M, int N, int K, const void* A2, int64_t slabA, int64_t planeA,
+                                  const float* scaleA, const void* X2, int64_t slabX,
+                                  int64_t planeX, int xrows, const float* scaleX, float* param,
+                                  float* momentum_buf, int ldp, const float* lr, float lr_mult,
+                                  float weight_decay, float momentum, int nesterov, int gpu_num,
+                                  int64_t iter_count, void* planes, int64_t plane_stride,
+                                  int plane_rows, const uint32_t* bound, uint32_t* rowmax,
+                                  float* inv_scale, int32_t* overflow, int32_t overflow_tag,
+                                  void* stream);
 
 /* ---- process-wide state and tuning (no reference counterpart) ------------------------------ */
 /* Kernels that need more than 64 KB of dynamic LDS have that limit raised once per (kernel,

@@ -36,6 +36,22 @@ struct BArgs {
   const float* rs;           // per-row factors undoing A's scaling
   const float* cs;           // per-column factors (null: 1)
   int tiles_m, tiles_n;
+  // SGD form (naws_gemm_f32_f16x2_nt_xk_sgd): C is never written; the tile's products are the
+  // gradient of param[M][ldp] and go straight into the update
+  float* mom;
+  float* param;
+  int ldp;
+  const float* lr;           // device scalar: the base learning rate
+  float lr_mult, wd, momentum, gscale;
+  int nesterov, first;
+  unsigned short* P;         // param's fp16x2 operand planes [2][N/16][prows][16] (hi, then lo)
+  long long planeP;
+  int prows;
+  const unsigned* bound;     // [M] max|param row| before this update (bit patterns)
+  unsigned* rowmax;          // [M] max|param row| after it (atomic max; caller zeroes)
+  float* inv_scale;          // [M]
+  int* overflow;
+  int overflow_tag;
 };
 
 // s_waitcnt lgkmcnt(0) that the fragments' consumers depend on (the asm reads are invisible to
@@ -61,7 +77,7 @@ constexpr int KS = 2, NPL = 2, STAGES = 2, NQ = NPL * KS;
 
 // <256, 256, 4, 2>: 512 threads, waves of 64 x 128;  <128, 128, 2, 2>: 256 threads, waves of 64 x 64
 // (the last column tiles of a problem whose tile count is not a multiple of the CU count)
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool SGD = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_h2_btr_kernel(BArgs g) {
   constexpr int NT = 64 * WM * WN, NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN, TI = WTM / 16, TJ = WTN / 16;
@@ -182,6 +198,82 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_h2_
   // lane holds FOUR CONSECUTIVE COLUMNS of one row - row l15, columns kg * 4 + e - and the
   // epilogue moves 16 bytes per lane (the products and their k order are the same: bit-identical
   // to the un-swapped form, which holds four rows of one column and stores 4 bytes at a time)
+  if constexpr (SGD) {
+    // ---- the update in place of the store (one process, no gradient exchange between the two:
+    // reference optimizer_wsl.py adds its all-reduce ops only for NUM_GPUS > 1).  g = the value
+    // the plain epilogue would have stored; then exactly acm_sgd_planes_kernel's element work:
+    // sgd_elem, the updated weight scaled by the row's bound-derived power of two and split into
+    // the hi / lo f16 planes (a lane's four columns = 8 bytes per plane, a fragment's 16 rows x
+    // 32 bytes = one contiguous 512-byte run of the K-slab), max|w| folded over the wave's
+    // columns, one guarded atomic per (row, wave) and the overflow word.
+    const float LR = g.lr[0] * g.lr_mult;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int row = m0 + wm * WTM + i * 16 + l15;
+      const bool row_on = row < g.M;
+      const int rr = row_on ? row : g.M - 1;
+      const float rsv = g.rs[rr];
+      const unsigned bb = g.bound[rr];
+      const unsigned b2 = ((bb >> 23) >= 1u && (bb >> 23) < 0xfeu) ? bb + (1u << 23) : bb;
+      float sc, isc;
+      naws_f16x2_scales(b2, sc, isc);
+      if (row_on && n0 + wn * WTN == 0 && kg == 0) g.inv_scale[row] = isc;
+      const long long prow = (long long)rr * 16;
+      float mx = 0.f;
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + wn * WTN + j * 16 + kg * 4;
+        if (!row_on || col >= g.N) continue;
+        f32x4 v = acc[i][j];
+        if (g.cs) {
+          const f32x4 c4 = *reinterpret_cast<const f32x4*>(g.cs + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * rsv * c4[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * rsv;
+        }
+        const long long o = (long long)row * g.ldp + col;
+        f32x4 p = *reinterpret_cast<const f32x4*>(g.param + o);
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};
+        if (!g.first) m = *reinterpret_cast<const f32x4*>(g.mom + o);
+        unsigned short hq[4], lq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float me = m[e], pe = p[e];
+          sgd_elem(v[e], me, pe, g.gscale, g.wd, LR, g.momentum, g.nesterov);
+          m[e] = me; p[e] = pe;
+          mx = fmaxf(mx, fabsf(pe));
+          bad = bad || (pe != pe);
+          const float t = pe * sc;
+          const _Float16 hi = (_Float16)t;
+          float rem = t - (float)hi;
+          if (!(fabsf(t) <= 65504.f)) rem = 0.f;         // NaN / overflow live in the hi plane only
+          const _Float16 lo = (_Float16)rem;
+          hq[e] = *reinterpret_cast<const unsigned short*>(&hi);
+          lq[e] = *reinterpret_cast<const unsigned short*>(&lo);
+        }
+        *reinterpret_cast<f32x4*>(g.mom + o) = m;
+        *reinterpret_cast<f32x4*>(g.param + o) = p;
+        const long long po = (long long)(col >> 4) * g.prows * 16 + prow + (col & 15);
+        *reinterpret_cast<uint2*>(g.P + po) =
+            make_uint2(hq[0] | ((unsigned)hq[1] << 16), hq[2] | ((unsigned)hq[3] << 16));
+        *reinterpret_cast<uint2*>(g.P + g.planeP + po) =
+            make_uint2(lq[0] | ((unsigned)lq[1] << 16), lq[2] | ((unsigned)lq[3] << 16));
+      }
+      // (a NaN weight must reach the overflow test: fmaxf drops NaNs, so it travels as +inf)
+      if (bad) mx = __uint_as_float(0x7f800000u);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (kg == 0 && row_on) {
+        const bool is_inf = __float_as_uint(mx) == 0x7f800000u;
+        if (mx > 0.f && !is_inf) naws_atomic_max_bits(g.rowmax + row, mx);
+        if (!(mx <= __uint_as_float(b2)) || is_inf) atomicMax(g.overflow, g.overflow_tag);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int row = m0 + wm * WTM + i * 16 + l15;
@@ -206,11 +298,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_h2_
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool SGD = false>
 int launch_btr(BArgs& g, hipStream_t s) {
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
-  auto kern = gemm_h2_btr_kernel<BM, BN, WM, WN>;
+  auto kern = gemm_h2_btr_kernel<BM, BN, WM, WN, SGD>;
   if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * WM * WN),
                      (size_t)STAGES * NQ * (BM + BN) * 32, s, g);
@@ -242,4 +334,51 @@ extern "C" int naws_gemm_f32_f16x2_nt_xk(int M, int N, int K, const void* A2, in
   // few tiles (the column remainder of fc6's dW): 128 x 128 tiles, two workgroups per CU
   if (naws_cdiv(M, 256) * naws_cdiv(N, 256) < 256) return launch_btr<128, 128, 2, 2>(g, s);
   return launch_btr<256, 256, 4, 2>(g, s);
+}
+
+// The same product with the ACM SGD update of `param` (an [M x N] block, ld ldp, of the parameter
+// arena; `mom` its momentum) in the epilogue instead of the store: the gradient
+// g = A^T-planes x X-planes never reaches memory.  For a run WITHOUT a gradient exchange (one
+// process: the reference adds its all-reduce ops only when NUM_GPUS > 1,
+// detectron/modeling/optimizer_wsl.py:52-72); with more ranks the gradient must be written,
+// reduced and then applied (naws_acm_sgd_update_f16x2).  Element arithmetic, scale bound, maxima
+// and overflow word exactly as naws_acm_sgd_update_f16x2 applies them to a region (head_ops.hip):
+// parameters, momentum and planes come out bit-identical to the two-kernel route.
+// replaces: FCGradient's dW for fc6 + ACMWeightDecayMomentumSGDUpdate on fc6_w
+// (reference detectron/ops/acm_weightdecay_momentum_sgd_op.h:72-109), ITER_SIZE 1.
+extern "C" int naws_gemm_f32_f16x2_nt_xk_sgd(
+    int M, int N, int K, const void* A2, int64_t slabA, int64_t planeA, const float* scaleA,
+    const void* X2, int64_t slabX, int64_t planeX, int xrows, const float* scaleX, float* param,
+    float* momentum_buf, int ldp, const float* lr, float lr_mult, float weight_decay, float momentum,
+    int nesterov, int gpu_num, int64_t iter_count, void* planes, int64_t plane_stride,
+    int plane_rows, const uint32_t* bound, uint32_t* rowmax, float* inv_scale, int32_t* overflow,
+    int32_t overflow_tag, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || xrows <= 0 || xrows > K || gpu_num <= 0 || iter_count < 0 ||
+      plane_rows <= 0)
+    return NAWS_ERR_SHAPE;
+  if (K % 32 != 0 || N % 16 != 0 || ldp < N || ldp % 4 != 0) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(A2); NAWS_REQUIRE_PTR(X2); NAWS_REQUIRE_PTR(scaleA); NAWS_REQUIRE_PTR(param);
+  NAWS_REQUIRE_PTR(momentum_buf); NAWS_REQUIRE_PTR(lr); NAWS_REQUIRE_PTR(planes);
+  NAWS_REQUIRE_PTR(bound); NAWS_REQUIRE_PTR(rowmax); NAWS_REQUIRE_PTR(inv_scale);
+  NAWS_REQUIRE_PTR(overflow);
+  if ((((uintptr_t)A2 | (uintptr_t)X2 | (uintptr_t)param | (uintptr_t)momentum_buf) & 15) != 0)
+    return NAWS_ERR_ARG;
+  if (((uintptr_t)planes & 7) != 0 || (const void*)bound == (const void*)rowmax) return NAWS_ERR_ARG;
+  if (scaleX && ((uintptr_t)scaleX & 15) != 0) return NAWS_ERR_ARG;
+  if (slabA < (int64_t)M * 16 || slabX < (int64_t)xrows * 16) return NAWS_ERR_ARG;
+  if (plane_rows < M) return NAWS_ERR_ARG;      // the block lies inside one batch item of the planes
+  BArgs g{};
+  g.A = (const unsigned short*)A2; g.X = (const unsigned short*)X2; g.C = nullptr;
+  g.M = M; g.N = N; g.K = K; g.ldc = ldp; g.xrows = xrows;
+  g.planeA = planeA; g.slabA = slabA; g.planeX = planeX; g.slabX = slabX;
+  g.rs = scaleA; g.cs = scaleX;
+  g.mom = momentum_buf; g.param = param; g.ldp = ldp; g.lr = lr; g.lr_mult = lr_mult;
+  g.wd = weight_decay; g.momentum = momentum; g.gscale = (float)(1.0 / (double)gpu_num);
+  g.nesterov = nesterov; g.first = iter_count == 0 ? 1 : 0;
+  g.P = (unsigned short*)planes; g.planeP = plane_stride; g.prows = plane_rows;
+  g.bound = bound; g.rowmax = rowmax; g.inv_scale = inv_scale; g.overflow = overflow;
+  g.overflow_tag = overflow_tag;
+  hipStream_t s = (hipStream_t)stream;
+  if (naws_cdiv(M, 256) * naws_cdiv(N, 256) < 256) return launch_btr<128, 128, 2, 2, true>(g, s);
+  return launch_btr<256, 256, 4, 2, true>(g, s);
 }

@@ -333,27 +333,7 @@ __global__ void stat_kernel(const float* __restrict__ I, const float* __restrict
 }
 
 // ---- fused ACM weight-decay momentum SGD over a parameter arena ------------
-// One element of the update, every product and sum rounded on its own (no FMA contraction): the
-// reference's CPU operator is scalar C++ built for generic x86-64 (math::Scale, math::Axpy, then
-// `lr * g + momentum * m`, acm_weightdecay_momentum_sgd_op.h:79-109), and the oracle restates it
-// with -ffp-contract=off; both SGD kernels below go through this one function, so they agree
-// with each other bit for bit.  a = the accumulated gradient (acm + g).
-__device__ __forceinline__ void sgd_elem(float a, float& m, float& p, float scale, float wd, float LR,
-                                         float momentum, int nesterov) {
-#pragma clang fp contract(off)          // (the build's -ffp-contract=fast-honor-pragmas honours this)
-  float t = a * scale;                                 // Normalize
-  t = t + wd * p;                                      // Regularize (Axpy)
-  if (!nesterov) {
-    const float adj = LR * t + momentum * m;
-    m = adj;
-    p = p - adj;
-  } else {
-    const float mi = m;
-    const float mi_new = momentum * mi + LR * t;
-    m = mi_new;
-    p = p - ((1.0f + momentum) * mi_new - momentum * mi);
-  }
-}
+// (sgd_elem: naws_common.h - shared with the wgrad GEMM that applies the update in its epilogue)
 __device__ __forceinline__ void sgd_update4(const float4& g, float4& m, float4& p, float scale,
                                             float wd, float LR, float momentum, int nesterov) {
   sgd_elem(g.x, m.x, p.x, scale, wd, LR, momentum, nesterov);
@@ -887,32 +867,34 @@ extern "C" int naws_acm_sgd_update_planes(int format, const float* grad, float* 
     a.lin_block0[++n_lin] = (int)lin_blocks;
     return true;
   };
+  int nr = 0;
   for (int i = 0; i < n_regions; ++i) {
     const naws_sgd_plane_region& g = regions[i];
     if (g.rows <= 0 || g.cols <= 0 || g.rows_per_batch <= 0) return NAWS_ERR_SHAPE;
     const long long n = (long long)g.rows * g.cols;
     if (g.start < cursor || g.start + n > total) return NAWS_ERR_SHAPE;     // ascending, disjoint
+    if (g.start % 4 != 0 || n % 4 != 0) return NAWS_ERR_UNSUPPORTED;
+    if (!add_linear(cursor / 4, g.start / 4)) return NAWS_ERR_UNSUPPORTED;
+    cursor = g.start + n;
+    if (g.planes == nullptr) continue;     // updated elsewhere (naws_gemm_f32_f16x2_nt_xk_sgd): left alone
     if (g.rows % 32 != 0 || g.cols % 256 != 0 || g.rows % g.rows_per_batch != 0 ||
-        g.rows_per_batch % 32 != 0 || g.start % 4 != 0)
+        g.rows_per_batch % 32 != 0)
       return NAWS_ERR_UNSUPPORTED;
-    NAWS_REQUIRE_PTR(g.planes);
     if (scaled) {
       NAWS_REQUIRE_PTR(g.bound); NAWS_REQUIRE_PTR(g.rowmax); NAWS_REQUIRE_PTR(g.inv_scale);
       if (g.bound == g.rowmax) return NAWS_ERR_ARG;
     }
     if (((uintptr_t)g.planes & 15) != 0) return NAWS_ERR_ARG;
     if (format == NAWS_PLANES_BF16 && g.cols % 64 != 0) return NAWS_ERR_UNSUPPORTED;
-    if (!add_linear(cursor / 4, g.start / 4)) return NAWS_ERR_UNSUPPORTED;
-    SgdPlaneRegion& r = a.r[i];
+    SgdPlaneRegion& r = a.r[nr++];
     r.start = g.start; r.rows = g.rows; r.cols = g.cols; r.rows_per_batch = g.rows_per_batch;
     r.tile0 = (int)tiles; r.planes = (unsigned short*)g.planes; r.plane_stride = g.plane_stride;
     r.bound = g.bound; r.rowmax = g.rowmax; r.inv_scale = g.inv_scale;
     tiles += (long long)(g.rows / 32) * (g.cols / 256);
-    cursor = g.start + n;
   }
   if (!add_linear(cursor / 4, total / 4)) return NAWS_ERR_UNSUPPORTED;
   if (tiles + lin_blocks > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
-  a.n = n_regions; a.tiles = (int)tiles; a.n_lin = n_lin;
+  a.n = nr; a.tiles = (int)tiles; a.n_lin = n_lin;
   for (int k = n_lin + 1; k < 5; ++k) a.lin_block0[k] = (int)lin_blocks;
   const float scale = (float)(1.0 / (double)gpu_num);
 #define NAWS_SGD_PLANES(F)                                                                          \

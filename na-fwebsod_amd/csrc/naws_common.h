@@ -83,6 +83,29 @@ __device__ __forceinline__ void naws_f16x2_scales(unsigned bound_bits, float& s,
   inv = __uint_as_float((unsigned)(e - 14) << 23);
 }
 
+// ---- ACM weight-decay momentum SGD, one element ------------------------------------------------------
+// One element of the update, every product and sum rounded on its own (no FMA contraction): the
+// reference's CPU operator is scalar C++ built for generic x86-64 (math::Scale, math::Axpy, then
+// `lr * g + momentum * m`, acm_weightdecay_momentum_sgd_op.h:79-109), and the oracle restates it
+// with -ffp-contract=off; both SGD kernels below go through this one function, so they agree
+// with each other bit for bit.  a = the accumulated gradient (acm + g).
+__device__ __forceinline__ void sgd_elem(float a, float& m, float& p, float scale, float wd, float LR,
+                                         float momentum, int nesterov) {
+#pragma clang fp contract(off)          // (the build's -ffp-contract=fast-honor-pragmas honours this)
+  float t = a * scale;                                 // Normalize
+  t = t + wd * p;                                      // Regularize (Axpy)
+  if (!nesterov) {
+    const float adj = LR * t + momentum * m;
+    m = adj;
+    p = p - adj;
+  } else {
+    const float mi = m;
+    const float mi_new = momentum * mi + LR * t;
+    m = mi_new;
+    p = p - ((1.0f + momentum) * mi_new - momentum * mi);
+  }
+}
+
 // ---- |C| maxima reported by a GEMM epilogue ---------------------------------------------------------
 // The fp16x2 operand split needs max|x| per row (NT operand) and / or per column (transposed
 // operand) of a matrix a GEMM has just produced.  Instead of re-reading the matrix, the producing

@@ -108,6 +108,8 @@ PROTOTYPES = {
     'naws_stream_create': [i32, p, i32, p],
     'naws_stream_destroy': [p],
     'naws_gemm_f32_f16x2_nt_xk': [i32, i32, i32, p, i64, i64, p, p, i64, i64, i32, p, p, i32, p],
+    'naws_gemm_f32_f16x2_nt_xk_sgd': [i32, i32, i32, p, i64, i64, p, p, i64, i64, i32, p, p, p, i32, p,
+                                      f32, f32, f32, i32, i32, i64, p, i64, i32, p, p, p, p, i32, p],
     'naws_conv3x3_winograd_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p],
     'naws_gemm_f32_f16x2_nt_amax': [i32, i32, i32, p, i64, i64, p, p, i64, i64, p, p, i32, i32,
                                     i64, i64, i64, i64, i64, i32, p, i64, p, i32, f32, f32, u64, i32,

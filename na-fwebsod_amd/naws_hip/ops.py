@@ -712,6 +712,43 @@ def gemm_f32_f16x2_nt_xk(a, x, out=None, ncols=None, scale_x=None):
     return out
 
 
+def gemm_f32_f16x2_nt_xk_sgd(a, x, param, momentum_buf, lr, lr_mult, weight_decay, momentum, nesterov,
+                             gpu_num, iter_count, wplanes, bound, rowmax, inv_scale, overflow,
+                             overflow_tag, ncols=None, rows=None):
+    """gemm_f32_f16x2_nt_xk whose epilogue applies the ACM SGD update to `param` (fp32 [M_all, N_all]
+    row-major view of the arena; `momentum_buf` likewise) instead of storing the gradient, and
+    writes param's own operand planes `wplanes` (F16x2 planes [2, N_all/16, M_all, 16]).  rows =
+    (r0, r1): a's rows are rows r0..r1 of param; ncols as in gemm_f32_f16x2_nt_xk.  bound / rowmax
+    (int32 [M_all]) / inv_scale (fp32 [M_all]) / overflow as acm_sgd_update_f16x2."""
+    a3, x3 = a.planes, x.planes
+    for t in (a3, x3, wplanes):
+        if (not t.is_cuda or t.dtype != torch.float16 or t.dim() != 4 or t.shape[0] != 2
+                or t.shape[-1] != 16 or t.stride(-1) != 1 or t.stride(-2) != 16):
+            raise TypeError('operands must be unbatched f16 split planes [2, K/16, rows, 16]')
+    mm, k = a3.shape[-2], a3.shape[-3] * 16
+    r, n_all = x3.shape[-2], x3.shape[-3] * 16
+    c0, c1 = (0, n_all) if ncols is None else ncols
+    r0, r1 = (0, mm) if rows is None else rows
+    if (c0 % 16 or c1 % 16 or not 0 <= c0 < c1 <= n_all or r > k or r1 - r0 != mm
+            or param.dim() != 2 or param.shape[1] != n_all or param.stride(1) != 1
+            or momentum_buf.shape != param.shape or momentum_buf.stride() != param.stride()
+            or wplanes.shape[1] * 16 != n_all or wplanes.shape[2] != param.shape[0]
+            or not 0 <= r0 < r1 <= param.shape[0]):
+        raise L.NawsError('naws_gemm_f32_f16x2_nt_xk_sgd', L.ERR_SHAPE)
+    for t, dt in ((bound, torch.int32), (rowmax, torch.int32), (inv_scale, _f32)):
+        if t.dtype != dt or t.numel() != param.shape[0] or not t.is_contiguous():
+            raise TypeError('bound / rowmax / inv_scale: contiguous [rows] int32 / int32 / fp32')
+    xs = x3[:, c0 // 16:]
+    ws = wplanes[:, c0 // 16:, r0:]
+    L.call('naws_gemm_f32_f16x2_nt_xk_sgd', mm, c1 - c0, k, a3.data_ptr(), a3.stride(-3), a3.stride(0),
+           a.inv_scale.data_ptr(), xs.data_ptr(), x3.stride(-3), x3.stride(0), r, None,
+           param[r0:r1, c0:c1].data_ptr(), momentum_buf[r0:r1, c0:c1].data_ptr(), param.stride(0),
+           lr.data_ptr(), float(lr_mult), float(weight_decay), float(momentum), int(nesterov),
+           int(gpu_num), int(iter_count), ws.data_ptr(), wplanes.stride(0), wplanes.shape[2],
+           bound[r0:].data_ptr(), rowmax[r0:].data_ptr(), inv_scale[r0:].data_ptr(),
+           overflow.data_ptr(), int(overflow_tag), _stream())
+
+
 def amax_scales(batch, outer, device):
     """Zeroed scale block [2, (batch,) outer] of an F16x2 whose maxima a GEMM epilogue will report:
     [0] (viewed as int32 bit patterns: `amax_words`) is the rowmax / colmax accumulator, [1]
