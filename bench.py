@@ -48,6 +48,10 @@ def parse():
                          '(RCCL refuses two ranks on one device): runs the real N > 1 schedule - '
                          'chunked fc6_w exchange, deferred update behind it - on a 1-GPU box.  The '
                          'line says shared_gpu: true; its value is NOT a throughput claim')
+    ap.add_argument('--no-fused-update', action='store_true',
+                    help='one rank only: write fc6_w\'s gradient and update it in the deferred SGD '
+                         'kernel (the route every rank takes when there is a gradient exchange) '
+                         'instead of in the wgrad GEMM\'s epilogue')
     ap.add_argument('--self-launch', action='store_true',
                     help='start the ranks as children through torch.distributed.run even for '
                          '--gpus 1 (the path a bare `python bench.py --gpus N`, N > 1, always takes)')
@@ -488,8 +492,11 @@ def main():
             eng.phase_events = None
             eng.update_events = None
             eng.comm_events = None
-        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
-        eng.sgd_step()
+        if args.no_fused_update:
+            out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            eng.sgd_step()
+        else:       # the same two calls; without a gradient exchange fc6_w is updated by its wgrad GEMM
+            out = eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
         return out
 
     for _ in range(args.warmup):
@@ -570,6 +577,9 @@ def main():
         sgd_bytes = 5 * 4 * eng.arena.total
         if h2 and eng.fused_planes and eng._sgd_regions is not None:
             sgd_bytes += 4 * 2 * 4096 * (eng.k6 + 4096)
+        wgrad_update = (not args.no_fused_update) and eng._can_fuse_wgrad_update()
+        if wgrad_update:       # the deferred kernel no longer touches fc6_w (nor reads its gradient)
+            sgd_bytes -= (5 * 4 + 4) * 2 * 4096 * eng.k6
         sgd_ms = sum(s.elapsed_time(e) for s, e in uev) / max(len(uev), 1)
         roof = {'bound': 'mfma', 'kernel': 'fc6 fwd (both branches, M=%d N=8192 K=%d): %s' % (rt, k6, kname),
                 'achieved': round(achieved, 2) if achieved else None,
@@ -626,6 +636,11 @@ def main():
                'rccl_world_size': (torch.distributed.get_world_size() if pg is not None else 1),
                'allreduce_chunks': eng.allreduce_chunks if eng.reducer.active else 0,
                'shared_gpu': bool(args.share_gpu),
+               # where fc6_w (86 % of the parameters) is updated: 'wgrad_epilogue' = inside its
+               # weight-gradient GEMM, possible only without a gradient exchange (one rank);
+               # 'deferred_kernel' = gradient written, (all-reduced,) then the SGD kernel on the
+               # side stream - what every rank does when world_size > 1
+               'fc6_update_path': 'wgrad_epilogue' if wgrad_update else 'deferred_kernel',
                # per-rank wall time of the timed region (value uses the max); the time the main
                # stream stood waiting for the deferred all-reduce + SGD + weight re-split before
                # the head could read the parameters (HIP events around engine.flush(): the

@@ -221,6 +221,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_h2_
       const long long prow = (long long)rr * 16;
       float mx = 0.f;
       bool bad = false;
+      // all of the row group's parameter / momentum loads first (16 x 16 bytes in flight per
+      // lane), then the arithmetic and the stores: fragment by fragment, every load waited
+      // behind the previous fragment's stores (0.73 ms on the fc6 problem instead of 0.3)
+      f32x4 pw[TJ], pm[TJ];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + wn * WTN + j * 16 + kg * 4;
+        const bool on = row_on && col < g.N;
+        const long long o = (long long)rr * g.ldp + (on ? col : 0);
+        pw[j] = *reinterpret_cast<const f32x4*>(g.param + o);
+        if (!g.first) pm[j] = *reinterpret_cast<const f32x4*>(g.mom + o);
+        else pm[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const int col = n0 + wn * WTN + j * 16 + kg * 4;
@@ -235,9 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_h2_
           for (int e = 0; e < 4; ++e) v[e] = v[e] * rsv;
         }
         const long long o = (long long)row * g.ldp + col;
-        f32x4 p = *reinterpret_cast<const f32x4*>(g.param + o);
-        f32x4 m = {0.f, 0.f, 0.f, 0.f};
-        if (!g.first) m = *reinterpret_cast<const f32x4*>(g.mom + o);
+        f32x4 p = pw[j], m = pm[j];
         unsigned short hq[4], lq[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -175,9 +175,8 @@ class NetExecutor(object):
     def _run_fused(self):
         ws, eng = self.ws, self.engine
         if self.model.train:
-            out = eng.forward_backward(ws['data'], ws['rois'], ws['obn_scores'], ws['labels_oh'],
-                                       seg=ws.get('_seg'))
-            eng.sgd_step()
+            out = eng.train_step(ws['data'], ws['rois'], ws['obn_scores'], ws['labels_oh'],
+                                 seg=ws.get('_seg'))
             ws['loss_cls'], ws['loss_cls_noise'] = out['loss_cls'], out['loss_cls_noise']
             ws['cls_prob'], ws['cls_prob_noise'] = out['cls_prob'], out['cls_prob_noise']
             ws['rois_class_weight'] = out['class_weight']

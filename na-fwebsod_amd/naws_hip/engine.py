@@ -168,6 +168,7 @@ class WsddnEngine(object):
         # 4096-multiples or the four fc8 biases = 4C floats, for any class count)
         if any(e % 4 for e in ends):
             raise NotImplementedError('SGD hyper-parameter runs must end on multiples of 4 floats')
+        self._seg_host = (list(ends), list(lr_mult), list(wd))
         self.seg_end = torch.tensor(ends, dtype=torch.int64, device=device)
         self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=device)
         self.seg_wd = torch.tensor(wd, dtype=torch.float32, device=device)
@@ -209,6 +210,12 @@ class WsddnEngine(object):
         # twice the row maximum before the update; a device-side conditional re-split covers a row
         # that outgrows it): no 0.96 GB read + 0.96 GB write re-split on the update stream
         self.fused_planes = True
+        # train_step() without a gradient exchange: fc6_w (86 % of the parameters) is updated in
+        # the epilogue of its own wgrad GEMM - the gradient is never written, the update's HBM
+        # traffic sits inside an MFMA-bound kernel (see train_step)
+        self.fuse_wgrad_update = True
+        self._w6_updated = False
+        self._sgd_regions_rest = None
         self._sgd_regions = None
         # RoIPoolF over 2x2 / 4x4 block maxima of conv5_3 (csrc/roi_ops.hip): same values, ~8x less
         # gather traffic
@@ -285,6 +292,11 @@ class WsddnEngine(object):
                 self._sgd_regions = ops.SgdPlaneRegions([
                     (o6, n6, self.k6, n6, p6.planes, self._wbound[:n6], sc[0, 0].view(torch.int32),
                      sc[0, 1]),
+                    (o7, n6, HIDDEN, HIDDEN, p7.planes, self._wbound[n6:], sc[1, 0].view(torch.int32),
+                     sc[1, 1])])
+                # the same table with fc6_w marked "updated elsewhere" (train_step)
+                self._sgd_regions_rest = ops.SgdPlaneRegions([
+                    (o6, n6, self.k6, n6, None, None, None, None),
                     (o7, n6, HIDDEN, HIDDEN, p7.planes, self._wbound[n6:], sc[1, 0].view(torch.int32),
                      sc[1, 1])])
         elif self._wplanes is None:
@@ -718,7 +730,8 @@ class WsddnEngine(object):
         b8p[:, :2 * C].copy_(b8)
         return w8p, b8p
 
-    def forward_backward(self, data, rois, obn_scores, labels_oh, compute_grads=True, seg=None):
+    def forward_backward(self, data, rois, obn_scores, labels_oh, compute_grads=True, seg=None,
+                         _fuse_update=False):
         """One training pass over this GPU's images.  Returns dict of loss tensors
         (per image) and keeps what backward / stats need.  `seg` = host list of per-image row
         offsets [0, R0, R0+R1, ...] (the loader knows it); when omitted it is derived from
@@ -768,12 +781,12 @@ class WsddnEngine(object):
         dl = (torch.zeros if ld8 != 2 * C else torch.empty)((rt, 2 * ld8), device=self.device,
                                                             dtype=torch.float32)
         ops.wsddn_outputs_grad(ac, ad, rp, cp, g, seg_off, out=dl, col_offsets=cols)
-        self._head_backward(x, h6, h7, dl)
+        self._head_backward(x, h6, h7, dl, fuse_update=_fuse_update)
         mark('head_bwd')
         out['d_logits'] = dl if ld8 == 2 * C else torch.cat([dl[:, o:o + C] for o in cols], 1)
         return out
 
-    def _head_backward(self, x, h6, h7, dl):
+    def _head_backward(self, x, h6, h7, dl, fuse_update=False):
         C, rt = self.C, h6.shape[0]
         G = self.grads
         scale = 1.0 / (1.0 - self.dropout) if self.dropout > 0 else 1.0
@@ -859,7 +872,9 @@ class WsddnEngine(object):
                 # 25088 = 98 column tiles of 256: 32 x 98 = 12.25 waves of 256 CUs.  96 column
                 # tiles make 12 full waves; the last 512 columns go out as one wave of 128x128 tiles
                 ncut = self._wgrad_column_cut(r1 - r0)
-                if xk:
+                if xk and fuse_update and self._can_fuse_wgrad_update():
+                    self._wgrad_update_w6(dz6t, x, r0, r1, ncut)
+                elif xk:
                     for c0, c1 in (((0, ncut), (ncut, self.k6)) if ncut else ((0, self.k6),)):
                         ops.gemm_f32_f16x2_nt_xk(dz6t.rows(r0, r1), x, ncols=(c0, c1),
                                                  out=gw6[r0:r1, c0:c1])
@@ -900,6 +915,51 @@ class WsddnEngine(object):
             ops.gemm(dlv, h7v, True, False, out=gw8)
             ops.colsum(dl, out=gb8)
         red.reduce_async(message_slice(self.arena, G, *plan[-1], self.k6))
+
+    def _can_fuse_wgrad_update(self):
+        return (self.fuse_wgrad_update and not self.reducer.active and self.iter_size == 1
+                and self.mfma_dtype == 'fp16x2' and self.fused_wmax and self.fused_planes
+                and self._sgd_regions is not None and self._wplanes is not None
+                and not self._planes_dirty and self.k6 % 256 == 0)
+
+    def _wgrad_update_w6(self, dz6t, x, r0, r1, ncut):
+        """fc6_w's rows r0..r1: wgrad GEMM with the SGD update + the rows' operand planes in its
+        epilogue (ops.gemm_f32_f16x2_nt_xk_sgd), on the main stream.  First chunk: the rows' maxima
+        become the bounds of this update; last chunk: the conditional exact re-split."""
+        n6 = 2 * HIDDEN
+        sc = self._wscales.view(2, 2, n6).view(torch.int32)        # [operand][maxima | 1/scale][rows]
+        maxima, bound = sc[0, 0], self._wbound[:n6]
+        tag = self.sgd_iter_count + 1
+        if r0 == 0:
+            bound.copy_(maxima)
+            maxima.zero_()
+        w6 = self.arena.span(self.params, 'fc6_w', '_[noisy]_fc6_w').view(n6, self.k6)
+        m6 = self.arena.span(self.momentum_buf, 'fc6_w', '_[noisy]_fc6_w').view(n6, self.k6)
+        ends, lr_mult, wd = self._seg_host
+        o6 = self.arena.offsets['fc6_w'][0]
+        sg = next(i for i, e in enumerate(ends) if e > o6)
+        assert ends[sg] >= o6 + n6 * self.k6       # one hyper-parameter run over both branches
+        for c0, c1 in (((0, ncut), (ncut, self.k6)) if ncut else ((0, self.k6),)):
+            ops.gemm_f32_f16x2_nt_xk_sgd(dz6t.rows(r0, r1), x, w6, m6, self.lr, lr_mult[sg], wd[sg],
+                                         self.momentum, 0, self.gpu_num, self.sgd_iter_count,
+                                         self._wplanes['w6'].planes, bound, maxima,
+                                         self._wscales.view(2, 2, n6)[0, 1], self._wovf, tag,
+                                         ncols=(c0, c1), rows=(r0, r1))
+        if r1 == n6:
+            ops.split_f16x2_rows_if(w6, maxima, self._wplanes['w6'], self._wovf, tag)
+            self._w6_updated = True
+
+    def train_step(self, data, rois, obn_scores, labels_oh, seg=None):
+        """forward_backward + sgd_step as one call.  With no gradient exchange between the two
+        (one process; the reference adds its all-reduce ops only for NUM_GPUS > 1,
+        optimizer_wsl.py:52-72) fc6_w's update runs in the epilogue of its wgrad GEMM: same
+        arithmetic, same planes, but the gradient (0.82 GB written and read back) never exists
+        and the update's traffic hides inside an MFMA-bound kernel instead of time-slicing with
+        the next conv body.  `self.grads` then holds no fc6_w gradient.  With an exchange, or
+        fuse_wgrad_update = False, this is exactly forward_backward(); sgd_step()."""
+        out = self.forward_backward(data, rois, obn_scores, labels_oh, seg=seg, _fuse_update=True)
+        self.sgd_step()
+        return out
 
     def _wgrad_column_cut(self, rows, cus=256):
         """fc6 wgrad tile quantisation: with 256x256 tiles the [rows, k6] output is tm x tn tiles;
@@ -1019,17 +1079,21 @@ class WsddnEngine(object):
                      and self._sgd_regions is not None and self.iter_size == 1
                      and not self._planes_dirty and self._wplanes is not None)
         rowmax = None
+        w6_done, self._w6_updated = self._w6_updated, False
+        assert planes or not w6_done
         if fused:
             maxima = self._wscales.view(2, 2, 2 * HIDDEN)[:, 0]
+            part = slice(1, 2) if w6_done else slice(0, 2)      # (fc6_w's half was handled by its wgrad)
             if planes:
-                self._wbound.view(2, 2 * HIDDEN).copy_(maxima.view(torch.int32))
-            maxima.zero_()
+                self._wbound.view(2, 2 * HIDDEN)[part].copy_(maxima.view(torch.int32)[part])
+            maxima[part].zero_()
             rowmax = self._wscales.view(torch.int32)
         if planes:
             tag = self.sgd_iter_count + 1
             ops.acm_sgd_update_f16x2(self.grads, self.momentum_buf, self.lr, self.params,
                                      self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
-                                     self.gpu_num, self.sgd_iter_count, self._sgd_regions,
+                                     self.gpu_num, self.sgd_iter_count,
+                                     self._sgd_regions_rest if w6_done else self._sgd_regions,
                                      self._wovf, tag)
         elif planes_bf:
             ops.acm_sgd_update_planes(self.grads, self.momentum_buf, self.lr, self.params,
@@ -1050,7 +1114,8 @@ class WsddnEngine(object):
             w6, w7 = self._weight_views()
             wp = self._wplanes
             sc = self._wscales.view(2, 2, 2 * HIDDEN).view(torch.int32)
-            ops.split_f16x2_rows_if(w6, sc[0, 0], wp['w6'], self._wovf, tag)
+            if not w6_done:
+                ops.split_f16x2_rows_if(w6, sc[0, 0], wp['w6'], self._wovf, tag)
             ops.split_f16x2_rows_if(w7, sc[1, 0], wp['w7'], self._wovf, tag)
             ops.split_f16x2(w7, transpose=True, out=wp['w7t'])
             self._planes_dirty = False

@@ -930,7 +930,7 @@ class _SgdPlaneRegion(C.Structure):
 class SgdPlaneRegions(object):
     """The weight matrices whose operand planes `acm_sgd_update_planes` writes itself:
     [(first arena element, rows, cols, rows_per_batch, planes, bound int32 [rows], rowmax int32
-      [rows], inv_scale fp32 [rows])], ascending.  planes: contiguous f16 [2, ...] (fp16x2), bf16
+      [rows], inv_scale fp32 [rows])], ascending; planes None = leave this matrix untouched.  planes: contiguous f16 [2, ...] (fp16x2), bf16
     [3, ...] (fp32x3) or bf16 [...] (bf16 plan); bound / rowmax / inv_scale only for fp16x2 (None
     otherwise)."""
 
@@ -942,6 +942,10 @@ class SgdPlaneRegions(object):
         want = {L.PLANES_F16X2: (torch.float16, 2), L.PLANES_BF16X3: (torch.bfloat16, 3),
                 L.PLANES_BF16: (torch.bfloat16, None)}[fmt]
         for i, (start, rows, cols, rpb, planes, bound, rowmax, inv) in enumerate(regions):
+            if planes is None:         # the matrix is left alone (updated by gemm_f32_f16x2_nt_xk_sgd)
+                self.host[i] = _SgdPlaneRegion(int(start), int(rows), int(cols), int(rpb), 0, None, 0,
+                                               None, None, None)
+                continue
             if planes.dtype != want[0] or not planes.is_contiguous() or \
                     (want[1] is not None and planes.shape[0] != want[1]) or \
                     planes.numel() != (want[1] or 1) * rows * cols:

@@ -54,8 +54,7 @@ def main():
     def run(n):
         h0 = time.perf_counter()
         for _ in range(n):
-            eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
-            eng.sgd_step()
+            eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
         eng.flush()
         host.append((time.perf_counter() - h0) / n * 1e3)     # enqueue time, before the GPU is done
         torch.cuda.synchronize()

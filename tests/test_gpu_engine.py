@@ -305,3 +305,60 @@ def test_weight_planes_written_by_the_update_equal_a_fresh_split(dev, mode):
             assert torch.equal(eng._wplanes[key].view(torch.int16), fresh.view(torch.int16)), (fused, key)
         runs[fused] = (eng.params.clone(), eng.momentum_buf.clone())
     assert torch.equal(runs[True][0], runs[False][0]) and torch.equal(runs[True][1], runs[False][1])
+
+
+def test_train_step_updates_fc6_in_the_wgrad_epilogue_bit_identically(dev):
+    """train_step(): with no gradient exchange fc6_w's update runs inside its weight-gradient
+    GEMM (no gradient blob, engine.train_step).  Parameters, momentum and all three operand plane
+    sets after four iterations (an lr change in between) equal forward_backward() + sgd_step()
+    bit for bit; the fused route really ran (its gradient slot stays untouched)."""
+    res = []
+    for fused in (False, True):
+        eng, mb, _blobs = _setup(dev, mfma_dtype='fp16x2')
+        eng.fuse_wgrad_update = fused
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        eng.set_lr(1e-3)
+        gw6 = eng.arena.span(eng.grads, 'fc6_w', '_[noisy]_fc6_w')
+        for it in range(4):
+            if it == 2:
+                eng.set_lr(1e-4)
+            if it == 3:
+                eng.flush()              # (the pending update of iteration 2 still reads the gradients)
+                gw6.fill_(123.0)
+            out = eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+            assert eng._can_fuse_wgrad_update() == fused
+        eng.flush()
+        torch.cuda.synchronize()
+        assert bool((gw6 == 123.0).all()) == fused
+        wp = eng._wplanes
+        res.append((eng.params.clone(), eng.momentum_buf.clone(),
+                    [wp[k].planes.view(torch.int16).clone() for k in ('w6', 'w7', 'w7t')],
+                    [wp[k].scales.clone() for k in ('w6', 'w7')], out['loss_cls'].clone(),
+                    int(eng._wovf.item())))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+    assert torch.equal(a[4], b[4]) and a[5] == b[5]
+
+
+def test_train_step_with_an_exchange_or_other_plans_is_the_two_call_form(dev):
+    """train_step() must not fuse when gradients are exchanged (reducer active) or in a plan
+    without fp16x2 planes: fc6_w's gradient is written as before."""
+    for kw, force in ((dict(mfma_dtype='fp32x3'), False), (dict(mfma_dtype='fp16x2'), True)):
+        eng, mb, _blobs = _setup(dev, **kw)
+        if force:
+            class _Red(object):          # an "active" reducer that reduces over one rank
+                active = True
+                world_size = 1
+                def reduce_async(self, _t): pass
+                def wait(self): pass
+            eng.reducer = _Red()
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        eng.set_lr(1e-3)
+        gw6 = eng.arena.span(eng.grads, 'fc6_w', '_[noisy]_fc6_w')
+        gw6.fill_(123.0)
+        eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+        eng.flush()
+        assert not eng._can_fuse_wgrad_update()
+        assert not bool((gw6 == 123.0).all())
