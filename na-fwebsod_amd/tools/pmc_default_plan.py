@@ -8,9 +8,10 @@ import csv
 import glob
 import sys
 
-HOT = ('gemm_x3', 'conv_h2', 'conv_x3', 'roi_pool', 'acm_sgd', 'split2h_dual', 'gemm_smallk', 'wino_',
+HOT = ('gemm_x3', 'gemm_h2_btr', 'conv_h2', 'conv_x3', 'roi_pool', 'acm_sgd', 'split2h_dual', 'gemm_smallk', 'wino_',
        'conv_c3')
-LABEL = {('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>', '262144', 493): 'fc6 fwd (M=4000 N=8192 K=25088)',
+LABEL = {('gemm_h2_btr_kernel<256, 256, 4, 2, true>', '1572864', 399): 'fc6 wgrad + SGD epilogue',
+         ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>', '262144', 493): 'fc6 fwd (M=4000 N=8192 K=25088)',
          ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>', '1572864', 472): 'fc6 wgrad (M=8192 N=24576 K=4000)'}
 
 
