@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--rois', type=int, default=500)
     ap.add_argument('--fused', type=int, default=1)
     ap.add_argument('--dump', default='')
+    ap.add_argument('--train-step', type=int, default=1,
+                    help='1: engine.train_step (one rank: fc6_w updated in its wgrad GEMM); 0: forward_backward + sgd_step')
     ap.add_argument('--mfma-dtype', default='fp16x2')
     ap.add_argument('--trace', type=int, default=0, help='print the loss every N steps')
     a = ap.parse_args()
@@ -46,7 +48,8 @@ def main():
     tags = 0
     for it in range(a.steps):
         t, seg = batches[it % len(batches)]
-        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg,
+                                   _fuse_update=bool(a.train_step))
         if a.trace and not bool(torch.isfinite(out['loss_cls'].sum() + out['loss_cls_noise'].sum())):
             for k, v in sorted(out.items()):
                 v = v.float()
