@@ -474,6 +474,177 @@ __global__ __launch_bounds__(256) void gemm_smallk_nn_kernel(GemmArgs g) {
   }
 }
 
+// The same product on the fp32 MFMA (v_mfma_f32_16x16x4_f32, operands swapped so that a lane
+// holds FOUR CONSECUTIVE COLUMNS of one row: 16-byte gate loads and stores).  The register-resident
+// form above keeps K float4s of B per thread (256 VGPRs, one wave per SIMD) and spends 160 FMAs
+// per output float4: 168 us without / 203 us with the maxima against a 58 us HBM floor
+// (tools/bench_smallk.py).  Here K is 10..16 MFMA steps, both operands of a 64 x 64 wave tile are
+// 2 x 40 VGPRs, and the kernel is the gate read + the store: a tile's 16 gate loads are issued
+// BEFORE its MFMAs.  A workgroup owns 64 rows x 1024 columns, wave w its 256-column strip in four
+// 64-column chunks; A's 64 rows sit in LDS (row stride K + 1: conflict-free fragment reads).
+// Maxima: rows through LDS (one guarded atomic per row and workgroup); columns are parked in LDS
+// too and leave at the end, four per thread in parallel - issued from the MFMA layout (16 per
+// lane, each a dependent load - compare - atomic round trip) they cost 80 us.
+typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SKM_ROWS = 64;
+template <int KS>
+__global__ __launch_bounds__(256) void gemm_smallk_mfma_kernel(GemmArgs g) {
+  constexpr int KP = KS * 4, LDA_S = KP + 1;
+  constexpr bool EARLY = KS <= 10;                 // registers for the gate loads ahead of the MFMAs
+  __shared__ float s_rm[SKM_ROWS][4];
+  __shared__ float s_cm[1024];
+  __shared__ float s_a[SKM_ROWS * LDA_S];
+  const long long bz = blockIdx.z;
+  const float* A = g.A + bz * g.sA;
+  const float* B = g.B + bz * g.sB;
+  float* C = g.C + bz * g.sC;
+  const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int m0 = blockIdx.y * SKM_ROWS;
+  const int c0 = blockIdx.x * 1024 + wave * 256;
+  const bool gate = g.epilogue == NAWS_EPI_GATE_POS;
+  for (int i = threadIdx.x; i < SKM_ROWS * KP; i += 256) {
+    const int r = i / KP, k = i - r * KP;
+    s_a[r * LDA_S + k] = (m0 + r < g.M && k < g.K) ? A[(long long)(m0 + r) * g.lda + k] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 1024; i += 256) s_cm[i] = 0.f;
+  __syncthreads();
+  float a[4][KS];                                         // a[i][ks] = A[m0 + i*16 + l15][ks*4 + kg]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[i][ks] = s_a[(i * 16 + l15) * LDA_S + ks * 4 + kg];
+  float cmul[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + i * 16 + l15;
+    cmul[i] = (g.am.colmul && row < g.M) ? fabsf(g.am.colmul[row]) : 1.f;
+  }
+  float rmx[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ch = 0; ch < 4; ++ch) {
+    const int n0 = c0 + ch * 64;
+    if (n0 >= g.N) break;                                 // (wave-uniform)
+    float b[4][KS];                                       // b[j][ks] = B[ks*4 + kg][n0 + j*16 + l15]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = ks * 4 + kg, n = n0 + j * 16 + l15;
+        b[j][ks] = (k < g.K && n < g.N) ? B[(long long)k * g.ldb + n] : 0.f;
+      }
+    sk_f32x4 x[4][4];
+    auto load_gate = [&](int i) {
+      const int row = m0 + i * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + j * 16 + kg * 4;
+        x[i][j] = sk_f32x4{1.f, 1.f, 1.f, 1.f};
+        if (gate && row < g.M && col < g.N)
+          x[i][j] = *reinterpret_cast<const sk_f32x4*>(aux + (long long)row * g.ldaux + col);
+      }
+    };
+    if constexpr (EARLY) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_gate(i);
+    }
+    sk_f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][ks], a[i][ks], acc[i][j], 0, 0, 0);
+    float cm[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cm[j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + i * 16 + l15;
+      const bool row_on = row < g.M;
+      if constexpr (!EARLY) load_gate(i);
+      float rm = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + j * 16 + kg * 4;
+        if (!row_on || col >= g.N) continue;              // N % 4 == 0: a float4 is all in or all out
+        sk_f32x4 v = acc[i][j];
+        if (gate) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = x[i][j][e] > 0.f ? v[e] * g.alpha : 0.f;
+        }
+        sk_f32x4* dst = reinterpret_cast<sk_f32x4*>(C + (long long)row * g.ldc + col);
+        if (g.accumulate) {
+          const sk_f32x4 o = *dst;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += o[e];
+        }
+        *dst = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float av = fabsf(v[e]);
+          rm = fmaxf(rm, av);
+          cm[j][e] = fmaxf(cm[j][e], av * cmul[i]);
+        }
+      }
+      rmx[i] = fmaxf(rmx[i], rm);
+    }
+    if (g.am.colmax) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = cm[j][e];
+#pragma unroll
+          for (int d = 8; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+          if (l15 == 0) s_cm[wave * 256 + ch * 64 + j * 16 + kg * 4 + e] = v;
+        }
+    }
+  }
+  if (g.am.rowmax) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = rmx[i];
+      v = fmaxf(v, __shfl_xor(v, 16));
+      v = fmaxf(v, __shfl_xor(v, 32));
+      if (kg == 0) s_rm[i * 16 + l15][wave] = v;
+    }
+  }
+  if (g.am.rowmax || g.am.colmax) __syncthreads();
+  if (g.am.rowmax && threadIdx.x < SKM_ROWS && m0 + threadIdx.x < g.M) {
+    const float m = fmaxf(fmaxf(s_rm[threadIdx.x][0], s_rm[threadIdx.x][1]),
+                          fmaxf(s_rm[threadIdx.x][2], s_rm[threadIdx.x][3]));
+    unsigned* rowmax = g.am.rowmax + bz * g.am.sRow +
+                       (long long)((blockIdx.x * 1024) / g.am.seg_cols) * g.M;
+    if (m > 0.f) naws_atomic_max_bits(rowmax + m0 + threadIdx.x, m);
+  }
+  if (g.am.colmax) {
+    // thread t: columns t, t + 256, ... of the workgroup's 1024 - the four current maxima are
+    // fetched together (independent loads), then compared
+    unsigned* cmx = g.am.colmax + bz * g.am.sCol + blockIdx.x * 1024;
+    unsigned cur[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = q * 256 + threadIdx.x;
+      cur[q] = (blockIdx.x * 1024 + col < g.N)
+                   ? __hip_atomic_load(cmx + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = q * 256 + threadIdx.x;
+      const unsigned v = __float_as_uint(s_cm[col]);
+      if (v > cur[q] && s_cm[col] > 0.f) atomicMax(cmx + col, v);
+    }
+  }
+}
+
 // Tuning knob for A/B experiments (tools/kernel_bench.py): naws_set_variant("gemm", v)
 //   0 default, 2: pad LDS so only 1 workgroup fits a CU, 4: BK=32 tile forms
 int gemm_variant() { return naws_knob(NAWS_KNOB_GEMM); }
@@ -587,11 +758,18 @@ extern "C" int naws_gemm_f32_amax(int transA, int transB, int M, int N, int K, c
       (!aux || (ldaux % 4 == 0 && ((uintptr_t)aux & 15) == 0)) && (long long)M * N >= (1 << 20) &&
       (!rowmax || g.am.seg_cols % 1024 == 0 || g.am.seg_cols >= N) && gemm_variant() != 7) {
     dim3 grid((unsigned)naws_cdiv(N, 1024), (unsigned)naws_cdiv(M, SK_ROWS), batch);
+    if (gemm_variant() != 8) grid.y = (unsigned)naws_cdiv(M, SKM_ROWS);
     if (grid.y <= 65535) {
-      if (K <= 40)
-        hipLaunchKernelGGL(gemm_smallk_nn_kernel<40>, grid, dim3(256), 0, s, g);
-      else
-        hipLaunchKernelGGL(gemm_smallk_nn_kernel<64>, grid, dim3(256), 0, s, g);
+      if (gemm_variant() == 8) {          // the register-resident FMA form (A/B: tools/ab_gemm.py)
+        if (K <= 40)
+          hipLaunchKernelGGL(gemm_smallk_nn_kernel<40>, grid, dim3(256), 0, s, g);
+        else
+          hipLaunchKernelGGL(gemm_smallk_nn_kernel<64>, grid, dim3(256), 0, s, g);
+      } else if (K <= 40) {
+        hipLaunchKernelGGL(gemm_smallk_mfma_kernel<10>, grid, dim3(256), 0, s, g);
+      } else {
+        hipLaunchKernelGGL(gemm_smallk_mfma_kernel<16>, grid, dim3(256), 0, s, g);
+      }
       return naws_check_launch();
     }
   }
