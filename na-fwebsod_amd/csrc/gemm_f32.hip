@@ -375,7 +375,9 @@ void gemm_f32_kernel(GemmArgs g) {
 // registers for all its rows, A's row (K floats, workgroup-uniform) comes through the scalar cache,
 // and every output float4 is one coalesced aux load + one coalesced store: HBM-bound.  Sums run in
 // k order like the MFMA chain.  Also reports |C| row / column maxima (NawsAmax).
-constexpr int SK_ROWS = 128, SK_MAXK = 64, SK_RG = 4;
+constexpr int SK_MAXK = 64;
+#ifdef NAWS_AB      // the register-resident FMA form: A/B build only (tools/bench_smallk.py)
+constexpr int SK_ROWS = 128, SK_RG = 4;
 template <int KMAX>
 __global__ __launch_bounds__(256) void gemm_smallk_nn_kernel(GemmArgs g) {
   __shared__ float s_rm[SK_ROWS][4];
@@ -473,6 +475,8 @@ __global__ __launch_bounds__(256) void gemm_smallk_nn_kernel(GemmArgs g) {
     if (cm.w > 0.f) naws_atomic_max_bits(cmx + 3, cm.w);
   }
 }
+
+#endif
 
 // The same product on the fp32 MFMA (v_mfma_f32_16x16x4_f32, operands swapped so that a lane
 // holds FOUR CONSECUTIVE COLUMNS of one row: 16-byte gate loads and stores).  The register-resident
@@ -757,15 +761,20 @@ extern "C" int naws_gemm_f32_amax(int transA, int transB, int M, int N, int K, c
       strideC % 4 == 0 && (epilogue == NAWS_EPI_NONE || epilogue == NAWS_EPI_GATE_POS) &&
       (!aux || (ldaux % 4 == 0 && ((uintptr_t)aux & 15) == 0)) && (long long)M * N >= (1 << 20) &&
       (!rowmax || g.am.seg_cols % 1024 == 0 || g.am.seg_cols >= N) && gemm_variant() != 7) {
-    dim3 grid((unsigned)naws_cdiv(N, 1024), (unsigned)naws_cdiv(M, SK_ROWS), batch);
-    if (gemm_variant() != 8) grid.y = (unsigned)naws_cdiv(M, SKM_ROWS);
+    dim3 grid((unsigned)naws_cdiv(N, 1024), (unsigned)naws_cdiv(M, SKM_ROWS), batch);
+#ifdef NAWS_AB
+    if (gemm_variant() == 8) grid.y = (unsigned)naws_cdiv(M, SK_ROWS);
+#endif
     if (grid.y <= 65535) {
-      if (gemm_variant() == 8) {          // the register-resident FMA form (A/B: tools/ab_gemm.py)
+#ifdef NAWS_AB
+      if (gemm_variant() == 8) {
         if (K <= 40)
           hipLaunchKernelGGL(gemm_smallk_nn_kernel<40>, grid, dim3(256), 0, s, g);
         else
           hipLaunchKernelGGL(gemm_smallk_nn_kernel<64>, grid, dim3(256), 0, s, g);
-      } else if (K <= 40) {
+      } else
+#endif
+      if (K <= 40) {
         hipLaunchKernelGGL(gemm_smallk_mfma_kernel<10>, grid, dim3(256), 0, s, g);
       } else {
         hipLaunchKernelGGL(gemm_smallk_mfma_kernel<16>, grid, dim3(256), 0, s, g);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """dZ7 = gate(dL W8) on the bench shape (M = 4000, N = 4096, K = 40, batch 2): the fp32-MFMA form
-against the register-resident FMA form (naws_set_variant('gemm', 8)), with and without the
+against the register-resident FMA form it replaced (naws_set_variant('gemm', 8); only in the
+`make AB=1` library: NAWS_LIB=.../libnaws_hip_ab.so, otherwise both rows time the MFMA form), with and without the
 epilogue's |C| maxima, interleaved in one process."""
 import os
 import sys
