@@ -148,6 +148,18 @@ int naws_gemm_f32(int transA, int transB, int M, int N, int K,
                   int epilogue, const float* bias, int64_t strideBias,
                   const float* aux, int ldaux, float alpha,
                   float drop_ratio, uint64_t seed, int accumulate, void* stream);
+/* The same product for a SMALL output with a LONG inner dimension (fc8: logits = H7 W8^T, an
+ * [R x 2C] block from K = 4096; dW8 = dL^T H7, [2C x 4096] from K = R): K is cut into `ksplit`
+ * slices so that more workgroups share the walk, the partial products go to `workspace`
+ * (naws_gemm_f32_splitk_workspace_floats floats, caller-owned) and a second pass adds them in
+ * slice order - deterministic - and applies the epilogue (NAWS_EPI_NONE or NAWS_EPI_BIAS only).
+ * ldc / C need no alignment here.  ref: Caffe2 FC / FCGradient of fc8c, fc8d
+ * (detectron/modeling/wsl_heads.py:213-227). */
+int64_t naws_gemm_f32_splitk_workspace_floats(int M, int N, int batch, int ksplit);
+int naws_gemm_f32_splitk(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                         const float* B, int ldb, float* C, int ldc, int batch, int64_t strideA,
+                         int64_t strideB, int64_t strideC, int epilogue, const float* bias,
+                         int64_t strideBias, int ksplit, float* workspace, void* stream);
 
 /* The dropout keep-mask the GEMM epilogue applies, materialised (tests and
  * the op-level Dropout API): mask[i] = keep(seed, i) ? 1 : 0, i in [0,n). */

@@ -52,6 +52,7 @@ struct GemmArgs {
   // implicit-GEMM conv (A gather): NHWC input [Nimg,H,W,Cin]
   int H, W, Cin, dil;
   NawsAmax am;   // |C| maxima for the consumer's fp16x2 operand split (naws_common.h)
+  int ksplit;    // > 1: blockIdx.z = batch item * ksplit + K slice; C = the slice's partial product
 };
 
 constexpr int PADK = 4;                // K-contiguous LDS row pad (floats)
@@ -214,12 +215,16 @@ void gemm_f32_kernel(GemmArgs g) {
   const int tn = (lid % per_group) / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const long long bz = blockIdx.z;
+  // split K (naws_gemm_f32_splitk): slice ks of batch item bz walks K-steps t0 .. t0 + T and
+  // stores its partial product, un-epilogued, as item blockIdx.z of the workspace
+  const int ksp = g.ksplit > 1 ? g.ksplit : 1;
+  const long long bz = blockIdx.z / ksp;
+  const int kslice = (int)(blockIdx.z - bz * ksp);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(g.A + bz * g.sA), 0, (int)g.bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(g.B + bz * g.sB), 0, (int)g.bytesB, 0x00020000);
-  float* C = g.C + bz * g.sC;
+  float* C = g.C + (ksp > 1 ? (long long)blockIdx.z : bz) * g.sC;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -241,11 +246,13 @@ void gemm_f32_kernel(GemmArgs g) {
   else stA.init(g.lda, m0, g.M);
   stB.init(g.ldb, n0, g.N);
 
-  const int T = (g.K + BK - 1) / BK;
+  const int Tall = (g.K + BK - 1) / BK;
+  const int Tc = (Tall + ksp - 1) / ksp, t0 = kslice * Tc;     // (the host keeps every slice >= 1 step)
+  const int T = ksp > 1 ? min(Tc, Tall - t0) : Tall;
   auto fetch = [&](int t, float4* ra, float4* rb) {
-    if constexpr (CONV) cvA.load(rsA, t, g.H, g.W, g.Cin, g.dil, ra);
-    else stA.load(rsA, t, g.K, ra);
-    stB.load(rsB, t, g.K, rb);
+    if constexpr (CONV) cvA.load(rsA, t0 + t, g.H, g.W, g.Cin, g.dil, ra);
+    else stA.load(rsA, t0 + t, g.K, ra);
+    stB.load(rsB, t0 + t, g.K, rb);
   };
   auto stash = [&](int buf, const float4* ra, const float4* rb) {
     Stage<BM, BK, A_KC, NT>::store(sm + A_OFF + buf * GA::FLOATS, ra);
@@ -664,9 +671,28 @@ int launch(GemmArgs& g, int batch, hipStream_t s) {
   if (gemm_variant() == 2) lds = std::max<size_t>(lds, 84 * 1024);
   auto kern = gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, CONV, WM, WN>;
   if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, batch);
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, batch * (g.ksplit > 1 ? g.ksplit : 1));
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, g);
   return naws_check_launch();
+}
+
+// C[b] = epilogue(sum over the K slices, in slice order, of the partial products) - the second,
+// deterministic pass of naws_gemm_f32_splitk.  One thread per element (the outputs are small:
+// that is why K was split).
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int batch, int M,
+                                     int N, float* __restrict__ C, int ldc, long long sC,
+                                     const float* __restrict__ bias, long long sBias) {
+  const long long per = (long long)M * N, total = per * batch;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / per, r = (i - b * per) / N;
+    const int c = (int)(i - b * per - r * N);
+    const float* p = part + (b * ksplit) * per + r * N + c;
+    float v = p[0];
+    for (int k = 1; k < ksplit; ++k) v += p[(long long)k * per];
+    if (bias) v += bias[b * sBias + c];
+    C[b * sC + r * ldc + c] = v;
+  }
 }
 
 // Tile choice.  BK = 16 keeps a workgroup's LDS at <= 40 KB so 3-5 workgroups share a CU:
@@ -787,6 +813,61 @@ extern "C" int naws_gemm_f32_amax(int transA, int transB, int M, int N, int K, c
   if (a_kc && !b_kc) return dispatch<true, false, false>(g, batch, s);
   if (!a_kc && b_kc) return dispatch<false, true, false>(g, batch, s);
   return dispatch<false, false, false>(g, batch, s);
+}
+
+extern "C" int64_t naws_gemm_f32_splitk_workspace_floats(int M, int N, int batch, int ksplit) {
+  if (M <= 0 || N <= 0 || batch <= 0 || ksplit <= 0) return 0;
+  return (int64_t)M * N * batch * ksplit;
+}
+
+// naws_gemm_f32 for a SMALL output with a LONG inner dimension (fc8: logits = H7 W8^T, M x 2C
+// from K = 4096; dW8 = dL^T H7, 2C x 4096 from K = proposals): with one 64 x 64 tile per
+// workgroup only ~126 workgroups exist and each walks K alone, one memory round trip per step.
+// K is cut into `ksplit` slices (more workgroups, more bytes in flight), the partial products go
+// to `workspace`, and a second pass adds them in slice order - deterministic, unlike atomics -
+// and applies the epilogue (NAWS_EPI_NONE or NAWS_EPI_BIAS).
+extern "C" int naws_gemm_f32_splitk(int transA, int transB, int M, int N, int K, const float* A,
+                                    int lda, const float* B, int ldb, float* C, int ldc, int batch,
+                                    int64_t strideA, int64_t strideB, int64_t strideC, int epilogue,
+                                    const float* bias, int64_t strideBias, int ksplit,
+                                    float* workspace, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || ksplit <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(A); NAWS_REQUIRE_PTR(B); NAWS_REQUIRE_PTR(C); NAWS_REQUIRE_PTR(workspace);
+  if (epilogue != NAWS_EPI_NONE && epilogue != NAWS_EPI_BIAS) return NAWS_ERR_UNSUPPORTED;
+  if (epilogue == NAWS_EPI_BIAS) NAWS_REQUIRE_PTR(bias);
+  if (!aligned4(lda) || !aligned4(ldb) || !aligned4(strideA) || !aligned4(strideB) || !ptr16(A) ||
+      !ptr16(B))
+    return NAWS_ERR_ARG;
+  if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return NAWS_ERR_ARG;
+  const long long exA = transA ? extent_bytes(K, M, lda) : extent_bytes(M, K, lda);
+  const long long exB = transB ? extent_bytes(N, K, ldb) : extent_bytes(K, N, ldb);
+  if (exA > MAX_EXTENT || exB > MAX_EXTENT || (long long)batch * ksplit > 65535) return NAWS_ERR_UNSUPPORTED;
+  // every slice at least one 32-deep K-step
+  const int Tall = (int)naws_cdiv(K, 32);
+  int ks = std::min(ksplit, Tall);
+  while (ks > 1 && (long long)(ks - 1) * naws_cdiv(Tall, ks) >= Tall) --ks;
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = workspace; g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = N;
+  g.sA = strideA; g.sB = strideB; g.sC = (long long)M * N;
+  g.bytesA = (unsigned)exA; g.bytesB = (unsigned)exB;
+  g.epilogue = NAWS_EPI_NONE; g.ksplit = ks;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  const bool a_kc = !transA, b_kc = transB != 0;
+  // (ksplit == 1 also goes through the workspace: one code path)
+  if (ks == 1) g.ksplit = 0;
+  if (a_kc && b_kc) rc = launch<64, 64, 32, true, true, false>(g, batch, s);
+  else if (a_kc && !b_kc) rc = launch<64, 64, 32, true, false, false>(g, batch, s);
+  else if (!a_kc && b_kc) rc = launch<64, 64, 32, false, true, false>(g, batch, s);
+  else rc = launch<64, 64, 32, false, false, false>(g, batch, s);
+  if (rc != NAWS_OK) return rc;
+  const long long total = (long long)M * N * batch;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 2048)),
+                     dim3(256), 0, s, (const float*)workspace, ks, batch, M, N, C, ldc,
+                     (long long)strideC, epilogue == NAWS_EPI_BIAS ? bias : nullptr,
+                     (long long)strideBias);
+  return naws_check_launch();
 }
 
 extern "C" int naws_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,

@@ -214,6 +214,8 @@ class WsddnEngine(object):
         # the epilogue of its own wgrad GEMM - the gradient is never written, the update's HBM
         # traffic sits inside an MFMA-bound kernel (see train_step)
         self.fuse_wgrad_update = True
+        self.fc8_ksplit = 4
+        self._fc8_ws = None
         self._w6_updated = False
         self._sgd_regions_rest = None
         self._sgd_regions = None
@@ -703,8 +705,21 @@ class WsddnEngine(object):
         w8g, b8g = self._fc8_operands(w8, b8)
         lg = torch.empty((rt, nb * ld8), device=self.device, dtype=torch.float32)
         lgv = lg.view(rt, nb, ld8).permute(1, 0, 2)
-        ops.gemm(h7v, w8g[:nb], False, True, out=lgv, epilogue=L.EPI_BIAS, bias=b8g)
+        self._fc8_gemm(h7v, w8g[:nb], False, True, lgv, L.EPI_BIAS, b8g)
         return h6, h7, lg
+
+    def _fc8_gemm(self, a, b, trans_a, trans_b, out, epilogue=L.EPI_NONE, bias=None):
+        """fc8's products have a small output and a long inner dimension (K = 4096 forward,
+        K = proposals for dW8): K in fc8_ksplit slices + a deterministic second pass
+        (ops.gemm_splitk: 58 vs 97 us on the bench shape, tools/bench_fc8.py); 0 = one pass."""
+        ks = int(self.fc8_ksplit)
+        if ks <= 1:
+            return ops.gemm(a, b, trans_a, trans_b, out=out, epilogue=epilogue, bias=bias)
+        need = out.shape[-2] * out.shape[-1] * (out.shape[0] if out.dim() == 3 else 1) * ks
+        if self._fc8_ws is None or self._fc8_ws.numel() < need:
+            self._fc8_ws = torch.empty((need,), device=self.device, dtype=torch.float32)
+        return ops.gemm_splitk(a, b, trans_a, trans_b, out=out, epilogue=epilogue, bias=bias,
+                               ksplit=ks, workspace=self._fc8_ws)
 
     def _new_amax_arena(self, rt, nb):
         """One zero-fill per step for every |.| maxima vector the GEMM epilogues accumulate into
@@ -908,11 +923,11 @@ class WsddnEngine(object):
         ops.colsum(dz7, out=gb7)
         if pad:
             gw8p = torch.empty((2, ld8, HIDDEN), device=self.device, dtype=torch.float32)
-            ops.gemm(dlv, h7v, True, False, out=gw8p)
+            self._fc8_gemm(dlv, h7v, True, False, gw8p)
             gw8.copy_(gw8p[:, :2 * C])
             gb8.view(2, 2 * C).copy_(ops.colsum(dl).view(2, ld8)[:, :2 * C])
         else:
-            ops.gemm(dlv, h7v, True, False, out=gw8)
+            self._fc8_gemm(dlv, h7v, True, False, gw8)
             ops.colsum(dl, out=gb8)
         red.reduce_async(message_slice(self.arena, G, *plan[-1], self.k6))
 

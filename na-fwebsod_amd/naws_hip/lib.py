@@ -103,6 +103,8 @@ PROTOTYPES = {
     'naws_conv3x3_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, f32, f32, p, i32,
                                     i32, p],
     'naws_amax_f32': [p, i64, p, p],
+    'naws_gemm_f32_splitk': [i32, i32, i32, i32, i32, p, i32, p, i32, p, i32, i32, i64, i64, i64, i32, p,
+                             i64, i32, p, p],
     'naws_launch_state_reset': [],
     'naws_set_variant': [C.c_char_p, i32],
     'naws_stream_create': [i32, p, i32, p],
@@ -131,6 +133,7 @@ SPECIAL = {
     'naws_roi_pool_workspace_floats': ([i32, i32, i32, i32], i64),
     'naws_winograd_f32x3_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
     'naws_winograd_f16x2_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
+    'naws_gemm_f32_splitk_workspace_floats': ([i32, i32, i32, i32], i64),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(SPECIAL))
 

@@ -277,6 +277,43 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, epilogue=L.EPI_NONE, bias
     return out
 
 
+def gemm_splitk(a, b, trans_a=False, trans_b=False, out=None, epilogue=L.EPI_NONE, bias=None,
+                ksplit=4, workspace=None):
+    """gemm() for a small output with a long inner dimension (fc8 forward / wgrad): K in `ksplit`
+    slices, partial products in `workspace` (fp32, >= M * N * batch * ksplit floats; allocated when
+    None), summed in slice order by a second pass that applies the epilogue (NONE / BIAS)."""
+    batched = a.dim() == 3
+    if batched:
+        batch = a.shape[0]
+        a2, b2 = a[0], b[0]
+    else:
+        batch, a2, b2 = 1, a, b
+    for t, nm in ((a2, 'A'), (b2, 'B')):
+        if not t.is_cuda or t.dtype != _f32 or t.stride(-1) != 1:
+            raise TypeError('%s must be a HIP fp32 tensor with a contiguous last dim' % nm)
+    m = a2.shape[1] if trans_a else a2.shape[0]
+    k = a2.shape[0] if trans_a else a2.shape[1]
+    kb = b2.shape[1] if trans_b else b2.shape[0]
+    n = b2.shape[0] if trans_b else b2.shape[1]
+    if k != kb:
+        raise L.NawsError('naws_gemm_f32_splitk', L.ERR_SHAPE)
+    if out is None:
+        out = torch.empty(((batch, m, n) if batched else (m, n)), device=a.device, dtype=_f32)
+    c2 = out[0] if batched else out
+    need = m * n * batch * int(ksplit)
+    if workspace is None:
+        workspace = torch.empty((need,), device=a.device, dtype=_f32)
+    if workspace.dtype != _f32 or workspace.numel() < need or not workspace.is_contiguous():
+        raise TypeError('workspace: contiguous fp32, >= M * N * batch * ksplit floats')
+    sbias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    L.call('naws_gemm_f32_splitk', int(trans_a), int(trans_b), m, n, k, a.data_ptr(), a2.stride(0),
+           b.data_ptr(), b2.stride(0), out.data_ptr(), c2.stride(0), batch,
+           (a.stride(0) if batched else 0), (b.stride(0) if batched else 0),
+           (out.stride(0) if batched else 0), epilogue, _ptr(bias), sbias, int(ksplit),
+           workspace.data_ptr(), _stream())
+    return out
+
+
 def gemm_bf16_nt(a, b, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, alpha=1.0,
                  drop_ratio=0.0, seed=0, accumulate=False):
     """C[M,N] (+)= A[M,K] B[N,K]^T with bf16 MFMA / fp32 accumulate.  a and b are 2-D (or batched

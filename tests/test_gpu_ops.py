@@ -529,3 +529,40 @@ def test_small_builtins(dev):
            rtol=1e-4, atol=1e-7)
     assert np.array_equal(ops.transpose2d(xd).cpu().numpy(), x.T)
     _close(ops.reduce_sum_axis0(xd), x.sum(0, keepdims=True), rtol=1e-5)
+
+
+@pytest.mark.parametrize('ta,tb,m,n,k,batch,ksplit', [
+    (False, True, 4000, 40, 4096, 2, 4),      # fc8 forward: logits = H7 W8^T + b
+    (True, False, 40, 4096, 4000, 2, 4),      # fc8 wgrad: dW8 = dL^T H7
+    (False, True, 70, 44, 100, 1, 8),         # more slices than 32-deep K-steps: clamped
+    (False, False, 130, 36, 64, 3, 1),        # one slice: the same two passes
+])
+def test_gemm_splitk_matches_the_one_pass_gemm(dev, ta, tb, m, n, k, batch, ksplit):
+    """naws_gemm_f32_splitk: K cut into slices, partial products summed in slice order by a second
+    pass (fc8's small outputs): equal to naws_gemm_f32 up to the order of the fp32 sums, and
+    bit-identical from run to run."""
+    from naws_hip import ops, lib as L
+    g = torch.Generator(device=dev).manual_seed(k + n)
+    a = torch.randn((batch, k, m) if ta else (batch, m, k), device=dev, generator=g)
+    b = torch.randn((batch, n, k) if tb else (batch, k, n), device=dev, generator=g) * 0.05
+    bias = torch.randn((batch, n), device=dev, generator=g)
+    for epi, bb in ((L.EPI_NONE, None), (L.EPI_BIAS, bias)):
+        want = ops.gemm(a, b, ta, tb, epilogue=epi, bias=bb)
+        got = ops.gemm_splitk(a, b, ta, tb, epilogue=epi, bias=bb, ksplit=ksplit)
+        again = ops.gemm_splitk(a, b, ta, tb, epilogue=epi, bias=bb, ksplit=ksplit)
+        ref = (a.double().transpose(1, 2) if ta else a.double()) @ \
+            (b.double().transpose(1, 2) if tb else b.double())
+        if bb is not None:
+            ref = ref + bb.double()[:, None, :]
+        scale = float(ref.abs().max())
+        assert float((got.double() - ref).abs().max()) <= 2e-6 * scale
+        assert float((got - want).abs().max()) <= 4e-6 * scale     # two fp32 results: both errors
+        assert torch.equal(got, again)
+    # strided output rows (the engine writes the two branches' logits side by side)
+    wide = torch.zeros((m, batch, n + 4), device=dev)
+    outv = wide.permute(1, 0, 2)[:, :, :n]
+    ops.gemm_splitk(a, b, ta, tb, out=outv, ksplit=ksplit)
+    assert torch.equal(outv, ops.gemm_splitk(a, b, ta, tb, ksplit=ksplit))
+    assert not wide[:, :, n:].any()
+    with pytest.raises(L.NawsError):
+        ops.gemm_splitk(a, b, ta, tb, epilogue=L.EPI_BIAS_RELU, bias=bias, ksplit=ksplit)
