@@ -292,6 +292,10 @@ typedef struct naws_sgd_plane_region {
   const uint32_t* bound;   /* [rows] */
   uint32_t* rowmax;        /* [rows] */
   float* inv_scale;        /* [rows] */
+  uint32_t* colmax;        /* [rows / rows_per_batch][cols], nullable, NAWS_PLANES_F16X2 only: receives
+                            * max|w| per column and batch item after the update (atomic max of bit
+                            * patterns; caller zeroes) - the maxima naws_split_f16x2_dual needs for
+                            * the TRANSPOSED operand planes (fc7_w^T of the dgrad) */
 } naws_sgd_plane_region;
 int naws_acm_sgd_update_f16x2(const float* grad, float* momentum_buf, const float* lr, float* param,
                               int64_t total, const int64_t* seg_end, const float* seg_lr_mult,

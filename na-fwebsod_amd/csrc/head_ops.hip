@@ -431,6 +431,7 @@ struct SgdPlaneRegion {
   const unsigned* bound;           // [rows] max|w| per row before the update (bit patterns)
   unsigned* rowmax;                // [rows] max|w| per row after it (atomic max; caller zeroes)
   float* inv_scale;                // [rows]
+  unsigned* colmax;                // [rows / rows_per_batch][cols] max|w| per column after the update (nullable)
 };
 struct SgdPlaneArgs {
   SgdPlaneRegion r[4];
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
     int overflow_tag) {
   constexpr int NPL = FMT == 0 ? 2 : (FMT == 1 ? 3 : 1);
   __shared__ __attribute__((aligned(16))) unsigned char img[NPL * SGP_PLANE];
+  __shared__ float cmred[FMT == 0 ? 4 * 256 : 1];     // column maxima of the four waves (colmax)
   const float base_lr = lr[0];
   const int bid = blockIdx.x;
   if (bid >= a.tiles) {
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
   unsigned bound_lane = 0;
   if constexpr (FMT == 0) bound_lane = R.bound[r0 + (lane & 31)];
   float rmax[8];
+  float cmx[4] = {0.f, 0.f, 0.f, 0.f};     // max|w_new| of this lane's four columns over its eight rows
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     float4 g[4], m[4], p[4];
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           mx = fmaxf(mx, fabsf(pv[k]));
+          cmx[k] = fmaxf(cmx[k], fabsf(pv[k]));
           const float v = pv[k] * sc;
           const _Float16 hi = (_Float16)v;
           float rr = v - (float)hi;
@@ -613,9 +617,25 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
       if (!(v1 <= __uint_as_float(b2)) || is_inf) atomicMax(overflow, overflow_tag);
     }
   }
+  if constexpr (FMT == 0) {
+    if (R.colmax) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cmred[wid * 256 + lane * 4 + k] = cmx[k];
+    }
+  }
   __syncthreads();
-  // ---- pass 2: the image leaves as (slab, 32 rows) blocks: 1 KB contiguous per wave-store
   const int batch = r0 / R.rows_per_batch, rb0 = r0 - batch * R.rows_per_batch;
+  if constexpr (FMT == 0) {
+    // max|w| per column after the update (the scale of the TRANSPOSED operand planes, fc7_w^T for
+    // the dgrad: naws_split_f16x2_dual then needs no maxima pass): one guarded atomic per column
+    // and tile, all 256 in parallel.  NaNs are skipped as fmaxf skips them in the stand-alone pass.
+    if (R.colmax) {
+      const int t = threadIdx.x;
+      const float v = fmaxf(fmaxf(cmred[t], cmred[256 + t]), fmaxf(cmred[512 + t], cmred[768 + t]));
+      if (v > 0.f) naws_atomic_max_bits(R.colmax + (long long)batch * R.cols + c0 + t, v);
+    }
+  }
+  // ---- pass 2: the image leaves as (slab, 32 rows) blocks: 1 KB contiguous per wave-store
   const long long sp = (long long)R.cols * R.rows_per_batch;       // one batch item of one plane
 #pragma unroll
   for (int pl = 0; pl < NPL; ++pl) {
@@ -890,6 +910,7 @@ extern "C" int naws_acm_sgd_update_planes(int format, const float* grad, float* 
     r.start = g.start; r.rows = g.rows; r.cols = g.cols; r.rows_per_batch = g.rows_per_batch;
     r.tile0 = (int)tiles; r.planes = (unsigned short*)g.planes; r.plane_stride = g.plane_stride;
     r.bound = g.bound; r.rowmax = g.rowmax; r.inv_scale = g.inv_scale;
+    r.colmax = scaled ? g.colmax : nullptr;
     tiles += (long long)(g.rows / 32) * (g.cols / 256);
   }
   if (!add_linear(cursor / 4, total / 4)) return NAWS_ERR_UNSUPPORTED;

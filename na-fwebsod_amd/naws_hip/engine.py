@@ -291,16 +291,19 @@ class WsddnEngine(object):
                 self._wbound = torch.zeros((2 * n6,), device=self.device, dtype=torch.int32)
                 self._wovf = torch.zeros((1,), device=self.device, dtype=torch.int32)
                 sc = self._wscales.view(2, 2, n6)            # [operand][maxima | 1/scale][rows]
+                # fc7_w's COLUMN maxima = the row maxima of fc7_w^T (the dgrad's operand): the
+                # kernel reports them too, so the transposed planes need no maxima pass either
+                cm7 = self._wplanes['w7t'].scales[0].view(torch.int32)
                 self._sgd_regions = ops.SgdPlaneRegions([
                     (o6, n6, self.k6, n6, p6.planes, self._wbound[:n6], sc[0, 0].view(torch.int32),
                      sc[0, 1]),
                     (o7, n6, HIDDEN, HIDDEN, p7.planes, self._wbound[n6:], sc[1, 0].view(torch.int32),
-                     sc[1, 1])])
+                     sc[1, 1], cm7)])
                 # the same table with fc6_w marked "updated elsewhere" (train_step)
                 self._sgd_regions_rest = ops.SgdPlaneRegions([
                     (o6, n6, self.k6, n6, None, None, None, None),
                     (o7, n6, HIDDEN, HIDDEN, p7.planes, self._wbound[n6:], sc[1, 0].view(torch.int32),
-                     sc[1, 1])])
+                     sc[1, 1], cm7)])
         elif self._wplanes is None:
             self._wplanes = dict(w6=cv(w6), w7=cv(w7), w7t=cv(w7, transpose=True))
             if self.k6 % 256 == 0:
@@ -1105,6 +1108,7 @@ class WsddnEngine(object):
             rowmax = self._wscales.view(torch.int32)
         if planes:
             tag = self.sgd_iter_count + 1
+            self._wplanes['w7t'].scales[0].zero_()
             ops.acm_sgd_update_f16x2(self.grads, self.momentum_buf, self.lr, self.params,
                                      self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
                                      self.gpu_num, self.sgd_iter_count,
@@ -1132,7 +1136,9 @@ class WsddnEngine(object):
             if not w6_done:
                 ops.split_f16x2_rows_if(w6, sc[0, 0], wp['w6'], self._wovf, tag)
             ops.split_f16x2_rows_if(w7, sc[1, 0], wp['w7'], self._wovf, tag)
-            ops.split_f16x2(w7, transpose=True, out=wp['w7t'])
+            # fc7_w^T from the column maxima the SGD kernel has just reported: one pass
+            # (was: a maxima pass + a transposing split, 92 + 116 us)
+            ops.split_f16x2_dual(w7, None, wp['w7t'].scales, out_t=wp['w7t'])
             self._planes_dirty = False
         elif fused:                            # same stream as the update: hidden with it
             w6, w7 = self._weight_views()

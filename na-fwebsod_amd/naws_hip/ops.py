@@ -961,13 +961,14 @@ class _SgdPlaneRegion(C.Structure):
     _fields_ = [('start', C.c_int64), ('rows', C.c_int32), ('cols', C.c_int32),
                 ('rows_per_batch', C.c_int32), ('reserved', C.c_int32), ('planes', C.c_void_p),
                 ('plane_stride', C.c_int64), ('bound', C.c_void_p), ('rowmax', C.c_void_p),
-                ('inv_scale', C.c_void_p)]
+                ('inv_scale', C.c_void_p), ('colmax', C.c_void_p)]
 
 
 class SgdPlaneRegions(object):
     """The weight matrices whose operand planes `acm_sgd_update_planes` writes itself:
     [(first arena element, rows, cols, rows_per_batch, planes, bound int32 [rows], rowmax int32
-      [rows], inv_scale fp32 [rows])], ascending; planes None = leave this matrix untouched.  planes: contiguous f16 [2, ...] (fp16x2), bf16
+      [rows], inv_scale fp32 [rows][, colmax int32 [rows / rows_per_batch, cols]])], ascending;
+    planes None = leave this matrix untouched.  planes: contiguous f16 [2, ...] (fp16x2), bf16
     [3, ...] (fp32x3) or bf16 [...] (bf16 plan); bound / rowmax / inv_scale only for fp16x2 (None
     otherwise)."""
 
@@ -978,11 +979,16 @@ class SgdPlaneRegions(object):
         self.host = (_SgdPlaneRegion * self.n)()
         want = {L.PLANES_F16X2: (torch.float16, 2), L.PLANES_BF16X3: (torch.bfloat16, 3),
                 L.PLANES_BF16: (torch.bfloat16, None)}[fmt]
-        for i, (start, rows, cols, rpb, planes, bound, rowmax, inv) in enumerate(regions):
+        for i, reg in enumerate(regions):
+            start, rows, cols, rpb, planes, bound, rowmax, inv = reg[:8]
+            colmax = reg[8] if len(reg) > 8 else None      # int32 [rows / rpb, cols] (optional)
             if planes is None:         # the matrix is left alone (updated by gemm_f32_f16x2_nt_xk_sgd)
                 self.host[i] = _SgdPlaneRegion(int(start), int(rows), int(cols), int(rpb), 0, None, 0,
-                                               None, None, None)
+                                               None, None, None, None)
                 continue
+            if colmax is not None and (colmax.dtype != torch.int32 or not colmax.is_contiguous()
+                                       or colmax.numel() != rows // rpb * cols):
+                raise TypeError('colmax: contiguous int32 [rows / rows_per_batch, cols]')
             if planes.dtype != want[0] or not planes.is_contiguous() or \
                     (want[1] is not None and planes.shape[0] != want[1]) or \
                     planes.numel() != (want[1] or 1) * rows * cols:
@@ -994,7 +1000,7 @@ class SgdPlaneRegions(object):
             self.host[i] = _SgdPlaneRegion(int(start), int(rows), int(cols), int(rpb), 0,
                                            planes.data_ptr(),
                                            planes.stride(0) if want[1] is not None else 0,
-                                           _ptr(bound), _ptr(rowmax), _ptr(inv))
+                                           _ptr(bound), _ptr(rowmax), _ptr(inv), _ptr(colmax))
 
 
 def acm_sgd_update_f16x2(grad, momentum_buf, lr, param, seg_end, seg_lr_mult, seg_wd, momentum,

@@ -291,9 +291,10 @@ def test_acm_sgd_update_f16x2_writes_the_operand_planes(dev, nesterov):
     bound = torch.zeros((r6 + 2 * r7,), device=dev, dtype=torch.int32)
     ovf = torch.zeros((1,), device=dev, dtype=torch.int32)
     mx6, mx7 = q6.scales[0].view(torch.int32), q7.scales[0].view(torch.int32).reshape(-1)
+    cm7 = torch.zeros((2, c7), device=dev, dtype=torch.int32)      # fc7-like: column maxima per batch item
     regs = ops.SgdPlaneRegions([(0, r6, c6, r6, q6.planes, bound[:r6], mx6, q6.scales[1]),
                                 (o7, 2 * r7, c7, r7, q7.planes, bound[r6:], mx7,
-                                 q7.scales[1].reshape(-1))])
+                                 q7.scales[1].reshape(-1), cm7)])
     rowscale = np.ones((total,), np.float32)            # gradients in proportion to their rows
     rowscale[:r6 * c6].reshape(r6, c6)[5] = 1e-6
     rowscale[:r6 * c6].reshape(r6, c6)[9] = 3e4
@@ -302,9 +303,10 @@ def test_acm_sgd_update_f16x2_writes_the_operand_planes(dev, nesterov):
         ops.acm_sgd_update(g, ma, lr, pa, None, ends, lm, wdd, 0.9, nesterov, 1, 2, it)
         bound[:r6].copy_(mx6); bound[r6:].copy_(mx7)
         old = bound.clone()
-        mx6.zero_(); mx7.zero_()
+        mx6.zero_(); mx7.zero_(); cm7.zero_()
         ops.acm_sgd_update_f16x2(g, mb, lr, pb, ends, lm, wdd, 0.9, nesterov, 2, it, regs, ovf, it + 1)
         assert torch.equal(pa, pb) and torch.equal(ma, mb), it
+        assert torch.equal(cm7.view(torch.float32), w7.abs().amax(dim=1)), it
         assert int(ovf.item()) == 0
         for w, q, mx, b in ((w6, q6, mx6, old[:r6]), (w7, q7, mx7, old[r6:])):
             w2 = w.reshape(-1, w.shape[-1])
