@@ -64,6 +64,9 @@ def _defaults():
             'TYPE': '', 'CONV_BODY': '', 'NUM_CLASSES': -1, 'MASK_ON': False,
             'KEYPOINTS_ON': False, 'RPN_ONLY': False, 'FASTER_RCNN': False,
             'EXECUTION_TYPE': 'dag',
+            # read back by the reference's weight-file loader (net_wsl.py:274-290); unused here (no
+            # bbox regression on this path)
+            'BBOX_REG_WEIGHTS': (10., 10., 5., 5.),
         },
         'TRAIN': {
             'WEIGHTS': '', 'DATASETS': (), 'PROPOSAL_FILES': (), 'SCALES': (600,),

@@ -61,9 +61,11 @@ def initialize_from_weights_file(model, weights_file, executor, broadcast=True):
         if s + '_momentum' in src_blobs:
             blobs[name + '_momentum'] = torch.from_numpy(
                 np.asarray(src_blobs[s + '_momentum'], np.float32))
-    used = set(resolve_source_name(n, src_blobs) for n in model.params)
-    for k, v in src_blobs.items():       # keep unconsumed blobs for re-saving (:129-137)
-        if k not in used and not k.endswith('_momentum') and v is not None:
+    # blobs of the file that are not parameters OF THIS MODEL BY NAME are kept for re-saving
+    # (:129-137) - including one that only initialised a '_[xyz]_' twin through the alias rule
+    names = set(model.params)
+    for k, v in src_blobs.items():
+        if k not in names and not k.endswith('_momentum') and v is not None:
             preserved['__preserve__/' + k] = v
     model.preserved_blobs = preserved
     executor.load_blobs(blobs)

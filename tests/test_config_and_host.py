@@ -423,3 +423,97 @@ def test_entropy_weight_builder_reproduces_reference_trace(cfgmod):
     w = webly_heads.add_entropy_weight(m, 'rois_pred', 'rois')
     assert w == OICR['entropy_weight']['weight']
     assert _norm_ops(m.net.ops) == OICR['entropy_weight']['ops']
+
+
+def _ckpt_fakes():
+    import torch
+
+    class Model(object):
+        params = ['fc6_w', 'fc6_b', '_[noisy]_fc6_w', '_[noisy]_fc6_b', 'fc8c_w', '_[noisy]_fc7_w']
+        param_shapes = {'fc6_w': (4, 6), 'fc6_b': (4,), '_[noisy]_fc6_w': (4, 6),
+                        '_[noisy]_fc6_b': (4,), 'fc8c_w': (3, 4), '_[noisy]_fc7_w': (2, 2)}
+
+        def TrainableParams(self):
+            return list(self.params)
+
+    class Executor(object):
+        def __init__(self):
+            self.b = {}
+            for n, s in Model.param_shapes.items():
+                self.b[n] = torch.full(s, 7.0)
+                self.b[n + '_momentum'] = torch.zeros(s)
+            self.loaded = None
+
+        def blobs(self, with_momentum=True):
+            return {k: v for k, v in self.b.items() if with_momentum or not k.endswith('_momentum')}
+
+        def load_blobs(self, blobs):
+            self.loaded = dict(blobs)
+            self.b.update(blobs)
+
+        def broadcast_parameters(self):
+            pass
+    return Model, Executor
+
+
+def test_weights_file_load_matches_what_the_reference_feeds(tmp_path, cfgmod):
+    """`initialize_gpu_from_weights_file` of the imported reference (net_wsl.py:51-137), run on a
+    pretrained-style file with a recording workspace (tests/golden/make_golden_checkpoint.py): the
+    same blobs arrive here - the '_[noisy]_foo' <- 'foo' alias incl. its momentum, float64
+    sources as float32, momentum only where the file has it, and the '__preserve__/' set (which
+    keeps a blob that only served an alias, and drops None entries and stray momenta)."""
+    from detectron.utils import net_wsl
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_checkpoint_load.npz'))
+    src = {k[4:]: ref[k] for k in ref.files if k.startswith('src/')}
+    src['unused_none'] = None
+    path = str(tmp_path / 'pretrained.pkl')
+    net_wsl.save_object({'blobs': src}, path)
+    Model, Executor = _ckpt_fakes()
+    model, ex = Model(), Executor()
+    net_wsl.initialize_from_weights_file(model, path, ex)
+    fed = {k[4:]: ref[k] for k in ref.files if k.startswith('fed/')}
+    want_params = {k[len('gpu_0/'):]: v for k, v in fed.items() if k.startswith('gpu_0/')}
+    # parameters the file does not hold keep their initialisation here and are simply not fed there
+    got = {k: v.numpy() for k, v in ex.loaded.items()
+           if k in want_params or not (v == 7.0).all()}
+    assert sorted(got) == sorted(want_params)
+    for k, v in want_params.items():
+        assert got[k].dtype == np.float32 == v.dtype and np.array_equal(got[k], v), k
+    want_keep = {k: v for k, v in fed.items() if k.startswith('__preserve__/')}
+    assert sorted(model.preserved_blobs) == sorted(want_keep)
+    for k, v in want_keep.items():
+        assert np.array_equal(model.preserved_blobs[k], v)
+
+
+def test_weights_file_written_by_the_reference_loads_and_resaves(tmp_path, cfgmod):
+    """tests/golden/reference_checkpoint.pkl is the pickle the reference's own
+    `save_model_to_weights_file` (net_wsl.py:140-180) wrote for a small state: it loads here, and
+    saving that state again gives the same blob names and arrays and a cfg entry the reference's
+    loader would accept (a yaml mapping with the same top-level keys)."""
+    import yaml
+    from detectron.utils import net_wsl
+    path = os.path.join(ROOT, 'tests', 'golden', 'reference_checkpoint.pkl')
+    theirs = net_wsl.load_object(path)
+    assert sorted(theirs) == ['blobs', 'cfg']
+    Model, Executor = _ckpt_fakes()
+    model, ex = Model(), Executor()
+    net_wsl.initialize_from_weights_file(model, path, ex)
+    for n in Model.params:
+        assert np.array_equal(ex.b[n].numpy(), theirs['blobs'][n]), n
+        assert np.array_equal(ex.b[n + '_momentum'].numpy(), theirs['blobs'][n + '_momentum']), n
+    assert list(model.preserved_blobs) == ['__preserve__/fc1000_w']
+    out = str(tmp_path / 'again.pkl')
+    net_wsl.save_model_to_weights_file(out, model, ex)
+    ours = net_wsl.load_object(out)
+    assert sorted(ours['blobs']) == sorted(theirs['blobs'])
+    for k, v in theirs['blobs'].items():
+        assert ours['blobs'][k].dtype == v.dtype and np.array_equal(ours['blobs'][k], v), k
+    # the reference dumps its AttrDict tree with python-object tags (AttrDict, numpy scalars): only
+    # its own process can rebuild that, so compare top-level section names; ours is a plain
+    # mapping, which the reference's load_cfg wraps into an AttrDict itself
+    import re
+    a = yaml.safe_load(ours['cfg'])
+    b = set(re.findall(r'^  ([A-Z][A-Z0-9_]*):', theirs['cfg'], re.M))
+    # (the mirror carries the sections of the hot path only, plus its own NAWS block)
+    assert b and set(a) - {'NAWS'} <= b, sorted(set(a) - b)
+    assert 'NUM_CLASSES' in a['MODEL'] and 'BBOX_REG_WEIGHTS' in a['MODEL']   # what the reference's loader reads
