@@ -525,6 +525,23 @@ def main():
     # after the timed steps: the conv body alone (nothing else on the device).  Inside a step it
     # shares the chip with the previous step's parameter update (side stream), so its stage time
     # there reads longer than the stack itself takes.
+    # One rank, fc6_w updated inside its wgrad GEMM: also time the route with a gradient between
+    # wgrad and update - the one every rank of an N > 1 job takes - so that a scaling series can be
+    # read against a like-for-like N = 1 number (reported beside `value`, never as `value`).
+    deferred_ms = None
+    if world == 1 and not args.no_fused_update and eng._can_fuse_wgrad_update():
+        eng.timing_events = eng.phase_events = eng.update_events = eng.comm_events = None
+        n_def = max(10, args.steps // 4)
+        for it in range(5 + n_def):
+            if it == 5:
+                eng.flush()
+                torch.cuda.synchronize()
+                d0 = time.perf_counter()
+            eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            eng.sgd_step()
+        eng.flush()
+        torch.cuda.synchronize()
+        deferred_ms = (time.perf_counter() - d0) / n_def * 1e3
     conv_alone_ms = None
     if rank == 0:
         eng.timing_events = eng.phase_events = eng.update_events = eng.comm_events = None
@@ -641,6 +658,9 @@ def main():
                # 'deferred_kernel' = gradient written, (all-reduced,) then the SGD kernel on the
                # side stream - what every rank does when world_size > 1
                'fc6_update_path': 'wgrad_epilogue' if wgrad_update else 'deferred_kernel',
+               'deferred_route_ms_per_step': None if deferred_ms is None else round(deferred_ms, 3),
+               'deferred_route_images_per_sec': (None if deferred_ms is None
+                                                 else round(world * B / deferred_ms * 1e3, 3)),
                # per-rank wall time of the timed region (value uses the max); the time the main
                # stream stood waiting for the deferred all-reduce + SGD + weight re-split before
                # the head could read the parameters (HIP events around engine.flush(): the
