@@ -22,9 +22,6 @@ Blob names, shapes and update rule follow the reference:
   webly_heads.py:32-74,123-216,265-391,463-502, optimizer_wsl.py:52-137,
   detectron/ops/acm_weightdecay_momentum_sgd_op.h:48-112.
 """
-import math
-
-import os
 
 import numpy as np
 import torch

@@ -13,7 +13,6 @@ import ctypes as C
 import os
 import shutil
 import sys
-import tempfile
 
 import torch
 

@@ -4,7 +4,6 @@
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Time the three stages of the Winograd convolution (input transform, batch-16 GEMM, output
 transform) in isolation at the VGG deep-layer shapes."""
-import os, sys, ctypes as C
+import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from naws_hip import ops, lib as L
+from naws_hip import ops
 
 dev = torch.device('cuda:0')
 

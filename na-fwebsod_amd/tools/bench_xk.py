@@ -1,4 +1,4 @@
-import sys, os, torch
+import sys, torch
 sys.path.insert(0, '/root/repo/na-fwebsod_amd')
 from naws_hip import ops
 dev = torch.device('cuda:0')
