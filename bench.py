@@ -622,6 +622,19 @@ def main():
                             conv_stack_alone_tflops=round(conv_gflop / conv_alone_ms, 1),
                             conv_stack_alone_frac_vs_fp32_mfma_peak=round(
                                 conv_gflop / conv_alone_ms / FP32_MFMA_PEAK_TFLOPS, 3))
+            if h2:
+                # The fraction above exceeds 1 because the default plan leaves the fp32 pipe: what
+                # the stack EXECUTES on the f16 MFMA is 3 passes over the direct layers
+                # (conv1_2..conv3_3: 221.0 of the 463.7 algorithmic GFLOP per image) and 3 passes
+                # over Winograd F(2x2,3x3)'s 1/2.25 of conv4_1..conv5_3 (242.7 GFLOP); conv1_1 runs
+                # on the vector unit.  Against the dense f16 peak:
+                ex_gflop = conv_gflop / 463.7 * (3 * 221.0 + 3 * 242.7 / 2.25)
+                roof.update(conv_stack_executed_f16_tflops=round(ex_gflop / stage_ms['conv_body'], 1),
+                            conv_stack_frac_vs_f16_mfma_peak=round(
+                                ex_gflop / stage_ms['conv_body'] / BF16_MFMA_PEAK_TFLOPS, 3))
+                if conv_alone_ms:
+                    roof.update(conv_stack_alone_frac_vs_f16_mfma_peak=round(
+                        ex_gflop / conv_alone_ms / BF16_MFMA_PEAK_TFLOPS, 3))
         if roipool_bytes and stage_ms.get('roi_pool'):
             gbs = roipool_bytes / stage_ms['roi_pool'] / 1e6
             roof.update(roipool_ms=stage_ms['roi_pool'], roipool_GBps=round(gbs, 1),

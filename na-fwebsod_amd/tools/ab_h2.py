@@ -11,7 +11,6 @@ spread - cdna_hip_programming.md rule 24.)
 import argparse
 import ctypes as C
 import os
-import shutil
 import sys
 
 import torch
@@ -20,15 +19,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 from naws_hip import lib as L, ops  # noqa: E402
 
 FN = 'naws_gemm_f32_f16x2_nt'
-
-
-def bind(variant, tmp):
-    path = os.path.join(tmp, 'libnaws_v%d.so' % variant)
-    shutil.copy(L.LIB_PATH, path)
-    lib = C.CDLL(path)
-    getattr(lib, FN).argtypes = L.PROTOTYPES[FN]
-    getattr(lib, FN).restype = C.c_int
-    return lib
 
 
 def call(lib, a, b, out, st):
@@ -111,7 +101,6 @@ def main():
                 v, med, fl / med / 1e9, min(times[i]), err))
         print('%s M=%d N=%d K=%d  ' % (name, m, n, k) + '   '.join(msg))
         del A, B, a2, b2, outs
-    shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == '__main__':
