@@ -115,3 +115,52 @@ def test_process_wide_state_entry_points():
     out = subprocess.run(['nm', '-D', '--undefined-only', lib.LIB_PATH], stdout=subprocess.PIPE,
                          text=True).stdout
     assert 'getenv' not in out
+
+
+def test_sgd_plane_region_table_layout():
+    """naws_sgd_plane_region as the ctypes mirror fills it (no launch): a region with planes =
+    None is the "updated elsewhere" marker (null planes, null vectors), a column-maxima vector is
+    optional and must be int32 [rows / rows_per_batch, cols]; the ctypes struct has the layout a C
+    compiler gives include/naws.h's (size and the offset of every pointer field)."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    import torch
+    from naws_hip import ops
+    fields = ['planes', 'plane_stride', 'bound', 'rowmax', 'inv_scale', 'colmax']
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, 't.c')
+        with open(src, 'w') as f:
+            f.write('#include <stdio.h>\n#include <stddef.h>\n#include "naws.h"\nint main(void){'
+                    'printf("%zu", sizeof(naws_sgd_plane_region));' +
+                    ''.join('printf(" %%zu", offsetof(naws_sgd_plane_region, %s));' % n for n in fields) +
+                    'return 0;}\n')
+        exe = os.path.join(d, 't')
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), src, '-o', exe])
+        want = [int(x) for x in subprocess.check_output([exe]).split()]
+    got = [C.sizeof(ops._SgdPlaneRegion)] + [getattr(ops._SgdPlaneRegion, n).offset for n in fields]
+    assert got == want, (got, want)
+    rows, cols, rpb = 64, 256, 32
+    planes = torch.zeros((2, 2, cols // 16, rpb, 16), dtype=torch.float16)
+    bound = torch.zeros((rows,), dtype=torch.int32)
+    rowmax = torch.zeros((rows,), dtype=torch.int32)
+    inv = torch.zeros((rows,), dtype=torch.float32)
+    cm = torch.zeros((rows // rpb, cols), dtype=torch.int32)
+    t = ops.SgdPlaneRegions([(0, rows, cols, rows, None, None, None, None),
+                             (rows * cols, rows, cols, rpb, planes, bound, rowmax, inv, cm)])
+    a, b = t.host[0], t.host[1]
+    assert (a.planes, a.bound, a.rowmax, a.inv_scale, a.colmax) == (None,) * 5
+    assert (a.start, a.rows, a.cols, a.rows_per_batch) == (0, rows, cols, rows)
+    assert b.planes == planes.data_ptr() and b.colmax == cm.data_ptr()
+    assert b.plane_stride == planes.stride(0) and b.start == rows * cols
+    with pytest.raises(TypeError):
+        ops.SgdPlaneRegions([(0, rows, cols, rpb, planes, bound, rowmax, inv, cm[:1])])
+    with pytest.raises(TypeError):
+        ops.SgdPlaneRegions([(0, rows, cols, rpb, planes.float(), bound, rowmax, inv)])
+
+
+def test_cu_mask_words():
+    from naws_hip import ops
+    assert ops.cu_mask_every(256, 8) == [0x01010101] * 8
+    assert ops.cu_mask_every(64, 4, 1) == [0x22222222] * 2
+    assert ops.cu_mask_every(40, 1) == [0xFFFFFFFF, 0xFF]
