@@ -164,3 +164,14 @@ def test_cu_mask_words():
     assert ops.cu_mask_every(256, 8) == [0x01010101] * 8
     assert ops.cu_mask_every(64, 4, 1) == [0x22222222] * 2
     assert ops.cu_mask_every(40, 1) == [0xFFFFFFFF, 0xFF]
+
+
+def test_public_header_is_plain_c_and_cpp():
+    """include/naws.h compiles on its own as C and as C++ (extern "C", plain pointers and sizes: no
+    torch or HIP types in the signatures)."""
+    import subprocess
+    hdr = os.path.join(ROOT, 'include', 'naws.h')
+    for cc, lang in (('gcc', 'c'), ('g++', 'c++')):
+        subprocess.check_call([cc, '-fsyntax-only', '-Wall', '-Werror', '-x', lang, hdr])
+    code = re.sub(r'/\*.*?\*/', '', open(hdr).read(), flags=re.S)        # (comments cite pytorch/caffe2)
+    assert 'torch' not in code and 'hipStream_t' not in code and 'at::' not in code
