@@ -82,14 +82,19 @@ __global__ __launch_bounds__(TB) void det_softmax_kernel(
 }
 
 // ---- softmax over classes per row, product with alpha_det ------------------
-// one lane = one (row, branch)
+// one lane = one (branch, row, class) element.  Every lane of a row recomputes the row's maximum
+// and sum in class order - 2 C cached loads and C expf, nothing next to a launch - so that the
+// launch has Rt * nb * C lanes instead of Rt * nb (125 waves on 1024 SIMDs: 28 us of latency)
+// and every element is rounded exactly as in the one-lane-per-row form it replaces.
 __global__ __launch_bounds__(TB) void cls_softmax_mul_kernel(
     const float* __restrict__ fc8c, const float* __restrict__ noisy_fc8c, int ld, int Rt, int C,
     int nb, const float* __restrict__ alpha_det, float* __restrict__ alpha_cls,
     float* __restrict__ rois_pred) {
   const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
-  if (t >= (int64_t)Rt * nb) return;
-  const int b = (int)(t / Rt), r = (int)(t % Rt);
+  if (t >= (int64_t)Rt * nb * C) return;
+  const int c0 = (int)(t % C);
+  const int64_t br = t / C;
+  const int b = (int)(br / Rt), r = (int)(br % Rt);
   const bool noise = (b == 1);
   const float* zc = fc8c + (int64_t)r * ld;
   const float* zn = noise ? noisy_fc8c + (int64_t)r * ld : nullptr;
@@ -106,13 +111,11 @@ __global__ __launch_bounds__(TB) void cls_softmax_mul_kernel(
     sum += expf(z - m);
   }
   const int64_t o = ((int64_t)b * Rt + r) * C;
-  for (int c = 0; c < C; ++c) {
-    float z = zc[c];
-    if (noise) z += zn[c];
-    float a = expf(z - m) / sum;
-    alpha_cls[o + c] = a;
-    rois_pred[o + c] = a * alpha_det[o + c];
-  }
+  float z = zc[c0];
+  if (noise) z += zn[c0];
+  const float a = expf(z - m) / sum;
+  alpha_cls[o + c0] = a;
+  rois_pred[o + c0] = a * alpha_det[o + c0];
 }
 
 // ---- cls_prob[b][s][c] = sum over the image's proposals --------------------
@@ -130,40 +133,44 @@ __global__ __launch_bounds__(TB) void seg_colsum_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[((int64_t)b * nseg + s) * C + c] = acc;
 }
 
-// ---- backward: one lane = one row, both branches ---------------------------
+// ---- backward: one lane = one (row, class) element, both branches -----------
 // Row softmax:  dz = y * (dy - <dy, y>).  Column softmax: the inner product
 // <dy_col, y_col> = sum_r g[c]*alpha_cls*alpha_det = g[c] * cls_prob[c].
+// (Every lane of a row recomputes the row's inner product in class order: same rounding as one
+// lane per row, Rt * C lanes instead of Rt - 49 us of serial strided loads on 63 waves before.)
 __global__ __launch_bounds__(TB) void wsddn_bwd_kernel(
     const float* __restrict__ alpha_cls, const float* __restrict__ alpha_det,
     const float* __restrict__ cls_prob, const float* __restrict__ d_cls_prob,
     const int32_t* __restrict__ seg_off, int nseg, int Rt, int C, int nb,
     float* __restrict__ d_fc8c, float* __restrict__ d_fc8d, float* __restrict__ d_nfc8c,
     float* __restrict__ d_nfc8d, int ldd) {
-  const int r = blockIdx.x * TB + threadIdx.x;
-  if (r >= Rt) return;
+  const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+  if (t >= (int64_t)Rt * C) return;
+  const int r = (int)(t / C), c = (int)(t % C);
   const int s = find_segment(seg_off, nseg, r);
+  const int64_t o = (int64_t)r * ldd + c;
+  float sum_c = 0.f, sum_d = 0.f;
   for (int b = 0; b < nb; ++b) {
     const float* ac = alpha_cls + ((int64_t)b * Rt + r) * C;
     const float* ad = alpha_det + ((int64_t)b * Rt + r) * C;
     const float* g = d_cls_prob + ((int64_t)b * nseg + s) * C;
     const float* y = cls_prob + ((int64_t)b * nseg + s) * C;
     float dot = 0.f;
-    for (int c = 0; c < C; ++c) dot += (g[c] * ad[c]) * ac[c];
-    for (int c = 0; c < C; ++c) {
-      float dzc = ac[c] * (g[c] * ad[c] - dot);
-      float dzd = ad[c] * (g[c] * ac[c] - g[c] * y[c]);
-      const int64_t o = (int64_t)r * ldd + c;
-      if (b == 0) {
-        d_fc8c[o] = dzc;
-        d_fc8d[o] = dzd;
-      } else {
-        d_fc8c[o] += dzc;  // fan-in of Add(fc8c, noisy_fc8c)
-        d_fc8d[o] += dzd;
-        d_nfc8c[o] = dzc;
-        d_nfc8d[o] = dzd;
-      }
+    for (int k = 0; k < C; ++k) dot += (g[k] * ad[k]) * ac[k];
+    const float dzc = ac[c] * (g[c] * ad[c] - dot);
+    const float dzd = ad[c] * (g[c] * ac[c] - g[c] * y[c]);
+    if (b == 0) {
+      sum_c = dzc;
+      sum_d = dzd;
+    } else {
+      sum_c += dzc;  // fan-in of Add(fc8c, noisy_fc8c)
+      sum_d += dzd;
+      d_nfc8c[o] = dzc;
+      d_nfc8d[o] = dzd;
     }
   }
+  d_fc8c[o] = sum_c;
+  d_fc8d[o] = sum_d;
 }
 
 // ---- entropy gate ----------------------------------------------------------
@@ -248,26 +255,50 @@ __global__ __launch_bounds__(GR) void gate_D_kernel(const float* __restrict__ ro
   }
 }
 
-// grid (C, nseg): hatE_sum, norm, clip, class weights
-__global__ __launch_bounds__(TB) void gate_finish_kernel(
+// hatE_sum, norm, clip, class weights in two deterministic levels.  Level 1, grid (row chunks of
+// GF_ROWS, nseg): one lane per (row, class) element - rois_pred and the JCH partial D planes are
+// read as contiguous runs - the e * e / leaky(d) terms parked in LDS as [row][class], then lane c
+// adds its class over the chunk's rows in row order.  Level 2, grid (nseg): lane c adds the chunk
+// sums in chunk order and finishes.  (One workgroup per (class, image) walking the rows with a
+// class-strided access took 44 us for 2 x 2000 x 20 elements.)
+constexpr int GF_ROWS = 64;
+__global__ __launch_bounds__(TB) void gate_partial_kernel(
     const float* __restrict__ rois_pred, const float* __restrict__ Dpart,
-    const float* __restrict__ cls_prob, const float* __restrict__ labels_oh,
-    const int32_t* __restrict__ seg_off, int Rt, int C, int JCH, float* __restrict__ cw,
-    float* __restrict__ cw_noise, float* __restrict__ hatE_sum, float* __restrict__ hatE_norm) {
-  __shared__ float red[TB / 64];
-  const int c = blockIdx.x, s = blockIdx.y;
-  const int lo = seg_off[s], hi = seg_off[s + 1];
-  float acc = 0.f;
-  for (int r = lo + threadIdx.x; r < hi; r += TB) {
-    const float e = entropy_term(rois_pred[(int64_t)r * C + c]);
+    const int32_t* __restrict__ seg_off, int Rt, int C, int JCH, int nchunk,
+    float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* vals = reinterpret_cast<float*>(smem_raw);          // [GF_ROWS][C]
+  const int ch = blockIdx.x, s = blockIdx.y;
+  const int lo = seg_off[s] + ch * GF_ROWS, hi = min(seg_off[s + 1], lo + GF_ROWS);
+  const int n = max(hi - lo, 0) * C;
+  for (int i = threadIdx.x; i < n; i += TB) {
+    const int64_t o = (int64_t)lo * C + i;                    // element (row lo + i / C, class i % C)
+    const float e = entropy_term(rois_pred[o]);
     float d = 0.f;
-    for (int q = 0; q < JCH; ++q) d += Dpart[((int64_t)q * Rt + r) * C + c];
+    for (int q = 0; q < JCH; ++q) d += Dpart[(int64_t)q * Rt * C + o];
     d = d >= 0.f ? d : 0.01f * d;  // LeakyRelu(alpha=0.01)
     const float g = e / d;         // Div
-    acc += e * g;                  // Mul, ReduceSum
+    vals[i] = e * g;               // Mul
   }
-  acc = block_sum(acc, red);
-  if (threadIdx.x == 0) {
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += TB) {
+    float acc = 0.f;
+    for (int r = 0; r < hi - lo; ++r) acc += vals[r * C + c];   // ReduceSum, row order
+    part[((int64_t)s * nchunk + ch) * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(TB) void gate_finish_kernel(
+    const float* __restrict__ part, const float* __restrict__ cls_prob,
+    const float* __restrict__ labels_oh, const int32_t* __restrict__ seg_off, int C, int nchunk,
+    float* __restrict__ cw, float* __restrict__ cw_noise, float* __restrict__ hatE_sum,
+    float* __restrict__ hatE_norm) {
+  const int s = blockIdx.x;
+  const int lo = seg_off[s], hi = seg_off[s + 1];
+  const int used = (hi - lo + GF_ROWS - 1) / GF_ROWS;          // chunks that hold rows of this image
+  for (int c = threadIdx.x; c < C; c += TB) {
+    float acc = 0.f;
+    for (int k = 0; k < used; ++k) acc += part[((int64_t)s * nchunk + k) * C + c];
     const int o = s * C + c;
     const float y = cls_prob[o];
     const float n = (float)(hi - lo);
@@ -715,8 +746,9 @@ extern "C" int naws_wsddn_outputs_fwd(const float* fc8c, const float* fc8d,
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(det_softmax_kernel, dim3(C, nseg, nb), dim3(TB), 0, s, fc8d, noisy_fc8d, ld,
                      seg_off, Rt, C, alpha_det);
-  const int64_t rows = (int64_t)Rt * nb;
-  hipLaunchKernelGGL(cls_softmax_mul_kernel, dim3((unsigned)naws_cdiv(rows, TB)), dim3(TB), 0, s,
+  const int64_t elems = (int64_t)Rt * nb * C;
+  if (naws_cdiv(elems, TB) > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(cls_softmax_mul_kernel, dim3((unsigned)naws_cdiv(elems, TB)), dim3(TB), 0, s,
                      fc8c, noisy_fc8c, ld, Rt, C, nb, alpha_det, alpha_cls, rois_pred);
   hipLaunchKernelGGL(seg_colsum_kernel, dim3(C, nseg, nb), dim3(TB), 0, s, rois_pred, seg_off,
                      nseg, Rt, C, cls_prob);
@@ -736,7 +768,8 @@ extern "C" int naws_wsddn_outputs_bwd(const float* alpha_cls, const float* alpha
   NAWS_REQUIRE_PTR(d_cls_prob); NAWS_REQUIRE_PTR(seg_off);
   NAWS_REQUIRE_PTR(d_fc8c); NAWS_REQUIRE_PTR(d_fc8d);
   if (nb == 2) { NAWS_REQUIRE_PTR(d_noisy_fc8c); NAWS_REQUIRE_PTR(d_noisy_fc8d); }
-  hipLaunchKernelGGL(wsddn_bwd_kernel, dim3((unsigned)naws_cdiv(Rt, TB)), dim3(TB), 0,
+  if (naws_cdiv((int64_t)Rt * C, TB) > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(wsddn_bwd_kernel, dim3((unsigned)naws_cdiv((int64_t)Rt * C, TB)), dim3(TB), 0,
                      (hipStream_t)stream, alpha_cls, alpha_det, cls_prob, d_cls_prob, seg_off, nseg,
                      Rt, C, nb, d_fc8c, d_fc8d, d_noisy_fc8c, d_noisy_fc8d, ldd);
   return naws_check_launch();
@@ -750,9 +783,10 @@ static int gate_chunks(int max_seg_len) {
 }
 
 extern "C" int64_t naws_entropy_gate_workspace_floats(int Rt, int C, int nseg, int max_seg_len) {
-  (void)nseg;
-  if (Rt <= 0 || C <= 0 || max_seg_len <= 0) return 0;
-  return (int64_t)gate_chunks(max_seg_len) * Rt * C;
+  if (Rt <= 0 || C <= 0 || max_seg_len <= 0 || nseg <= 0) return 0;
+  // the JCH partial D planes + the per-chunk class sums of the two-level finish
+  return (int64_t)gate_chunks(max_seg_len) * Rt * C +
+         (int64_t)nseg * naws_cdiv(max_seg_len, GF_ROWS) * C;
 }
 
 extern "C" int naws_entropy_gate_fwd(const float* rois, const float* rois_pred,
@@ -773,9 +807,15 @@ extern "C" int naws_entropy_gate_fwd(const float* rois, const float* rois_pred,
   const size_t lds = GJ * 4 * sizeof(int) + GJ * GCC * sizeof(float);
   hipLaunchKernelGGL(gate_D_kernel, dim3((unsigned)naws_cdiv(max_seg_len, GR), nseg, JCH),
                      dim3(GR), lds, s, rois, rois_pred, seg_off, Rt, C, JCH, workspace);
-  hipLaunchKernelGGL(gate_finish_kernel, dim3(C, nseg), dim3(TB), 0, s, rois_pred, workspace,
-                     cls_prob, labels_oh, seg_off, Rt, C, JCH, class_weight, class_weight_noise,
-                     hatE_sum, hatE_sum_norm);
+  const int nchunk = (int)naws_cdiv(max_seg_len, GF_ROWS);
+  if ((size_t)GF_ROWS * C * sizeof(float) > 64 * 1024 || nchunk > 65535) return NAWS_ERR_UNSUPPORTED;
+  float* part = workspace + (int64_t)JCH * Rt * C;
+  hipLaunchKernelGGL(gate_partial_kernel, dim3((unsigned)nchunk, nseg), dim3(TB),
+                     (size_t)GF_ROWS * C * sizeof(float), s, rois_pred, (const float*)workspace,
+                     seg_off, Rt, C, JCH, nchunk, part);
+  hipLaunchKernelGGL(gate_finish_kernel, dim3(nseg), dim3(TB), 0, s, (const float*)part, cls_prob,
+                     labels_oh, seg_off, C, nchunk, class_weight, class_weight_noise, hatE_sum,
+                     hatE_sum_norm);
   return naws_check_launch();
 }
 
