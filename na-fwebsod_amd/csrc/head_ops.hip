@@ -261,7 +261,7 @@ __global__ __launch_bounds__(GR) void gate_D_kernel(const float* __restrict__ ro
 // adds its class over the chunk's rows in row order.  Level 2, grid (nseg): lane c adds the chunk
 // sums in chunk order and finishes.  (One workgroup per (class, image) walking the rows with a
 // class-strided access took 44 us for 2 x 2000 x 20 elements.)
-constexpr int GF_ROWS = 64;
+constexpr int GF_ROWS = 16;
 __global__ __launch_bounds__(TB) void gate_partial_kernel(
     const float* __restrict__ rois_pred, const float* __restrict__ Dpart,
     const int32_t* __restrict__ seg_off, int Rt, int C, int JCH, int nchunk,
@@ -293,12 +293,30 @@ __global__ __launch_bounds__(TB) void gate_finish_kernel(
     const float* __restrict__ labels_oh, const int32_t* __restrict__ seg_off, int C, int nchunk,
     float* __restrict__ cw, float* __restrict__ cw_noise, float* __restrict__ hatE_sum,
     float* __restrict__ hatE_norm) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* grp = reinterpret_cast<float*>(smem_raw);             // [G][C]
   const int s = blockIdx.x;
   const int lo = seg_off[s], hi = seg_off[s + 1];
   const int used = (hi - lo + GF_ROWS - 1) / GF_ROWS;          // chunks that hold rows of this image
+  // G = TB / C lane groups: group g adds the chunks g, g + G, ... of its class (in that order),
+  // then lane c adds the G group sums in group order - fixed association, G-fold fewer serial loads
+  const int G = max(1, TB / C);
+  for (int c = threadIdx.x % C, g = threadIdx.x / C; g < G && c < C; g += TB) {
+    float acc = 0.f;
+    for (int k = g; k < used; k += G) acc += part[((int64_t)s * nchunk + k) * C + c];
+    grp[g * C + c] = acc;
+  }
+  if (C > TB) {               // more classes than lanes: lane c walks its classes, one group
+    for (int c = threadIdx.x + TB; c < C; c += TB) {
+      float acc = 0.f;
+      for (int k = 0; k < used; ++k) acc += part[((int64_t)s * nchunk + k) * C + c];
+      grp[c] = acc;
+    }
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += TB) {
     float acc = 0.f;
-    for (int k = 0; k < used; ++k) acc += part[((int64_t)s * nchunk + k) * C + c];
+    for (int g = 0; g < G; ++g) acc += grp[g * C + c];
     const int o = s * C + c;
     const float y = cls_prob[o];
     const float n = (float)(hi - lo);
@@ -813,7 +831,9 @@ extern "C" int naws_entropy_gate_fwd(const float* rois, const float* rois_pred,
   hipLaunchKernelGGL(gate_partial_kernel, dim3((unsigned)nchunk, nseg), dim3(TB),
                      (size_t)GF_ROWS * C * sizeof(float), s, rois_pred, (const float*)workspace,
                      seg_off, Rt, C, JCH, nchunk, part);
-  hipLaunchKernelGGL(gate_finish_kernel, dim3(nseg), dim3(TB), 0, s, (const float*)part, cls_prob,
+  const int G = std::max(1, TB / C);
+  hipLaunchKernelGGL(gate_finish_kernel, dim3(nseg), dim3(TB), (size_t)G * C * sizeof(float), s,
+                     (const float*)part, cls_prob,
                      labels_oh, seg_off, C, nchunk, class_weight, class_weight_noise, hatE_sum,
                      hatE_sum_norm);
   return naws_check_launch();
