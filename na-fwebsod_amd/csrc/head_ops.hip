@@ -237,6 +237,7 @@ __global__ __launch_bounds__(GR) void gate_D_kernel(const float* __restrict__ ro
       }
       __syncthreads();
       if (active) {
+#pragma unroll 4
         for (int jj = 0; jj < nj; ++jj) {
           const float w = (j0 + jj == r)
                               ? 1.0f
@@ -794,9 +795,11 @@ extern "C" int naws_wsddn_outputs_bwd(const float* alpha_cls, const float* alpha
 }
 
 // j-chunks per row block: the pair loop is a serial chain per wave (~80 instructions per j), so
-// the launch is sized for >= one wave per SIMD at 2 x 2000 proposals (64 rows x 128 j per wave)
+// the launch is sized for two waves per SIMD at 2 x 2000 proposals (64 rows x 64 j per wave: a
+// lone wave cannot cover its own LDS / IoU latencies - 47 us at one wave per SIMD, 34 at two; the
+// finish then adds 32 partial planes instead of 16: +8 us)
 static int gate_chunks(int max_seg_len) {
-  int q = (max_seg_len + 127) / 128;
+  int q = (max_seg_len + 63) / 64;
   return q < 1 ? 1 : (q > 32 ? 32 : q);
 }
 
