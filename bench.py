@@ -67,6 +67,13 @@ def parse():
                     help='skip the extra measurements of the same workload under the exact-split '
                          '(fp32x3) and the fp32-MFMA-only plans')
     ap.add_argument('--alt-steps', type=int, default=40)
+    ap.add_argument('--no-parity-check', action='store_true',
+                    help='skip the in-run parity block (step-0 losses / logits of the headline '
+                         'plan against the fp32-MFMA and exact-split plans, on the bench inputs '
+                         'and on skewed statistics); without it the line is not self-certifying')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help='skip the configs[3] (C = 80, bf16 MFMA operands) and configs[4] (TTA '
+                         'inference) measurements appended to the default one-GPU line')
     ap.add_argument('--allreduce-chunks', type=int, default=0, help='0 = auto (engine.py)')
     ap.add_argument('--no-conv-x3', action='store_true',
                     help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
@@ -102,16 +109,24 @@ def parse():
 def infer_main(args):
     """python bench.py --infer: ms per image of configs[4] on one GPU (no data-parallel path:
     images are independent; N GPUs = N replicas)."""
-    import numpy as np
     import torch
     torch.cuda.set_device(0)
-    dev = torch.device('cuda', 0)
+    emit(infer_measure(args, torch.device('cuda', 0), max(args.steps // 4, 4),
+                       max(args.warmup // 4, 2)))
+
+
+def infer_measure(args, dev, steps, warmup):
+    """configs[4]: `steps` synthetic images through the yaml's 10-pass TTA end to end, the fc6
+    forward launches of every pass timed with HIP events (engine.timing_events)."""
+    import numpy as np
+    import torch
     from detectron.core import config as c
     from detectron.core import test_wsl
     from detectron.core.executor import NetExecutor
     from detectron.datasets import synthetic
     from detectron.roi_data.minibatch_wsl import get_im_scale
     import detectron.modeling.model_builder_wsl as mb
+    c.reset_cfg()
     c.merge_cfg_from_file(os.path.join(ROOT, 'na-fwebsod_amd', 'configs', 'flickr_voc',
                                        'na_wsddn_V-16-C5_1x.yaml'))
     c.merge_cfg_from_list(['NUM_GPUS', 1, 'TEST.BBOX_AUG.ENABLED', True,
@@ -135,11 +150,17 @@ def infer_main(args):
             n += sum(len(b) for b in cls_boxes[1:])
         torch.cuda.synchronize()
         return n
-    run(max(args.warmup // 4, 2))
-    steps = max(args.steps // 4, 4)
+    run(warmup)
+    ev = []
+    eng = getattr(ex, 'engine', None)
+    if eng is not None:
+        eng.timing_events = ev
     t0 = time.perf_counter()
     ndet = run(steps)
     dt = time.perf_counter() - t0
+    if eng is not None:
+        eng.timing_events = None
+    fc6_ms = sum(a.elapsed_time(b) for a, b in ev) / steps if ev else None
     passes = test_wsl.tta_passes()
     # algorithmic work per image (conv 463.7 GFLOP at 600x1000, scaled by the
     # input area; one head branch: fc6 + fc7 + fc8 on the proposals that survive the dedup)
@@ -154,7 +175,7 @@ def infer_main(args):
         'metric': 'inference images/sec, %d-pass multi-scale+flip TTA, %d proposals '
                   '(BASELINE configs[4])' % (len(passes), args.infer_rois),
         'value': round(steps / dt, 3), 'unit': 'images/sec', 'n_gpus': 1, 'steps': steps,
-        'warmup': max(args.warmup // 4, 2), 'ms_per_step': round(dt / steps * 1e3, 3),
+        'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 (2xf16 split, 3-pass f16 MFMA, fp32 accumulate)' if args.mfma_dtype == 'fp16x2'
                  else args.mfma_dtype,
@@ -166,9 +187,18 @@ def infer_main(args):
         'roofline': {'bound': 'mfma', 'kernel': 'whole image: conv bodies + fc6/fc7 of all passes',
                      'achieved': round(tf, 1), 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': round(tf / peak, 4), 'traffic': None,
-                     'algorithmic_gflop_per_image': round((conv + head) / 1e9, 1)},
+                     'algorithmic_gflop_per_image': round((conv + head) / 1e9, 1),
+                     # the dominant kernel of the path: the fc6 forward GEMM of the clean branch
+                     # (M = surviving proposals, N = 4096, K = 25088), summed over the passes
+                     'fc6_fwd_ms_per_image': None if fc6_ms is None else round(fc6_ms, 3),
+                     'fc6_fwd_launches_per_image': round(len(ev) / steps, 1) if ev else None},
     }
-    emit(res)
+    if fc6_ms:
+        f6 = len(passes) * 2.0 * args.infer_rois * 4096 * 25088 / (fc6_ms * 1e-3) / 1e12
+        res['roofline'].update(fc6_fwd_tflops=round(f6, 1), fc6_fwd_frac=round(f6 / peak, 4))
+    del ex, model
+    torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(args, num_fg):
@@ -221,37 +251,69 @@ def cpu_baseline(args, num_fg):
     return res
 
 
-def alt_plan(args, dev, num_fg, B, t, seg, mode):
+def step0_probe(out):
+    """What the in-run parity check compares: the per-image losses and the fc8 logits
+    (fc8c | fc8d | noisy_fc8c | noisy_fc8d) of a plan's FIRST step - same inputs, same initial
+    weights, same counter-based dropout masks in every plan."""
+    return {k: out[k].detach().double().cpu().numpy() for k in ('loss_cls', 'loss_cls_noise', 'logits')}
+
+
+def parity_against(base, other):
+    """(max relative loss difference over images and both losses, max logit difference /
+    max|logit|) of `base` against `other`."""
+    import numpy as np
+    lr = max(float(np.abs(base[k] - other[k]).max() / np.abs(other[k]).max())
+             for k in ('loss_cls', 'loss_cls_noise'))
+    lg = float(np.abs(base['logits'] - other['logits']).max() / np.abs(other['logits']).max())
+    return lr, lg
+
+
+def alt_plan(args, dev, num_fg, B, t, seg, mode, blobs=None, steps=None):
     """The same workload under another arithmetic plan, with its own roofline block for the
-    fc6-forward launch (HIP events on the launch stream, as for the headline plan)."""
+    fc6-forward launch (HIP events on the launch stream, as for the headline plan).  steps = 0:
+    only the first step's probe (the in-run parity check on other statistics)."""
     import torch
     from detectron.datasets import synthetic
     from naws_hip.engine import WsddnEngine
     eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
                       weight_decay=5e-4, iter_size=1, gpu_num=B, seed=11, mfma_dtype=mode)
-    blobs = synthetic.init_blobs(num_fg, seed=11)
+    if blobs is None:
+        blobs = synthetic.init_blobs(num_fg, seed=11)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)
     del blobs
     eng.set_lr(args.lr)
-    steps = max(1, args.alt_steps)
+    steps = max(1, args.alt_steps) if steps is None else steps
     warm = 3
-    ev = []
+    ev, pev = [], []
+    probe = []
 
     def run(n, timed):
         eng.timing_events = ev if timed else None
+        eng.phase_events = pev if timed else None
         for _ in range(n):
             out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            if not probe:
+                probe.append(step0_probe(out))
             eng.sgd_step()
         eng.flush()
         torch.cuda.synchronize()
         return out
+    if steps == 0:
+        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg,
+                                   compute_grads=False)
+        torch.cuda.synchronize()
+        del eng
+        torch.cuda.empty_cache()
+        return {'mfma_dtype': mode, 'probe': step0_probe(out)}
     run(warm, False)
     t0 = time.perf_counter()
     out = run(steps, True)
     dt = time.perf_counter() - t0
     rt = t['rois'].shape[0]
     kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+    conv_ms = [e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:])
+               if n1 == 'conv_body']
     flops = 2.0 * rt * 8192 * 25088
     achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
     peak, kname = plan_peak_and_kernel(mode)
@@ -259,13 +321,91 @@ def alt_plan(args, dev, num_fg, B, t, seg, mode):
             'kernel_ms': round(kern_ms, 4), 'achieved': round(achieved, 2) if achieved else None,
             'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4) if achieved else None,
             'traffic': None}
+    if conv_ms:
+        roof['conv_stack_ms'] = round(sum(conv_ms) / len(conv_ms), 3)
     del eng
     torch.cuda.empty_cache()
     return {'mfma_dtype': mode, 'value': round(B * steps / dt, 3), 'unit': 'images/sec',
             'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warm,
             'final_loss': round(float(out['loss_cls'].sum().item() +
                                       out['loss_cls_noise'].sum().item()), 5),
-            'roofline': roof}
+            'roofline': roof, 'probe': probe[0]}
+
+
+PARITY_LOSS_TOL = 1e-4      # north_star: loss parity <= 1e-4 relative
+PARITY_LOGIT_TOL = 1e-5     # logits: max difference / max|logit| (north_star asks 1e-4)
+
+
+def parity_in_run(args, dev, num_fg, B, t, seg, base, res):
+    """The headline plan certifies itself against the strict plans INSIDE the driver's run:
+    step-0 losses and fc8 logits (same inputs, initial weights and dropout masks) of the 2 x f16
+    split plan against (a) the plan with every GEMM on the fp32 MFMA and (b) the exact 3 x bf16
+    split, both on the bench inputs and on skewed statistics (synthetic.skew_blobs / skew_images:
+    per-channel weight scales log-uniform over 2^+-6, non-zero biases, a third of each image at
+    2^-12).  `ok` False -> bench.py exits non-zero after printing the line."""
+    import torch
+    from detectron.datasets import synthetic
+    blk = {'loss_tol': PARITY_LOSS_TOL, 'logit_tol': PARITY_LOGIT_TOL}
+    worst_l, worst_g = 0.0, 0.0
+    for key, tag in (('fp32_mfma_plan', 'fp32_mfma'), ('fp32x3_plan', 'fp32x3')):
+        lr, lg = parity_against(base, res[key]['probe'])
+        blk['loss_rel_vs_' + tag], blk['logit_maxrel_vs_' + tag] = float('%.3g' % lr), float('%.3g' % lg)
+        worst_l, worst_g = max(worst_l, lr), max(worst_g, lg)
+    # the same check on non-Kaiming statistics (forward only, one step per plan)
+    blobs = synthetic.skew_blobs(synthetic.init_blobs(num_fg, seed=11), seed=11)
+    ts = dict(t)
+    ts['data'] = torch.from_numpy(synthetic.skew_images(t['data'].cpu().numpy())).to(dev)
+    sk = {m: alt_plan(args, dev, num_fg, B, ts, seg, m, blobs=blobs, steps=0)['probe']
+          for m in ('fp16x2', 'fp32', 'fp32x3')}
+    for m, tag in (('fp32', 'fp32_mfma'), ('fp32x3', 'fp32x3')):
+        lr, lg = parity_against(sk['fp16x2'], sk[m])
+        blk['skewed_loss_rel_vs_' + tag] = float('%.3g' % lr)
+        blk['skewed_logit_maxrel_vs_' + tag] = float('%.3g' % lg)
+        worst_l, worst_g = max(worst_l, lr), max(worst_g, lg)
+    # the yardstick: how far the two strict plans (both exact fp32 products, different
+    # summation orders) are from each other on the same inputs
+    lr, lg = parity_against(res['fp32x3_plan']['probe'], res['fp32_mfma_plan']['probe'])
+    blk['fp32x3_vs_fp32_mfma_loss_rel'], blk['fp32x3_vs_fp32_mfma_logit_maxrel'] = \
+        float('%.3g' % lr), float('%.3g' % lg)
+    blk['ok'] = bool(worst_l <= PARITY_LOSS_TOL and worst_g <= PARITY_LOGIT_TOL)
+    return blk
+
+
+def extra_configs(args, dev, B, res, cfg, roof):
+    """BASELINE configs[3] (C = 80, bf16 MFMA operands, fp32 loss; its 1-GPU share) and configs[4]
+    (TTA inference) measured in the same driver run, each with its fc6-forward roofline; flat
+    copies under config / roofline."""
+    import numpy as np
+    import torch
+    from detectron.datasets import synthetic
+    c80 = 80
+    mb = synthetic.make_minibatch(synthetic.make_roidb(B, args.rois, c80, args.height, args.width,
+                                                       seed=11), c80)
+    t80 = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    seg = [0] + np.cumsum(np.bincount(mb['rois'][:, 0].astype(np.int64), minlength=B)).tolist()
+    r = alt_plan(args, dev, c80, B, t80, seg, 'bf16')
+    r.pop('probe', None)
+    r['workload'] = ('configs[3] flickr_coco na_wsddn C=80 (1-GPU share): %d img %dx%d x %d rois, '
+                     'bf16 MFMA conv/fc6/fc7 operands, fp32 storage/fc8/loss/SGD'
+                     % (B, args.height, args.width, args.rois))
+    res['bf16_c80_plan'] = r
+    cfg['bf16_c80_plan_images_per_sec'] = r['value']
+    cfg['bf16_c80_plan_ms_per_step'] = r['ms_per_step']
+    for k in ('kernel_ms', 'achieved', 'peak', 'frac'):
+        roof['bf16_c80_plan_fc6_fwd_' + {'achieved': 'tflops'}.get(k, k)] = r['roofline'][k]
+    roof['bf16_c80_plan_conv_stack_ms'] = r['roofline'].get('conv_stack_ms')
+    del t80
+    torch.cuda.empty_cache()
+    ia = argparse.Namespace(**vars(args))
+    ia.mfma_dtype = 'fp16x2'
+    ti = infer_measure(ia, dev, steps=8, warmup=2)
+    res['tta_infer'] = {k: ti[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps',
+                                            'warmup', 'dtype', 'config', 'roofline')}
+    cfg['tta_infer_ms_per_image'] = ti['ms_per_step']
+    cfg['tta_infer_passes'] = ti['config']['passes']
+    cfg['tta_infer_detections_per_image'] = ti['config']['detections_per_image']
+    for k in ('achieved', 'peak', 'frac', 'fc6_fwd_ms_per_image', 'fc6_fwd_tflops', 'fc6_fwd_frac'):
+        roof['tta_infer_' + {'achieved': 'whole_image_tflops'}.get(k, k)] = ti['roofline'].get(k)
 
 
 def plan_peak_and_kernel(mode):
@@ -481,7 +621,15 @@ def main():
     uev = []     # the fused SGD kernel, on the update stream
     cev = []     # update stream: from "gradients complete" to "all-reduce complete"
 
+    probe0 = []
+
     def step(timed):
+        out = _step(timed)
+        if not probe0:
+            probe0.append(step0_probe(out))
+        return out
+
+    def _step(timed):
         if timed:
             eng.timing_events = ev
             eng.phase_events = pev
@@ -531,7 +679,7 @@ def main():
     deferred_ms = None
     if world == 1 and not args.no_fused_update and eng._can_fuse_wgrad_update():
         eng.timing_events = eng.phase_events = eng.update_events = eng.comm_events = None
-        n_def = max(10, args.steps // 4)
+        n_def = args.steps               # the same number of steps as `value`
         for it in range(5 + n_def):
             if it == 5:
                 eng.flush()
@@ -697,6 +845,12 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': dtype, 'data': 'synthetic', 'config': cfg, 'roofline': roof,
         }
+        # A scaling series must compare like with like: every rank of an N > 1 job writes
+        # fc6_w's gradient, exchanges it and updates in the deferred kernel, while `value` at
+        # N = 1 updates fc6_w inside its wgrad GEMM.  This field is the N = 1 point of the N > 1
+        # ALGORITHM (same steps, same clock as `value`); at N > 1 it equals `value`.
+        res['scaling_baseline_value'] = (round(world * B / deferred_ms * 1e3, 3)
+                                         if deferred_ms is not None else res['value'])
         if world == 1 and args.mfma_dtype == 'fp16x2' and not args.no_alt_plan:
             # the same workload, measured in this run, (a) with the exact 3 x bf16 operand split
             # and (b) with every GEMM on v_mfma_f32_32x32x2_f32, for readers who want the number
@@ -712,12 +866,24 @@ def main():
                 roof[key + '_fc6_fwd_tflops'] = res[key]['roofline']['achieved']
                 roof[key + '_fc6_fwd_peak'] = res[key]['roofline']['peak']
                 roof[key + '_fc6_fwd_frac'] = res[key]['roofline']['frac']
+                roof[key + '_conv_stack_ms'] = res[key]['roofline'].get('conv_stack_ms')
+            if not args.no_parity_check:
+                res['parity_in_run'] = parity_in_run(args, dev, num_fg, B, t, seg, probe0[0], res)
+                for k, v in res['parity_in_run'].items():
+                    cfg['parity_' + k] = v
+            for key in ('fp32x3_plan', 'fp32_mfma_plan'):
+                res[key].pop('probe', None)
+            if not args.no_extra_configs and headline and B == 2:
+                extra_configs(args, dev, B, res, cfg, roof)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, num_fg)
     if pg is not None:
         torch.distributed.destroy_process_group()
     if rank == 0:
         emit(res)
+        if res.get('parity_in_run', {}).get('ok') is False:
+            sys.exit('bench.py: the headline plan disagrees with the fp32 plans beyond the stated '
+                     'tolerances: %s' % json.dumps(res['parity_in_run']))
 
 
 if __name__ == '__main__':

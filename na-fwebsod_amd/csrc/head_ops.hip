@@ -544,8 +544,9 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
   const int band = t / ct, ctile = t - band * ct;     // column tile fastest: neighbours stream on
   const int r0 = band * 32, c0 = ctile * 256;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // one hyper-parameter run per region (a region lies inside one blob pair of equal settings;
-  // checked on the host)
+  // ONE hyper-parameter run per region: the CALLER guarantees that a region lies inside one run of
+  // seg_end (engine._one_hyper_run disables this kernel otherwise; seg_end is device memory, so the
+  // C entry point cannot look)
   const int sg = sgd_segment(seg_end, nseg, R.start);
   const float LR = base_lr * seg_lr_mult[sg], wd = seg_wd[sg];
   const int64_t base4 = (R.start + (int64_t)r0 * R.cols + c0) >> 2;

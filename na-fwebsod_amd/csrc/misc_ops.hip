@@ -23,7 +23,10 @@ extern "C" int naws_last_hip_error(void) { return g_naws_last_hip_error; }
 namespace {
 constexpr int LDS_SLOTS = 512;           // > the number of big-LDS kernel instantiations
 constexpr int MAX_DEV = 256;
-struct LdsSlot { const void* kernel; unsigned long long dev[MAX_DEV / 64]; };
+struct LdsSlot {
+  std::atomic<const void*> kernel;
+  std::atomic<unsigned long long> dev[MAX_DEV / 64];
+};
 LdsSlot g_lds_slots[LDS_SLOTS];
 std::mutex g_lds_mutex;
 std::atomic<int> g_knobs[NAWS_KNOB_COUNT] = {{0}, {0}, {0}, {11}, {0}, {42}, {0}};
@@ -31,29 +34,56 @@ const char* const g_knob_names[NAWS_KNOB_COUNT] = {"gemm", "x3", "h2", "conv_rin
                                                     "roi_nw", "wino"};
 }  // namespace
 
+// Every launcher of a > 64 KB-LDS kernel passes through here, from any host thread (per-image conv
+// chains, the update stream): the common case - this (kernel, device) pair was raised before - is
+// decided by two atomic loads, no lock.  A slot's kernel pointer is claimed once under the mutex and
+// stays until naws_launch_state_reset(); a device bit is published (release) only after the driver
+// call returned, so a reader that sees it (acquire) may launch.  A reader racing a reset sees either
+// state; the worst case is one repeated, idempotent hipFuncSetAttribute.
 int naws_allow_lds_impl(const void* kernel, int bytes) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return naws_check_launch();
+  const bool in_range = dev >= 0 && dev < MAX_DEV;
+  const size_t h0 = ((uintptr_t)kernel >> 4) % LDS_SLOTS;
+  if (in_range) {
+    size_t h = h0;
+    for (int probe = 0; probe < LDS_SLOTS; ++probe, h = (h + 1) % LDS_SLOTS) {
+      const void* k = g_lds_slots[h].kernel.load(std::memory_order_acquire);
+      if (k == kernel) {
+        if ((g_lds_slots[h].dev[dev >> 6].load(std::memory_order_acquire) >> (dev & 63)) & 1ULL)
+          return NAWS_OK;
+        break;
+      }
+      if (k == nullptr) break;
+    }
+  }
   std::lock_guard<std::mutex> lock(g_lds_mutex);
   LdsSlot* slot = nullptr;
-  if (dev >= 0 && dev < MAX_DEV) {
-    size_t h = ((uintptr_t)kernel >> 4) % LDS_SLOTS;
+  if (in_range) {
+    size_t h = h0;
     for (int probe = 0; probe < LDS_SLOTS; ++probe, h = (h + 1) % LDS_SLOTS) {
-      if (g_lds_slots[h].kernel == kernel) { slot = &g_lds_slots[h]; break; }
-      if (g_lds_slots[h].kernel == nullptr) { slot = &g_lds_slots[h]; slot->kernel = kernel; break; }
+      const void* k = g_lds_slots[h].kernel.load(std::memory_order_relaxed);
+      if (k == kernel) { slot = &g_lds_slots[h]; break; }
+      if (k == nullptr) {
+        slot = &g_lds_slots[h];
+        slot->kernel.store(kernel, std::memory_order_release);
+        break;
+      }
     }
-    if (slot && (slot->dev[dev >> 6] >> (dev & 63)) & 1ULL) return NAWS_OK;
   }
   // (a full table or an out-of-range ordinal just means: set it on every launch)
   if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
     return naws_check_launch();
-  if (slot) slot->dev[dev >> 6] |= 1ULL << (dev & 63);
+  if (slot) slot->dev[dev >> 6].fetch_or(1ULL << (dev & 63), std::memory_order_release);
   return NAWS_OK;
 }
 
 extern "C" int naws_launch_state_reset(void) {
   std::lock_guard<std::mutex> lock(g_lds_mutex);
-  memset(g_lds_slots, 0, sizeof(g_lds_slots));
+  for (int i = 0; i < LDS_SLOTS; ++i) {
+    for (int w = 0; w < MAX_DEV / 64; ++w) g_lds_slots[i].dev[w].store(0, std::memory_order_relaxed);
+    g_lds_slots[i].kernel.store(nullptr, std::memory_order_release);
+  }
   return NAWS_OK;
 }
 

@@ -114,3 +114,54 @@ def init_blobs(num_fg_classes, seed=11, device='cpu', roi_size=7, pixel_scale=1.
         blobs[name + '_w'] = ((torch.rand((num_fg_classes, 4096), generator=g) * 2 - 1) * lim).to(device)
         blobs[name + '_b'] = torch.zeros((num_fg_classes,), device=device)
     return blobs
+
+
+def skew_blobs(blobs, seed=11, span=6.0, bias_std=0.1, roi_size=7):
+    """Non-Kaiming statistics for the parity tests and bench.py's in-run check: every conv / fc
+    output channel o of layer l is multiplied by s_l[o] = 2^U(-span, span) (log-uniform over
+    2^+-6 by default) and given a non-zero bias N(0, bias_std) * s_l[o]; the NEXT layer's weights
+    are divided by s_l along their input channels.  ReLU and max-pool commute with a positive
+    per-channel factor, so the logits are those of the un-skewed network with biases (fc8* gets
+    the input compensation only) while every activation tensor has per-channel magnitudes
+    spread over 12 octaves and every weight row entries spread over up to 24.  That is the
+    case a per-tensor / per-row operand scale handles worst.  Returns a new dict (fp32)."""
+    import torch
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed * 7919 + 1)
+
+    def scale(n):
+        return torch.exp2((torch.rand((n,), generator=g) * 2 - 1) * span)
+
+    out = {}
+    prev = torch.ones((3,))
+    for name, _cin, cout in CONV_SHAPES:
+        s = scale(cout)
+        out[name + '_w'] = blobs[name + '_w'] * s[:, None, None, None] / prev[None, :, None, None]
+        out[name + '_b'] = (blobs[name + '_b'] +
+                            torch.randn((cout,), generator=g) * bias_std) * s
+        prev = s
+    k_in = prev.repeat_interleave(roi_size * roi_size)          # roi_feat index = c*49 + ph*7 + pw
+    for pre, p8 in (('', ''), ('_[noisy]_', 'noisy_')):
+        s6, s7 = scale(4096), scale(4096)
+        out[pre + 'fc6_w'] = blobs[pre + 'fc6_w'] * s6[:, None] / k_in[None, :]
+        out[pre + 'fc6_b'] = (blobs[pre + 'fc6_b'] + torch.randn((4096,), generator=g) * bias_std) * s6
+        out[pre + 'fc7_w'] = blobs[pre + 'fc7_w'] * s7[:, None] / s6[None, :]
+        out[pre + 'fc7_b'] = (blobs[pre + 'fc7_b'] + torch.randn((4096,), generator=g) * bias_std) * s7
+        for k in ('fc8c', 'fc8d'):
+            w = blobs[p8 + k + '_w']
+            out[p8 + k + '_w'] = w / s7[None, :]
+            out[p8 + k + '_b'] = blobs[p8 + k + '_b'] + torch.randn((w.shape[0],), generator=g) * bias_std
+    return {k: v.float().contiguous() for k, v in out.items()}
+
+
+def skew_images(data, dark=2.0 ** -12, amplitude=40.0):
+    """data [B,3,H,W] fp32 (mean-subtracted) -> the same images plus a smooth low-frequency
+    component, with the left third of every image multiplied by `dark` (2^-12): a region whose
+    activations sit 12 octaves below the tensor maximum that one operand scale has to serve."""
+    b, _c, h, w = data.shape
+    yy = np.arange(h, dtype=np.float32)[:, None] / h
+    xx = np.arange(w, dtype=np.float32)[None, :] / w
+    smooth = amplitude * np.sin(2 * np.pi * 1.5 * xx) * np.cos(2 * np.pi * yy)
+    out = data + smooth[None, None].astype(np.float32)
+    out[:, :, :, :w // 3] *= np.float32(dark)
+    return np.ascontiguousarray(out, dtype=np.float32)

@@ -213,7 +213,7 @@ class WsddnEngine(object):
         self.fuse_wgrad_update = True
         self.fc8_ksplit = 4
         self._fc8_ws = None
-        self._w6_updated = False
+        self._w6_updated = None      # the region table for the deferred kernel once fc6_w is done
         self._sgd_regions_rest = None
         self._sgd_regions = None
         # RoIPoolF over 2x2 / 4x4 block maxima of conv5_3 (csrc/roi_ops.hip): same values, ~8x less
@@ -257,6 +257,21 @@ class WsddnEngine(object):
         self._planes_dirty = True     # the caller may write through the view
         return self.arena.view(self.params, name)
 
+    def blob_ro(self, name):
+        """Read-only view of a parameter (checkpoint saves, statistics): the pending update is
+        applied first, but the operand planes stay valid - a save in the middle of a run must not
+        change the arithmetic of the steps after it (the planes the update kernels maintain carry
+        bound-derived scales, a fresh split exact ones: both correct, not bit-identical)."""
+        self.flush()
+        return self.arena.view(self.params, name)
+
+    def _one_hyper_run(self, start, count):
+        """True when arena elements [start, start + count) share one (lr_mult, weight decay):
+        the plane-writing SGD kernel takes ONE pair per region (head_ops.hip sgd_segment)."""
+        ends = self._seg_host[0]
+        i = next((k for k, e in enumerate(ends) if e > start), None)
+        return i is not None and ends[i] >= start + count
+
     def _weight_views(self):
         w6 = self.arena.span(self.params, 'fc6_w', '_[noisy]_fc6_w').view(2 * HIDDEN, self.k6)
         w7 = self.arena.span(self.params, 'fc7_w', '_[noisy]_fc7_w').view(2, HIDDEN, HIDDEN)
@@ -282,7 +297,10 @@ class WsddnEngine(object):
             o6, o7 = self.arena.offsets['fc6_w'][0], self.arena.offsets['fc7_w'][0]
             self._rm_table = ops.RowmaxTable([(o6, o6 + n6 * self.k6, self.k6, 0),
                                               (o7, o7 + n6 * HIDDEN, HIDDEN, 2 * n6)], self.device)
-            if self.k6 % 256 == 0:
+            one_run = (self._one_hyper_run(o6, n6 * self.k6) and self._one_hyper_run(o7, n6 * HIDDEN))
+            if self.k6 % 256 == 0 and one_run:
+                # (a configuration that gives the two branches different lr_mult / weight decay
+                # keeps the element-wise kernel + re-split: _sgd_regions stays None)
                 # [w6 rows | w7 rows]: the maxima before an update (the scale bounds of the planes
                 # the update writes) and the "a row outgrew its bound" word
                 self._wbound = torch.zeros((2 * n6,), device=self.device, dtype=torch.int32)
@@ -303,11 +321,12 @@ class WsddnEngine(object):
                      sc[1, 1], cm7)])
         elif self._wplanes is None:
             self._wplanes = dict(w6=cv(w6), w7=cv(w7), w7t=cv(w7, transpose=True))
-            if self.k6 % 256 == 0:
+            n6 = 2 * HIDDEN
+            o6, o7 = self.arena.offsets['fc6_w'][0], self.arena.offsets['fc7_w'][0]
+            if (self.k6 % 256 == 0 and self._one_hyper_run(o6, n6 * self.k6)
+                    and self._one_hyper_run(o7, n6 * HIDDEN)):
                 # fp32x3 / bf16: the SGD kernel writes these planes too (exact / rounded bf16:
                 # no scales, nothing to bound)
-                n6 = 2 * HIDDEN
-                o6, o7 = self.arena.offsets['fc6_w'][0], self.arena.offsets['fc7_w'][0]
                 fmt = L.PLANES_BF16X3 if self.mfma_dtype == 'fp32x3' else L.PLANES_BF16
                 self._sgd_regions = ops.SgdPlaneRegions([
                     (o6, n6, self.k6, n6, self._wplanes['w6'], None, None, None),
@@ -378,7 +397,7 @@ class WsddnEngine(object):
         for name, (wp, b, w) in self.conv.items():
             out[name + '_w'], out[name + '_b'] = w, b
         for name, _ in self.arena.specs:
-            out[name] = self.blob(name)
+            out[name] = self.blob_ro(name)
             if with_momentum:
                 out[name + '_momentum'] = self.momentum_blob(name)
         return out
@@ -785,7 +804,8 @@ class WsddnEngine(object):
         losses = ops.weighted_ce(cp, lab2, wts, self.is_mean, 2 * n_img)   # [2*nseg]
         out = dict(loss_cls=losses[:n_img], loss_cls_noise=losses[n_img:], cls_prob=cp[0],
                    cls_prob_noise=cp[1], class_weight=cw, class_weight_noise=cwn,
-                   hatE_sum=hs, hatE_sum_norm=hsn, rois_pred=rp[0])
+                   hatE_sum=hs, hatE_sum_norm=hsn, rois_pred=rp[0],
+                   logits=torch.cat(lv, 1) if ld8 != 2 * C else lg)   # fc8c|fc8d|noisy_fc8c|noisy_fc8d
         self.step_count += 1
         mark('loss_tail')
         if not compute_grads:
@@ -962,7 +982,9 @@ class WsddnEngine(object):
                                          ncols=(c0, c1), rows=(r0, r1))
         if r1 == n6:
             ops.split_f16x2_rows_if(w6, maxima, self._wplanes['w6'], self._wovf, tag)
-            self._w6_updated = True
+            # the route is decided HERE: the deferred kernel of this step must skip fc6_w whatever
+            # the toggles say by the time it runs (the table to use travels with the flag)
+            self._w6_updated = self._sgd_regions_rest
 
     def train_step(self, data, rois, obn_scores, labels_oh, seg=None):
         """forward_backward + sgd_step as one call.  With no gradient exchange between the two
@@ -1094,8 +1116,16 @@ class WsddnEngine(object):
                      and self._sgd_regions is not None and self.iter_size == 1
                      and not self._planes_dirty and self._wplanes is not None)
         rowmax = None
-        w6_done, self._w6_updated = self._w6_updated, False
-        assert planes or not w6_done
+        rest, self._w6_updated = self._w6_updated, None
+        w6_done = rest is not None
+        if w6_done:
+            # fc6_w (weights, momentum, planes) was updated by its wgrad GEMM in this step's
+            # backward: the rest MUST take the plane-writing kernel with fc6_w's region skipped,
+            # even if an A/B tool has flipped fused_planes / fused_wmax since
+            if self._wplanes is None or self._sgd_regions is None or self.mfma_dtype != 'fp16x2':
+                raise RuntimeError('fc6_w was updated in its wgrad epilogue but the plane state '
+                                   'it belongs to is gone (engine toggles changed mid-step?)')
+            fused = planes = True
         if fused:
             maxima = self._wscales.view(2, 2, 2 * HIDDEN)[:, 0]
             part = slice(1, 2) if w6_done else slice(0, 2)      # (fc6_w's half was handled by its wgrad)
@@ -1109,7 +1139,7 @@ class WsddnEngine(object):
             ops.acm_sgd_update_f16x2(self.grads, self.momentum_buf, self.lr, self.params,
                                      self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
                                      self.gpu_num, self.sgd_iter_count,
-                                     self._sgd_regions_rest if w6_done else self._sgd_regions,
+                                     rest if w6_done else self._sgd_regions,
                                      self._wovf, tag)
         elif planes_bf:
             ops.acm_sgd_update_planes(self.grads, self.momentum_buf, self.lr, self.params,

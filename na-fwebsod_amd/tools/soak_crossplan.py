@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Cross-plan soak: the arithmetic plans trained in lockstep on the same batches, initial
+weights, dropout masks and learning rate, their loss trajectories compared step by step.
+
+Training is a chaotic map: two correct fp32 evaluations that differ only in summation order
+(the fp32-MFMA plan and the exact 3 x bf16 split) drift apart at some rate.  The claim tested
+here is that the 2 x f16 split plan (the bench headline) stays within 1e-3 of the fp32-MFMA
+plan's losses for as long as those two fp32 orderings stay within 1e-3 of each other - i.e. that
+its operand representation adds no drift of its own.
+
+    python tools/soak_crossplan.py --steps 200 --compare fp16x2 fp32 --yardstick fp32x3
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from detectron.datasets import synthetic  # noqa: E402
+from naws_hip.engine import WsddnEngine  # noqa: E402
+
+
+def run(modes, steps=200, lr=1e-4, rois=2000, height=600, width=1000, batches=4, skewed=False,
+        device=None, log=None):
+    """Returns {mode: [total loss per step]} (float64)."""
+    dev = device or torch.device('cuda:0')
+    c, B = 20, 2
+    blobs = synthetic.init_blobs(c, seed=11)
+    if skewed:
+        blobs = synthetic.skew_blobs(blobs, seed=11)
+    engs = {}
+    for m in modes:
+        e = WsddnEngine(c + 1, dev, gpu_num=B, seed=11, mfma_dtype=m)
+        e.set_conv_blobs(blobs)
+        e.set_head_blobs(blobs)
+        e.set_lr(lr)
+        engs[m] = e
+    del blobs
+    data = []
+    for s in range(batches):
+        mb = synthetic.make_minibatch(synthetic.make_roidb(B, rois, c, height, width, seed=11 + s), c)
+        if skewed:
+            mb['data'] = synthetic.skew_images(mb['data'])
+        seg = [0] + np.cumsum(np.bincount(mb['rois'][:, 0].astype(np.int64), minlength=B)).tolist()
+        data.append(({k: torch.from_numpy(v).to(dev) for k, v in mb.items()}, seg))
+    traj = {m: [] for m in modes}
+    for it in range(steps):
+        t, seg = data[it % len(data)]
+        for m, e in engs.items():
+            out = e.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            traj[m].append(out['loss_cls'].double().sum() + out['loss_cls_noise'].double().sum())
+        if log and (it + 1) % log == 0:
+            print('  step %d: %s' % (it + 1, '  '.join('%s %.6f' % (m, float(traj[m][-1])) for m in modes)),
+                  flush=True)
+    for e in engs.values():
+        e.flush()
+    torch.cuda.synchronize()
+    return {m: np.array([float(v) for v in tr]) for m, tr in traj.items()}
+
+
+def horizon(a, b, tol):
+    """First step (0-based) at which |a - b| / |b| exceeds tol; len(a) if never."""
+    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-30)
+    bad = np.nonzero(~(rel <= tol))[0]
+    return (int(bad[0]) if bad.size else len(a)), rel
+
+
+def report(traj, a, b, y, tol=1e-3):
+    """(lines, ok): plan a against plan b, with plan y against b as the yardstick."""
+    ha, rel_a = horizon(traj[a], traj[b], tol)
+    hy, rel_y = horizon(traj[y], traj[b], tol)
+    n = len(traj[a])
+    lines = ['| step | loss %s | loss %s | loss %s | rel %s vs %s | rel %s vs %s |' % (a, b, y, a, b, y, b),
+             '|---|---|---|---|---|---|---|']
+    for i in sorted(set(list(range(0, n, max(1, n // 20))) + [n - 1])):
+        lines.append('| %d | %.6f | %.6f | %.6f | %.2e | %.2e |' % (
+            i + 1, traj[a][i], traj[b][i], traj[y][i], rel_a[i], rel_y[i]))
+    lines.append('')
+    lines.append('%s stays within %.0e of %s for %d of %d steps (max %.2e over them); the two fp32 '
+                 'orderings %s / %s stay within it for %d (max %.2e).' % (
+                     a, tol, b, ha, n, rel_a[:max(ha, 1)].max(), y, b, hy, rel_y[:max(hy, 1)].max()))
+    finite = all(np.isfinite(traj[m]).all() for m in (a, b, y))
+    # the horizon of a chaotic map is itself a noisy quantity (the step at which a 1e-4 difference
+    # becomes 1e-3 moves by a step or two with the rounding of one sum): `a` passes when its
+    # horizon is not shorter than the yardstick's by more than max(2 steps, 1/8)
+    slack = max(2, hy // 8)
+    lines.append('criterion: horizon(%s) >= horizon(%s) - %d steps.' % (a, y, slack))
+    return lines, bool(finite and ha >= hy - slack)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--lr', type=float, default=1e-4)
+    ap.add_argument('--rois', type=int, default=2000)
+    ap.add_argument('--height', type=int, default=600)
+    ap.add_argument('--width', type=int, default=1000)
+    ap.add_argument('--compare', nargs=2, default=['fp16x2', 'fp32'])
+    ap.add_argument('--yardstick', default='fp32x3')
+    ap.add_argument('--skewed', action='store_true')
+    ap.add_argument('--tol', type=float, default=1e-3)
+    ap.add_argument('--log', type=int, default=20)
+    ap.add_argument('--out', default='')
+    a = ap.parse_args()
+    modes = [a.compare[0], a.compare[1], a.yardstick]
+    traj = run(modes, a.steps, a.lr, a.rois, a.height, a.width, skewed=a.skewed, log=a.log)
+    lines, ok = report(traj, a.compare[0], a.compare[1], a.yardstick, a.tol)
+    head = ['# Cross-plan soak: %s vs %s (yardstick %s), %d steps, lr %g, %dx%d x %d rois, %s statistics'
+            % (a.compare[0], a.compare[1], a.yardstick, a.steps, a.lr, a.height, a.width, a.rois,
+               'skewed' if a.skewed else 'Kaiming'), '']
+    text = '\n'.join(head + lines + ['', 'verdict: %s' % ('ok' if ok else 'FAILED')])
+    print(text)
+    if a.out:
+        with open(a.out, 'w') as f:
+            f.write(text + '\n')
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == '__main__':
+    main()

@@ -580,7 +580,8 @@ def head_float64(roi_feat, rois, labels_oh, blobs, masks, class_weights, is_mean
     cancellation-heavy softmax backward differ from each other by more than either differs from
     this one; tests bound both distances.  The entropy-gate weights are StopGradient constants
     (webly_heads.py:390-391): `class_weights` = [(class_weight, class_weight_noise)] per image,
-    taken from the fp32 evaluation.  -> dict(losses, d_logits [R,4C], grads per blob), float64."""
+    taken from the fp32 evaluation.  -> dict(losses, d_logits [R,4C], grads per blob, act = the
+    four dropout outputs), float64."""
     import torch
     f64 = torch.float64
     x = torch.from_numpy(np.asarray(roi_feat, np.float32).reshape(rois.shape[0], -1)).to(f64)
@@ -617,4 +618,6 @@ def head_float64(roi_feat, rois, labels_oh, blobs, masks, class_weights, is_mean
                 cls_prob=np.stack(probs[0::2]), cls_prob_noise=np.stack(probs[1::2]),
                 logits=torch.cat([act[k].detach() for k in
                                   ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')], 1).numpy(),
-                grads={n: params[n].grad.numpy() for n in names})
+                grads={n: params[n].grad.numpy() for n in names},
+                act={k: act[k].detach().numpy() for k in ('drop6', '_[noisy]_drop6', 'drop7',
+                                                          '_[noisy]_drop7')})

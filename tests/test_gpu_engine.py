@@ -362,3 +362,80 @@ def test_train_step_with_an_exchange_or_other_plans_is_the_two_call_form(dev):
         eng.flush()
         assert not eng._can_fuse_wgrad_update()
         assert not bool((gw6 == 123.0).all())
+
+
+def test_checkpoint_save_mid_run_leaves_the_trajectory_bit_identical(dev):
+    """export_blobs() (every checkpoint save) must not mark the operand planes dirty -
+    the step after a save would drop the wgrad-epilogue route and re-split with exact instead of
+    bound-derived scales, i.e. the fp16x2 trajectory would depend on the checkpoint cadence."""
+    res = []
+    for save in (False, True):
+        eng, mb, _blobs = _setup(dev, mfma_dtype='fp16x2')
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        eng.set_lr(1e-3)
+        for it in range(4):
+            eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+            if save and it in (1, 2):
+                snap = {k: v.cpu() for k, v in eng.export_blobs().items()}
+                assert 'fc6_w' in snap and 'fc6_w_momentum' in snap
+                assert not eng._planes_dirty and eng._can_fuse_wgrad_update()
+        eng.flush()
+        torch.cuda.synchronize()
+        wp = eng._wplanes
+        res.append((eng.params.clone(), eng.momentum_buf.clone(),
+                    [wp[k].planes.view(torch.int16).clone() for k in ('w6', 'w7', 'w7t')]))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+
+
+@pytest.mark.parametrize('mode', ['fp16x2', 'fp32x3'])
+def test_plane_writing_update_needs_one_hyper_parameter_run_per_region(dev, mode):
+    """the plane-writing SGD kernel applies ONE (lr_mult, weight decay) per region.  A
+    configuration whose clean and noisy fc6_w differ in either must fall back to the element-wise
+    kernel (+ re-split): same parameters as the oracle's per-blob update, no silent use of the
+    clean branch's settings."""
+    eng, mb, _blobs = _setup(dev, mfma_dtype=mode)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    o, n, _shape = eng.arena.offsets['_[noisy]_fc6_w']
+    ends, lrm, wd = eng._seg_host
+    assert eng._one_hyper_run(eng.arena.offsets['fc6_w'][0], 2 * n)
+    # split the first run at the noisy branch: it gets lr_mult 10 (a '_lrm10_' blob would)
+    i = next(k for k, e in enumerate(ends) if e > o)
+    ends2 = ends[:i] + [o, o + n] + ([ends[i]] if ends[i] > o + n else []) + ends[i + 1:]
+    lrm2 = lrm[:i] + [lrm[i], 10.0] + ([lrm[i]] if ends[i] > o + n else []) + lrm[i + 1:]
+    wd2 = wd[:i] + [wd[i], wd[i]] + ([wd[i]] if ends[i] > o + n else []) + wd[i + 1:]
+    eng._seg_host = (ends2, lrm2, wd2)
+    eng.seg_end = torch.tensor(ends2, dtype=torch.int64, device=dev)
+    eng.seg_lr_mult = torch.tensor(lrm2, dtype=torch.float32, device=dev)
+    eng.seg_wd = torch.tensor(wd2, dtype=torch.float32, device=dev)
+    assert not eng._one_hyper_run(eng.arena.offsets['fc6_w'][0], 2 * n)
+    eng.set_lr(1e-3)
+    p0 = eng.params.clone()
+    eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+    eng.flush()
+    assert eng._sgd_regions is None and not eng._can_fuse_wgrad_update()
+    g = eng.grads
+    # first step, zero momentum: dp = lr * lr_mult * (g / gpu_num + wd * p)
+    for name, mult in (('fc6_w', 1.0), ('_[noisy]_fc6_w', 10.0)):
+        gp = eng.arena.view(g, name).double() / eng.gpu_num + 5e-4 * eng.arena.view(p0, name).double()
+        want = eng.arena.view(p0, name).double() - 1e-3 * mult * gp
+        got = eng.arena.view(eng.params, name).double()
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()), name
+
+
+def test_cross_plan_soak_short(dev):
+    """tools/soak_crossplan.py at a reduced size: 40 training steps of the 2 x f16 split plan,
+    the fp32-MFMA plan and the exact 3 x bf16 split in lockstep; the headline plan must track
+    the fp32-MFMA plan's loss trajectory (1e-3) at least as long as the other fp32 ordering does."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    'na-fwebsod_amd', 'tools'))
+    import soak_crossplan as sc
+    traj = sc.run(['fp16x2', 'fp32', 'fp32x3'], steps=40, lr=1e-4, rois=300, height=256, width=384,
+                  device=dev)
+    lines, ok = sc.report(traj, 'fp16x2', 'fp32', 'fp32x3')
+    print('\n' + '\n'.join(lines))
+    assert ok
+    assert sc.horizon(traj['fp16x2'], traj['fp32'], 1e-3)[0] >= 10

@@ -45,9 +45,13 @@ def _engine(dev, c, blobs, mode):
     return eng
 
 
-@pytest.fixture(scope='module')
-def ref20(dev):
-    """Oracle forward + backward of one full-size image, C = 20, plus the float64 arbiter."""
+def _reference(dev, stats):
+    """Oracle forward + backward of one full-size image, C = 20, plus the float64 arbiter.
+    stats = 'kaiming': seeded Kaiming-normal weights, zero biases, uniform-random pixels (the
+    bench workload); 'skewed': synthetic.skew_blobs / skew_images on top of that - per-channel
+    weight scales log-uniform over 2^+-6 in every conv and fc layer, non-zero biases, the left
+    third of the image at 2^-12 of the rest plus a smooth low-frequency component (VERDICT r3
+    weak #2: the split plans' error depends on the operand statistics)."""
     from detectron.datasets import synthetic
     from oracle import oracle
     torch.set_num_threads(max(1, torch.get_num_threads()))
@@ -55,6 +59,9 @@ def ref20(dev):
     blobs = synthetic.init_blobs(c, seed=SEED)
     mb = synthetic.make_minibatch(synthetic.make_roidb(1, R, c, H, W, seed=SEED), c)
     assert mb['rois'].shape[0] == R
+    if stats == 'skewed':
+        blobs = synthetic.skew_blobs(blobs, seed=SEED)
+        mb['data'] = synthetic.skew_images(mb['data'])
     eng = _engine(dev, c, blobs, 'fp32')
     masks = _masks(eng, R, dev)           # the counter-based masks every plan draws at step 0
     del eng
@@ -62,6 +69,16 @@ def ref20(dev):
     cw = [(t['class_weight'], t['class_weight_noise']) for t in ref['tails']]
     arb = oracle.head_float64(ref['roi_feat'], mb['rois'], mb['labels_oh'], blobs, masks, cw)
     return dict(c=c, blobs=blobs, mb=mb, masks=masks, ref=ref, arb=arb)
+
+
+@pytest.fixture(scope='module')
+def ref20(dev):
+    return _reference(dev, 'kaiming')
+
+
+@pytest.fixture(scope='module')
+def ref20_skewed(dev):
+    return _reference(dev, 'skewed')
 
 
 def _relmax(a, b):
@@ -96,20 +113,64 @@ def test_roi_pool_bitexact_at_full_size(dev, ref20):
     assert torch.equal(y2, y)
 
 
+def _region_relmax(got_nchw, want_nchw):
+    """Relative measures that a tensor-wide maximum hides: (a) per channel, max error / the
+    channel's own max (channels 12 octaves below the loudest one must still be right), (b) the
+    same over the columns that see only the dark third of the image."""
+    g = got_nchw.detach().cpu().numpy().astype(np.float64)
+    w = want_nchw.astype(np.float64)
+    err = np.abs(g - w)
+    cmax = np.abs(w).max(axis=(0, 2, 3))
+    live = cmax > 0
+    per_channel = float((err.max(axis=(0, 2, 3))[live] / cmax[live]).max())
+    wd = w.shape[3] // 3 - 4                                   # conv5_3 columns inside the dark third
+    dark = float(err[..., :wd].max() / max(np.abs(w[..., :wd]).max(), 1e-300))
+    return per_channel, dark
+
+
 @pytest.mark.parametrize('mode', ['fp16x2', 'fp32x3', 'fp32'])
-def test_full_size_training_step_matches_oracle(dev, ref20, mode):
-    c, blobs, mb, ref, arb = (ref20[k] for k in ('c', 'blobs', 'mb', 'ref', 'arb'))
+@pytest.mark.parametrize('stats', ['kaiming', 'skewed'])
+def test_full_size_training_step_matches_oracle(dev, request, stats, mode):
+    r20 = request.getfixturevalue('ref20' if stats == 'kaiming' else 'ref20_skewed')
+    c, blobs, mb, ref, arb = (r20[k] for k in ('c', 'blobs', 'mb', 'ref', 'arb'))
+    mode_tag = '%s, %s' % (mode, stats)
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
     eng = _engine(dev, c, blobs, mode)
     # ---- stage by stage (the same kernels forward_backward launches)
     conv5 = eng.conv_body(t['data'])
     m = {'conv5_3': _relmax(conv5.permute(0, 3, 1, 2), ref['conv5_3'])}
+    m['conv5_3/channel'], m['conv5_3/dark third'] = _region_relmax(conv5.permute(0, 3, 1, 2),
+                                                                   ref['conv5_3'])
     x = eng._roi_features(conv5, t['rois'], t['obn_scores'])
     m['roi_feat'] = _relmax(_dense_roi_feat(x), ref['roi_feat'].reshape(R, -1))
     h6, h7, lg = eng.head_forward(x, train=True)
     act = ref['act']
     for got, names in ((h6, ('drop6', '_[noisy]_drop6')), (h7, ('drop7', '_[noisy]_drop7'))):
-        m[names[0]] = _relmax(got, np.concatenate([act[n] for n in names], 1))
+        want = np.concatenate([act[n] for n in names], 1)
+        m[names[0]] = _relmax(got, want)
+    # ---- the head's GEMMs alone, per output UNIT (its own maximum as the yardstick: a unit 12
+    # octaves below the loudest one weighs as much in the next layer once that layer's weights
+    # undo the factor).  Input: the oracle's roi_feat, so that the float64 arbiter sees the same
+    # operand; yardstick: the fp32 oracle's own per-unit distance from float64 (a dot product of
+    # 25088 fp32 terms has an error floor that no fp32 plan can beat).
+    xo = torch.from_numpy(ref['roi_feat'].reshape(R, -1)).to(dev)
+    h6o, h7o, _lgo = eng.head_forward(xo, train=True)
+    unit = {}
+    for got, names in ((h6o, ('drop6', '_[noisy]_drop6')), (h7o, ('drop7', '_[noisy]_drop7'))):
+        w64 = np.concatenate([arb['act'][n] for n in names], 1)
+        w32 = np.concatenate([act[n] for n in names], 1).astype(np.float64)
+        cmax = np.abs(w64).max(axis=0)
+        live = cmax > 0
+        e_hip = (np.abs(got.cpu().numpy().astype(np.float64) - w64).max(axis=0)[live] / cmax[live])
+        e_orc = (np.abs(w32 - w64).max(axis=0)[live] / cmax[live])
+        unit[names[0]] = (float(e_hip.max()), float(e_orc.max()),
+                          float(np.median(e_hip)), float(np.median(e_orc)))
+    print('[%s] per-unit max error / unit max vs float64 (HIP max, fp32 oracle max, HIP median, '
+          'oracle median): %s' % (mode_tag, ', '.join('%s %.1e/%.1e/%.1e/%.1e' % ((k,) + v)
+                                                      for k, v in unit.items())))
+    for k, (hmax, omax, hmed, omed) in unit.items():
+        assert hmax <= max(1e-4, 4 * omax) and hmed <= max(1e-5, 4 * omed), (k, unit[k])
+    del xo, h6o, h7o, _lgo
     ld8 = eng.ld8
     cols = [0, c, ld8, ld8 + c]
     logits = np.concatenate([act[k] for k in LOGIT_KEYS], 1)
@@ -117,7 +178,7 @@ def test_full_size_training_step_matches_oracle(dev, ref20, mode):
     m['logits'] = _relmax(got_logits, logits)
     lmax = float(np.abs(logits).max())
     print('\n[%s] max error / max|blob| vs oracle: %s; max|logit| %.2f' % (
-        mode, ', '.join('%s %.1e' % kv for kv in m.items()), lmax))
+        mode_tag, ', '.join('%s %.1e' % kv for kv in m.items()), lmax))
     for k, v in m.items():
         assert v < 1e-4, (k, v)
     del conv5, x, h6, h7, lg
@@ -135,14 +196,14 @@ def test_full_size_training_step_matches_oracle(dev, ref20, mode):
     ptol = 2e-4 * max(1.0, lmax)
     e64 = float(np.abs(got_logits.cpu().numpy() - arb['logits']).max() / np.abs(arb['logits']).max())
     o64 = float(np.abs(logits - arb['logits']).max() / np.abs(arb['logits']).max())
-    print('[%s] logits vs float64: HIP %.1e, fp32 oracle %.1e' % (mode, e64, o64))
+    print('[%s] logits vs float64: HIP %.1e, fp32 oracle %.1e' % (mode_tag, e64, o64))
     assert e64 <= 1e-5          # north_star asks 1e-4; the oracle's head alone is at 4e-7
     for k in ('cls_prob', 'cls_prob_noise'):
         got, want, p64 = out[k][0].cpu().numpy(), tl[k][0], arb[k][0]
         rel = float(np.abs(got / want - 1).max())
         r64, o64 = float(np.abs(got / p64 - 1).max()), float(np.abs(want / p64 - 1).max())
         print('[%s] %s max relative error: vs fp32 oracle %.1e; vs float64: HIP %.1e, fp32 '
-              'oracle %.1e (bound %.1e)' % (mode, k, rel, r64, o64, ptol))
+              'oracle %.1e (bound %.1e)' % (mode_tag, k, rel, r64, o64, ptol))
         assert rel <= ptol and r64 <= ptol, (k, rel, r64)
     np.testing.assert_allclose(out['class_weight'][0].cpu().numpy(), tl['class_weight'][0],
                                rtol=1e-4, atol=1e-6)
@@ -154,7 +215,7 @@ def test_full_size_training_step_matches_oracle(dev, ref20, mode):
     dlg = out['d_logits'].cpu().numpy().astype(np.float64)
     n64 = np.linalg.norm(dl64)
     e_hip, e_orc = np.linalg.norm(dlg - dl64) / n64, np.linalg.norm(dl32 - dl64) / n64
-    print('[%s] d_logits normwise error vs float64: HIP %.1e, fp32 oracle %.1e' % (mode, e_hip, e_orc))
+    print('[%s] d_logits normwise error vs float64: HIP %.1e, fp32 oracle %.1e' % (mode_tag, e_hip, e_orc))
     assert e_hip <= 1e-4, ('d_logits', e_hip, e_orc)
     report = {}
     for name, g64 in arb['grads'].items():
@@ -170,7 +231,7 @@ def test_full_size_training_step_matches_oracle(dev, ref20, mode):
         e_hip, e_orc = np.linalg.norm(got - g64) / n, np.linalg.norm(g32 - g64) / n
         report[name] = (e_hip, e_orc)
     print('\n[%s] normwise gradient error vs float64 (HIP, fp32 oracle): %s' % (
-        mode, ', '.join('%s %.1e/%.1e' % (k, a, b) for k, (a, b) in report.items())))
+        mode_tag, ', '.join('%s %.1e/%.1e' % (k, a, b) for k, (a, b) in report.items())))
     # A gradient entry is (probability) x (activation): its relative error is the ABSOLUTE logit
     # error (here 3e-6 x max|logit| 58 = 1.7e-4, of which the conv body's 2e-6 - not seen by the
     # arbiter, which starts from the oracle's roi_feat - is the larger part).  Measured 1e-5
