@@ -48,6 +48,13 @@ def parse():
                          '(RCCL refuses two ranks on one device): runs the real N > 1 schedule - '
                          'chunked fc6_w exchange, deferred update behind it - on a 1-GPU box.  The '
                          'line says shared_gpu: true; its value is NOT a throughput claim')
+    ap.add_argument('--emulate-exchange', default='',
+                    help='N[,CUS[,GB/s]]: one rank only - run the N-rank schedule (gradient written, '
+                         'chunked fc6_w messages, deferred update) with naws_emulate_exchange '
+                         'standing in for the RCCL all-reduce: CUS compute units (default 32) '
+                         'move 2 (N-1)/N of every message through HBM at the links\' pace '
+                         '(default 0.6 x 153 GB/s x min(N-1, 7)).  The line is labelled a '
+                         'projection.  The default one-GPU run appends the N = 8 projection')
     ap.add_argument('--no-fused-update', action='store_true',
                     help='one rank only: write fc6_w\'s gradient and update it in the deferred SGD '
                          'kernel (the route every rank takes when there is a gradient exchange) '
@@ -408,6 +415,39 @@ def extra_configs(args, dev, B, res, cfg, roof):
         roof['tta_infer_' + {'achieved': 'whole_image_tflops'}.get(k, k)] = ti['roofline'].get(k)
 
 
+def project_n_ranks(eng, t, seg, n, cus, gbps, steps):
+    """ms/step of the N-rank schedule on this one GPU with reducer.EmulatedExchange in the
+    all-reduce's place (restores the engine's own reducer afterwards)."""
+    import torch
+    from naws_hip.reducer import EmulatedExchange
+    eng.flush()
+    saved = (eng.reducer, eng.allreduce_chunks, eng.phase_events, eng.timing_events,
+             eng.update_events, eng.comm_events)
+    ex = EmulatedExchange(eng.device, n, cus, gbps)
+    eng.reducer, eng.allreduce_chunks = ex, (4 if n == 2 else 2)
+    eng.timing_events = eng.update_events = eng.comm_events = None
+    pev = []
+    try:
+        for it in range(5 + steps):
+            if it == 5:
+                eng.flush()
+                torch.cuda.synchronize()
+                eng.phase_events = pev
+                t0 = time.perf_counter()
+            eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            eng.sgd_step()
+        eng.flush()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        (eng.reducer, eng.allreduce_chunks, eng.phase_events, eng.timing_events,
+         eng.update_events, eng.comm_events) = saved
+    exposed = [e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]) if n1 == 'join_update']
+    return {'ms_per_step': round(ms, 3), 'cus': ex.cus, 'gbps': ex.gbps, 'chunks': 4 if n == 2 else 2,
+            'bytes_per_step': ex.bytes_per_step,
+            'exposed_ms': sum(exposed) / max(len(exposed), 1)}
+
+
 def plan_peak_and_kernel(mode):
     """(ceiling in ALGORITHMIC TFLOP/s, name) of a plan's fc6-forward kernel.  The split plans
     execute 3 (fp16x2) / 6 (fp32x3) 16-bit MFMA flops per algorithmic fp32 flop, so their
@@ -449,7 +489,18 @@ def launcher_command(n, port, argv, python=None, script=None):
 
 def launcher_env(environ):
     """Environment of the children: the parent's, minus any rank variables (a stale RANK /
-    WORLD_SIZE would be trusted by the ranks), plus the dmabuf-IPC switch RCCL needs here."""
+    WORLD_SIZE would be trusted by the ranks), plus HSA_ENABLE_IPC_MODE_LEGACY=0.
+
+    Where that switch comes from: the build environment's own operating notes for this GPU
+    pool - the hosts' kernel driver supports only dmabuf IPC, and with the ROCr default
+    (legacy IPC handles) any cross-process device-memory sharing, which is how RCCL sets up
+    its intra-node xGMI transport, fails with `hipIpcGetMemHandle: invalid argument`.  The
+    pool exports the variable itself (in this container and on the GPU boxes); `setdefault`
+    only restores it for a caller who scrubbed the environment and never overrides a value
+    the operator chose.  It has NOT been exercised here with two RCCL ranks (no multi-GPU
+    box was ever available to this project); the one-rank RCCL path (--force-dist) runs with
+    it.  Should a site's driver want legacy IPC, exporting HSA_ENABLE_IPC_MODE_LEGACY=1
+    before the launch wins."""
     env = {k: v for k, v in environ.items()
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK',
                         'MASTER_ADDR', 'MASTER_PORT')}
@@ -690,6 +741,16 @@ def main():
         eng.flush()
         torch.cuda.synchronize()
         deferred_ms = (time.perf_counter() - d0) / n_def * 1e3
+    # One rank: what the N-rank schedule costs THIS GPU when something occupies compute units and
+    # HBM the way the RCCL exchange would (reducer.EmulatedExchange; a projection, labelled so)
+    projections = {}
+    if world == 1 and args.mfma_dtype == 'fp16x2' and not args.share_gpu and not args.force_dist:
+        spec = [x for x in args.emulate_exchange.split(',') if x]
+        cases = [(int(spec[0]), int(spec[1]) if len(spec) > 1 else 32,
+                  float(spec[2]) if len(spec) > 2 else None)] if spec else \
+            [(n, 32, None) for n in (2, 4, 8)]
+        for n, cus, gbps in cases:
+            projections[n] = project_n_ranks(eng, t, seg, n, cus, gbps, max(20, args.steps // 3))
     conv_alone_ms = None
     if rank == 0:
         eng.timing_events = eng.phase_events = eng.update_events = eng.comm_events = None
@@ -833,6 +894,14 @@ def main():
                'exposed_comm_ms': None,
                'allreduce_wait_ms': (round(sum(s.elapsed_time(e) for s, e in cev) / len(cev), 3)
                                      if cev else None)}
+        for n, pr in sorted(projections.items()):
+            # PROJECTIONS, not measurements of an N-GPU job: the one-rank step with the N-rank
+            # schedule and a paced copy kernel in the all-reduce's place (see EmulatedExchange)
+            cfg['projected_ms_per_step_n%d' % n] = pr['ms_per_step']
+            cfg['projected_images_per_sec_n%d' % n] = round(n * B / pr['ms_per_step'] * 1e3, 1)
+            cfg['projected_exchange_n%d' % n] = (
+                '%d CUs x %.0f GB/s, %.2f GB per step, allreduce_chunks %d, exposed %.2f ms'
+                % (pr['cus'], pr['gbps'], pr['bytes_per_step'] / 1e9, pr['chunks'], pr['exposed_ms']))
         for k, v in stage_ms.items():                 # flat: the driver's parser drops nested dicts
             cfg['stage_ms_' + k] = v
         cfg['exposed_comm_ms'] = stage_ms.get('join_update')

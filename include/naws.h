@@ -732,6 +732,13 @@ int naws_set_variant(const char* knob, int value);
  * wave slots from an MFMA-bound one.  The handle is a hipStream_t; release it with
  * naws_stream_destroy.  No reference counterpart (Caffe2 runs one stream per GPU). */
 int naws_stream_create(int priority, const uint32_t* cu_mask, int mask_words, void** stream);
+/* MEASUREMENT AID, not on the product path (bench.py --emulate-exchange): `cus` workgroups copy
+ * `bytes` (a multiple of 16) from src to dst at an aggregate pace of gbytes_per_sec - what an RCCL
+ * ring all-reduce does to a rank's compute units and HBM for the duration the xGMI links allow,
+ * so that a one-GPU box can show what the exchange costs the kernels it runs beside.  Replaces
+ * nothing in the reference (its exchange is NCCLAllreduce, detectron/modeling/optimizer_wsl.py:52-72). */
+int naws_emulate_exchange(const void* src, void* dst, int64_t bytes, int cus, float gbytes_per_sec,
+                          void* stream);
 int naws_stream_destroy(void* stream);
 
 #ifdef __cplusplus

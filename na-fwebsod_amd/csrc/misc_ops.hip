@@ -128,6 +128,55 @@ extern "C" int naws_stream_create(int priority, const uint32_t* cu_mask, int mas
   return NAWS_OK;
 }
 
+// ---- measurement aid: a stand-in for an RCCL collective on a one-GPU box --------------------------
+// `cus` workgroups copy `bytes` from src to dst at a paced aggregate rate (the link rate a ring
+// all-reduce would see), i.e. they hold `cus` compute units and move the exchange's bytes through
+// HBM for as long as the collective would last.  bench.py --emulate-exchange queues it where the
+// reducer queues its all-reduce; nothing on the product path calls it.
+namespace {
+__global__ void __launch_bounds__(256) exchange_proxy_kernel(const float4* __restrict__ src,
+                                                             float4* __restrict__ dst, int64_t n16,
+                                                             double ticks_per_chunk) {
+  const int64_t per = ((n16 + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024;
+  const int64_t i0 = (int64_t)blockIdx.x * per;
+  const int64_t i1 = i0 + per < n16 ? i0 + per : n16;
+  const uint64_t t0 = wall_clock64();
+  int64_t k = 0;
+  for (int64_t i = i0; i < i1; i += 1024, ++k) {        // 16 KB per workgroup and round
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t j = i + u * 256 + threadIdx.x;
+      v[u] = j < i1 ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t j = i + u * 256 + threadIdx.x;
+      if (j < i1) dst[j] = v[u];
+    }
+    const uint64_t due = (uint64_t)((double)(k + 1) * ticks_per_chunk);
+    while (wall_clock64() - t0 < due) __builtin_amdgcn_s_sleep(4);
+  }
+}
+}  // namespace
+
+extern "C" int naws_emulate_exchange(const void* src, void* dst, int64_t bytes, int cus,
+                                     float gbytes_per_sec, void* stream) {
+  NAWS_REQUIRE_PTR(src);
+  NAWS_REQUIRE_PTR(dst);
+  if (bytes < 0 || bytes % 16 != 0 || cus < 1 || !(gbytes_per_sec > 0.f)) return NAWS_ERR_ARG;
+  if (bytes == 0) return NAWS_OK;
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+    return naws_check_launch();
+  // one workgroup moves 16 KB per round at gbytes_per_sec / cus
+  const double ticks = 16384.0 * cus / (gbytes_per_sec * 1e9) * (khz * 1e3);
+  exchange_proxy_kernel<<<cus, 256, 0, (hipStream_t)stream>>>((const float4*)src, (float4*)dst,
+                                                              bytes / 16, ticks);
+  return naws_check_launch();
+}
+
 extern "C" int naws_stream_destroy(void* stream) {
   if (!stream) return NAWS_OK;
   if (hipStreamDestroy((hipStream_t)stream) != hipSuccess) {

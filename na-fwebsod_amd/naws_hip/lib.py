@@ -109,6 +109,7 @@ PROTOTYPES = {
     'naws_set_variant': [C.c_char_p, i32],
     'naws_stream_create': [i32, p, i32, p],
     'naws_stream_destroy': [p],
+    'naws_emulate_exchange': [p, p, i64, i32, f32, p],
     'naws_gemm_f32_f16x2_nt_xk': [i32, i32, i32, p, i64, i64, p, p, i64, i64, i32, p, p, i32, p],
     'naws_gemm_f32_f16x2_nt_xk_sgd': [i32, i32, i32, p, i64, i64, p, p, i64, i64, i32, p, p, p, i32, p,
                                       f32, f32, f32, i32, i32, i64, p, i64, i32, p, p, p, p, i32, p],

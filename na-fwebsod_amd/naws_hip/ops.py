@@ -417,6 +417,17 @@ def conv3x3_winograd_nhwc_f32x3(x, u3, bias, dilation=1, relu=True, out=None):
     return y
 
 
+def emulate_exchange(src, dst, nbytes, cus, gbytes_per_sec):
+    """MEASUREMENT AID (bench.py --emulate-exchange): `cus` workgroups copy nbytes from src to
+    dst at the given aggregate pace on the current stream - see naws_emulate_exchange."""
+    _chk(src, 'src'); _chk(dst, 'dst')
+    nbytes = int(nbytes) // 16 * 16
+    if nbytes > src.numel() * 4 or nbytes > dst.numel() * 4:
+        raise ValueError('emulate_exchange: nbytes exceeds a buffer')
+    L.call('naws_emulate_exchange', src.data_ptr(), dst.data_ptr(), nbytes, int(cus),
+           float(gbytes_per_sec), _stream())
+
+
 def amax_word(x, out=None):
     """Bit pattern (int32 [1]) of max|x| over a contiguous fp32 tensor."""
     _chk(x, 'x')

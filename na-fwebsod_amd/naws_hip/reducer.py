@@ -68,3 +68,50 @@ class ArenaReducer(object):
         for w in self._pending:
             w.wait()
         self._pending = []
+
+
+class EmulatedExchange(object):
+    """MEASUREMENT AID - `bench.py --emulate-exchange N[,CUS[,GB/s]]` on a one-GPU box: takes the
+    reducer's place and, for every gradient message the engine hands over, queues what an
+    N-rank ring all-reduce of that message does to THIS rank: a reduce-scatter phase and an
+    all-gather phase, each moving (N-1)/N of the message through HBM on `cus` compute units at
+    the pace the xGMI links allow, on a communication stream ordered behind the kernels that
+    produced the message.  The gradients are only read (the copy lands in a scratch buffer), so
+    the arithmetic is the one-rank step's; the schedule - chunked fc6_w messages during the
+    backward pass, the deferred update waiting for the last of them underneath the next conv
+    body - is the N-rank one.  The step time measured this way is a PROJECTION of the N-rank
+    step (it has the contention for compute units and HBM, not the links' own hiccups)."""
+
+    def __init__(self, device, n_ranks, cus=32, gbytes_per_sec=None):
+        import torch
+        self.device = device
+        self.n = int(n_ranks)
+        self.cus = int(cus)
+        # default pace: min(N-1, 7) xGMI links x 153 GB/s per direction at 60 % efficiency
+        self.gbps = float(gbytes_per_sec) if gbytes_per_sec else 0.6 * 153.0 * min(self.n - 1, 7)
+        self.world_size = 1            # (the update's 1/gpu_num is the caller's business)
+        self.force = True
+        self._stream = torch.cuda.Stream(device=device)
+        self._scratch = None
+        self.bytes_per_step = 0
+        self._step_bytes = 0
+
+    active = True
+
+    def reduce_async(self, flat_slice):
+        import torch
+        from . import ops
+        n = flat_slice.numel()
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.empty((n,), device=self.device, dtype=torch.float32)
+        part = int(n * 4 * (self.n - 1) / self.n) // 16 * 16
+        self._stream.wait_event(torch.cuda.current_stream(self.device).record_event())
+        with torch.cuda.stream(self._stream):
+            for _phase in range(2):        # reduce-scatter, all-gather
+                ops.emulate_exchange(flat_slice, self._scratch, part, self.cus, self.gbps)
+        self._step_bytes += 2 * part
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream(self.device).wait_event(self._stream.record_event())
+        self.bytes_per_step, self._step_bytes = self._step_bytes, 0

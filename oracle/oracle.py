@@ -438,9 +438,13 @@ def prep_image(im_u8, im_scale, flip=False, crop=None, means=(0, 0, 0), stds=(1,
     return resize_bilinear_cv2(im, im_scale)
 
 
-def vgg16_conv5_body(data, blobs):
+def vgg16_conv5_body(data, blobs, stats=None):
     """ref: detectron/modeling/VGG16.py:9-48 with WSL.DILATION == 2.
-    data: torch CPU [N,3,H,W]; blobs: {name_w: [O,I,3,3], name_b: [O]} -> conv5_3 NCHW."""
+    data: torch CPU [N,3,H,W]; blobs: {name_w: [O,I,3,3], name_b: [O]} -> conv5_3 NCHW.
+    stats (a dict): receives name + '_rms' = the per-channel RMS of every layer's output BEFORE
+    its ReLU - the scale of a channel's dot products, the yardstick of the per-channel parity
+    measure (a channel's post-ReLU maximum would not do: a nearly dead channel has a tiny
+    maximum but the full rounding error of its sums)."""
     import torch
     import torch.nn.functional as F
     x = data
@@ -451,8 +455,11 @@ def vgg16_conv5_body(data, blobs):
             x = F.max_pool2d(x, 2, 1, 0, ceil_mode=False)
         else:
             name, _, _, dil = item
-            x = F.relu(F.conv2d(x, blobs[name + '_w'], blobs[name + '_b'], stride=1,
-                                padding=dil, dilation=dil))
+            x = F.conv2d(x, blobs[name + '_w'], blobs[name + '_b'], stride=1, padding=dil,
+                         dilation=dil)
+            if stats is not None:
+                stats[name + '_rms'] = x.double().pow(2).mean(dim=(0, 2, 3)).sqrt().numpy()
+            x = F.relu(x)
     return x
 
 
@@ -467,11 +474,15 @@ def head_forward(roi_feat, blobs, masks, train=True):
     out = {}
     x = roi_feat.reshape(roi_feat.shape[0], -1)
     for pre in ('', '_[noisy]_'):
-        h = F.relu(F.linear(x, blobs[pre + 'fc6_w'], blobs[pre + 'fc6_b']))
+        z = F.linear(x, blobs[pre + 'fc6_w'], blobs[pre + 'fc6_b'])
+        out[pre + 'fc6_rms'] = z.detach().pow(2).mean(0).sqrt()   # per unit: the scale of its dot product
+        h = F.relu(z)
         if train:
             h = h * masks[pre + 'drop6'] * 2.0
         out[pre + 'drop6'] = h
-        h = F.relu(F.linear(h, blobs[pre + 'fc7_w'], blobs[pre + 'fc7_b']))
+        z = F.linear(h, blobs[pre + 'fc7_w'], blobs[pre + 'fc7_b'])
+        out[pre + 'fc7_rms'] = z.detach().pow(2).mean(0).sqrt()
+        h = F.relu(z)
         if train:
             h = h * masks[pre + 'drop7'] * 2.0
         out[pre + 'drop7'] = h
@@ -532,10 +543,11 @@ def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatia
         clock[0] = now
     rois = mb['rois']
     argmax = None
+    conv_stats = {}
     if conv5 is None:
         data = torch.from_numpy(mb['data'])
-        with torch.no_grad():
-            conv5 = vgg16_conv5_body(data, blobs).numpy()    # StopGradient: forward only
+        with torch.no_grad():                                # StopGradient: forward only
+            conv5 = vgg16_conv5_body(data, blobs, conv_stats if timings is None else None).numpy()
     lap('conv')
     if roi_feat is None:
         pooled, argmax = roi_pool_f(conv5, rois, roi_size, roi_size, spatial_scale)
@@ -560,7 +572,7 @@ def full_forward_backward(blobs, mb, masks, num_fg_classes, is_mean=True, spatia
         for k in dl:
             dl[k][sel] = t['d_' + k]
     lap('loss')
-    res = dict(conv5_3=conv5, roi_feat=roi_feat, roi_argmax=argmax,
+    res = dict(conv5_3=conv5, roi_feat=roi_feat, roi_argmax=argmax, conv_stats=conv_stats,
                act={k: v.detach().numpy() for k, v in act.items()}, tails=tails, d_logits=dl)
     if backward:
         outs = [act[k] for k in ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')]
@@ -620,4 +632,6 @@ def head_float64(roi_feat, rois, labels_oh, blobs, masks, class_weights, is_mean
                                   ('fc8c', 'fc8d', 'noisy_fc8c', 'noisy_fc8d')], 1).numpy(),
                 grads={n: params[n].grad.numpy() for n in names},
                 act={k: act[k].detach().numpy() for k in ('drop6', '_[noisy]_drop6', 'drop7',
-                                                          '_[noisy]_drop7')})
+                                                          '_[noisy]_drop7', 'fc6_rms',
+                                                          '_[noisy]_fc6_rms', 'fc7_rms',
+                                                          '_[noisy]_fc7_rms')})

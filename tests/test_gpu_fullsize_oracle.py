@@ -113,16 +113,15 @@ def test_roi_pool_bitexact_at_full_size(dev, ref20):
     assert torch.equal(y2, y)
 
 
-def _region_relmax(got_nchw, want_nchw):
-    """Relative measures that a tensor-wide maximum hides: (a) per channel, max error / the
-    channel's own max (channels 12 octaves below the loudest one must still be right), (b) the
-    same over the columns that see only the dark third of the image."""
+def _region_relmax(got_nchw, want_nchw, channel_rms):
+    """Relative measures that a tensor-wide maximum hides: (a) per channel, max error / the RMS
+    of the channel's pre-activation (channels 12 octaves below the loudest one must still be
+    right), (b) max error / max value over the columns that see only the dark third of the image."""
     g = got_nchw.detach().cpu().numpy().astype(np.float64)
     w = want_nchw.astype(np.float64)
     err = np.abs(g - w)
-    cmax = np.abs(w).max(axis=(0, 2, 3))
-    live = cmax > 0
-    per_channel = float((err.max(axis=(0, 2, 3))[live] / cmax[live]).max())
+    live = channel_rms > 0
+    per_channel = float((err.max(axis=(0, 2, 3))[live] / channel_rms[live]).max())
     wd = w.shape[3] // 3 - 4                                   # conv5_3 columns inside the dark third
     dark = float(err[..., :wd].max() / max(np.abs(w[..., :wd]).max(), 1e-300))
     return per_channel, dark
@@ -139,8 +138,8 @@ def test_full_size_training_step_matches_oracle(dev, request, stats, mode):
     # ---- stage by stage (the same kernels forward_backward launches)
     conv5 = eng.conv_body(t['data'])
     m = {'conv5_3': _relmax(conv5.permute(0, 3, 1, 2), ref['conv5_3'])}
-    m['conv5_3/channel'], m['conv5_3/dark third'] = _region_relmax(conv5.permute(0, 3, 1, 2),
-                                                                   ref['conv5_3'])
+    m['conv5_3/channel'], m['conv5_3/dark third'] = _region_relmax(
+        conv5.permute(0, 3, 1, 2), ref['conv5_3'], ref['conv_stats']['conv5_3_rms'])
     x = eng._roi_features(conv5, t['rois'], t['obn_scores'])
     m['roi_feat'] = _relmax(_dense_roi_feat(x), ref['roi_feat'].reshape(R, -1))
     h6, h7, lg = eng.head_forward(x, train=True)
@@ -148,28 +147,31 @@ def test_full_size_training_step_matches_oracle(dev, request, stats, mode):
     for got, names in ((h6, ('drop6', '_[noisy]_drop6')), (h7, ('drop7', '_[noisy]_drop7'))):
         want = np.concatenate([act[n] for n in names], 1)
         m[names[0]] = _relmax(got, want)
-    # ---- the head's GEMMs alone, per output UNIT (its own maximum as the yardstick: a unit 12
-    # octaves below the loudest one weighs as much in the next layer once that layer's weights
-    # undo the factor).  Input: the oracle's roi_feat, so that the float64 arbiter sees the same
-    # operand; yardstick: the fp32 oracle's own per-unit distance from float64 (a dot product of
-    # 25088 fp32 terms has an error floor that no fp32 plan can beat).
+    # ---- the head's GEMMs alone, per output UNIT.  Yardstick: the RMS over the proposals of the
+    # unit's own pre-activation (float64) - the scale of its dot product, which a unit 12 octaves
+    # below the loudest one keeps once the next layer's weights undo the factor (a unit's maximum
+    # would not do: a nearly dead unit has a tiny maximum but the full rounding error of its
+    # 25088-term sum).  Input: the oracle's roi_feat, so that the float64 arbiter sees the same
+    # operand.  Every fp32 plan must stay below 1e-4 of that scale; the fp32 oracle's own distance
+    # is printed beside it.
     xo = torch.from_numpy(ref['roi_feat'].reshape(R, -1)).to(dev)
     h6o, h7o, _lgo = eng.head_forward(xo, train=True)
     unit = {}
-    for got, names in ((h6o, ('drop6', '_[noisy]_drop6')), (h7o, ('drop7', '_[noisy]_drop7'))):
+    for got, names, rms in ((h6o, ('drop6', '_[noisy]_drop6'), ('fc6_rms', '_[noisy]_fc6_rms')),
+                            (h7o, ('drop7', '_[noisy]_drop7'), ('fc7_rms', '_[noisy]_fc7_rms'))):
         w64 = np.concatenate([arb['act'][n] for n in names], 1)
         w32 = np.concatenate([act[n] for n in names], 1).astype(np.float64)
-        cmax = np.abs(w64).max(axis=0)
-        live = cmax > 0
-        e_hip = (np.abs(got.cpu().numpy().astype(np.float64) - w64).max(axis=0)[live] / cmax[live])
-        e_orc = (np.abs(w32 - w64).max(axis=0)[live] / cmax[live])
+        yard = 2.0 * np.concatenate([arb['act'][n] for n in rms])       # (Dropout scale 2)
+        live = yard > 0
+        e_hip = np.abs(got.cpu().numpy().astype(np.float64) - w64).max(axis=0)[live] / yard[live]
+        e_orc = np.abs(w32 - w64).max(axis=0)[live] / yard[live]
         unit[names[0]] = (float(e_hip.max()), float(e_orc.max()),
                           float(np.median(e_hip)), float(np.median(e_orc)))
-    print('[%s] per-unit max error / unit max vs float64 (HIP max, fp32 oracle max, HIP median, '
-          'oracle median): %s' % (mode_tag, ', '.join('%s %.1e/%.1e/%.1e/%.1e' % ((k,) + v)
-                                                      for k, v in unit.items())))
+    print('[%s] per-unit max error / unit pre-activation RMS vs float64 (HIP max, fp32 oracle max, '
+          'HIP median, oracle median): %s' % (mode_tag, ', '.join(
+              '%s %.1e/%.1e/%.1e/%.1e' % ((k,) + v) for k, v in unit.items())))
     for k, (hmax, omax, hmed, omed) in unit.items():
-        assert hmax <= max(1e-4, 4 * omax) and hmed <= max(1e-5, 4 * omed), (k, unit[k])
+        assert hmax <= 1e-4 and hmed <= 1e-5, (k, unit[k])
     del xo, h6o, h7o, _lgo
     ld8 = eng.ld8
     cols = [0, c, ld8, ld8 + c]
@@ -237,8 +239,10 @@ def test_full_size_training_step_matches_oracle(dev, request, stats, mode):
     # arbiter, which starts from the oracle's roi_feat - is the larger part).  Measured 1e-5
     # (fc6/fc7, clean fc8) .. 2e-4 (the noise branch's fc8, whose loss is 100x smaller); round 1
     # allowed 5e-3.
+    # (skewed statistics: the noise branch's fc8d gradient is ill-conditioned enough that the fp32
+    # oracle itself sits at 1.8e-3 from float64; there the HIP path must be no further than it)
     for name, (e_hip, e_orc) in report.items():
-        assert e_hip <= 5e-4, (name, e_hip, e_orc)
+        assert e_hip <= max(5e-4, e_orc), (name, e_hip, e_orc)
 
 
 def test_full_size_bf16_c80_matches_oracle(dev, ref20):
