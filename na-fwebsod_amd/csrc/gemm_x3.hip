@@ -883,7 +883,11 @@ extern "C" int naws_gemm_f32x3_nt(int M, int N, int K, const void* A3, int64_t s
   // two 4-wave workgroups per CU overlap one's epilogue with the other's K loop
   if (K <= 1024 && g_x3_variant != 4) {
     if (g_x3_variant == 5) return launch_x3<128, 128, 2, 2, 2>(g, batch, s);
-    return launch_x3<256, 128, 2, 2, 2>(g, batch, s);
+    if (g_x3_variant == 6) return launch_x3<256, 128, 2, 2, 2>(g, batch, s);     // rounds 1-3
+    // round 4: the form the f16 batch GEMMs settled on in round 2 - 128 x 128 tiles, 16-deep
+    // K-steps on a ring of 3 stages (72 KB with three planes: two workgroups per CU), the DMA two
+    // steps ahead
+    return launch_x3<128, 128, 2, 2, 3>(g, batch, s);
   }
   switch (g_x3_variant) {
     case 7: return launch_x3<256, 256, 2, 4, 3>(g, batch, s);      // round 1 / 2's form (tools/ab_x3.py)

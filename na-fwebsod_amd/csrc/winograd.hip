@@ -198,6 +198,77 @@ __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float* __restr
   }
 }
 
+// The exact 3 x bf16 split of (B^T d B), written as operand planes P[3][16][Cin/16][tiles][16] by
+// the transform itself (x == p1 + p2 + p3 exactly, split3: no scale, nothing to bound) - the
+// strict plan's counterpart of wino_input_h2_kernel; replaces wino_input_kernel's fp32 V (16 P Cin
+// floats written and read back) + naws_split_bf16x3 over it.
+__device__ __forceinline__ void put_x3(float4 v, unsigned short* __restrict__ p1,
+                                       unsigned short* __restrict__ p2,
+                                       unsigned short* __restrict__ p3) {
+  const float t[4] = {v.x, v.y, v.z, v.w};
+  unsigned short a[4], b[4], c[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3(t[e], a[e], b[e], c[e]);
+  u32x2 w;
+  w.x = a[0] | ((unsigned)a[1] << 16); w.y = a[2] | ((unsigned)a[3] << 16);
+  *reinterpret_cast<u32x2*>(p1) = w;
+  w.x = b[0] | ((unsigned)b[1] << 16); w.y = b[2] | ((unsigned)b[3] << 16);
+  *reinterpret_cast<u32x2*>(p2) = w;
+  w.x = c[0] | ((unsigned)c[1] << 16); w.y = c[2] | ((unsigned)c[3] << 16);
+  *reinterpret_cast<u32x2*>(p3) = w;
+}
+
+__global__ __launch_bounds__(256) void wino_input_x3_kernel(const float* __restrict__ X, WinoGeom g,
+                                                            int Cin, unsigned short* __restrict__ Vp) {
+  const long long total = g.P * (Cin / 4);
+  const long long xi_stride = (long long)Cin * g.P;                 // elements between the 16 xi
+  const long long plane = 16 * xi_stride;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (long long)gridDim.x * 256) {
+    const int cq = (int)(t & 3);
+    const long long p = (t >> 2) % g.P;
+    const int s = (int)((t >> 2) / g.P);
+    const int c = s * 16 + cq * 4;
+    int n, py, px, ty, tx;
+    tile_coords(g, p, n, py, px, ty, tx);
+    float4 dd[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ys = 2 * ty - 1 + i;
+      const int y = ys * g.d + py;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xs = 2 * tx - 1 + j;
+        const int x = xs * g.d + px;
+        const bool ok = ys >= 0 && xs >= 0 && y < g.H && x < g.W;
+        dd[i][j] = ok ? *reinterpret_cast<const float4*>(
+                            X + (((long long)n * g.H + y) * g.W + x) * Cin + c)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 tt[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // B^T d
+      tt[0][j] = f4sub(dd[0][j], dd[2][j]);
+      tt[1][j] = f4add(dd[1][j], dd[2][j]);
+      tt[2][j] = f4sub(dd[2][j], dd[1][j]);
+      tt[3][j] = f4sub(dd[1][j], dd[3][j]);
+    }
+    unsigned short* p1 = Vp + ((long long)s * g.P + p) * 16 + cq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // (.) B   (the same expressions as wino_input_kernel)
+      unsigned short* q = p1 + (i * 4) * xi_stride;
+      put_x3(f4sub(tt[i][0], tt[i][2]), q, q + plane, q + 2 * plane);
+      q += xi_stride;
+      put_x3(f4add(tt[i][1], tt[i][2]), q, q + plane, q + 2 * plane);
+      q += xi_stride;
+      put_x3(f4sub(tt[i][2], tt[i][1]), q, q + plane, q + 2 * plane);
+      q += xi_stride;
+      put_x3(f4sub(tt[i][1], tt[i][3]), q, q + plane, q + 2 * plane);
+    }
+  }
+}
+
 // Y tile = A^T m A (+ bias, ReLU);  one lane = one tile x 4 output channels
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, WinoGeom g,
                                                           int Cout, long long slab,
@@ -842,19 +913,19 @@ extern "C" int naws_conv3x3_winograd_nhwc_f32x3_fwd(const float* X, const void* 
   hipStream_t s = (hipStream_t)stream;
   const long long pad = wino_pad();
   const long long slabV = g.P * Cin + pad, slabM = g.P * Cout + pad;
-  float* V = workspace;
   float* Mb = workspace + 16 * slabV;
   float* Vp = Mb + 16 * slabM;
   Vp += (16 - ((uintptr_t)Vp & 63) / 4) & 15;            // 64-byte aligned planes
   {
+    // the input transform writes the three bf16 operand planes itself (the first 16 slabV floats
+    // of the workspace, once the fp32 V of this layout's first version, are unused)
     const long long total = g.P * (Cin / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, X, g, Cin, slabV, V);
+    hipLaunchKernelGGL(wino_input_x3_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
+                       dim3(256), 0, s, X, g, Cin, (unsigned short*)Vp);
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
   }
-  int rc = naws_split_bf16x3(V, 16, (int)g.P, Cin, Cin, slabV, 0, Cin, Vp, stream);
-  if (rc != NAWS_OK) return rc;
+  int rc;
   rc = naws_gemm_f32x3_nt((int)g.P, Cout, Cin, Vp, g.P * 16, 16 * g.P * Cin, U3, (int64_t)Cout * 16,
                           (int64_t)16 * Cout * Cin, Mb, Cout, 16, g.P * Cin, (int64_t)Cout * Cin,
                           slabM, NAWS_EPI_NONE, nullptr, 0, nullptr, 0, 1.0f, 0.0f, 0, 0, stream);
