@@ -55,6 +55,9 @@ def parse():
                          'move 2 (N-1)/N of every message through HBM at the links\' pace '
                          '(default 0.6 x 153 GB/s x min(N-1, 7)).  The line is labelled a '
                          'projection.  The default one-GPU run appends the N = 8 projection')
+    ap.add_argument('--sharded-update', action='store_true',
+                    help='N > 1: NAWS.SHARDED_UPDATE - fc6_w gradient rows reduced to one owner each, '
+                         'owner-only update, updated rows all-gathered (engine._apply_update_sharded)')
     ap.add_argument('--no-fused-update', action='store_true',
                     help='one rank only: write fc6_w\'s gradient and update it in the deferred SGD '
                          'kernel (the route every rank takes when there is a gradient exchange) '
@@ -84,8 +87,8 @@ def parse():
     ap.add_argument('--allreduce-chunks', type=int, default=0, help='0 = auto (engine.py)')
     ap.add_argument('--no-conv-x3', action='store_true',
                     help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
-    ap.add_argument('--wino-x3', action='store_true',
-                    help='fp32x3 plan: run the Winograd batched GEMMs in the split too (no gain)')
+    ap.add_argument('--no-wino-x3', action='store_true',
+                    help='fp32x3 plan: keep the Winograd batched GEMMs on the fp32 MFMA (rounds 1-3)')
     ap.add_argument('--no-fuse-pool', action='store_true',
                     help='fp16x2 plan: pool1..pool3 as separate kernels instead of in the conv epilogue')
     ap.add_argument('--no-roi-planes', action='store_true',
@@ -640,13 +643,13 @@ def main():
     eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
                       weight_decay=5e-4, iter_size=1, gpu_num=world * B, seed=11,
                       process_group=pg, world_size=world, allreduce_chunks=args.allreduce_chunks,
-                      mfma_dtype=args.mfma_dtype)
+                      mfma_dtype=args.mfma_dtype, sharded_update=args.sharded_update, rank=rank)
     if args.force_dist:
         eng.reducer.force = True
     if args.no_conv_x3:
         eng.conv_x3 = False
-    if args.wino_x3:
-        eng.wino_x3 = True
+    if args.no_wino_x3:
+        eng.wino_x3 = False
     if args.no_conv_streams:
         eng.conv_streams = False
     if args.no_roi_planes:
@@ -875,6 +878,7 @@ def main():
                'rccl_world_size': (torch.distributed.get_world_size() if pg is not None else 1),
                'allreduce_chunks': eng.allreduce_chunks if eng.reducer.active else 0,
                'shared_gpu': bool(args.share_gpu),
+               'sharded_update': bool(eng._shard_blocks() is not None),
                # where fc6_w (86 % of the parameters) is updated: 'wgrad_epilogue' = inside its
                # weight-gradient GEMM, possible only without a gradient exchange (one rank);
                # 'deferred_kernel' = gradient written, (all-reduced,) then the SGD kernel on the

@@ -279,6 +279,8 @@ int naws_acm_sgd_update_rowmax(const float* grad, float* momentum_buf, const flo
  * overflow, overflow_tag) behind this call and the planes are redone from the exact maxima, on
  * the device's own decision.  regions: HOST array, ascending and disjoint; rows and
  * rows_per_batch multiples of 32, cols of 256, one (lr_mult, weight decay) run per region.
+ * rows < rows_per_batch describes a block of rows of ONE batch item of a larger matrix: planes then
+ * points at the block's first row inside that matrix's planes (colmax must be NULL).
  * Parameters, momentum: bit-identical to naws_acm_sgd_update.
  *   ref: detectron/ops/acm_weightdecay_momentum_sgd_op.h:72-109. */
 typedef struct naws_sgd_plane_region {

@@ -713,6 +713,8 @@ int launch_conv_x3_halo(CArgs& g, int N, hipStream_t s) {
 
 }  // namespace
 
+namespace { int launch_conv_wp_x3(CArgs& g, int N, hipStream_t s); }
+
 extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const float* bias,
                                            int N, int H, int W, int Cin, int Cout, int dilation,
                                            int relu, float* Y, void* stream) {
@@ -731,7 +733,12 @@ extern "C" int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const
   g.planeB = (long long)9 * Cin * Cout;
   g.bytesX = (unsigned)(pix * Cin * 4);
   hipStream_t s = (hipStream_t)stream;
-  // wide shallow layers: the halo-tile kernel (input gathered once per channel slab, not per tap)
+  // wide shallow layers (conv1_2 .. conv2_2): the halo-tile kernel with wave-private weight
+  // fragments, three bf16 planes (round 4; knob "x3" = 8: the LDS-DMA halo kernel of rounds 1-3)
+  if (dilation == 1 && Cout <= 256 && Cout % 64 == 0 && g_x3_variant != 6 && g_x3_variant != 8 &&
+      3 * g.planeB * 2 <= 0x7fffffffLL)
+    return launch_conv_wp_x3(g, N, s);
+  // (input gathered once per channel slab, not per tap)
   if (dilation == 1 && Cout <= 128 && Cout % 32 == 0 && g_x3_variant != 6) {
     if (Cout <= 64) return launch_conv_x3_halo<64>(g, N, s);
     return launch_conv_x3_halo<128>(g, N, s);
@@ -761,11 +768,15 @@ template <int DIL> struct NawsWpGeom {
   static constexpr int RAW = (HPIX + 7) / 8 * 8 * 16;
   static constexpr int A_HALF = ((RAW / 4) % 64 == 32 && RAW > HPIX * 16) ? RAW : RAW + 128;   // bytes per k-half (+ a spare slot)
 };
-template <int WR, int WC, int DIL, bool PIPE = true>
-__global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArgs g) {
+// NPL = 3: the same kernel on the EXACT 3 x bf16 split (the strict fp32x3 plan): three planes per
+// operand, no scales, six MFMA terms per product in gemm_x3_kernel's order - replaces
+// conv_x3_halo_kernel<BN, false> (weights through LDS-DMA, one step ahead) for conv1_2 .. conv2_2.
+template <int WR, int WC, int DIL, bool PIPE = true, int NPL = 2>
+__global__ __launch_bounds__(256, ((WC == 4 || NPL == 3) ? 2 : 3)) void conv_h2_wp_kernel(CArgs g) {
   static_assert(WR * WC == 4, "four waves");
-  constexpr int NPL = 2, BN = 32 * WC, TI = 8 / WR;
-  typedef f16x8 vec_t;
+  static_assert(NPL == 2 || NPL == 3, "2 x f16 or 3 x bf16");
+  constexpr int BN = 32 * WC, TI = 8 / WR;
+  typedef typename OperandVec<NPL == 2>::type vec_t;
   constexpr int TH = 8, TW = 32, HWD = TW + 2 * DIL, HPIX = (TH + 2 * DIL) * HWD;
   // halo image per plane: [k-half][halo pixel][16 B] - a wave's fragment read (32 consecutive
   // pixels of one k-half per 32 lanes) is a contiguous 512-byte run, conflict-free without a
@@ -794,10 +805,10 @@ __global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArg
   const __amdgpu_buffer_rsrc_t rsX =
       __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)g.bytesX, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)g.B, 0, (int)(2 * g.planeB * 2), 0x00020000);
+      (void*)g.B, 0, (int)(NPL * g.planeB * 2), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  float scA, iscA;
-  {
+  float scA = 1.f, iscA = 1.f;
+  if constexpr (NPL == 2) {
     const float bound = __uint_as_float(*g.amax_in) * g.in_mul + g.in_add;
     f16x2_scales(__float_as_uint(bound), scA, iscA);
   }
@@ -827,18 +838,22 @@ __global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArg
     unsigned char* base = smA + st * A_STAGE;
 #pragma unroll
     for (int r = 0; r < UR; ++r) {
-      unsigned short q[2][8];
+      unsigned short q[3][8];
       const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
                              ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float t = __uint_as_float(w[e]) * scA;
-        const _Float16 hi = (_Float16)t;
-        float rr = t - (float)hi;
-        if (!(fabsf(t) <= 65504.f)) rr = 0.f;
-        const _Float16 lo = (_Float16)rr;
-        q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
-        q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+        if constexpr (NPL == 3) {
+          split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+        } else {
+          const float t = __uint_as_float(w[e]) * scA;
+          const _Float16 hi = (_Float16)t;
+          float rr = t - (float)hi;
+          if (!(fabsf(t) <= 65504.f)) rr = 0.f;
+          const _Float16 lo = (_Float16)rr;
+          q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+          q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+        }
       }
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
@@ -912,6 +927,17 @@ __global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArg
   #pragma unroll
           for (int i = 0; i < TIH; ++i)
             acc[ih * TIH + i] = mfma16(a[1][i], bq[tap % 3][0], acc[ih * TIH + i]);
+          if constexpr (NPL == 3) {
+  #pragma unroll
+            for (int i = 0; i < TIH; ++i)
+              acc[ih * TIH + i] = mfma16(a[1][i], bq[tap % 3][1], acc[ih * TIH + i]);
+  #pragma unroll
+            for (int i = 0; i < TIH; ++i)
+              acc[ih * TIH + i] = mfma16(a[0][i], bq[tap % 3][2], acc[ih * TIH + i]);
+  #pragma unroll
+            for (int i = 0; i < TIH; ++i)
+              acc[ih * TIH + i] = mfma16(a[2][i], bq[tap % 3][0], acc[ih * TIH + i]);
+          }
         }
         if (tap == 8 && more) storeA((slab + 1) & 1);
       }
@@ -935,18 +961,22 @@ __global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArg
     };
     auto storeA1 = [&](int r, int st) {
       unsigned char* base = smA + st * A_STAGE;
-      unsigned short q[2][8];
+      unsigned short q[3][8];
       const unsigned w[8] = {ra[r][0].x, ra[r][0].y, ra[r][0].z, ra[r][0].w,
                              ra[r][1].x, ra[r][1].y, ra[r][1].z, ra[r][1].w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float t = __uint_as_float(w[e]) * scA;
-        const _Float16 hi = (_Float16)t;
-        float rr = t - (float)hi;
-        if (!(fabsf(t) <= 65504.f)) rr = 0.f;
-        const _Float16 lo = (_Float16)rr;
-        q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
-        q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+        if constexpr (NPL == 3) {
+          split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+        } else {
+          const float t = __uint_as_float(w[e]) * scA;
+          const _Float16 hi = (_Float16)t;
+          float rr = t - (float)hi;
+          if (!(fabsf(t) <= 65504.f)) rr = 0.f;
+          const _Float16 lo = (_Float16)rr;
+          q[0][e] = *reinterpret_cast<const unsigned short*>(&hi);
+          q[1][e] = *reinterpret_cast<const unsigned short*>(&lo);
+        }
       }
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
@@ -1009,6 +1039,17 @@ __global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArg
 #pragma unroll
         for (int i = 0; i < TIH; ++i)
           acc[ih * TIH + i] = mfma16(a[grp & 1][1][i], bq[tap % 3][0], acc[ih * TIH + i]);
+        if constexpr (NPL == 3) {
+#pragma unroll
+          for (int i = 0; i < TIH; ++i)
+            acc[ih * TIH + i] = mfma16(a[grp & 1][1][i], bq[tap % 3][1], acc[ih * TIH + i]);
+#pragma unroll
+          for (int i = 0; i < TIH; ++i)
+            acc[ih * TIH + i] = mfma16(a[grp & 1][0][i], bq[tap % 3][2], acc[ih * TIH + i]);
+#pragma unroll
+          for (int i = 0; i < TIH; ++i)
+            acc[ih * TIH + i] = mfma16(a[grp & 1][2][i], bq[tap % 3][0], acc[ih * TIH + i]);
+        }
         if (ih == IH - 1 && tap % 2 == 1 && tap / 2 < UR) storeA1(tap / 2, (slab + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1024,7 +1065,7 @@ __global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArg
   const int ty = ty0 + wr * TI;
   if (col < g.Cout) {
     const float bv = g.bias ? g.bias[col] : 0.f;
-    const float un = iscA * g.scaleB[col];               // powers of two: exact
+    const float un = NPL == 2 ? iscA * g.scaleB[col] : 1.f;   // powers of two: exact
     if (g.pool) {
       const int Ho = g.H / 2, Wo = g.W / 2;
 #pragma unroll
@@ -1078,17 +1119,23 @@ __global__ __launch_bounds__(256, (WC == 4 ? 2 : 3)) void conv_h2_wp_kernel(CArg
   }
 }
 
-template <int WR, int WC, int DIL, bool PIPE = true>
+template <int WR, int WC, int DIL, bool PIPE = true, int NPL = 2>
 int launch_conv_h2_wp(CArgs& g, int N, hipStream_t s) {
   constexpr int BN = 32 * WC;
   g.tiles_n = (int)naws_cdiv(g.Cout, BN);
   const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
   if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)2 * 2 * 2 * NawsWpGeom<DIL>::A_HALF;
-  auto kern = conv_h2_wp_kernel<WR, WC, DIL, PIPE>;
+  const size_t lds = (size_t)2 * NPL * 2 * NawsWpGeom<DIL>::A_HALF;
+  auto kern = conv_h2_wp_kernel<WR, WC, DIL, PIPE, NPL>;
   if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
   return naws_check_launch();
+}
+}  // namespace
+
+namespace {
+int launch_conv_wp_x3(CArgs& g, int N, hipStream_t s) {
+  return launch_conv_h2_wp<2, 2, 1, true, 3>(g, N, s);
 }
 }  // namespace
 

@@ -961,9 +961,12 @@ extern "C" int naws_acm_sgd_update_planes(int format, const float* grad, float* 
     if (!add_linear(cursor / 4, g.start / 4)) return NAWS_ERR_UNSUPPORTED;
     cursor = g.start + n;
     if (g.planes == nullptr) continue;     // updated elsewhere (naws_gemm_f32_f16x2_nt_xk_sgd): left alone
-    if (g.rows % 32 != 0 || g.cols % 256 != 0 || g.rows % g.rows_per_batch != 0 ||
-        g.rows_per_batch % 32 != 0)
+    // rows < rows_per_batch: a block of rows of ONE batch item of a larger matrix (planes points at
+    // the block's first row inside that matrix's planes; the sharded update, engine.py)
+    if (g.rows % 32 != 0 || g.cols % 256 != 0 || g.rows_per_batch % 32 != 0 ||
+        (g.rows > g.rows_per_batch && g.rows % g.rows_per_batch != 0))
       return NAWS_ERR_UNSUPPORTED;
+    if (g.rows < g.rows_per_batch && g.colmax) return NAWS_ERR_ARG;
     if (scaled) {
       NAWS_REQUIRE_PTR(g.bound); NAWS_REQUIRE_PTR(g.rowmax); NAWS_REQUIRE_PTR(g.inv_scale);
       if (g.bound == g.rowmax) return NAWS_ERR_ARG;

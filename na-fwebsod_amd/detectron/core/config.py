@@ -153,6 +153,13 @@ def _defaults():
             'DEVICE_POST': True,     # inference: roi projection / dedup hash / scatter-back / TTA mean /
                                      # DETECTIONS_PER_IM cut on the GPU (csrc/infer_ops.hip): one result
                                      # download per image; False = the numpy path of the reference
+            'SHARDED_UPDATE': False,  # NUM_GPUS > 1, fp16x2 plan: fc6_w's gradient rows are reduced to one owner
+                                     # rank each, the owner updates its 8192 / N rows (fp32 master rows and momentum
+                                     # live there only) and the updated rows + scale words return by all-gather:
+                                     # same bytes on the links as the all-reduce, 1 / N of the update's HBM traffic
+                                     # beside the next conv body; parameters bit-identical (tests).  A checkpoint
+                                     # then needs engine.gather_sharded_state() on every rank (the training loop
+                                     # calls it).  Unmeasured on hardware: no multi-GPU node was available
             'MFMA_DTYPE': 'fp16x2',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact
                                      # 3-way bf16 splits on the bf16 MFMA (fp32-accurate, faster);
                                      # 'fp16x2': the same GEMMs as row-scaled 2-way f16 splits on

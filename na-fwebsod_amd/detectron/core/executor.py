@@ -85,7 +85,8 @@ class NetExecutor(object):
                 gpu_num=self.world * self.ims, seed=cfg.RNG_SEED, process_group=process_group,
                 world_size=world_size, allreduce_chunks=cfg.NAWS.ALLREDUCE_CHUNKS,
                 mfma_dtype=cfg.NAWS.MFMA_DTYPE, scale_momentum=cfg.SOLVER.SCALE_MOMENTUM,
-                scale_momentum_threshold=cfg.SOLVER.SCALE_MOMENTUM_THRESHOLD)
+                scale_momentum_threshold=cfg.SOLVER.SCALE_MOMENTUM_THRESHOLD,
+                sharded_update=cfg.NAWS.SHARDED_UPDATE, rank=self.rank)
         else:
             if self.ims != 1:
                 raise NotImplementedError('the op-by-op plan follows the reference: one image '

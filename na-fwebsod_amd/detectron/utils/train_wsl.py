@@ -89,6 +89,8 @@ def train_model(roidb=None, max_iter=None, printer=print):
 
     def after(cur_iter):
         stats.IterToc()
+        if (cur_iter + 1) % period == 0 and cur_iter > start_iter and executor.engine is not None:
+            executor.engine.gather_sharded_state()    # collective under NAWS.SHARDED_UPDATE, else a no-op
         if (cur_iter + 1) % period == 0 and cur_iter > start_iter and rank == 0:
             checkpoints[cur_iter] = os.path.join(output_dir, 'model_iter{}.pkl'.format(cur_iter))
             nu.save_model_to_weights_file(checkpoints[cur_iter], model, executor)
@@ -101,6 +103,7 @@ def train_model(roidb=None, max_iter=None, printer=print):
                          account, after)
     if executor.engine is not None:
         executor.engine.flush()
+        executor.engine.gather_sharded_state()
     if rank == 0:
         checkpoints['final'] = os.path.join(output_dir, 'model_final.pkl')
         nu.save_model_to_weights_file(checkpoints['final'], model, executor)

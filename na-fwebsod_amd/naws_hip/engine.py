@@ -28,7 +28,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .reducer import ArenaReducer, message_plan, message_slice
+from .reducer import ArenaReducer, message_plan, message_slice, owner_blocks, owner_pieces
 
 VGG16_CONVS = [
     # (name, cin, cout, dilation) and pool markers
@@ -89,7 +89,8 @@ class WsddnEngine(object):
     def __init__(self, num_classes, device, dilation=2, roi_size=7, dropout=0.5, is_mean=True,
                  momentum=0.9, weight_decay=5e-4, iter_size=1, gpu_num=1, seed=11,
                  process_group=None, world_size=1, allreduce_chunks=0, freeze_conv_body=True,
-                 mfma_dtype='fp16x2', scale_momentum=True, scale_momentum_threshold=1.1):
+                 mfma_dtype='fp16x2', scale_momentum=True, scale_momentum_threshold=1.1,
+                 sharded_update=False, rank=None):
         if not freeze_conv_body:
             raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
                                       '(SURVEY.md fact 2): the conv body has no backward')
@@ -126,6 +127,20 @@ class WsddnEngine(object):
         self.scale_momentum_threshold = float(scale_momentum_threshold)
         self.pg, self.world_size = process_group, int(world_size)
         self.reducer = ArenaReducer(process_group, world_size)
+        # NAWS.SHARDED_UPDATE (N > 1, fp16x2 plan): fc6_w's gradient rows are reduced to ONE owner
+        # each (reduce-scatter), the owner updates its 8192 / N rows (fp32 master rows + momentum
+        # live there only), and the updated fp32 rows + their scale words come back by all-gather;
+        # every rank then splits the rows into operand planes with the owners' scales.  Same bytes
+        # on the links as the all-reduce, 1 / N of the update's HBM traffic beside the next conv
+        # body; parameters bit-identical to the all-reduce route (tests/test_distributed_cpu.py,
+        # tests/test_gpu_two_ranks.py).  See _apply_update_sharded.
+        self.sharded_update = bool(sharded_update)
+        if rank is None and process_group is not None:
+            import torch.distributed as dist
+            rank = dist.get_rank(process_group)
+        self.rank = int(rank or 0)
+        self._shard = None
+        self._mom_synced = True
         # fc6_w's gradient (822 MB of the 958 MB all-reduce) can be reduced in row chunks while
         # the rest of its wgrad GEMM still runs.  0 = auto.  The collective has the tail of the
         # backward pass + the next iteration's parameter-free conv body + RoIPool (~5.7 ms) to
@@ -184,10 +199,15 @@ class WsddnEngine(object):
         # (csrc/gemm_x3.hip conv_x3_kernel), 1.8x the fp32-MFMA direct kernel; the deep layers
         # have too few 256-row tiles to fill 256 CUs and stay on Winograd ('all' forces them too)
         self.conv_x3 = True
-        # fp32x3: the Winograd layers' 16 batched GEMMs in the split too.  Off: with K = Cin <= 512
-        # those GEMMs are bound by V/M traffic and tile epilogues, not by the MFMA rate
-        # (measured per layer: 0.26-0.62 ms either way, tools/kernel_bench.py --what conv)
-        self.wino_x3 = False
+        # fp32x3: layers up to this many output channels (conv1_2 .. conv3_3) take the direct
+        # 3-plane kernel, the 512-channel ones Winograd (0: rounds 1-3's rule, Winograd from conv3_1)
+        self.x3_direct_max_cout = 256
+        # fp32x3: the Winograd layers' 16 batched GEMMs in the exact 3 x bf16 split too.  Round 4:
+        # the input transform writes the three operand planes itself (wino_input_x3_kernel: no fp32
+        # V round trip, no split pass) and the batch GEMM runs the 128 x 128 / 3-stage short-K form:
+        # conv body 5.45 vs 6.15 ms, the plan 87.0 vs 84.5 img/s (rounds 1-3, with the fp32 V + split
+        # passes, measured no gain and kept these layers on the fp32 MFMA)
+        self.wino_x3 = True
         # fp16x2: the Winograd layers' 16 batched GEMMs on the f16 MFMA, operand planes written
         # by the input transform itself (csrc/winograd.hip, naws_conv3x3_winograd_nhwc_f16x2_fwd)
         self.wino_h2 = True
@@ -354,6 +374,8 @@ class WsddnEngine(object):
             b = blobs[name + '_b'].to(self.device, torch.float32).contiguous()
             use_wino = (self.winograd and self.mfma_dtype != 'bf16' and
                         w.shape[1] >= 128 and w.shape[0] >= 256)
+            if self.mfma_dtype == 'fp32x3' and w.shape[0] <= self.x3_direct_max_cout:
+                use_wino = False          # conv3_x: the 3-plane direct kernel fills the chip there
             x3conv = (self.mfma_dtype in ('fp32x3', 'fp16x2') and self.conv_x3 and name != 'conv1_1' and
                       (not use_wino or self.conv_x3 == 'all'))
             use_wino = use_wino and not x3conv
@@ -393,6 +415,9 @@ class WsddnEngine(object):
 
     def export_blobs(self, with_momentum=True):
         self.flush()
+        if with_momentum and not self._mom_synced:
+            raise RuntimeError('NAWS.SHARDED_UPDATE: fc6_w momentum rows live with their owners; '
+                               'call gather_sharded_state() on EVERY rank before a checkpoint')
         out = {}
         for name, (wp, b, w) in self.conv.items():
             out[name + '_w'], out[name + '_b'] = w, b
@@ -925,7 +950,12 @@ class WsddnEngine(object):
                 ops.gemm_bf16_slab_nt(dz6t[:, r0:r1], xt, out=gw6[r0:r1])
             else:
                 ops.gemm(dz6[:, r0:r1], x, True, False, out=gw6[r0:r1])
-            red.reduce_async(message_slice(self.arena, G, kind, rows, self.k6))
+            blocks = self._shard_blocks()
+            if blocks is None:
+                red.reduce_async(message_slice(self.arena, G, kind, rows, self.k6))
+            else:      # each owner's rows of this chunk go to that owner only
+                for o, p0, p1 in owner_pieces(r0, r1, blocks):
+                    red.reduce_to_owner_async(gw6[p0:p1].reshape(-1), o)
         # 3. the small gradients (under the fc6_w exchange): fc6 db; fc7 dW = dZ7^T H6, db;
         # fc8 dW = dL^T H7, db
         ops.colsum(dz6, out=gb6)
@@ -1098,6 +1128,8 @@ class WsddnEngine(object):
             cev.append((c0, c1))
         else:
             self.wait_allreduce()
+        if self._shard_blocks() is not None:
+            return self._apply_update_sharded()
         uev = getattr(self, 'update_events', None)   # bench.py: HIP events on the update stream
         if uev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1181,6 +1213,124 @@ class WsddnEngine(object):
             self._planes_dirty = False
         elif self.mfma_dtype != 'fp32' and self._wplanes is not None:
             self._refresh_weight_planes()
+
+    # ------------------------------------------------- NAWS.SHARDED_UPDATE
+    def _shard_blocks(self):
+        """The owners' row blocks of fc6_w when the sharded update is in force, else None."""
+        if not (self.sharded_update and self.reducer.active):
+            return None
+        if self._shard is None:
+            if self.mfma_dtype != 'fp16x2' or self.iter_size != 1 or self.k6 % 256 != 0:
+                raise NotImplementedError('NAWS.SHARDED_UPDATE needs the fp16x2 plan, ITER_SIZE 1 '
+                                          'and a 256-multiple fc6 input')
+            blocks = owner_blocks(2 * HIDDEN, self.reducer.world_size)
+            if blocks is None:
+                raise NotImplementedError('NAWS.SHARDED_UPDATE: 8192 rows do not divide into '
+                                          '32-row multiples over %d ranks' % self.reducer.world_size)
+            self._shard = dict(blocks=blocks)
+        return self._shard['blocks']
+
+    def _shard_tables(self):
+        sh = self._shard
+        if 'regions' not in sh:
+            if self._wplanes is None or self._sgd_regions is None:
+                raise RuntimeError('the sharded update needs the plane-writing SGD kernel '
+                                   '(one hyper-parameter run over fc6_w / fc7_w)')
+            n6 = 2 * HIDDEN
+            b0, b1 = sh['blocks'][self.rank]
+            nb = b1 - b0
+            o6, o7 = self.arena.offsets['fc6_w'][0], self.arena.offsets['fc7_w'][0]
+            sc = self._wscales.view(2, 2, n6)                # [operand][maxima | 1/scale][rows]
+            p6, p7 = self._wplanes['w6'], self._wplanes['w7']
+            cm7 = self._wplanes['w7t'].scales[0].view(torch.int32)
+            regs = []
+            if b0 > 0:
+                regs.append((o6, b0, self.k6, 32, None, None, None, None))
+            regs.append((o6 + b0 * self.k6, nb, self.k6, n6,
+                         p6.planes if nb == n6 else (p6.planes, b0), self._wbound[b0:b1],
+                         sc[0, 0].view(torch.int32)[b0:b1], sc[0, 1][b0:b1]))
+            if b1 < n6:
+                regs.append((o6 + b1 * self.k6, n6 - b1, self.k6, 32, None, None, None, None))
+            regs.append((o7, n6, HIDDEN, HIDDEN, p7.planes, self._wbound[n6:],
+                         sc[1, 0].view(torch.int32), sc[1, 1], cm7))
+            sh['regions'] = ops.SgdPlaneRegions(regs)
+            # what travels back beside the fp32 rows: per owner [row maxima | 1/scale | overflow word]
+            sh['meta'] = torch.zeros((len(sh['blocks']), 2 * nb + 4), device=self.device,
+                                     dtype=torch.int32)
+        return sh['regions'], sh['meta']
+
+    def _apply_update_sharded(self):
+        """The deferred update of a rank under NAWS.SHARDED_UPDATE (update stream):
+          1. wait for the reduces of this rank's fc6_w rows and for the small all-reduce;
+          2. the plane-writing SGD kernel over [this rank's fc6_w rows | fc7_w | fc8 | biases] - the
+             other owners' fc6_w rows are skip regions (neither read nor written);
+          3. all-gather, in place: the updated fp32 rows (822 MB / N per rank) and, per owner, the
+             rows' exact maxima, the 1/scale the owner's planes carry, and its overflow word;
+          4. one split of all 8192 rows with exactly the scales the all-reduce route would hold:
+             the owners' bound-derived ones, or - if ANY row of any owner outgrew its bound, which
+             is what the single overflow word of the all-reduce route records - the exact maxima.
+        fc7_w / fc8 / biases: as in the all-reduce route (every rank updates them)."""
+        n6 = 2 * HIDDEN
+        blocks = self._shard['blocks']
+        b0, b1 = blocks[self.rank]
+        nb = b1 - b0
+        red = self.reducer
+        self.wait_allreduce()
+        if self._planes_dirty or self._wplanes is None:
+            raise RuntimeError('sharded update: the operand planes are stale (blob() written '
+                               'through between backward and update?)')
+        regions, meta = self._shard_tables()
+        sc = self._wscales.view(2, 2, n6)
+        max6, max7 = sc[0, 0].view(torch.int32), sc[1, 0].view(torch.int32)
+        tag = self.sgd_iter_count + 1
+        self._wbound[b0:b1].copy_(max6[b0:b1])
+        max6[b0:b1].zero_()
+        self._wbound[n6:].copy_(max7)
+        max7.zero_()
+        self._wplanes['w7t'].scales[0].zero_()
+        uev = getattr(self, 'update_events', None)
+        if uev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ops.acm_sgd_update_f16x2(self.grads, self.momentum_buf, self.lr, self.params, self.seg_end,
+                                 self.seg_lr_mult, self.seg_wd, self.momentum, 0, self.gpu_num,
+                                 self.sgd_iter_count, regions, self._wovf, tag)
+        if uev is not None:
+            e1.record()
+            uev.append((e0, e1))
+        self.sgd_iter_count += 1
+        self._mom_synced = len(blocks) == 1
+        mine = meta[self.rank]
+        mine[:nb].copy_(max6[b0:b1])
+        mine[nb:2 * nb].copy_(sc[0, 1][b0:b1].view(torch.int32))
+        mine[2 * nb:2 * nb + 1].copy_(self._wovf)
+        w6, w7 = self._weight_views()
+        red.gather_blocks_async(w6.reshape(-1), self.rank)
+        red.gather_blocks_async(meta.view(-1), self.rank)
+        red.wait()
+        raised = (meta[:, 2 * nb] == tag).any()
+        rowmax = meta[:, :nb].reshape(n6)
+        bound_scale = (meta[:, nb:2 * nb].reshape(n6).view(torch.float32) * 16384.0).view(torch.int32)
+        max6.copy_(rowmax)
+        eff = torch.where(raised, rowmax, bound_scale)     # 1/scale = 2^(e-14)  ->  a maximum 2^e
+        self._wovf.copy_(torch.where(raised, torch.full_like(self._wovf, tag), self._wovf))
+        wp = self._wplanes
+        ops.split_f16x2_rows_if(w6, eff, wp['w6'], None, 0)
+        ops.split_f16x2_rows_if(w7, max7, wp['w7'], self._wovf, tag)
+        ops.split_f16x2_dual(w7, None, wp['w7t'].scales, out_t=wp['w7t'])
+        self._planes_dirty = False
+
+    def gather_sharded_state(self):
+        """COLLECTIVE (every rank): bring the owners' momentum rows of fc6_w to all ranks so that
+        any rank can write a complete checkpoint.  The fp32 weights are complete on every rank
+        after each update; the momentum of a row lives with its owner only.  No-op otherwise."""
+        if self._shard_blocks() is None or self._mom_synced:
+            return
+        self.flush()
+        m6 = self.arena.span(self.momentum_buf, 'fc6_w', '_[noisy]_fc6_w')
+        self.reducer.gather_blocks_async(m6, self.rank)
+        self.reducer.wait()
+        self._mom_synced = True
 
     # -------------------------------------------------------------- inference
     def infer(self, data, rois, obn_scores, seg=None):

@@ -1000,7 +1000,16 @@ class SgdPlaneRegions(object):
             if colmax is not None and (colmax.dtype != torch.int32 or not colmax.is_contiguous()
                                        or colmax.numel() != rows // rpb * cols):
                 raise TypeError('colmax: contiguous int32 [rows / rows_per_batch, cols]')
-            if planes.dtype != want[0] or not planes.is_contiguous() or \
+            raw = None
+            if isinstance(planes, tuple):
+                # (tensor holding the planes of the larger matrix, first row of this block): a row
+                # block of one batch item - rows < rows_per_batch (the sharded update)
+                whole, first_row = planes
+                if whole.dtype != want[0] or not whole.is_contiguous() or want[1] is None or \
+                        whole.shape[0] != want[1] or rows >= rpb or first_row + rows > rpb:
+                    raise TypeError('row-block planes: (contiguous planes of the whole matrix, first row)')
+                raw = (whole.data_ptr() + first_row * 16 * whole.element_size(), whole.stride(0))
+            elif planes.dtype != want[0] or not planes.is_contiguous() or \
                     (want[1] is not None and planes.shape[0] != want[1]) or \
                     planes.numel() != (want[1] or 1) * rows * cols:
                 raise TypeError('planes must be the contiguous operand planes of a [rows, cols] matrix')
@@ -1009,8 +1018,9 @@ class SgdPlaneRegions(object):
                     if t.dtype != dt or t.numel() != rows or not t.is_contiguous():
                         raise TypeError('bound / rowmax / inv_scale: contiguous [rows] int32 / int32 / fp32')
             self.host[i] = _SgdPlaneRegion(int(start), int(rows), int(cols), int(rpb), 0,
-                                           planes.data_ptr(),
-                                           planes.stride(0) if want[1] is not None else 0,
+                                           raw[0] if raw else planes.data_ptr(),
+                                           raw[1] if raw else
+                                           (planes.stride(0) if want[1] is not None else 0),
                                            _ptr(bound), _ptr(rowmax), _ptr(inv), _ptr(colmax))
 
 

@@ -42,6 +42,28 @@ def message_slice(arena, grads, kind, rows, k6):
     return arena.span(grads, 'fc6_b', 'noisy_fc8d_b')
 
 
+def owner_blocks(rows, world, align=32):
+    """fc6_w's rows cut into one contiguous block per rank (NAWS.SHARDED_UPDATE): rank r owns
+    rows [r * rows / world, (r + 1) * rows / world) - its fp32 master rows, their momentum and
+    their update.  None when the rows do not divide into `align`-multiples."""
+    world = int(world)
+    if world < 1 or rows % world != 0 or (rows // world) % align != 0:
+        return None
+    b = rows // world
+    return [(r * b, (r + 1) * b) for r in range(world)]
+
+
+def owner_pieces(r0, r1, blocks):
+    """[(owner, p0, p1)]: the row range [r0, r1) of one gradient message cut at the owners'
+    block boundaries."""
+    out = []
+    for o, (b0, b1) in enumerate(blocks):
+        p0, p1 = max(r0, b0), min(r1, b1)
+        if p0 < p1:
+            out.append((o, p0, p1))
+    return out
+
+
 class ArenaReducer(object):
     def __init__(self, process_group=None, world_size=1):
         self.pg = process_group
@@ -68,6 +90,44 @@ class ArenaReducer(object):
         for w in self._pending:
             w.wait()
         self._pending = []
+
+    # ---- NAWS.SHARDED_UPDATE: gradient rows to their owner, updated rows back to everybody ----
+    def _emulated(self, t):
+        """gloo carries device tensors only through all_reduce and broadcast: the two-ranks-on-
+        one-GPU test (and nothing else) takes the emulation below."""
+        import torch.distributed as dist
+        return t.is_cuda and dist.get_backend(self.pg) == 'gloo'
+
+    def reduce_to_owner_async(self, flat_slice, owner):
+        """Sum `flat_slice` over all ranks INTO rank `owner`'s copy (the other ranks' copies are
+        left unspecified): one leg of the reduce-scatter of fc6_w's gradient rows."""
+        if not self.active:
+            return
+        import torch.distributed as dist
+        assert flat_slice.is_contiguous()
+        if self._emulated(flat_slice):
+            w = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            w = dist.reduce(flat_slice, dst=dist.get_global_rank(self.pg, owner),
+                            op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._pending.append(w)
+
+    def gather_blocks_async(self, flat, rank):
+        """`flat` = world equal contiguous blocks, block r valid on rank r -> every block valid
+        everywhere, in place (all-gather; on gloo: one broadcast per owner)."""
+        if not self.active:
+            return
+        import torch.distributed as dist
+        assert flat.is_contiguous() and flat.numel() % self.world_size == 0
+        n = flat.numel() // self.world_size
+        if dist.get_backend(self.pg) == 'gloo':
+            for o in range(self.world_size):
+                self._pending.append(dist.broadcast(flat[o * n:(o + 1) * n],
+                                                    src=dist.get_global_rank(self.pg, o),
+                                                    group=self.pg, async_op=True))
+        else:
+            self._pending.append(dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n],
+                                                             group=self.pg, async_op=True))
 
 
 class EmulatedExchange(object):

@@ -146,6 +146,95 @@ def test_engine_message_order_replayed_over_gloo_equals_single_rank():
         assert sum(sizes) == arena.total and sum(sizes[:4]) == rows6 * k6
 
 
+def _sharded_worker(rank, world, port, q):
+    """NAWS.SHARDED_UPDATE on a CPU arena: the engine's message plan with every fc6_w chunk cut
+    at the owners' block boundaries and reduced TO ITS OWNER (reduce-scatter, emulated by
+    per-owner dist.reduce), the small gradients all-reduced, the SGD restatement on the owner's
+    rows only, the updated rows all-gathered (per-owner broadcast on gloo)."""
+    sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from naws_hip.reducer import (ArenaReducer, message_plan, message_slice, owner_blocks,
+                                  owner_pieces)
+    arena, params, grads_of, k6, rows6, sgd = _replay_setup()
+    B = 2
+    g = grads_of(rank)
+    red = ArenaReducer(dist.group.WORLD, world)
+    blocks = owner_blocks(rows6, world)
+    o6 = arena.offsets['fc6_w'][0]
+    gw6 = g[o6:o6 + rows6 * k6].view(rows6, k6)
+    plan = message_plan(arena, rows6, 4, red.active)
+    legs = []
+    for kind, rows in plan:
+        if kind == 'fc6_w':
+            for o, p0, p1 in owner_pieces(rows[0], rows[1], blocks):
+                red.reduce_to_owner_async(gw6[p0:p1].reshape(-1), o)
+                legs.append((o, p0, p1))
+        else:
+            red.reduce_async(message_slice(arena, g, kind, rows, k6))
+    red.wait()
+    # the update: this rank's fc6_w rows + everything that is not fc6_w
+    b0, b1 = blocks[rank]
+    p = params.clone()
+    pn, mn = sgd(p, g, gpu_num=world * B)           # (non-owned fc6_w rows: garbage in, ignored)
+    mine = torch.zeros_like(p, dtype=torch.bool)
+    mine[o6 + b0 * k6:o6 + b1 * k6] = True
+    mine[o6 + rows6 * k6:] = True
+    mine[:o6] = True
+    newp = torch.where(mine, pn, p)
+    w6 = newp[o6:o6 + rows6 * k6]
+    red.gather_blocks_async(w6, rank)
+    red.wait()
+    mom6 = mn[o6:o6 + rows6 * k6].clone()
+    own_mom = mom6[b0 * k6:b1 * k6].clone()
+    red.gather_blocks_async(mom6, rank)               # what gather_sharded_state does
+    red.wait()
+    q.put((rank, newp.numpy(), mom6.numpy(), own_mom.numpy(), legs, (b0, b1)))
+    dist.destroy_process_group()
+
+
+def test_sharded_update_over_gloo_equals_the_allreduce_route():
+    """reduce-to-owner + owner-only update + all-gather gives parameters
+    (and, once gathered, momentum) bit-identical to the all-reduce route = one process holding
+    both ranks' gradients; every fc6_w row travels to exactly one owner."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+    arena, params, grads_of, k6, rows6, sgd = _replay_setup()
+    want_p, want_m = sgd(params.clone(), grads_of(0) + grads_of(1), gpu_num=4)
+    o6 = arena.offsets['fc6_w'][0]
+    want_m6 = want_m.numpy()[o6:o6 + rows6 * k6]
+    for rank, p, mom6, own_mom, legs, (b0, b1) in res:
+        assert np.array_equal(p, want_p.numpy()), rank
+        assert np.array_equal(own_mom, want_m6[b0 * k6:b1 * k6]), rank
+        assert np.array_equal(mom6, want_m6), rank
+        # 4 chunks of 128 rows, 2 owners of 256 rows: every chunk lies inside one owner's block
+        assert [l[0] for l in legs] == [0, 0, 1, 1]
+        assert sum(l[2] - l[1] for l in legs) == rows6
+    assert res[0][5] == (0, rows6 // 2) and res[1][5] == (rows6 // 2, rows6)
+
+
+def test_owner_blocks_and_pieces():
+    from naws_hip.reducer import owner_blocks, owner_pieces
+    assert owner_blocks(8192, 8) == [(i * 1024, (i + 1) * 1024) for i in range(8)]
+    assert owner_blocks(8192, 3) is None and owner_blocks(96, 2, align=32) is None
+    blocks = owner_blocks(8192, 2)
+    assert owner_pieces(0, 2048, blocks) == [(0, 0, 2048)]
+    assert owner_pieces(2048, 6144, blocks) == [(0, 2048, 4096), (1, 4096, 6144)]
+    cover = [pc for r0 in range(0, 8192, 2048) for pc in owner_pieces(r0, r0 + 2048, owner_blocks(8192, 8))]
+    assert sum(p1 - p0 for _o, p0, p1 in cover) == 8192 and [c[0] for c in cover] == list(range(8))
+
+
 def test_row_chunks_cover():
     from naws_hip.reducer import row_chunks
     for rows, n in [(8192, 8), (8192, 3), (100, 8), (128, 1)]:

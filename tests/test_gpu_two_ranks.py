@@ -27,11 +27,11 @@ def _batches():
     return roidb, halves
 
 
-def _engine(dev, gpu_num, pg=None, world=1):
+def _engine(dev, gpu_num, pg=None, world=1, sharded=False):
     from detectron.datasets import synthetic
     from naws_hip.engine import WsddnEngine
     eng = WsddnEngine(C + 1, dev, dropout=0.0, gpu_num=gpu_num, seed=5, process_group=pg,
-                      world_size=world, allreduce_chunks=4)
+                      world_size=world, allreduce_chunks=4, sharded_update=sharded)
     blobs = synthetic.init_blobs(C, seed=5)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)
@@ -53,7 +53,7 @@ def _run(eng, mb, dev):
     return np.stack(losses)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, sharded=False):
     sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
     import torch.distributed as dist
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
@@ -61,11 +61,26 @@ def _worker(rank, world, port, outdir):
     dev = torch.device('cuda', 0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     _roidb, halves = _batches()
-    eng = _engine(dev, world * B, dist.group.WORLD, world)
-    assert eng.reducer.active
+    eng = _engine(dev, world * B, dist.group.WORLD, world, sharded=sharded)
+    assert eng.reducer.active and (eng._shard_blocks() is not None) == sharded
     losses = _run(eng, halves[rank], dev)
-    np.save(os.path.join(outdir, 'params%d.npy' % rank), eng.params.cpu().numpy())
-    np.save(os.path.join(outdir, 'losses%d.npy' % rank), losses)
+    tag = 's' if sharded else ''
+    if sharded:
+        # momentum rows live with their owner until a checkpoint gathers them
+        try:
+            eng.export_blobs()
+            raise AssertionError('export_blobs must refuse before gather_sharded_state')
+        except RuntimeError:
+            pass
+        eng.gather_sharded_state()
+        eng.export_blobs()
+    wp = eng._wplanes
+    np.save(os.path.join(outdir, 'params%s%d.npy' % (tag, rank)), eng.params.cpu().numpy())
+    np.save(os.path.join(outdir, 'mom%s%d.npy' % (tag, rank)), eng.momentum_buf.cpu().numpy())
+    np.save(os.path.join(outdir, 'planes%s%d.npy' % (tag, rank)),
+            wp['w6'].planes.view(torch.int16).cpu().numpy())
+    np.save(os.path.join(outdir, 'scales%s%d.npy' % (tag, rank)), wp['w6'].inv_scale.cpu().numpy())
+    np.save(os.path.join(outdir, 'losses%s%d.npy' % (tag, rank)), losses)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -105,3 +120,27 @@ def synthetic_flat(eng):
         off, n, _s = eng.arena.offsets[name]
         out[off:off + n] = np.asarray(blobs[name], np.float32).reshape(-1)
     return out
+
+
+def test_sharded_update_two_ranks_bit_identical_to_the_allreduce_route(dev, tmp_path):
+    """NAWS.SHARDED_UPDATE on hardware (two ranks on one GPU over gloo): after three training
+    steps the parameters, the momentum (once gathered), fc6_w's operand planes and their scales
+    are bit-identical to the all-reduce route's, on both ranks."""
+    ctx = mp.get_context('spawn')
+    for sharded in (False, True):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), sharded)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0
+    for what in ('params', 'mom', 'planes', 'scales', 'losses'):
+        ref = np.load(str(tmp_path / ('%s0.npy' % what)))
+        for r in range(2):
+            got = np.load(str(tmp_path / ('%ss%d.npy' % (what, r))))
+            if what == 'losses':
+                want = np.load(str(tmp_path / ('%s%d.npy' % (what, r))))
+                assert np.array_equal(got, want), (what, r)
+            else:
+                assert np.array_equal(got, ref), (what, r)
