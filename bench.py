@@ -85,15 +85,6 @@ def parse():
                     help='skip the configs[3] (C = 80, bf16 MFMA operands) and configs[4] (TTA '
                          'inference) measurements appended to the default one-GPU line')
     ap.add_argument('--allreduce-chunks', type=int, default=0, help='0 = auto (engine.py)')
-    ap.add_argument('--no-conv-x3', action='store_true',
-                    help='fp32x3 plan: keep the conv body on the fp32 MFMA (direct + Winograd)')
-    ap.add_argument('--no-wino-x3', action='store_true',
-                    help='fp32x3 plan: keep the Winograd batched GEMMs on the fp32 MFMA (rounds 1-3)')
-    ap.add_argument('--no-fuse-pool', action='store_true',
-                    help='fp16x2 plan: pool1..pool3 as separate kernels instead of in the conv epilogue')
-    ap.add_argument('--no-roi-planes', action='store_true',
-                    help='fp16x2 plan: RoIPoolF writes fp32 features that are then split (two '
-                         'more passes) instead of writing the fc6 operand planes itself')
     ap.add_argument('--no-conv-streams', action='store_true',
                     help='one launch per conv layer for all images instead of one stream per image')
     ap.add_argument('--mfma-dtype', default='fp16x2', choices=['fp16x2', 'fp32x3', 'fp32', 'bf16'],
@@ -646,16 +637,8 @@ def main():
                       mfma_dtype=args.mfma_dtype, sharded_update=args.sharded_update, rank=rank)
     if args.force_dist:
         eng.reducer.force = True
-    if args.no_conv_x3:
-        eng.conv_x3 = False
-    if args.no_wino_x3:
-        eng.wino_x3 = False
     if args.no_conv_streams:
         eng.conv_streams = False
-    if args.no_roi_planes:
-        eng.roi_planes = False
-    if args.no_fuse_pool:
-        eng.fuse_pool = False
     blobs = synthetic.init_blobs(num_fg, seed=11)     # identical on every rank (= broadcast)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)

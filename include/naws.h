@@ -526,6 +526,18 @@ int naws_roi_pool_f_f16x2_hier_fwd(const float* X, int N, int C, int H, int W, c
                                    int R, const float* boost, int pooled_h, int pooled_w,
                                    float spatial_scale, const uint32_t* amax_words, int n_words,
                                    float* workspace, void* planes, float* scales, void* stream);
+/* The two halves of naws_roi_pool_f_f16x2_hier_fwd as separate calls: naws_roi_maxmaps_fwd builds
+ * the 2x2 / 4x4 block-maxima maps M2 / M4 (each [N][H][W][C] floats, 16-byte aligned, C % 4 == 0)
+ * of N images - e.g. one image at a time on that image's own stream -, and
+ * naws_roi_pool_f_f16x2_mapped_fwd pools over maps that already exist.  Same operator and values
+ * (detectron/modeling/detector.py:319-329, detectron/ops/roi_loop_pool_op.cu:31-101). */
+int naws_roi_maxmaps_fwd(const float* X, int N, int C, int H, int W, float* M2, float* M4,
+                         void* stream);
+int naws_roi_pool_f_f16x2_mapped_fwd(const float* X, int N, int C, int H, int W, const float* rois,
+                                     int R, const float* boost, int pooled_h, int pooled_w,
+                                     float spatial_scale, const uint32_t* amax_words, int n_words,
+                                     const float* M2, const float* M4, void* planes, float* scales,
+                                     void* stream);
 /* Q f16 [2][Rpad/16][K][16] = transposition of P f16 [2][K/16][R][16] (Rpad = R rounded up to 32,
  * rows >= R zero): the K(=rois)-contiguous form of the same scaled matrix, B operand of
  * fc6's dW = dY^T X with a scale vector of ones, provided dY is split by

@@ -601,11 +601,10 @@ extern "C" int64_t naws_roi_pool_workspace_floats(int N, int C, int H, int W) {
   return (int64_t)2 * N * H * W * C;
 }
 
-static int roi_maxmaps(const float* X, int N, int C, int H, int W, float* ws, hipStream_t s) {
+static int roi_maxmaps(const float* X, int N, int C, int H, int W, float* M2, float* M4,
+                       hipStream_t s) {
   const long long total4 = (long long)N * H * W * (C / 4);
   if (naws_cdiv(total4, 256) > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
-  float* M2 = ws;
-  float* M4 = ws + (long long)N * H * W * C;
   hipLaunchKernelGGL(roi_maxmap_kernel<1>, dim3((unsigned)naws_cdiv(total4, 256)), dim3(256), 0, s, X, H,
                      W, C, M2, total4);
   hipLaunchKernelGGL(roi_maxmap_kernel<2>, dim3((unsigned)naws_cdiv(total4, 256)), dim3(256), 0, s,
@@ -625,7 +624,7 @@ extern "C" int naws_roi_pool_f_nhwc_hier_fwd(const float* X, int N, int C, int H
     return NAWS_ERR_UNSUPPORTED;
   if ((((uintptr_t)X | (uintptr_t)workspace) & 15) != 0) return NAWS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int rc = roi_maxmaps(X, N, C, H, W, workspace, s);
+  const int rc = roi_maxmaps(X, N, C, H, W, workspace, workspace + (long long)N * H * W * C, s);
   if (rc != NAWS_OK) return rc;
   hipLaunchKernelGGL((roi_pool_nhwc_xcd_kernel<false, true, 4>), dim3((unsigned)(R * (C / 64))), dim3(256),
                      (size_t)(64 * pooled_h * pooled_w + 1) * sizeof(float), s, X, C, H, W, rois, R,
@@ -634,23 +633,13 @@ extern "C" int naws_roi_pool_f_nhwc_hier_fwd(const float* X, int N, int C, int H
   return naws_check_launch();
 }
 
-extern "C" int naws_roi_pool_f_f16x2_hier_fwd(const float* X, int N, int C, int H, int W,
-                                              const float* rois, int R, const float* boost,
-                                              int pooled_h, int pooled_w, float spatial_scale,
-                                              const uint32_t* amax_words, int n_words,
-                                              float* workspace, void* planes, float* scales,
-                                              void* stream) {
-  if (R <= 0 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0 || n_words <= 0)
-    return NAWS_ERR_SHAPE;
-  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(rois); NAWS_REQUIRE_PTR(amax_words);
-  NAWS_REQUIRE_PTR(planes); NAWS_REQUIRE_PTR(scales); NAWS_REQUIRE_PTR(workspace);
+// the pooling launch over block-maxima maps that already exist
+static int roi_pool_planes_mapped(const float* X, int N, int C, int H, int W, const float* rois,
+                                  int R, const float* boost, int pooled_h, int pooled_w,
+                                  float spatial_scale, const uint32_t* amax_words, int n_words,
+                                  const float* M2, const float* M4, void* planes, float* scales,
+                                  hipStream_t s) {
   const long long K = (long long)C * pooled_h * pooled_w;
-  if (C % 64 != 0 || pooled_h * pooled_w > 256 || K % 32 != 0 || (int64_t)R * (C / 64) >= 0x7fffffffLL)
-    return NAWS_ERR_UNSUPPORTED;
-  if ((((uintptr_t)X | (uintptr_t)planes | (uintptr_t)workspace) & 15) != 0) return NAWS_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  const int rc = roi_maxmaps(X, N, C, H, W, workspace, s);
-  if (rc != NAWS_OK) return rc;
   RoiPlaneOut po;
   po.P = (unsigned short*)planes; po.inv_scale = scales + R; po.amax_words = (const unsigned*)amax_words;
   po.n_words = n_words; po.plane = K * R; po.R = R;
@@ -661,7 +650,7 @@ extern "C" int naws_roi_pool_f_f16x2_hier_fwd(const float* X, int N, int C, int 
                      dim3((unsigned)(naws_cdiv(R, RGV) * (C / 64))), dim3(64 * NWV),                  \
                      (size_t)(RGV * 64 * pooled_h * pooled_w + RGV) * sizeof(float), s, X, C, H, W,  \
                      rois, R, boost, pooled_h, pooled_w, spatial_scale, C / 64, (float*)nullptr, po, \
-                     (const float*)workspace, (const float*)(workspace + (long long)N * H * W * C))
+                     M2, M4)
 #ifdef NAWS_AB   // the other (waves, rois per workgroup) forms: A/B build only (tools/bench_roi.py)
   if (nw == 41) NAWS_ROI_LAUNCH(4, 1);
   else if (nw == 44) NAWS_ROI_LAUNCH(4, 4);
@@ -672,6 +661,66 @@ extern "C" int naws_roi_pool_f_f16x2_hier_fwd(const float* X, int N, int C, int 
   NAWS_ROI_LAUNCH(4, 2);     // measured best (tools/bench_roi.py): 0.35 ms incl. the maps vs 0.58 direct
 #undef NAWS_ROI_LAUNCH
   return naws_check_launch();
+}
+
+static int roi_pool_planes_check(const float* X, int N, int C, int H, int W, const float* rois, int R,
+                                 int pooled_h, int pooled_w, const uint32_t* amax_words, int n_words,
+                                 const void* planes, const float* scales) {
+  if (R <= 0 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0 || n_words <= 0)
+    return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(rois); NAWS_REQUIRE_PTR(amax_words);
+  NAWS_REQUIRE_PTR(planes); NAWS_REQUIRE_PTR(scales);
+  const long long K = (long long)C * pooled_h * pooled_w;
+  if (C % 64 != 0 || pooled_h * pooled_w > 256 || K % 32 != 0 || (int64_t)R * (C / 64) >= 0x7fffffffLL)
+    return NAWS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)X | (uintptr_t)planes) & 15) != 0) return NAWS_ERR_ARG;
+  return NAWS_OK;
+}
+
+extern "C" int naws_roi_pool_f_f16x2_hier_fwd(const float* X, int N, int C, int H, int W,
+                                              const float* rois, int R, const float* boost,
+                                              int pooled_h, int pooled_w, float spatial_scale,
+                                              const uint32_t* amax_words, int n_words,
+                                              float* workspace, void* planes, float* scales,
+                                              void* stream) {
+  int rc = roi_pool_planes_check(X, N, C, H, W, rois, R, pooled_h, pooled_w, amax_words, n_words,
+                                 planes, scales);
+  if (rc != NAWS_OK) return rc;
+  NAWS_REQUIRE_PTR(workspace);
+  if (((uintptr_t)workspace & 15) != 0) return NAWS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* M4 = workspace + (long long)N * H * W * C;
+  rc = roi_maxmaps(X, N, C, H, W, workspace, M4, s);
+  if (rc != NAWS_OK) return rc;
+  return roi_pool_planes_mapped(X, N, C, H, W, rois, R, boost, pooled_h, pooled_w, spatial_scale,
+                                amax_words, n_words, workspace, M4, planes, scales, s);
+}
+
+// The two halves of naws_roi_pool_f_f16x2_hier_fwd as separate entries: the engine builds each
+// image's maps at the tail of that image's conv chain (its own stream, beside the other image's
+// last layers) and pools once the chains have joined.
+extern "C" int naws_roi_maxmaps_fwd(const float* X, int N, int C, int H, int W, float* M2, float* M4,
+                                    void* stream) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(M2); NAWS_REQUIRE_PTR(M4);
+  if (C % 4 != 0) return NAWS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)X | (uintptr_t)M2 | (uintptr_t)M4) & 15) != 0 || M2 == M4) return NAWS_ERR_ARG;
+  return roi_maxmaps(X, N, C, H, W, M2, M4, (hipStream_t)stream);
+}
+
+extern "C" int naws_roi_pool_f_f16x2_mapped_fwd(const float* X, int N, int C, int H, int W,
+                                                const float* rois, int R, const float* boost,
+                                                int pooled_h, int pooled_w, float spatial_scale,
+                                                const uint32_t* amax_words, int n_words,
+                                                const float* M2, const float* M4, void* planes,
+                                                float* scales, void* stream) {
+  const int rc = roi_pool_planes_check(X, N, C, H, W, rois, R, pooled_h, pooled_w, amax_words,
+                                       n_words, planes, scales);
+  if (rc != NAWS_OK) return rc;
+  NAWS_REQUIRE_PTR(M2); NAWS_REQUIRE_PTR(M4);
+  if ((((uintptr_t)M2 | (uintptr_t)M4) & 15) != 0) return NAWS_ERR_ARG;
+  return roi_pool_planes_mapped(X, N, C, H, W, rois, R, boost, pooled_h, pooled_w, spatial_scale,
+                                amax_words, n_words, M2, M4, planes, scales, (hipStream_t)stream);
 }
 
 // Q[2][Rpad/16][K][16] = transposition of the f16 planes P[2][K/16][R][16]; Rpad = R rounded up to

@@ -190,83 +190,48 @@ class WsddnEngine(object):
         self.step_count = 0          # forward/backward passes run (dropout stream)
         self.conv = {}               # name -> (weight (OIHW or packed), bias)
         self.stat_state = None
-        self.conv_streams = True     # one HIP stream per image for the conv body
-        # Winograd F(2x2,3x3) for the layers with Cin >= 128 and Cout >= 256 (conv3_1..conv5_3):
-        # 2.25x fewer MFMA flops, 28-42% less time per layer; the shallow layers stay on the
-        # direct implicit GEMM (their transforms would be HBM-bound)
-        self.winograd = True
-        # fp32x3: the direct (non-Winograd) layers conv1_2..conv2_2 as fp32x3 implicit GEMMs
-        # (csrc/gemm_x3.hip conv_x3_kernel), 1.8x the fp32-MFMA direct kernel; the deep layers
-        # have too few 256-row tiles to fill 256 CUs and stay on Winograd ('all' forces them too)
-        self.conv_x3 = True
-        # fp32x3: layers up to this many output channels (conv1_2 .. conv3_3) take the direct
-        # 3-plane kernel, the 512-channel ones Winograd (0: rounds 1-3's rule, Winograd from conv3_1)
-        self.x3_direct_max_cout = 256
-        # fp32x3: the Winograd layers' 16 batched GEMMs in the exact 3 x bf16 split too.  Round 4:
-        # the input transform writes the three operand planes itself (wino_input_x3_kernel: no fp32
-        # V round trip, no split pass) and the batch GEMM runs the 128 x 128 / 3-stage short-K form:
-        # conv body 5.45 vs 6.15 ms, the plan 87.0 vs 84.5 img/s (rounds 1-3, with the fp32 V + split
-        # passes, measured no gain and kept these layers on the fp32 MFMA)
-        self.wino_x3 = True
-        # fp16x2: the Winograd layers' 16 batched GEMMs on the f16 MFMA, operand planes written
-        # by the input transform itself (csrc/winograd.hip, naws_conv3x3_winograd_nhwc_f16x2_fwd)
-        self.wino_h2 = True
-        # fp16x2: conv1_2..conv2_2 (the halo-tile kernel) in the 2 x f16 split as well
-        self.conv_h2 = True
-        self.conv_wino = {}
-        # fp16x2: RoIPoolF writes the fc6 operand planes itself (no fp32 feature matrix, no split
-        # passes over it); its per-roi scale comes from max|conv5_3| of the roi's image
-        self.roi_planes = True
-        # fp16x2: pool1..pool3 inside the epilogue of the direct conv kernel that feeds them
-        self.fuse_pool = True
-        # fp16x2: the SGD kernel reports the updated weight rows' maxima (no maxima pass in the
-        # re-split that follows it on the update stream)
-        self.fused_wmax = True
-        self._rm_table = None
-        # fp16x2: the SGD kernel also WRITES the updated fc6_w / fc7_w operand planes (scale from
-        # twice the row maximum before the update; a device-side conditional re-split covers a row
-        # that outgrows it): no 0.96 GB read + 0.96 GB write re-split on the update stream
+        # ---- the public toggles (everything else about the plan is fixed; the arms that lost
+        # their A/B are gone - docs/history/ has each measurement) ---------------------------------
+        #   mfma_dtype           the arithmetic plan (constructor)
+        #   sharded_update       NAWS.SHARDED_UPDATE (constructor)
+        #   allreduce_chunks     fc6_w wgrad / exchange row chunks (constructor)
+        self.conv_streams = True     # one HIP stream per image for the conv body (bench --no-conv-streams)
+        # the SGD kernel writes the updated fc6_w / fc7_w operand planes itself (fp16x2: scale from
+        # twice the row maximum before the update, a device-side conditional re-split covers a row
+        # that outgrows it; fp32x3 / bf16: exact / rounded planes); False: update, then re-split
         self.fused_planes = True
         # train_step() without a gradient exchange: fc6_w (86 % of the parameters) is updated in
-        # the epilogue of its own wgrad GEMM - the gradient is never written, the update's HBM
-        # traffic sits inside an MFMA-bound kernel (see train_step)
+        # the epilogue of its own wgrad GEMM - the gradient is never written (see train_step)
         self.fuse_wgrad_update = True
-        self.fc8_ksplit = 4
-        self._fc8_ws = None
-        self._w6_updated = None      # the region table for the deferred kernel once fc6_w is done
-        self._sgd_regions_rest = None
-        self._sgd_regions = None
-        # RoIPoolF over 2x2 / 4x4 block maxima of conv5_3 (csrc/roi_ops.hip): same values, ~8x less
-        # gather traffic
-        self.roi_hier = True
-        # fp16x2, optional: conv4_1..conv5_3 through the direct halo-tile kernel (dilation 2 for
-        # conv5_x) as ONE launch per layer for all images after the per-image streams have joined
-        # behind pool3.  Kernel for kernel it wins (tools/kernel_bench.py --what x3: 0.28 ms per
-        # layer for two images vs 2 x 0.17 ms of Winograd transform + 16 batch GEMMs + transform),
-        # but the serial tail loses what the two per-image Winograd chains gain by overlapping:
-        # interleaved in one process (tools/ab_engine.py --attr deep_direct) 14.10 vs 14.02 ms per
-        # step.  Off by default; the direct kernel still takes any deep layer whose single launch
-        # has >= 256 tiles (the larger TTA scales).
-        self.deep_direct = False
-        self.direct_min_tiles = 256          # (512 / 1024 / never: TTA inference 45.3 / 47.5 / 47.4 vs 44.6 ms per image)
-        self.wgrad_xk = True
-        self._seg_ring = None
-        self._amax5 = None
-        self.conv_direct_h2 = {}
-        self._streams = []
         # With the conv body frozen, the next iteration's conv + RoIPool do not depend on the
         # parameters: the all-reduce wait and the SGD kernel run on a side stream underneath
         # them (see sgd_step).  Same arithmetic, same order of updates; flush() joins the
         # streams (before the head, checkpoints, lr changes, end of run).
         self.defer_update = None     # None/True -> side stream; False -> inline on the main stream
+        # ---- fixed choices, named where the code branches on them ------------------------------
+        # Winograd F(2x2,3x3) for conv4_1..conv5_3 (and conv3_x in the fp32 plan); the layers with
+        # >= 256 halo tiles per launch (conv1_2..conv3_3 at 600x1000, the deep layers of the larger
+        # TTA scales) take the direct kernel: 512 / 1024 / never measured 45.3 / 47.5 / 47.4 vs 44.6
+        # ms per TTA image
+        self.DIRECT_MIN_TILES = 256
+        # fp32x3: up to this many output channels the direct 3-plane kernel, Winograd above
+        self.X3_DIRECT_MAX_COUT = 256
+        # fc8's products (tiny output, long K): K in 4 slices + a deterministic second pass (58 vs
+        # 97 us, tools/bench_fc8.py)
+        self.FC8_KSPLIT = 4
+        self.conv_wino = {}
+        self._rm_table = None
+        self._fc8_ws = None
+        self._w6_updated = None      # the region table for the deferred kernel once fc6_w is done
+        self._sgd_regions_rest = None
+        self._sgd_regions = None
+        self._seg_ring = None
+        self._amax5 = None
+        self.conv_direct_h2 = {}
+        self._streams = []
         self._update_pending = False
         self._update_waiting = False
-        self.update_after_conv1 = 1
         self._upd_stream = None
-        self._upd_stream_kind = None
-        self.update_stream = 'torch'
-        self._bg_streams = []
-        self._upd_streams = {}
         self._upd_event = None
         self._wplanes = None         # split planes of fc6_w / fc7_w / fc7_w^T (16-bit MFMA plans)
         self._planes_dirty = True
@@ -372,20 +337,17 @@ class WsddnEngine(object):
             name, dil = item[0], item[3]
             w = blobs[name + '_w'].to(self.device, torch.float32).contiguous()
             b = blobs[name + '_b'].to(self.device, torch.float32).contiguous()
-            use_wino = (self.winograd and self.mfma_dtype != 'bf16' and
-                        w.shape[1] >= 128 and w.shape[0] >= 256)
-            if self.mfma_dtype == 'fp32x3' and w.shape[0] <= self.x3_direct_max_cout:
+            use_wino = (self.mfma_dtype != 'bf16' and w.shape[1] >= 128 and w.shape[0] >= 256)
+            if self.mfma_dtype == 'fp32x3' and w.shape[0] <= self.X3_DIRECT_MAX_COUT:
                 use_wino = False          # conv3_x: the 3-plane direct kernel fills the chip there
-            x3conv = (self.mfma_dtype in ('fp32x3', 'fp16x2') and self.conv_x3 and name != 'conv1_1' and
-                      (not use_wino or self.conv_x3 == 'all'))
-            use_wino = use_wino and not x3conv
+            x3conv = (self.mfma_dtype in ('fp32x3', 'fp16x2') and name != 'conv1_1' and not use_wino)
             if name == 'conv1_1':
                 packed = w
                 # |conv1_1(x)| <= max|x| * max_c sum|w_c| + max|b|: the operand-scale bound of
                 # the layer that consumes it, without a pass over its 154 MB output
                 self._c11_bound = (float(w.abs().sum(dim=(1, 2, 3)).max().item()),
                                    float(b.abs().max().item()))
-            elif (x3conv and self.mfma_dtype == 'fp16x2' and self.conv_h2 and dil == 1
+            elif (x3conv and self.mfma_dtype == 'fp16x2' and dil == 1
                   and w.shape[0] <= 128 and w.shape[0] % 32 == 0 and w.shape[1] % 16 == 0):
                 # f16 hi / lo planes [2][9*Cin/16][Cout][16] + per-channel scales
                 packed = ops.split_f16x2(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
@@ -394,14 +356,14 @@ class WsddnEngine(object):
                 packed = ops.split_bf16x3(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
             elif use_wino:
                 packed = ops.winograd_weight_transform(w)      # [16][Cout][Cin]
-                if self.mfma_dtype == 'fp16x2' and self.wino_h2:
+                if self.mfma_dtype == 'fp16x2':
                     packed = ops.split_f16x2(packed)           # F16x2, planes [2][16][Cin/16][Cout][16]
-                    if self.conv_h2 and w.shape[0] % 128 == 0 and \
+                    if w.shape[0] % 128 == 0 and \
                             (dil == 1 or (dil is None and self.dilation in (1, 2))):
                         # also the direct form: chosen per input size in _conv_chain
                         self.conv_direct_h2[name] = ops.split_f16x2(
                             ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
-                elif self.mfma_dtype in ('fp32x3', 'fp16x2') and self.wino_x3:
+                elif self.mfma_dtype == 'fp32x3':
                     packed = ops.split_bf16x3(packed)          # planes [3][16][Cin/16][Cout][16]
             else:
                 packed = ops.conv3x3_pack_weight(w)            # [Cout][3][3][Cin]
@@ -428,8 +390,6 @@ class WsddnEngine(object):
         return out
 
     # ---------------------------------------------------------------- forward
-    DEEP_FIRST = 10                      # index of conv4_1 in VGG16_CONVS
-
     def _conv_chain(self, data, out=None, amax_final=None, first=0, end=None, x=None,
                     bound_in=None, amax_last=None, affine_in=None):
         """data NCHW [b,3,H,W] -> conv5_3 NHWC, on the current stream.  amax_final (int32 [1],
@@ -466,7 +426,7 @@ class WsddnEngine(object):
                 if name == 'conv1_1':
                     x = ops.conv3x3_c3_nchw_to_nhwc(data, wp, b, True)
                     prev = None
-                    if self.mfma_dtype == 'fp16x2' and self.conv_h2:
+                    if self.mfma_dtype == 'fp16x2':
                         ops.amax_word(data, out=amax[li:li + 1])     # 7 MB: the network input
                         prev, affine = li, self._c11_bound
                 else:
@@ -478,9 +438,7 @@ class WsddnEngine(object):
                         # x 128-channel tile per CU: conv3_x at 600x1000, and every deep layer once
                         # the images share a launch), Winograd below that
                         tiles = x.shape[0] * ((x.shape[1] + 7) // 8) * ((x.shape[2] + 31) // 32)
-                        if (self.deep_direct and li >= self.DEEP_FIRST
-                                and tiles * (wd.planes.shape[-2] // 64) >= 512) or \
-                                tiles * (wd.planes.shape[-2] // 128) >= self.direct_min_tiles:
+                        if tiles * (wd.planes.shape[-2] // 128) >= self.DIRECT_MIN_TILES:
                             wp = wd
                     if isinstance(wp, ops.F16x2):
                         bound = None if prev is None else amax[prev:prev + 1]
@@ -492,7 +450,7 @@ class WsddnEngine(object):
                         if wp.planes.dim() == 4:         # direct halo-tile kernel
                             mul, add = affine if prev == affine_slot else (1.0, 0.0)
                             # a 2x2 / stride-2 max-pool that follows is taken in the epilogue
-                            fused_pool = (self.fuse_pool and li + 1 < len(VGG16_CONVS)
+                            fused_pool = (li + 1 < len(VGG16_CONVS)
                                           and VGG16_CONVS[li + 1][0] == 'pool')
                             x = ops.conv3x3_nhwc_f16x2(x, wp, b, True, out=dst, amax_in=bound,
                                                        in_mul=mul, in_add=add, amax_out=word,
@@ -525,22 +483,17 @@ class WsddnEngine(object):
         hardware packs the tail of one image's layer with the head of the other's."""
         n = data.shape[0]
         # fp16x2: max|conv5_3| per image (per chain) for the RoIPool -> fc6 operand scale
-        planes = (self.roi_planes and self.mfma_dtype == 'fp16x2' and self.k6 % 32 == 0
+        planes = (self.mfma_dtype == 'fp16x2' and self.k6 % 32 == 0
                   and isinstance(self.conv[VGG16_CONVS[-1][0]][0], ops.F16x2))
         per_image = n > 1 and self.conv_streams
         self._pool_done = False
-        # the deep layers of all images as one launch per layer (see deep_direct above)
-        deep = (per_image and self.deep_direct and self.mfma_dtype == 'fp16x2' and self.conv_h2
-                and all(k in self.conv_direct_h2 for k in ('conv4_1', 'conv5_3')))
-        self._amax5 = (torch.empty((n if per_image and not deep else 1,), device=self.device,
+        self._roi_maps = None
+        self._amax5 = (torch.empty((n if per_image else 1,), device=self.device,
                                    dtype=torch.int32) if planes else None)
-        if self._update_waiting and (not per_image or deep or self.mfma_dtype != 'fp16x2'
-                                     or not self.conv_h2):
+        if self._update_waiting and (not per_image or self.mfma_dtype != 'fp16x2'):
             self._launch_update(())        # no per-image conv1_1 head to put it behind
         if not per_image:
             return self._conv_chain(data, amax_final=self._amax5)
-        if deep:
-            return self._conv_body_deep_batched(data)
         h, w = data.shape[2], data.shape[3]
         for _ in range(3):
             h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
@@ -549,12 +502,12 @@ class WsddnEngine(object):
         else:
             h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
         out = torch.empty((n, h, w, 512), device=self.device, dtype=torch.float32)
+        self._roi_maps = (torch.empty_like(out), torch.empty_like(out)) if planes else None
         main = torch.cuda.current_stream(self.device)
         start = main.record_event()
         while len(self._streams) < n:
             self._streams.append(torch.cuda.Stream(device=self.device))
-        split = (self._update_waiting and self.mfma_dtype == 'fp16x2' and self.conv_h2)
-        k = int(self.update_after_conv1)          # leading VGG16_CONVS entries queued before the update
+        split = (self._update_waiting and self.mfma_dtype == 'fp16x2')
         if split:
             # the head of every image's chain first (conv1_1: HBM-bound, 0.06 ms alone), THEN the
             # deferred parameter update, then the rest of the chains: started together, the SGD
@@ -565,13 +518,9 @@ class WsddnEngine(object):
                 st = self._streams[i]
                 st.wait_event(start)
                 with torch.cuda.stream(st):
-                    if k == 1:
-                        wp, b, _w = self.conv['conv1_1']
-                        y = ops.conv3x3_c3_nchw_to_nhwc(data[i:i + 1], wp, b, True)
-                        bound, aff = ops.amax_word(data[i:i + 1]), self._c11_bound
-                    else:
-                        bound, aff = torch.zeros((1,), device=self.device, dtype=torch.int32), None
-                        y = self._conv_chain(data[i:i + 1], first=0, end=k, amax_last=bound)
+                    wp, b, _w = self.conv['conv1_1']
+                    y = ops.conv3x3_c3_nchw_to_nhwc(data[i:i + 1], wp, b, True)
+                    bound, aff = ops.amax_word(data[i:i + 1]), self._c11_bound
                     heads.append((y, bound, aff))
                     evs.append(st.record_event())
             pool_done = self._pool_done
@@ -584,43 +533,16 @@ class WsddnEngine(object):
                 af = None if self._amax5 is None else self._amax5[i:i + 1]
                 if split:
                     self._pool_done = pool_done
-                    self._conv_chain(None, out=out[i:i + 1], amax_final=af, first=k, x=heads[i][0],
+                    self._conv_chain(None, out=out[i:i + 1], amax_final=af, first=1, x=heads[i][0],
                                      bound_in=heads[i][1], affine_in=heads[i][2])
                 else:
                     self._conv_chain(data[i:i + 1], out=out[i:i + 1], amax_final=af)
+                if self._roi_maps is not None:
+                    # RoIPoolF's block-maxima maps of this image, beside the other image's tail
+                    ops.roi_maxmaps(out[i:i + 1], self._roi_maps[0][i:i + 1], self._roi_maps[1][i:i + 1])
                 done = st.record_event()
             main.wait_event(done)
         return out
-
-    def _conv_body_deep_batched(self, data):
-        """conv1_1 .. pool3 of every image on its own stream, then conv4_1 .. conv5_3 for all images
-        in one launch per layer on the main stream."""
-        n = data.shape[0]
-        cut = self.DEEP_FIRST               # VGG16_CONVS[cut] = conv4_1 (pool3 is VGG16_CONVS[cut - 1])
-        h, w = data.shape[2], data.shape[3]
-        for _ in range(3):
-            h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
-        mid = torch.empty((n, h, w, 256), device=self.device, dtype=torch.float32)
-        # max|pool3| per image (bit patterns of non-negative floats: integer order = float order).
-        # One word per chain, reduced after the join: a chain whose last layer takes the Winograd
-        # route zeroes its word itself (winograd.hip), which would erase another chain's maximum
-        # in a shared word
-        words = torch.zeros((n,), device=self.device, dtype=torch.int32)
-        main = torch.cuda.current_stream(self.device)
-        start = main.record_event()
-        while len(self._streams) < n:
-            self._streams.append(torch.cuda.Stream(device=self.device))
-        for i in range(n):
-            st = self._streams[i]
-            st.wait_event(start)
-            with torch.cuda.stream(st):
-                y = self._conv_chain(data[i:i + 1], first=0, end=cut, amax_last=words[i:i + 1])
-                mid[i:i + 1].copy_(y)
-                done = st.record_event()
-            main.wait_event(done)
-        self._pool_done = True              # pool3 was taken (fused or not) inside the chains
-        shared = words.max().view(1)
-        return self._conv_chain(None, amax_final=self._amax5, first=cut, x=mid, bound_in=shared)
 
     def _seg_to_device(self, seg):
         """Per-image row offsets -> int32 device tensor WITHOUT stalling the host: a copy from
@@ -659,11 +581,12 @@ class WsddnEngine(object):
         """RoIPoolF + boost -> the fc6 input: fp32 [Rt, k6], or (fp16x2 plan) the GEMM operand
         planes written by the pooling kernel itself."""
         if self._amax5 is not None:
+            maps, self._roi_maps = getattr(self, '_roi_maps', None), None
             return ops.roi_pool_f_f16x2(conv5, rois, self._amax5, self.roi_size, self.roi_size,
                                         self.spatial_scale, boost=obn_scores.reshape(-1),
-                                        hier=self.roi_hier)
+                                        hier=True, maps=maps)
         roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
-                                  boost=obn_scores.reshape(-1), layout='NHWC', hier=self.roi_hier)
+                                  boost=obn_scores.reshape(-1), layout='NHWC', hier=True)
         return roi_feat.view(rois.shape[0], self.k6)
 
     def head_forward(self, roi_feat, train, both_branches=True):
@@ -754,9 +677,9 @@ class WsddnEngine(object):
 
     def _fc8_gemm(self, a, b, trans_a, trans_b, out, epilogue=L.EPI_NONE, bias=None):
         """fc8's products have a small output and a long inner dimension (K = 4096 forward,
-        K = proposals for dW8): K in fc8_ksplit slices + a deterministic second pass
+        K = proposals for dW8): K in FC8_KSPLIT slices + a deterministic second pass
         (ops.gemm_splitk: 58 vs 97 us on the bench shape, tools/bench_fc8.py); 0 = one pass."""
-        ks = int(self.fc8_ksplit)
+        ks = int(self.FC8_KSPLIT)
         if ks <= 1:
             return ops.gemm(a, b, trans_a, trans_b, out=out, epilogue=epilogue, bias=bias)
         need = out.shape[-2] * out.shape[-1] * (out.shape[0] if out.dim() == 3 else 1) * ks
@@ -910,15 +833,13 @@ class WsddnEngine(object):
         # 2. fc6: dW = dZ6^T X in row chunks (both operands K(=rows)-contiguous through the
         # transposing split); each chunk's all-reduce starts while the next one is computed
         if h2:
-            # planes [2, Rt/16, 8192, 16] of (diag(1/s_r) dZ6)^T; x^T: the pooling kernel's planes
-            # transposed as they are, or a transposing split of the fp32 features
+            # planes [2, Rt/16, 8192, 16] of (diag(1/s_r) dZ6)^T
             dz6t = ops.split_f16x2_dual(dz6, None, sc6t.view(2, 2 * HIDDEN),
                                         rowmul=x.inv_scale if planes_x else None)[1]
-            # x^T: with the pooling kernel's planes the wgrad GEMM reads them as they are through
-            # transposing LDS reads (csrc/gemm_btr.hip); otherwise a transposing split of the features
-            xk = planes_x and self.wgrad_xk
-            xt = None if xk else (ops.f16_planes_transpose(x) if planes_x   # [2, Rt/16, 25088, 16]
-                                  else ops.split_f16x2(x, transpose=True))
+            # x^T: the pooling kernel's planes are read as they are, through transposing LDS reads
+            # (csrc/gemm_btr.hip); fp32 features (a caller's own roi_feat) are split transposed
+            xk = planes_x
+            xt = None if xk else ops.split_f16x2(x, transpose=True)    # [2, Rt/16, 25088, 16]
         elif x3:
             dz6t = ops.split_bf16x3(dz6, transpose=True)       # [3, Rt/16, 8192, 16]
             xt = ops.split_bf16x3(x, transpose=True)           # [3, Rt/16, 25088, 16]
@@ -983,7 +904,7 @@ class WsddnEngine(object):
 
     def _can_fuse_wgrad_update(self):
         return (self.fuse_wgrad_update and not self.reducer.active and self.iter_size == 1
-                and self.mfma_dtype == 'fp16x2' and self.fused_wmax and self.fused_planes
+                and self.mfma_dtype == 'fp16x2' and self.fused_planes
                 and self._sgd_regions is not None and self._wplanes is not None
                 and not self._planes_dirty and self.k6 % 256 == 0)
 
@@ -1068,38 +989,16 @@ class WsddnEngine(object):
             self._apply_update()
             return
         main = torch.cuda.current_stream(self.device)
-        if self._upd_stream is None or self._upd_stream_kind != self.update_stream:
-            kind = self.update_stream
-            if kind not in self._upd_streams:
-                self._upd_streams[kind] = self._make_update_stream(kind)
-            self._upd_stream, self._upd_stream_kind = self._upd_streams[kind], kind
+        if self._upd_stream is None:
+            # an ordinary stream: a low-priority one, or one confined to a subset of the compute
+            # units, measured worse in every form (docs/history: 13.7-23 vs 13.5 ms per step)
+            self._upd_stream = torch.cuda.Stream(device=self.device)
         self._grads_ready = main.record_event()
-        if self.update_after_conv1 > 0:
-            self._update_waiting = True      # launched by the next conv body (or by flush)
-        else:
-            self._launch_update(())
+        # launched by the next conv body behind conv1_1 of every image (or by flush): started at
+        # once, the SGD kernel's workgroups fill the CUs and the two conv1_1 launches at the head
+        # of the dependent chains took 0.7 ms each
+        self._update_waiting = True
         self._update_pending = True
-
-    def _make_update_stream(self, kind):
-        """'torch': a plain stream; 'low': lowest priority; 'cu<stride>' / 'cu<stride>+<offset>':
-        every stride-th compute unit only; 'first<n>': compute units 0..n-1."""
-        if kind in (None, '', 'torch'):
-            return torch.cuda.Stream(device=self.device)
-        if kind == 'low':
-            bs = ops.BackgroundStream(self.device, priority=1)
-        else:
-            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            if kind.startswith('first'):
-                n = int(kind[5:])
-                mask = [((1 << min(32, max(0, n - 32 * w))) - 1) for w in range((n_cu + 31) // 32)]
-            elif kind.startswith('cu'):
-                stride, _, off = kind[2:].partition('+')
-                mask = ops.cu_mask_every(n_cu, int(stride), int(off or 0))
-            else:
-                raise ValueError('update_stream: %r' % (kind,))
-            bs = ops.BackgroundStream(self.device, cu_mask=mask)
-        self._bg_streams.append(bs)         # keeps the handle alive as long as the engine
-        return bs.stream
 
     def _launch_update(self, after):
         """Queue the update on its side stream, behind the gradients and the events in `after`."""
@@ -1137,7 +1036,7 @@ class WsddnEngine(object):
         # fp16x2: the SGD kernel reports max|w| of every updated fc6_w / fc7_w row into the scale
         # blocks of their operand planes, so the re-split reads the weights once (k6 % 256: a
         # wave's 256 floats stay in one row)
-        fused = (self.fused_wmax and self.mfma_dtype == 'fp16x2' and self._wplanes is not None
+        fused = (self.mfma_dtype == 'fp16x2' and self._wplanes is not None
                  and self.iter_size == 1 and self.k6 % 256 == 0)
         # (planes marked dirty - a caller wrote through blob() - carry stale maxima: that update
         # takes the exact route below)
@@ -1153,7 +1052,7 @@ class WsddnEngine(object):
         if w6_done:
             # fc6_w (weights, momentum, planes) was updated by its wgrad GEMM in this step's
             # backward: the rest MUST take the plane-writing kernel with fc6_w's region skipped,
-            # even if an A/B tool has flipped fused_planes / fused_wmax since
+            # even if an A/B tool has flipped fused_planes since
             if self._wplanes is None or self._sgd_regions is None or self.mfma_dtype != 'fp16x2':
                 raise RuntimeError('fc6_w was updated in its wgrad epilogue but the plane state '
                                    'it belongs to is gone (engine toggles changed mid-step?)')

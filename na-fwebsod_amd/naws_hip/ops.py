@@ -146,8 +146,19 @@ def roi_pool_f(x, rois, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
     return (y, am) if with_argmax else y
 
 
+def roi_maxmaps(x, m2, m4):
+    """The 2x2 / 4x4 block-maxima maps of NHWC features x into m2 / m4 (same shape as x), on the
+    current stream (the first half of roi_pool_f_f16x2(hier=True))."""
+    _chk(x, 'x'); _chk(m2, 'm2'); _chk(m4, 'm4')
+    if m2.shape != x.shape or m4.shape != x.shape or not (x.is_contiguous() and m2.is_contiguous()
+                                                          and m4.is_contiguous()):
+        raise TypeError('roi_maxmaps: contiguous maps of x\'s shape')
+    n, h, w, c = x.shape
+    L.call('naws_roi_maxmaps_fwd', x.data_ptr(), n, c, h, w, m2.data_ptr(), m4.data_ptr(), _stream())
+
+
 def roi_pool_f_f16x2(x, rois, amax_words, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
-                     hier=True):
+                     hier=True, maps=None):
     """RoIPoolF (+ boost) on NHWC features, written directly as the fp16x2 operand of the fc6
     GEMM: F16x2 with planes [2, K/16, R, 16], K = C*ph*pw, scaled per roi from the bound
     max|x| of the roi's image (`amax_words`: int32 [n] bit patterns) * |boost|."""
@@ -164,6 +175,16 @@ def roi_pool_f_f16x2(x, rois, amax_words, pooled_h=7, pooled_w=7, spatial_scale=
         raise TypeError('amax_words must be a contiguous int32 tensor')
     out = F16x2(torch.empty((2, k // 16, r, 16), device=x.device, dtype=torch.float16),
                 torch.empty((2, r), device=x.device, dtype=_f32))
+    if maps is not None:           # (m2, m4) already built by roi_maxmaps
+        m2, m4 = maps
+        _chk(m2, 'm2'); _chk(m4, 'm4')
+        if m2.shape != x.shape or m4.shape != x.shape:
+            raise TypeError('maps must have x\'s shape')
+        L.call('naws_roi_pool_f_f16x2_mapped_fwd', x.data_ptr(), n, c, h, w, rois.data_ptr(), r,
+               _ptr(boost), pooled_h, pooled_w, float(spatial_scale), amax_words.data_ptr(),
+               amax_words.numel(), m2.data_ptr(), m4.data_ptr(), out.planes.data_ptr(),
+               out.scales.data_ptr(), _stream())
+        return out
     if hier:
         ws = torch.empty((L.load().naws_roi_pool_workspace_floats(n, c, h, w),), device=x.device,
                          dtype=_f32)

@@ -2,7 +2,7 @@
 """Interleaved in-process A/B of the conv body alone (engine.conv_body on the bench images, no
 head, nothing else on the device) over engine attributes and per-call environment knobs.
 
-    python tools/ab_convbody.py --cases "" deep_direct=1 conv_streams=0 NAWS_CONV_RING=0
+    python tools/ab_convbody.py --cases "" conv_streams=0 NAWS_CONV_RING=0
 """
 import argparse
 import os

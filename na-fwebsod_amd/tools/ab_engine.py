@@ -4,7 +4,7 @@ bench workload: blocks of training steps alternate between the values, same proc
 same data (DVFS and device spread make numbers from separate runs incomparable:
 cdna_hip_programming.md rule 24).
 
-    python tools/ab_engine.py --attr fused_wmax --values 1 0 [--rounds 6 --steps 10]
+    python tools/ab_engine.py --attr fused_planes --values 1 0 [--rounds 6 --steps 10]
 """
 import argparse
 import os

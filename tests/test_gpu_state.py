@@ -78,23 +78,28 @@ def test_background_streams_priority_and_cu_mask(dev):
 
 
 def test_engine_update_on_a_masked_stream_is_the_same_update(dev):
-    """engine.update_stream only moves the deferred SGD to another queue: parameters after three
-    steps are bit-identical to the default stream's."""
+    """The stream the deferred SGD runs on only moves it to another queue (the engine uses an
+    ordinary torch stream; a masked or low-priority one from naws_stream_create is injected
+    here): parameters after three steps are bit-identical."""
     import numpy as np
     from detectron.datasets import synthetic
+    from naws_hip import ops
     from naws_hip.engine import WsddnEngine
     c, B = 20, 2
     mb = synthetic.make_minibatch(synthetic.make_roidb(B, 64, c, 96, 128, seed=3), c)
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
     seg = [0] + np.cumsum(np.bincount(mb['rois'][:, 0].astype(np.int64), minlength=B)).tolist()
     blobs = synthetic.init_blobs(c, seed=3)
-    res = []
-    for kind in ('torch', 'cu4', 'low'):
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    res, keep = [], []
+    for kw in (None, dict(cu_mask=ops.cu_mask_every(n_cu, 4)), dict(priority=1)):
         eng = WsddnEngine(c + 1, dev, gpu_num=B, seed=3)
         eng.set_conv_blobs(blobs)
         eng.set_head_blobs(blobs)
         eng.set_lr(1e-4)
-        eng.update_stream = kind
+        if kw is not None:
+            keep.append(ops.BackgroundStream(dev, **kw))
+            eng._upd_stream = keep[-1].stream
         for _ in range(3):
             eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
             eng.sgd_step()
