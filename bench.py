@@ -409,9 +409,11 @@ def extra_configs(args, dev, B, res, cfg, roof):
         roof['tta_infer_' + {'achieved': 'whole_image_tflops'}.get(k, k)] = ti['roofline'].get(k)
 
 
-def project_n_ranks(eng, t, seg, n, cus, gbps, steps):
+def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False):
     """ms/step of the N-rank schedule on this one GPU with reducer.EmulatedExchange in the
-    all-reduce's place (restores the engine's own reducer afterwards)."""
+    all-reduce's place (restores the engine's own reducer afterwards).  sharded: the
+    NAWS.SHARDED_UPDATE schedule, this process playing rank 0 of N (it updates 1 / N of fc6_w's
+    rows; the rest keep their values - timing only)."""
     import torch
     from naws_hip.reducer import EmulatedExchange
     eng.flush()
@@ -419,6 +421,7 @@ def project_n_ranks(eng, t, seg, n, cus, gbps, steps):
              eng.update_events, eng.comm_events)
     ex = EmulatedExchange(eng.device, n, cus, gbps)
     eng.reducer, eng.allreduce_chunks = ex, (4 if n == 2 else 2)
+    eng.sharded_update, eng._shard = bool(sharded), None
     eng.timing_events = eng.update_events = eng.comm_events = None
     pev = []
     try:
@@ -434,8 +437,10 @@ def project_n_ranks(eng, t, seg, n, cus, gbps, steps):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
     finally:
+        eng.flush()
         (eng.reducer, eng.allreduce_chunks, eng.phase_events, eng.timing_events,
          eng.update_events, eng.comm_events) = saved
+        eng.sharded_update, eng._shard, eng._mom_synced = False, None, True
     exposed = [e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]) if n1 == 'join_update']
     return {'ms_per_step': round(ms, 3), 'cus': ex.cus, 'gbps': ex.gbps, 'chunks': 4 if n == 2 else 2,
             'bytes_per_step': ex.bytes_per_step,
@@ -737,6 +742,9 @@ def main():
             [(n, 32, None) for n in (2, 4, 8)]
         for n, cus, gbps in cases:
             projections[n] = project_n_ranks(eng, t, seg, n, cus, gbps, max(20, args.steps // 3))
+        n, cus, gbps = cases[-1]
+        projections['%d_sharded' % n] = project_n_ranks(eng, t, seg, n, cus, gbps,
+                                                        max(20, args.steps // 3), sharded=True)
     conv_alone_ms = None
     if rank == 0:
         eng.timing_events = eng.phase_events = eng.update_events = eng.comm_events = None
@@ -881,12 +889,15 @@ def main():
                'exposed_comm_ms': None,
                'allreduce_wait_ms': (round(sum(s.elapsed_time(e) for s, e in cev) / len(cev), 3)
                                      if cev else None)}
-        for n, pr in sorted(projections.items()):
+        for n, pr in sorted(projections.items(), key=lambda kv: str(kv[0])):
             # PROJECTIONS, not measurements of an N-GPU job: the one-rank step with the N-rank
-            # schedule and a paced copy kernel in the all-reduce's place (see EmulatedExchange)
-            cfg['projected_ms_per_step_n%d' % n] = pr['ms_per_step']
-            cfg['projected_images_per_sec_n%d' % n] = round(n * B / pr['ms_per_step'] * 1e3, 1)
-            cfg['projected_exchange_n%d' % n] = (
+            # schedule and a paced copy kernel in the all-reduce's place (see EmulatedExchange);
+            # "<N>_sharded" = the NAWS.SHARDED_UPDATE schedule (reduce-scatter, 1 / N of fc6_w
+            # updated here, all-gather)
+            nn = int(str(n).split('_')[0])
+            cfg['projected_ms_per_step_n%s' % n] = pr['ms_per_step']
+            cfg['projected_images_per_sec_n%s' % n] = round(nn * B / pr['ms_per_step'] * 1e3, 1)
+            cfg['projected_exchange_n%s' % n] = (
                 '%d CUs x %.0f GB/s, %.2f GB per step, allreduce_chunks %d, exposed %.2f ms'
                 % (pr['cus'], pr['gbps'], pr['bytes_per_step'] / 1e9, pr['chunks'], pr['exposed_ms']))
         for k, v in stage_ms.items():                 # flat: the driver's parser drops nested dicts

@@ -55,6 +55,10 @@ struct XArgs {
   const float* cs;           //         operand scaling (null otherwise)
   long long sRs, sCs;
   NawsAmax am;               // |C| maxima for the consumer's operand split (naws_common.h)
+  // COL2 (the Winograd frequency-column form, winograd.hip): K = 4 blocks of col_steps K-steps;
+  // C receives blocks 0 + 1 + 2, C + sC2 receives blocks 1 - 2 - 3
+  long long sC2;
+  int col_steps;
 };
 
 // Operand planes are stored K-slab-major, P[plane][k/16][row][k%16]: the 16-deep K-step of a
@@ -73,9 +77,11 @@ struct XArgs {
 // pipeline as a plain bf16 GEMM for the bf16 plan (one plane, 64-deep K-steps of 4 slabs, so a
 // step still carries 32 MFMAs per wave between barriers).  F16 (NPL = 2): the fp16x2 GEMM, see
 // the note above naws_split_f16x2 - two f16 planes per operand, 3 MFMA terms per slab.
-template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1, bool F16 = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1, bool F16 = false,
+          bool COL2 = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_kernel(XArgs g) {
   static_assert(!F16 || NPL == 2, "fp16x2 uses two planes");
+  static_assert(!COL2 || (F16 && KS == 1), "the column form is an fp16x2 batch GEMM");
   typedef typename OperandVec<F16>::type vec_t;
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -154,12 +160,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   };
 
   f32x16 acc[TI][TJ];
+  f32x16 acc1[COL2 ? TI : 1][COL2 ? TJ : 1];     // COL2: the second Winograd row (blocks 1 - 2 - 3)
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TJ; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        if constexpr (COL2) acc1[i][j][e] = 0.f;
+      }
 
   const int rd_a = (wm * WTM + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
   const int rd_b = NQ * A_PLANE + (wn * WTN + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) * 16);
@@ -175,9 +185,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
     __builtin_amdgcn_s_barrier();
     if (t + STAGES - 1 < T) issue(t + STAGES - 1, st_fill);
     const unsigned char* st = smx + st_cur * STAGE;
-#define NAWS_X3_TERM(P, Q)                                                                      \
+#define NAWS_X3_TERM_TO(ACC, AF, P, Q)                                                          \
   _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) \
-      acc[i][j] = mfma16(a[P][i], b[Q][j], acc[i][j]);
+      ACC[i][j] = mfma16(AF[P][i], b[Q][j], ACC[i][j]);
+#define NAWS_X3_TERM(P, Q) NAWS_X3_TERM_TO(acc, a, P, Q)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       vec_t a[NPL][TI], b[NPL][TJ];
@@ -190,6 +201,35 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
         for (int j = 0; j < TJ; ++j)
           b[pl][j] = *reinterpret_cast<const vec_t*>(st + rd_b + (pl * KS + ks) * B_PLANE + j * 1024);
       }
+      if constexpr (COL2) {
+        // frequency block of this K-step (wave-uniform): row 0 of A^T takes blocks 0, 1, 2, row 1
+        // takes 1, -2, -3 - the same fragments feed both accumulator sets, the sign is a flip of
+        // the A fragments' sign bits (hi and lo planes alike: exact)
+        const int blk = t / g.col_steps;
+        if (blk <= 2) {
+          NAWS_X3_TERM(0, 0)
+          NAWS_X3_TERM(0, 1)
+          NAWS_X3_TERM(1, 0)
+        }
+        if (blk == 1) {
+          NAWS_X3_TERM_TO(acc1, a, 0, 0)
+          NAWS_X3_TERM_TO(acc1, a, 0, 1)
+          NAWS_X3_TERM_TO(acc1, a, 1, 0)
+        } else if (blk >= 2) {
+          vec_t an[NPL][TI];
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+              u32x4 w = *reinterpret_cast<const u32x4*>(&a[pl][i]);
+              w.x ^= 0x80008000u; w.y ^= 0x80008000u; w.z ^= 0x80008000u; w.w ^= 0x80008000u;
+              an[pl][i] = *reinterpret_cast<const vec_t*>(&w);
+            }
+          NAWS_X3_TERM_TO(acc1, an, 0, 0)
+          NAWS_X3_TERM_TO(acc1, an, 0, 1)
+          NAWS_X3_TERM_TO(acc1, an, 1, 0)
+        }
+      } else {
       // consecutive MFMAs go to different accumulators
       NAWS_X3_TERM(0, 0)
       if constexpr (NPL >= 2) {
@@ -201,8 +241,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
         NAWS_X3_TERM(0, 2)
         NAWS_X3_TERM(2, 0)
       }
+      }
     }
 #undef NAWS_X3_TERM
+#undef NAWS_X3_TERM_TO
     st_cur = (st_cur + 1 == STAGES) ? 0 : st_cur + 1;
     st_fill = (st_fill + 1 == STAGES) ? 0 : st_fill + 1;
   }
@@ -210,6 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
   const int epi = g.epilogue;
+  auto write_tile = [&](f32x16 (&acc)[TI][TJ], float* C) {
   if constexpr (F16) {
     // undo the row scaling first (powers of two: exact).  Accumulator register e of a lane in
     // half h is row (e&3) + 8(e>>2) + 4h of the 32x32 block: lane l fetches the factor of row l,
@@ -260,16 +303,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
       }
     }
   }
+  };
+  write_tile(acc, C);
+  if constexpr (COL2) write_tile(acc1, C + g.sC2);
   if (g.am.rowmax || g.am.colmax)
     naws_tile_amax_32<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1, bool F16 = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL = 3, int KS = 1, bool F16 = false,
+          bool COL2 = false>
 int launch_x3(XArgs& g, int batch, hipStream_t s) {
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;
-  auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16>;
+  auto kern = gemm_x3_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16, COL2>;
   if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   g.batch = batch;
   if ((long long)g.tiles_m * g.tiles_n * batch > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
@@ -1090,6 +1137,30 @@ extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, 
     default: return launch_x3_m16<256, 256, 4, 2, 2, 2, 2, true>(g, batch, s);
   }
 }
+
+#ifdef NAWS_AB   // Winograd frequency-column batch GEMM: A/B build only (tools/ab_wino_col.py)
+int naws_wino_col_gemm_impl(int P, int Cout, int Cin, const void* V2, const float* invV,
+                            const void* U2, const float* scaleU, float* S, hipStream_t stream) {
+  if (P <= 0 || Cout <= 0 || Cin <= 0 || Cin % 16 != 0) return NAWS_ERR_SHAPE;
+  if ((long long)(P - 1) * Cout + Cout > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  XArgs g{};
+  g.A = (const unsigned short*)V2; g.B = (const unsigned short*)U2; g.C = S;
+  g.M = P; g.N = Cout; g.K = 4 * Cin; g.ldc = Cout;
+  g.slabA = (long long)P * 16; g.slabB = (long long)Cout * 16;
+  g.planeA = (long long)16 * P * Cin; g.planeB = (long long)16 * Cout * Cin;
+  g.sA = (long long)4 * Cin * P; g.sB = (long long)4 * Cin * Cout;
+  g.sC = (long long)2 * P * Cout; g.sC2 = (long long)P * Cout;
+  g.col_steps = Cin / 16;
+  g.rs = invV; g.cs = scaleU; g.sRs = 0; g.sCs = Cout;
+  g.epilogue = NAWS_EPI_NONE; g.alpha = 1.f; g.drop_scale = 1.f;
+  // tile forms of the column GEMM (knob "wino", tools/ab_wino_col.py): 8 = 64 x 128 on 1 x 2 waves
+  // (twice the workgroups: 608 per image), 9 = 128 x 64 on 2 x 1 waves
+  const int wv = naws_knob(NAWS_KNOB_WINO);
+  if (wv == 8) return launch_x3<64, 128, 1, 2, 3, 2, 1, true, true>(g, 4, stream);
+  if (wv == 9) return launch_x3<128, 64, 2, 1, 3, 2, 1, true, true>(g, 4, stream);
+  return launch_x3<128, 128, 2, 2, 3, 2, 1, true, true>(g, 4, stream);
+}
+#endif  // NAWS_AB
 
 extern "C" int naws_gemm_f32_f16x2_nt(int M, int N, int K, const void* A2, int64_t slabA,
                                       int64_t planeA, const float* scaleA, const void* B2,

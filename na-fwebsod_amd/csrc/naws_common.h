@@ -28,6 +28,13 @@ static inline int naws_allow_lds(K kernel, int bytes = 160 * 1024) {
   return naws_allow_lds_impl(reinterpret_cast<const void*>(kernel), bytes);
 }
 
+// Winograd frequency-column batch GEMM (gemm_x3.hip, used by winograd.hip): for each of the 4
+// columns j, S0_j = sum over rows i = 0, 1, 2 and S1_j = (i = 1) - (i = 2) - (i = 3) of V_ij U_ij^T
+// in ONE K loop of 4 Cin.  V2: planes [2][4 j][4 Cin / 16][P][16] (column-major frequency order),
+// invV [P]; U2: planes [2][4 j][4 Cin / 16][Cout][16], scaleU [4][Cout]; S: [4 j][2][P][Cout] fp32.
+int naws_wino_col_gemm_impl(int P, int Cout, int Cin, const void* V2, const float* invV,
+                            const void* U2, const float* scaleU, float* S, hipStream_t stream);
+
 // Tuning knobs of the A/B tools (naws_set_variant; defaults below).  None changes a result.
 enum NawsKnob { NAWS_KNOB_GEMM = 0, NAWS_KNOB_X3, NAWS_KNOB_H2, NAWS_KNOB_CONV_RING,
                 NAWS_KNOB_CONV_BN, NAWS_KNOB_ROI_NW, NAWS_KNOB_WINO, NAWS_KNOB_COUNT };

@@ -139,6 +139,7 @@ __device__ __forceinline__ void put_h2(float4 v, float sc, unsigned short* __res
 // whole tensor: |B^T d B| <= 4 max|x|, so s = 2^(12 - floor(log2 max|x|)) keeps it below 2^15.
 // One lane = one tile x 4 channels; lane order (4 channel groups of a 16-channel slab, then tiles):
 // a wave writes 16 tiles x 32 B = 512 contiguous bytes per (xi, plane).
+template <bool COLMAJOR = false>
 __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float* __restrict__ X, WinoGeom g,
                                                             int Cin, const unsigned* __restrict__ amax,
                                                             float* __restrict__ inv_scale,
@@ -188,13 +189,17 @@ __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float* __restr
     }
     unsigned short* hi = Vp + ((long long)s * g.P + p) * 16 + cq * 4;
     unsigned short* lo = hi + plane;
+    // frequency (row i, column j) lives at index 4 i + j, or - COLMAJOR, the column form of the
+    // batch GEMM - at 4 j + i, so that a column's four row blocks are one contiguous K range
+#define NAWS_XI(I, J) ((COLMAJOR ? (J) * 4 + (I) : (I) * 4 + (J)) * xi_stride)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {       // (.) B
-      put_h2(f4sub(tt[i][0], tt[i][2]), sc, hi + (i * 4 + 0) * xi_stride, lo + (i * 4 + 0) * xi_stride);
-      put_h2(f4add(tt[i][1], tt[i][2]), sc, hi + (i * 4 + 1) * xi_stride, lo + (i * 4 + 1) * xi_stride);
-      put_h2(f4sub(tt[i][2], tt[i][1]), sc, hi + (i * 4 + 2) * xi_stride, lo + (i * 4 + 2) * xi_stride);
-      put_h2(f4sub(tt[i][1], tt[i][3]), sc, hi + (i * 4 + 3) * xi_stride, lo + (i * 4 + 3) * xi_stride);
+      put_h2(f4sub(tt[i][0], tt[i][2]), sc, hi + NAWS_XI(i, 0), lo + NAWS_XI(i, 0));
+      put_h2(f4add(tt[i][1], tt[i][2]), sc, hi + NAWS_XI(i, 1), lo + NAWS_XI(i, 1));
+      put_h2(f4sub(tt[i][2], tt[i][1]), sc, hi + NAWS_XI(i, 2), lo + NAWS_XI(i, 2));
+      put_h2(f4sub(tt[i][1], tt[i][3]), sc, hi + NAWS_XI(i, 3), lo + NAWS_XI(i, 3));
     }
+#undef NAWS_XI
   }
 }
 
@@ -330,6 +335,66 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
   }
 }
+
+#ifdef NAWS_AB   // the frequency-column form: measured slower (profiles/r04_wino_column_pmc.md); A/B build only
+// Output transform of the frequency-column form: the batch GEMM has already taken A^T over the
+// rows (S[j][0] = m0j + m1j + m2j, S[j][1] = m1j - m2j - m3j in its accumulators), so a tile reads
+// 8 planes instead of 16 and only the column stage (.) A is left.  One lane = one tile x 4 channels.
+__global__ __launch_bounds__(256) void wino_output_col_kernel(const float* __restrict__ S, WinoGeom g,
+                                                              int Cout, const float* __restrict__ bias,
+                                                              int relu, float* __restrict__ Y,
+                                                              unsigned* __restrict__ amax_out) {
+  const int c4n = Cout / 4;
+  const long long total = g.P * c4n;
+  const long long slab = g.P * Cout;                  // one (column, row) plane
+  float vmax = 0.f;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (long long)gridDim.x * 256) {
+    const int c4 = (int)(t % c4n);
+    const long long p = t / c4n;
+    int n, py, px, ty, tx;
+    tile_coords(g, p, n, py, px, ty, tx);
+    const float* in = S + p * Cout + c4 * 4;
+    float4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) s[i][j] = *reinterpret_cast<const float4*>(in + (j * 2 + i) * slab);
+    const float4 b = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = (2 * ty + i) * g.d + py;
+      if (y >= g.H) continue;
+      float4 o[2];
+      o[0] = f4add(f4add(s[i][0], s[i][1]), s[i][2]);   // (.) A
+      o[1] = f4sub(f4sub(s[i][1], s[i][2]), s[i][3]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int x = (2 * tx + j) * g.d + px;
+        if (x >= g.W) continue;
+        float4 v = f4add(o[j], b);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(Y + (((long long)n * g.H + y) * g.W + x) * Cout + c4 * 4) = v;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    }
+  }
+  if (amax_out) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned v = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+      if (v > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(amax_out, v);
+    }
+  }
+}
+
+#endif  // NAWS_AB
 
 // ---- fp16x2: the 16 batched GEMMs AND the output transform in one kernel ------------------------
 // (VERDICT r2 #4.)  The three-kernel route writes M = V U (16 x P x Cout fp32, 78 MB per conv4/5
@@ -980,7 +1045,7 @@ extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* 
       amax = own;
     }
     const long long total = g.P * (Cin / 4);
-    hipLaunchKernelGGL(wino_input_h2_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
+    hipLaunchKernelGGL(wino_input_h2_kernel<false>, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
                        dim3(256), 0, s, X, g, Cin, amax, invA, Vp, (unsigned*)amax_out);
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
@@ -1030,3 +1095,49 @@ extern "C" int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* 
   }
   return naws_check_launch();
 }
+
+#ifdef NAWS_AB
+// The frequency-COLUMN form of naws_conv3x3_winograd_nhwc_f16x2_fwd (same operator, same arguments,
+// reference detectron/modeling/VGG16.py:24-46): the batch GEMM runs one K loop of 4 Cin per
+// (tile block, channel block, column j) and takes the A^T stage over the rows in two accumulator
+// sets, so M shrinks from 16 to 8 planes and the tiles' prologues / epilogues from 16 to 4 per
+// position.  U2 = naws_split_f16x2 of the transformed weight regrouped [4 j][Cout][4 i x Cin]
+// (planes [2][4][4 Cin / 16][Cout][16], scaleU [4][Cout]: one scale per (column, channel) row).
+// Results differ from the 16-plane form in the last bits (the row sums are taken in the MFMA
+// accumulators).  Cin % 32 == 0, Cout % 4 == 0.
+extern "C" int naws_conv3x3_winograd_nhwc_f16x2_col_fwd(const float* X, const void* U2,
+                                                        const float* scaleU, const float* bias,
+                                                        int N, int H, int W, int Cin, int Cout,
+                                                        int dilation, int relu, float* workspace,
+                                                        float* Y, const uint32_t* amax_in,
+                                                        uint32_t* amax_out, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (dilation < 1) return NAWS_ERR_ARG;
+  if (Cin % 32 != 0 || Cout % 4 != 0) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(U2); NAWS_REQUIRE_PTR(scaleU);
+  NAWS_REQUIRE_PTR(workspace); NAWS_REQUIRE_PTR(Y); NAWS_REQUIRE_PTR(amax_in);
+  if ((((uintptr_t)X | (uintptr_t)U2 | (uintptr_t)workspace | (uintptr_t)Y) & 15) != 0)
+    return NAWS_ERR_ARG;
+  const WinoGeom g = wino_geom(N, H, W, dilation);
+  if (g.P > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned short* Vp = (unsigned short*)workspace;                   // 16 * P * Cin floats
+  float* Sb = workspace + 16 * g.P * Cin;                            // 8 * P * Cout floats
+  float* invA = Sb + 16 * g.P * Cout;                                // P floats (layout of the 16-plane form)
+  {
+    const long long total = g.P * (Cin / 4);
+    hipLaunchKernelGGL(wino_input_h2_kernel<true>, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
+                       dim3(256), 0, s, X, g, Cin, (const unsigned*)amax_in, invA, Vp, (unsigned*)amax_out);
+    int rc = naws_check_launch();
+    if (rc != NAWS_OK) return rc;
+  }
+  int rc = naws_wino_col_gemm_impl((int)g.P, Cout, Cin, Vp, invA, U2, scaleU, Sb, s);
+  if (rc != NAWS_OK) return rc;
+  {
+    const long long total = g.P * (Cout / 4);
+    hipLaunchKernelGGL(wino_output_col_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
+                       dim3(256), 0, s, Sb, g, Cout, bias, relu, Y, (unsigned*)amax_out);
+  }
+  return naws_check_launch();
+}
+#endif  // NAWS_AB

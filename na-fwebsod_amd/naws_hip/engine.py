@@ -1199,10 +1199,13 @@ class WsddnEngine(object):
             uev.append((e0, e1))
         self.sgd_iter_count += 1
         self._mom_synced = len(blocks) == 1
-        mine = meta[self.rank]
-        mine[:nb].copy_(max6[b0:b1])
-        mine[nb:2 * nb].copy_(sc[0, 1][b0:b1].view(torch.int32))
-        mine[2 * nb:2 * nb + 1].copy_(self._wovf)
+        # every owner's block starts from this rank's own view of those rows (what the previous
+        # gather left: right for the rows this rank does not own only until the gather below
+        # overwrites them - and what an exchange that moves no data, bench.py's projection, keeps)
+        meta[:, :nb].copy_(max6.view(len(blocks), nb))
+        meta[:, nb:2 * nb].copy_(sc[0, 1].view(torch.int32).view(len(blocks), nb))
+        meta[:, 2 * nb].zero_()
+        meta[self.rank, 2 * nb:2 * nb + 1].copy_(self._wovf)
         w6, w7 = self._weight_views()
         red.gather_blocks_async(w6.reshape(-1), self.rank)
         red.gather_blocks_async(meta.view(-1), self.rank)

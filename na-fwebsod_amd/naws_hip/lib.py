@@ -140,6 +140,12 @@ SPECIAL = {
     'naws_gemm_f32_splitk_workspace_floats': ([i32, i32, i32, i32], i64),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(SPECIAL))
+# entries that exist only in the A/B build (make AB=1, loaded through NAWS_LIB): experiments whose
+# losing arm is kept reproducible for the tools, never part of the product ABI
+AB_PROTOTYPES = {
+    'naws_conv3x3_winograd_nhwc_f16x2_col_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p,
+                                                 p, p],
+}
 
 
 class NawsError(RuntimeError):
@@ -172,6 +178,10 @@ def load():
     for name, (argtypes, restype) in SPECIAL.items():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = argtypes, restype
+    for name, argtypes in AB_PROTOTYPES.items():       # present in libnaws_hip_ab.so only
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes, fn.restype = argtypes, i32
     _lib = lib
     for env, knob in _ENV_KNOBS.items():
         if os.environ.get(env):

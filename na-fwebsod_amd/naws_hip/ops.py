@@ -480,6 +480,17 @@ def conv3x3_nhwc_f16x2(x, w2, bias, relu=True, out=None, amax_in=None, in_mul=1.
     return y
 
 
+def winograd_weight_columns(u):
+    """The transformed weight U [16 = (row i, column j)][Cout][Cin] regrouped for the
+    frequency-column batch GEMM and split: F16x2 with planes [2, 4 (j), 4 Cin/16, Cout, 16] -
+    row (j, cout) = the four row blocks i of column j side by side, one scale per row."""
+    _chk(u, 'u')
+    sixteen, cout, cin = u.shape
+    assert sixteen == 16
+    cols = u.view(4, 4, cout, cin).permute(1, 2, 0, 3).reshape(4, cout, 4 * cin).contiguous()
+    return split_f16x2(cols)
+
+
 def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None, amax_in=None,
                                 amax_out=None):
     """Winograd F(2x2,3x3) with fp16x2 GEMMs; u2 = split_f16x2(winograd_weight_transform(w))
@@ -488,12 +499,22 @@ def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None, am
     _chk(x, 'x')
     n, h, w, cin = x.shape
     cout = u2.planes.shape[-2]
-    if u2.planes.dtype != torch.float16 or tuple(u2.planes.shape[:3]) != (2, 16, cin // 16):
-        raise TypeError('u2 must hold the f16 planes [2, 16, Cin/16, Cout, 16] of U')
+    col = tuple(u2.planes.shape[:3]) == (2, 4, 4 * cin // 16)     # winograd_weight_columns
+    if u2.planes.dtype != torch.float16 or not (
+            col or tuple(u2.planes.shape[:3]) == (2, 16, cin // 16)):
+        raise TypeError('u2 must hold the f16 planes [2, 16, Cin/16, Cout, 16] of U (or the '
+                        'column form [2, 4, 4 Cin/16, Cout, 16])')
     y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
     nws = L.load().naws_winograd_f16x2_workspace_floats(n, h, w, cin, cout, dilation)
     ws = torch.empty((nws,), device=x.device, dtype=_f32)
-    L.call('naws_conv3x3_winograd_nhwc_f16x2_fwd', x.data_ptr(), u2.planes.data_ptr(),
+    if col and not hasattr(L.load(), 'naws_conv3x3_winograd_nhwc_f16x2_col_fwd'):
+        raise RuntimeError('the frequency-column Winograd form lives in the A/B build only '
+                           '(make -C na-fwebsod_amd/csrc AB=1; NAWS_LIB=.../libnaws_hip_ab.so): it '
+                           'measured slower than the 16-plane form, profiles/r04_wino_column_pmc.md')
+    if col and amax_in is None:
+        amax_in = amax_word(x)
+    L.call('naws_conv3x3_winograd_nhwc_f16x2_col_fwd' if col else
+           'naws_conv3x3_winograd_nhwc_f16x2_fwd', x.data_ptr(), u2.planes.data_ptr(),
            u2.inv_scale.data_ptr(), _ptr(bias), n, h, w, cin, cout, dilation, int(relu),
            ws.data_ptr(), y.data_ptr(), _ptr(amax_in), _ptr(amax_out), _stream())
     return y

@@ -149,8 +149,8 @@ class EmulatedExchange(object):
         self.cus = int(cus)
         # default pace: min(N-1, 7) xGMI links x 153 GB/s per direction at 60 % efficiency
         self.gbps = float(gbytes_per_sec) if gbytes_per_sec else 0.6 * 153.0 * min(self.n - 1, 7)
-        self.world_size = 1            # (the update's 1/gpu_num is the caller's business)
-        self.force = True
+        self.world_size = self.n       # (only NAWS.SHARDED_UPDATE's ownership reads it; the
+        self.force = True              #  update's 1/gpu_num is the caller's business)
         self._stream = torch.cuda.Stream(device=device)
         self._scratch = None
         self.bytes_per_step = 0
@@ -171,7 +171,32 @@ class EmulatedExchange(object):
                 ops.emulate_exchange(flat_slice, self._scratch, part, self.cus, self.gbps)
         self._step_bytes += 2 * part
 
+    def _phase(self, flat, phases):
+        import torch
+        from . import ops
+        n = flat.numel()
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.empty((n,), device=self.device, dtype=torch.float32)
+        part = int(n * 4 * (self.n - 1) / self.n) // 16 * 16
+        self._stream.wait_event(torch.cuda.current_stream(self.device).record_event())
+        with torch.cuda.stream(self._stream):
+            for _phase in range(phases):
+                ops.emulate_exchange(flat, self._scratch, part, self.cus, self.gbps)
+        self._step_bytes += phases * part
+
+    # NAWS.SHARDED_UPDATE under projection: this process plays rank 0 of N - it updates rows
+    # [0, 8192 / N) of fc6_w only (the other rows simply stay as they are: the arithmetic of the
+    # projection run is not a training run's), the reduce-scatter and the all-gather each move
+    # (N-1)/N of their message
+    def reduce_to_owner_async(self, flat_slice, owner):
+        self._phase(flat_slice, 1)
+
+    def gather_blocks_async(self, flat, rank):
+        if flat.dtype.is_floating_point and flat.numel() >= 4096:
+            self._phase(flat, 1)
+
     def wait(self):
         import torch
         torch.cuda.current_stream(self.device).wait_event(self._stream.record_event())
-        self.bytes_per_step, self._step_bytes = self._step_bytes, 0
+        if self._step_bytes:
+            self.bytes_per_step, self._step_bytes = self._step_bytes, 0

@@ -37,8 +37,8 @@ def main():
                    'gemm_x3_m16_kernel<256,256,4x2,2 stages,2 planes x 2 slabs,f16> fc6 fwd', 1.354, '262144'),
         'fp32x3': ('gemm_x3_m16_kernel<256, 128, 4, 2, 2, 3, 2, false>',
                    'gemm_x3_m16_kernel<256,128,4x2,2 stages,3 planes x 2 slabs> fc6 fwd', 1.966, '524288'),
-        'bf16': ('gemm_bf16_kernel<256, 128, 4, 2, false, false, false>',
-                 'gemm_bf16_kernel<256,128,4x2,fp32 sources> fc6 fwd', 1.354, None),
+        'bf16': ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 1, 4, false>',
+                 'gemm_x3_m16_kernel<256,256,4x2,2 stages,1 plane x 4 slabs,bf16> fc6 fwd', 0.677, '262144'),
     }[mode]
     rows = list(csv.DictReader(open(_find(stats_dir, '*_kernel_stats.csv')[0])))
     lines = ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']

@@ -244,6 +244,47 @@ def test_conv3x3_winograd_f16x2(dev, cin, cout, dil, h, w, amp):
     assert np.abs(ops.nhwc_to_nchw(y4).cpu().numpy() - ref).max() < 1e-5 * scale
 
 
+@pytest.mark.parametrize('cin,cout,dil,h,w,amp', [(512, 512, 1, 75, 125, 3.0), (512, 512, 2, 74, 124, 0.02),
+                                                   (64, 128, 1, 37, 41, 50.0), (256, 512, 2, 19, 23, 1.0)])
+def test_conv3x3_winograd_f16x2_frequency_columns(dev, cin, cout, dil, h, w, amp):
+    """The frequency-column form of the Winograd batch GEMM (K = 4 Cin per column, the A^T row
+    stage in two accumulator sets, naws_conv3x3_winograd_nhwc_f16x2_col_fwd): held to the same
+    bounds against a float64 convolution as the 16-plane form, which it matches to the last bits
+    of the fp32 row sums; bias / ReLU / max|y| reporting / zero input as there."""
+    from naws_hip import lib, ops
+    import torch.nn.functional as F
+    if not hasattr(lib.load(), 'naws_conv3x3_winograd_nhwc_f16x2_col_fwd'):
+        pytest.skip('the column form lost its A/B (profiles/r04_wino_column_pmc.md) and lives in '
+                    'the A/B build only: run with NAWS_LIB=na-fwebsod_amd/lib/libnaws_hip_ab.so')
+    rng = np.random.default_rng(58)
+    n = 2
+    x = (np.maximum(rng.standard_normal((n, cin, h, w)), 0) * amp).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.uniform(-0.5, 0.5, cout) * amp).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    u = ops.winograd_weight_transform(_t(wt, dev))
+    ucol = ops.winograd_weight_columns(u)
+    assert tuple(ucol.planes.shape) == (2, 4, 4 * cin // 16, cout, 16)
+    y16 = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc_f16x2(xd, ops.split_f16x2(u), _t(b, dev), dil,
+                                                           True)).cpu().numpy()
+    am = torch.zeros((2,), device=dev, dtype=torch.int32)
+    am[0] = int(np.float32(np.abs(x).max()).view(np.int32))
+    y = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc_f16x2(xd, ucol, _t(b, dev), dil, True,
+                                                         amax_in=am[0:1], amax_out=am[1:2])).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(y - ref).max() < 1e-5 * scale
+    assert np.abs(y - ref).max() <= 2.0 * np.abs(y16 - ref).max() + 1e-6 * scale
+    assert np.abs(y - y16).max() < 4e-6 * scale
+    assert np.int32(am[1].item()).view(np.float32) == np.float32(y.max())
+    y2 = ops.conv3x3_winograd_nhwc_f16x2(xd, ucol, None, dil, False)       # (measures max|x| itself)
+    r2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, padding=dil,
+                  dilation=dil).numpy()
+    assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 1e-5 * np.abs(r2).max()
+    assert not ops.conv3x3_winograd_nhwc_f16x2(torch.zeros_like(xd), ucol, None, dil, False).any()
+
+
 def test_amax_word(dev):
     from naws_hip import ops
     rng = np.random.default_rng(49)

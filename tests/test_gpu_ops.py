@@ -77,6 +77,41 @@ def test_roi_pool_hierarchical_bitexact(dev, h, w, nroi):
     b = ops.roi_pool_f_f16x2(xz, _t(rois, dev), amax, 7, 7, 0.125, boost=_t(boost, dev), hier=False)
     assert torch.equal(a.planes.view(torch.int16), b.planes.view(torch.int16))
     assert torch.equal(a.inv_scale, b.inv_scale)
+    # the two halves as separate calls, the maps of each image built on their own (the engine
+    # does that on the image's conv stream): identical planes
+    m2, m4 = torch.empty_like(xz), torch.empty_like(xz)
+    for i in range(n):
+        ops.roi_maxmaps(xz[i:i + 1], m2[i:i + 1], m4[i:i + 1])
+    c2 = ops.roi_pool_f_f16x2(xz, _t(rois, dev), amax, 7, 7, 0.125, boost=_t(boost, dev), maps=(m2, m4))
+    assert torch.equal(c2.planes.view(torch.int16), b.planes.view(torch.int16))
+    assert torch.equal(c2.inv_scale, b.inv_scale)
+
+
+def test_emulate_exchange_copies_at_the_requested_pace(dev):
+    """naws_emulate_exchange (bench.py's N-rank projection aid): copies exactly `bytes` and lasts
+    about bytes / rate; argument checks."""
+    from naws_hip import ops, lib
+    n = 8 << 20
+    src = torch.arange(n, device=dev, dtype=torch.float32)
+    dst = torch.zeros_like(src)
+    nbytes = 4 * n - 64
+    t = []
+    for gbps in (400.0, 100.0):
+        dst.zero_()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        ops.emulate_exchange(src, dst, nbytes, 32, gbps)
+        e.record()
+        torch.cuda.synchronize()
+        t.append(s.elapsed_time(e))
+        k = nbytes // 4
+        assert torch.equal(dst[:k], src[:k]) and not dst[k:].any()
+        want = nbytes / (gbps * 1e9) * 1e3
+        assert 0.9 * want <= t[-1] <= 1.6 * want + 0.2, (gbps, t[-1], want)
+    with pytest.raises(lib.NawsError):
+        lib.call('naws_emulate_exchange', src.data_ptr(), dst.data_ptr(), 1024, 0, 100.0, 0)
+    with pytest.raises(ValueError):
+        ops.emulate_exchange(src, dst, 4 * n + 16, 32, 100.0)
 
 
 def test_roi_pool_empty_and_errors(dev):
