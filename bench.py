@@ -399,7 +399,7 @@ def extra_configs(args, dev, B, res, cfg, roof):
     torch.cuda.empty_cache()
     ia = argparse.Namespace(**vars(args))
     ia.mfma_dtype = 'fp16x2'
-    ti = infer_measure(ia, dev, steps=8, warmup=2)
+    ti = infer_measure(ia, dev, steps=16, warmup=4)
     res['tta_infer'] = {k: ti[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps',
                                             'warmup', 'dtype', 'config', 'roofline')}
     cfg['tta_infer_ms_per_image'] = ti['ms_per_step']

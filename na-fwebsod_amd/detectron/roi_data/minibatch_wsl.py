@@ -11,6 +11,16 @@ on the GPU (naws_prep_image_fwd): the loader threads then only decode, and a min
 the raw uint8 images + their parameters (`_raw`) instead of a float `data` blob.
 The HSV distortion (WSL.USE_DISTORTION: cv2.cvtColor BGR2HSV -> scale S, V -> HSV2BGR on uint8)
 is restated from OpenCV's 8-bit algorithm (`distort_hsv`), on the host or inside the device prep.
+
+PARITY UNPINNED for three third-party behaviours the reference inherits from OpenCV (an
+un-vendored, un-pinned dependency that is absent here, so no vector of it could be captured):
+(1) cv2.resize(INTER_LINEAR)'s fixed-point taps, (2) cv2.cvtColor's 8-bit BGR<->HSV tables, both
+restated from the published algorithms and pinned only by hand-derived known answers
+(tests/test_oracle_kat.py, tests/test_gpu_prep.py: device == oracle restatement bit for bit);
+(3) JPEG decoding: cv2.imread and PIL both sit on libjpeg but may differ in IDCT / upsampling
+options by +-1 in some pixels.  None of this touches the synthetic benchmark or the parity tests
+(their pixels are generated); it matters only for bit-level reproduction of a reference run on
+real JPEGs.
 """
 import os
 
