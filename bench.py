@@ -443,7 +443,7 @@ def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False):
         eng.sharded_update, eng._shard, eng._mom_synced = False, None, True
     exposed = [e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]) if n1 == 'join_update']
     return {'ms_per_step': round(ms, 3), 'cus': ex.cus, 'gbps': ex.gbps, 'chunks': 4 if n == 2 else 2,
-            'bytes_per_step': ex.bytes_per_step,
+            'bytes_per_step': ex.total_bytes / (5 + steps),
             'exposed_ms': sum(exposed) / max(len(exposed), 1)}
 
 
@@ -818,26 +818,32 @@ def main():
         # underneath the next iteration's conv body)
         if conv_gflop and stage_ms.get('conv_body'):
             tf = conv_gflop / stage_ms['conv_body']
-            roof.update(conv_stack_ms=stage_ms['conv_body'], conv_stack_tflops=round(tf, 1),
-                        conv_stack_frac_vs_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 3))
+            roof.update(conv_stack_ms=stage_ms['conv_body'], conv_stack_tflops=round(tf, 1))
             if conv_alone_ms:
                 roof.update(conv_stack_alone_ms=round(conv_alone_ms, 3),
-                            conv_stack_alone_tflops=round(conv_gflop / conv_alone_ms, 1),
-                            conv_stack_alone_frac_vs_fp32_mfma_peak=round(
-                                conv_gflop / conv_alone_ms / FP32_MFMA_PEAK_TFLOPS, 3))
-            if h2:
-                # The fraction above exceeds 1 because the default plan leaves the fp32 pipe: what
-                # the stack EXECUTES on the f16 MFMA is 3 passes over the direct layers
-                # (conv1_2..conv3_3: 221.0 of the 463.7 algorithmic GFLOP per image) and 3 passes
-                # over Winograd F(2x2,3x3)'s 1/2.25 of conv4_1..conv5_3 (242.7 GFLOP); conv1_1 runs
-                # on the vector unit.  Against the dense f16 peak:
-                ex_gflop = conv_gflop / 463.7 * (3 * 221.0 + 3 * 242.7 / 2.25)
-                roof.update(conv_stack_executed_f16_tflops=round(ex_gflop / stage_ms['conv_body'], 1),
-                            conv_stack_frac_vs_f16_mfma_peak=round(
-                                ex_gflop / stage_ms['conv_body'] / BF16_MFMA_PEAK_TFLOPS, 3))
+                            conv_stack_alone_tflops=round(conv_gflop / conv_alone_ms, 1))
+            # THE fraction: what the stack EXECUTES on its matrix pipe against that pipe's peak.
+            # Split plans: npass passes over the direct layers (conv1_2..conv3_3: 221.0 of the
+            # 463.7 algorithmic GFLOP per image) and over Winograd F(2x2,3x3)'s 1/2.25 of
+            # conv4_1..conv5_3 (242.7 GFLOP); conv1_1 runs on the vector unit.
+            if h2 or x3:
+                npass = 3 if h2 else 6
+                ex_gflop = conv_gflop / 463.7 * npass * (221.0 + 242.7 / 2.25)
+                tag = 'f16' if h2 else 'bf16'
+                roof['conv_stack_executed_%s_tflops' % tag] = round(ex_gflop / stage_ms['conv_body'], 1)
+                roof['conv_stack_frac_vs_%s_mfma_peak' % tag] = round(
+                    ex_gflop / stage_ms['conv_body'] / BF16_MFMA_PEAK_TFLOPS, 3)
                 if conv_alone_ms:
-                    roof.update(conv_stack_alone_frac_vs_f16_mfma_peak=round(
-                        ex_gflop / conv_alone_ms / BF16_MFMA_PEAK_TFLOPS, 3))
+                    roof['conv_stack_alone_frac_vs_%s_mfma_peak' % tag] = round(
+                        ex_gflop / conv_alone_ms / BF16_MFMA_PEAK_TFLOPS, 3)
+                # NOT a fraction: how many times faster than the fp32-MFMA floor (all 463.7
+                # algorithmic GFLOP per image at 157.3 TFLOP/s) - above 1 because the work is not
+                # on the fp32 pipe, not because any of it is skipped
+                roof['conv_stack_speedup_over_fp32_mfma_floor'] = round(tf / FP32_MFMA_PEAK_TFLOPS, 3)
+            elif bf:      # one pass, every layer direct (no Winograd in this plan)
+                roof['conv_stack_frac_vs_bf16_mfma_peak'] = round(tf / BF16_MFMA_PEAK_TFLOPS, 3)
+            else:
+                roof['conv_stack_frac_vs_fp32_mfma_peak'] = round(tf / FP32_MFMA_PEAK_TFLOPS, 3)
         if roipool_bytes and stage_ms.get('roi_pool'):
             gbs = roipool_bytes / stage_ms['roi_pool'] / 1e6
             roof.update(roipool_ms=stage_ms['roi_pool'], roipool_GBps=round(gbs, 1),

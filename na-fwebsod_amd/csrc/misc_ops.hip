@@ -137,20 +137,23 @@ namespace {
 __global__ void __launch_bounds__(256) exchange_proxy_kernel(const float4* __restrict__ src,
                                                              float4* __restrict__ dst, int64_t n16,
                                                              double ticks_per_chunk) {
-  const int64_t per = ((n16 + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024;
+  // 64 KB per workgroup and round (16 float4 per thread in flight): at ~2 us per load -> store round
+  // trip that sustains ~30 GB/s per workgroup, above any pace the callers ask of 32 workgroups
+  constexpr int U = 16, CHUNK = 256 * U;
+  const int64_t per = ((n16 + gridDim.x - 1) / gridDim.x + CHUNK - 1) / CHUNK * CHUNK;
   const int64_t i0 = (int64_t)blockIdx.x * per;
   const int64_t i1 = i0 + per < n16 ? i0 + per : n16;
   const uint64_t t0 = wall_clock64();
   int64_t k = 0;
-  for (int64_t i = i0; i < i1; i += 1024, ++k) {        // 16 KB per workgroup and round
-    float4 v[4];
+  for (int64_t i = i0; i < i1; i += CHUNK, ++k) {
+    float4 v[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t j = i + u * 256 + threadIdx.x;
       v[u] = j < i1 ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t j = i + u * 256 + threadIdx.x;
       if (j < i1) dst[j] = v[u];
     }
@@ -170,8 +173,8 @@ extern "C" int naws_emulate_exchange(const void* src, void* dst, int64_t bytes, 
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
     return naws_check_launch();
-  // one workgroup moves 16 KB per round at gbytes_per_sec / cus
-  const double ticks = 16384.0 * cus / (gbytes_per_sec * 1e9) * (khz * 1e3);
+  // one workgroup moves 64 KB per round at gbytes_per_sec / cus
+  const double ticks = 65536.0 * cus / (gbytes_per_sec * 1e9) * (khz * 1e3);
   exchange_proxy_kernel<<<cus, 256, 0, (hipStream_t)stream>>>((const float4*)src, (float4*)dst,
                                                               bytes / 16, ticks);
   return naws_check_launch();

@@ -153,8 +153,7 @@ class EmulatedExchange(object):
         self.force = True              #  update's 1/gpu_num is the caller's business)
         self._stream = torch.cuda.Stream(device=device)
         self._scratch = None
-        self.bytes_per_step = 0
-        self._step_bytes = 0
+        self.total_bytes = 0           # moved since construction (bench: / steps)
 
     active = True
 
@@ -169,7 +168,7 @@ class EmulatedExchange(object):
         with torch.cuda.stream(self._stream):
             for _phase in range(2):        # reduce-scatter, all-gather
                 ops.emulate_exchange(flat_slice, self._scratch, part, self.cus, self.gbps)
-        self._step_bytes += 2 * part
+        self.total_bytes += 2 * part
 
     def _phase(self, flat, phases):
         import torch
@@ -182,7 +181,7 @@ class EmulatedExchange(object):
         with torch.cuda.stream(self._stream):
             for _phase in range(phases):
                 ops.emulate_exchange(flat, self._scratch, part, self.cus, self.gbps)
-        self._step_bytes += phases * part
+        self.total_bytes += phases * part
 
     # NAWS.SHARDED_UPDATE under projection: this process plays rank 0 of N - it updates rows
     # [0, 8192 / N) of fc6_w only (the other rows simply stay as they are: the arithmetic of the
@@ -198,5 +197,3 @@ class EmulatedExchange(object):
     def wait(self):
         import torch
         torch.cuda.current_stream(self.device).wait_event(self._stream.record_event())
-        if self._step_bytes:
-            self.bytes_per_step, self._step_bytes = self._step_bytes, 0

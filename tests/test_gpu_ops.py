@@ -96,7 +96,8 @@ def test_emulate_exchange_copies_at_the_requested_pace(dev):
     dst = torch.zeros_like(src)
     nbytes = 4 * n - 64
     t = []
-    for gbps in (400.0, 100.0):
+    ops.emulate_exchange(src, dst, nbytes, 32, 1000.0)           # (first launch: code object load)
+    for gbps in (600.0, 100.0):
         dst.zero_()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
