@@ -58,6 +58,9 @@ def parse():
     ap.add_argument('--sharded-update', action='store_true',
                     help='N > 1: NAWS.SHARDED_UPDATE - fc6_w gradient rows reduced to one owner each, '
                          'owner-only update, updated rows all-gathered (engine._apply_update_sharded)')
+    ap.add_argument('--no-projection', action='store_true',
+                    help='skip the N-rank contention projections (profile runs: their proxy kernel '
+                         'and chunked wgrad launches would otherwise sit in the kernel tables)')
     ap.add_argument('--no-fused-update', action='store_true',
                     help='one rank only: write fc6_w\'s gradient and update it in the deferred SGD '
                          'kernel (the route every rank takes when there is a gradient exchange) '
@@ -735,7 +738,8 @@ def main():
     # One rank: what the N-rank schedule costs THIS GPU when something occupies compute units and
     # HBM the way the RCCL exchange would (reducer.EmulatedExchange; a projection, labelled so)
     projections = {}
-    if world == 1 and args.mfma_dtype == 'fp16x2' and not args.share_gpu and not args.force_dist:
+    if world == 1 and args.mfma_dtype == 'fp16x2' and not args.share_gpu and not args.force_dist \
+            and not args.no_projection:
         spec = [x for x in args.emulate_exchange.split(',') if x]
         cases = [(int(spec[0]), int(spec[1]) if len(spec) > 1 else 32,
                   float(spec[2]) if len(spec) > 2 else None)] if spec else \
@@ -862,7 +866,7 @@ def main():
         if tj and headline and B == 2:
             roof['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
             roof['traffic_source'] = os.path.relpath(tj[-1], ROOT)
-        pmc = {'fp16x2': 'profiles/r03_default_plan_pmc.md', 'fp32x3': 'profiles/r01_x3_gemm_pmc.md'}
+        pmc = {'fp16x2': 'profiles/r04_default_plan_pmc.md', 'fp32x3': 'profiles/r01_x3_gemm_pmc.md'}
         if args.mfma_dtype in pmc:
             roof['profile_ref'] = pmc[args.mfma_dtype]
         cfg = {'workload': 'configs[1] flickr_voc na_wsddn_V-16-C5_1x C=%d: %d img %dx%d/GPU x %d '

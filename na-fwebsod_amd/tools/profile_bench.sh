@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 R=${1:-r04}
 O=gpurun_out/prof_$R
-B="python bench.py --no-cpu-baseline --no-alt-plan --no-extra-configs --no-parity-check"
+B="python bench.py --no-cpu-baseline --no-alt-plan --no-extra-configs --no-parity-check --no-projection"
 for P in fp16x2 fp32x3 fp32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${P}_stats -o st -- $B --mfma-dtype $P --steps 20 --warmup 5 > $O.$P.log 2>&1
   tail -1 $O.$P.log | cut -c1-300
