@@ -296,10 +296,10 @@ def alt_plan(args, dev, num_fg, B, t, seg, mode, blobs=None, steps=None):
         eng.timing_events = ev if timed else None
         eng.phase_events = pev if timed else None
         for _ in range(n):
-            out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            # (= forward_backward + sgd_step; one rank, split plans: fc6_w updated in its wgrad GEMM)
+            out = eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
             if not probe:
                 probe.append(step0_probe(out))
-            eng.sgd_step()
         eng.flush()
         torch.cuda.synchronize()
         return out
@@ -799,11 +799,12 @@ def main():
         # 3 reads + 2 writes of the arena; the fp16x2 plan's update also writes the hi / lo operand
         # planes of fc6_w / fc7_w (4 B per weight) in the same kernel
         sgd_bytes = 5 * 4 * eng.arena.total
-        if h2 and eng.fused_planes and eng._sgd_regions is not None:
-            sgd_bytes += 4 * 2 * 4096 * (eng.k6 + 4096)
+        plane_bytes = 4 if h2 else 6 if x3 else 2 if bf else 0      # per fc6 / fc7 weight
+        if plane_bytes and eng.fused_planes and eng._sgd_regions is not None:
+            sgd_bytes += plane_bytes * 2 * 4096 * (eng.k6 + 4096)
         wgrad_update = (not args.no_fused_update) and eng._can_fuse_wgrad_update()
         if wgrad_update:       # the deferred kernel no longer touches fc6_w (nor reads its gradient)
-            sgd_bytes -= (5 * 4 + 4) * 2 * 4096 * eng.k6
+            sgd_bytes -= (5 * 4 + plane_bytes) * 2 * 4096 * eng.k6
         sgd_ms = sum(s.elapsed_time(e) for s, e in uev) / max(len(uev), 1)
         roof = {'bound': 'mfma', 'kernel': 'fc6 fwd (both branches, M=%d N=8192 K=%d): %s' % (rt, k6, kname),
                 'achieved': round(achieved, 2) if achieved else None,

@@ -565,6 +565,12 @@ int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_t slabA, co
 int naws_conv3x3_nhwc_f32x3_fwd(const float* X, const void* W3, const float* bias, int N, int H,
                                 int W, int Cin, int Cout, int dilation, int relu, float* Y,
                                 void* stream);
+/* The same convolution (dilation 1) followed by the reference's 2x2 / stride-2 MaxPool (pool1 ..
+ * pool3, detectron/modeling/VGG16.py:14-30), taken in the kernel's epilogue: Y is
+ * [N][H/2][W/2][Cout], bit-identical to naws_conv3x3_nhwc_f32x3_fwd + naws_maxpool2x2_nhwc_fwd.
+ * Cout % 64 == 0, Cout <= 256. */
+int naws_conv3x3_nhwc_f32x3_pool_fwd(const float* X, const void* W3, const float* bias, int N, int H,
+                                     int W, int Cin, int Cout, int relu, float* Y, void* stream);
 /* Winograd F(2x2,3x3) convolution (as naws_conv3x3_winograd_nhwc_fwd) with the 16 batched GEMMs
  * in the fp32x3 split; U3 = naws_split_bf16x3 (batch 16, transpose 0) of the transformed weight
  * U[16][Cout][Cin].  Cin % 16 == 0. */

@@ -1153,6 +1153,29 @@ extern "C" int naws_debug_conv_stamp_buffer(void* buf) {
 // fp16x2 form of the shallow-layer convolution (the halo-tile kernel): W2 / scaleW =
 // naws_split_f16x2 of the packed weight viewed [Cout][9*Cin]; the activation scale comes from
 // *amax_in * in_mul + in_add (an upper bound of max|X|); dilation 1, Cout <= 128, Cout % 32 == 0.
+// naws_conv3x3_nhwc_f32x3_fwd followed by the 2x2 / stride-2 max-pool of the reference
+// (pool1 .. pool3), taken in the epilogue of the 3-plane wave-private kernel: Y is [N][H/2][W/2][Cout].
+extern "C" int naws_conv3x3_nhwc_f32x3_pool_fwd(const float* X, const void* W3, const float* bias,
+                                                int N, int H, int W, int Cin, int Cout, int relu,
+                                                float* Y, void* stream) {
+  if (N <= 0 || H < 2 || W < 2 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (Cin % 16 != 0 || Cout % 64 != 0 || Cout > 256) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W3); NAWS_REQUIRE_PTR(Y);
+  if (!bias && relu) return NAWS_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)W3) & 15) != 0) return NAWS_ERR_ARG;
+  const long long pix = (long long)N * H * W;
+  if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
+  CArgs g{};
+  g.X = X; g.B = (const unsigned short*)W3; g.bias = bias; g.Y = Y;
+  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = 1; g.relu = relu;
+  g.slabB = (long long)Cout * 16;
+  g.planeB = (long long)9 * Cin * Cout;
+  g.bytesX = (unsigned)(pix * Cin * 4);
+  g.pool = 1;
+  if (3 * g.planeB * 2 > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  return launch_conv_wp_x3(g, N, (hipStream_t)stream);
+}
+
 extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,
                                            const float* bias, int N, int H, int W, int Cin,
                                            int Cout, int dilation, int relu, float* Y,

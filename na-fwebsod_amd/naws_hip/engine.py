@@ -316,6 +316,7 @@ class WsddnEngine(object):
                 self._sgd_regions = ops.SgdPlaneRegions([
                     (o6, n6, self.k6, n6, self._wplanes['w6'], None, None, None),
                     (o7, n6, HIDDEN, HIDDEN, self._wplanes['w7'], None, None, None)], fmt)
+
         else:
             cv(w6, out=self._wplanes['w6'])
             cv(w7, out=self._wplanes['w7'])
@@ -469,7 +470,13 @@ class WsddnEngine(object):
                         else:
                             conv = (ops.conv3x3_winograd_nhwc if self.conv_wino[name]
                                     else ops.conv3x3_nhwc)
-                        x = conv(x, wp, b, d, True, out=dst)
+                        if (conv is ops.conv3x3_nhwc_f32x3 and d == 1 and dst is None
+                                and li + 1 < len(VGG16_CONVS) and VGG16_CONVS[li + 1][0] == 'pool'
+                                and wp.shape[-2] % 64 == 0 and wp.shape[-2] <= 256):
+                            x = conv(x, wp, b, d, True, pool2=True)     # pool1..3 in the epilogue
+                            fused_pool = True
+                        else:
+                            x = conv(x, wp, b, d, True, out=dst)
                         prev = None
         self._pool_done = fused_pool     # a range that ends on a fused pool: the next one skips it
         return x

@@ -80,6 +80,7 @@ PROTOTYPES = {
     'naws_conv3x3_nhwc_bf16_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
     'naws_transpose_to_bf16': [p, i32, i32, i32, i32, i32, p, p],
     'naws_conv3x3_nhwc_f32x3_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
+    'naws_conv3x3_nhwc_f32x3_pool_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, p, p],
     'naws_conv3x3_winograd_nhwc_f32x3_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p],
     'naws_soft_nms_fwd': [p, p, i32, i32, f32, f32, f32, i32, p, p, p, p],
     'naws_nms_sorted_fwd': [p, p, i32, i32, f32, p, p, p],

@@ -408,14 +408,20 @@ def split_bf16x3(x, transpose=False, out=None):
     return p
 
 
-def conv3x3_nhwc_f32x3(x, w3, bias, dilation=1, relu=True, out=None):
+def conv3x3_nhwc_f32x3(x, w3, bias, dilation=1, relu=True, out=None, pool2=False):
     """3x3 conv on NHWC fp32 activations with weight planes w3 = split_bf16x3(packed weight
-    viewed [Cout, 9*Cin]); fp32-accurate, bf16 MFMA."""
+    viewed [Cout, 9*Cin]); fp32-accurate, bf16 MFMA.  pool2: the 2x2 / stride-2 max-pool that
+    follows is taken in the kernel's epilogue (dilation 1, Cout % 64 == 0, Cout <= 256)."""
     _chk(x, 'x')
     n, h, w, cin = x.shape
     cout = w3.shape[-2]
     if w3.dtype != torch.bfloat16 or w3.shape[0] != 3 or w3.shape[1] * 16 != 9 * cin:
         raise TypeError('w3 must be the bf16 planes [3, 9*Cin/16, Cout, 16] of the packed weight')
+    if pool2:
+        y = torch.empty((n, h // 2, w // 2, cout), device=x.device, dtype=_f32)
+        L.call('naws_conv3x3_nhwc_f32x3_pool_fwd', x.data_ptr(), w3.data_ptr(), _ptr(bias), n, h, w,
+               cin, cout, int(relu), y.data_ptr(), _stream())
+        return y
     y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
     L.call('naws_conv3x3_nhwc_f32x3_fwd', x.data_ptr(), w3.data_ptr(), _ptr(bias), n, h, w, cin,
            cout, dilation, int(relu), y.data_ptr(), _stream())

@@ -189,6 +189,11 @@ def test_conv3x3_f32x3(dev, cin, cout, dil, h, w):
     r2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, padding=dil,
                   dilation=dil).numpy()
     assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 1e-5 * scale
+    if dil == 1 and cout % 64 == 0 and cout <= 256 and h >= 2 and w >= 2:
+        # the 2x2 / stride-2 max-pool in the epilogue == the pooling kernel on the un-pooled output
+        yd = ops.conv3x3_nhwc_f32x3(xd, w3, _t(b, dev), 1, True)
+        yp = ops.conv3x3_nhwc_f32x3(xd, w3, _t(b, dev), 1, True, pool2=True)
+        assert torch.equal(yp, ops.maxpool2x2_nhwc(yd, 2))
 
 
 @pytest.mark.parametrize('cin,cout,dil,h,w', [(128, 256, 1, 19, 23), (512, 512, 2, 20, 31),
