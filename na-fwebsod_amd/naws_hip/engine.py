@@ -316,7 +316,6 @@ class WsddnEngine(object):
                 self._sgd_regions = ops.SgdPlaneRegions([
                     (o6, n6, self.k6, n6, self._wplanes['w6'], None, None, None),
                     (o7, n6, HIDDEN, HIDDEN, self._wplanes['w7'], None, None, None)], fmt)
-
         else:
             cv(w6, out=self._wplanes['w6'])
             cv(w7, out=self._wplanes['w7'])
