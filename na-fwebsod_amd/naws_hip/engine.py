@@ -982,7 +982,10 @@ class WsddnEngine(object):
             ratio = max(new_lr / max(cur, 1e-10), cur / max(new_lr, 1e-10))
             self.lr.fill_(new_lr)
             if self.scale_momentum and cur > 1e-7 and ratio > self.scale_momentum_threshold:
-                ops.unary(L.UN_SCALE, self.momentum_buf, new_lr / cur, out=self.momentum_buf)
+                # the correction is a float32 quotient in the reference (np.float32 / np.float32,
+                # detector.py:536) and the Scale op's float argument
+                corr = float(np.float32(new_lr) / np.float32(cur))
+                ops.unary(L.UN_SCALE, self.momentum_buf, corr, out=self.momentum_buf)
         return new_lr
 
     def sgd_step(self):

@@ -424,6 +424,32 @@ def test_plane_writing_update_needs_one_hyper_parameter_run_per_region(dev, mode
         assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()), name
 
 
+def test_set_lr_reproduces_the_reference_momentum_correction(dev):
+    """UpdateWorkspaceLr / _SetNewLr / _CorrectMomentum (detector.py:509-559) captured from the
+    imported reference with a recording workspace (tests/golden/make_golden_lr_update.py): for
+    every lr of the sequence the engine holds the same lr and has scaled - or not scaled - the
+    momentum arena by the same float32 factor, bit for bit."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                                       'reference_lr_update.json')))
+    eng, _mb, _blobs = _setup(dev, mfma_dtype='fp32')
+    assert eng.scale_momentum == gold['SCALE_MOMENTUM']
+    assert eng.scale_momentum_threshold == gold['SCALE_MOMENTUM_THRESHOLD']
+    g = torch.Generator(device='cpu').manual_seed(5)
+    ref = torch.randn((4096,), generator=g)
+    eng.momentum_buf[:4096].copy_(ref.to(dev))
+    want = ref.numpy().copy()
+    for case in gold['cases']:
+        assert np.float32(eng._lr_host) == np.float32(case['cur_lr'])
+        eng.set_lr(case['new_lr'])
+        assert np.float32(eng._lr_host) == np.float32(case['returned'])
+        assert float(eng.lr.item()) == (case['fed'][-1] if case['fed'] else float(np.float32(case['cur_lr'])))
+        if case['correction'] is not None:
+            want = want * np.float32(case['correction'])
+        assert np.array_equal(eng.momentum_buf[:4096].cpu().numpy(), want), case
+
+
 def test_cross_plan_soak_short(dev):
     """tools/soak_crossplan.py at a reduced size: 40 training steps of the 2 x f16 split plan,
     the fp32-MFMA plan and the exact 3 x bf16 split in lockstep; the headline plan must track
