@@ -67,16 +67,14 @@ def train_model(roidb=None, max_iter=None, printer=print):
         if not all_ok:
             handle_critical_error(model, 'roi_data_loader failed' if not my_ok else
                                   'roi_data_loader failed on another rank')
-        stats.UpdateIterStats(vals)
+        stats.UpdateIterStats(vals, loader.queue_size())
         if rank == 0:
+            mem = torch.cuda.max_memory_allocated(device) if device.type == 'cuda' else 0
             if it == last - 1 and last != cfg.SOLVER.MAX_ITER:      # a shortened run: log its last iteration too
                 from detectron.utils.training_stats_wsl import log_json_stats
-                log_json_stats(stats.GetStats(it, it_lr, loader.queue_size(),
-                                              torch.cuda.max_memory_allocated(device) // (1 << 20)),
-                               stats.printer)
+                log_json_stats(stats.GetStats(it, it_lr, mem), stats.printer)
             else:
-                stats.LogIterStats(it, it_lr, loader.queue_size(),
-                                   torch.cuda.max_memory_allocated(device) // (1 << 20))
+                stats.LogIterStats(it, it_lr, mem)
         if np.isnan(stats.iter_total_loss):
             handle_critical_error(model, 'Loss is NaN')
 
@@ -173,30 +171,39 @@ def begin_iteration_values(executor, model, pg, world, ok=True):
     as ONE small device tensor copied to pinned host memory without blocking.  Returns a handle
     for finish_iteration_values."""
     ws = executor.ws
-    vals = [ws[k].reshape(-1).float().mean() for k in model.losses]
-    dev = vals[0].device
-    vals.append(torch.full((), 0.0 if ok else float(world), device=dev))
-    t = torch.stack(vals)
-    if pg is not None and world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t, group=pg)
-        t = t / world
+    # The reference averages the per-GPU float32 scalars of EVERY loss and metric on the host in
+    # double (sum_multi_gpu_blob: `val += float(blob)`, then / NUM_GPUS).  Here a "GPU" of the
+    # reference is one image: per-image values are summed in float64 on the device, the sums travel
+    # in ONE all-reduce with the ok flag, and the division by the image count happens once - the
+    # same double the reference's loop produces (sums of a few float32 values are exact in float64
+    # in any order).
+    per = [ws[k].reshape(-1).double() for k in model.losses]
+    dev = per[0].device
+    n_img = per[0].numel()
+    cols = [p.sum() for p in per]
+    cols.append(torch.full((), 0.0 if ok else 1.0, device=dev, dtype=torch.float64))
     names = []
     labels = ws['labels_int32'].reshape(-1).to(torch.int64)
-    accs = []
     fused = {'accuracy_cls': 'cls_prob', 'accuracy_cls_noise': 'cls_prob_noise'}
     for k in model.metrics:
         if k in ws:
-            # the op-by-op plan ran the graph's own Accuracy op (OICR: accuracy_cls1..3 too)
-            accs.append(ws[k].reshape(-1).float().mean().to(dev))
+            # the op-by-op plan ran the graph's own Accuracy op (OICR: accuracy_cls1..3 too): one
+            # value per process there (one image per process)
+            cols.append(ws[k].reshape(-1).double().sum().to(dev) * (n_img / max(ws[k].numel(), 1)))
             names.append(k)
         elif k in fused and fused[k] in ws:
             # the fused engine keeps cls_prob only: top-1 against labels_int32 on the device
             p = ws[fused[k]].reshape(labels.numel(), -1)
-            accs.append((p.argmax(1) == labels.to(p.device)).float().mean())
+            cols.append((p.argmax(1) == labels.to(p.device)).double().sum().to(dev))
             names.append(k)
-    if accs:
-        t = torch.cat([t, torch.stack(accs).to(t.dtype)])
+    t = torch.stack(cols)
+    if pg is not None and world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=pg)
+    nl = len(model.losses)
+    den = torch.full_like(t, float(n_img * max(world, 1)))
+    den[nl] = 1.0                                     # the flag: a count of failed ranks
+    t = t / den                                       # (a division, as the reference's `/ NUM_GPUS`)
     if dev.type == 'cuda':
         host = _stats_slot(t.numel())
         host.copy_(t, non_blocking=True)
@@ -214,7 +221,7 @@ def _stats_slot(n):
     hipHostMalloc, which synchronises the device; at most two handles are alive at a time)."""
     r = _STATS_RING
     if r['slots'] is None or r['slots'][0].numel() < n:
-        r['slots'] = [torch.empty((max(n, 16),), dtype=torch.float32).pin_memory() for _ in range(4)]
+        r['slots'] = [torch.empty((max(n, 16),), dtype=torch.float64).pin_memory() for _ in range(4)]
         r['next'] = 0
     slot = r['slots'][r['next']]
     r['next'] = (r['next'] + 1) % len(r['slots'])

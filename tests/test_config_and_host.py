@@ -517,3 +517,45 @@ def test_weights_file_written_by_the_reference_loads_and_resaves(tmp_path, cfgmo
     # (the mirror carries the sections of the hot path only, plus its own NAWS block)
     assert b and set(a) - {'NAWS'} <= b, sorted(set(a) - b)
     assert 'NUM_CLASSES' in a['MODEL'] and 'BBOX_REG_WEIGHTS' in a['MODEL']   # what the reference's loader reads
+
+
+def test_training_stats_reproduce_the_reference_log_lines(cfgmod, monkeypatch):
+    """tests/golden/reference_training_stats.json: the reference's own TrainingStats +
+    log_json_stats driven for 400 iterations (NUM_GPUS = 8) on a seeded series with a
+    deterministic clock.  The mirror, fed the same per-iteration values - averaged the way
+    net_wsl.average_multi_gpu_blob averages them -, prints the same `json_stats:` lines character
+    for character at the same iterations (window averages, rounded window-averaged queue size,
+    global-average timer with its one reset, '%.6f' strings)."""
+    import json
+    import os
+    import numpy as np
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                                       'reference_training_stats.json')))
+    c = cfgmod
+    c.merge_cfg_from_list(['NUM_GPUS', gold['NUM_GPUS'], 'SOLVER.MAX_ITER', gold['MAX_ITER']])
+    import detectron.utils.training_stats_wsl as ts
+
+    class _Model(object):
+        losses, metrics = gold['losses'], gold['metrics']
+
+    clock = [1000.0]
+    monkeypatch.setattr(ts.time, 'time', lambda: clock[0])
+    lines = []
+    stats = ts.TrainingStats(_Model(), printer=lambda s: lines.append([it, s]))
+    assert stats.LOG_PERIOD == gold['LOG_PERIOD'] and stats.WIN_SZ == gold['WIN_SZ']
+    for it in range(len(gold['lr'])):
+        stats.IterTic()
+        clock[0] += gold['dt'][it]
+        stats.IterToc()
+        vals = {}
+        for k, series in gold['values'].items():
+            tot = 0
+            for v in series[it]:                       # sum_multi_gpu_blob: val += float(blob)
+                tot += float(np.float32(v))
+            vals[k] = tot / gold['NUM_GPUS']
+        stats.UpdateIterStats(vals, gold['qsize'][it])
+        stats.LogIterStats(it, np.float32(gold['lr'][it]), gold['mem_bytes'])
+        if it == stats.LOG_PERIOD:
+            stats.ResetIterTimer()
+    assert lines == gold['lines']
+    assert len(lines) == 4 and lines[1][0] == 160
