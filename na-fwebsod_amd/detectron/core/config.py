@@ -229,10 +229,61 @@ def merge_cfg_from_cfg(cfg_other):
     _merge(cfg_other, cfg, [])
 
 
+# Options the reference still accepts and ignores / refuses with a pointer to the new name
+# (detectron/core/config.py:1109-1164): same keys, same messages - a yaml or command line written
+# for the reference behaves identically here.
+_DEPRECATED_KEYS = {
+    'FINAL_MSG', 'MODEL.DILATION', 'ROOT_GPU_ID', 'RPN.ON', 'TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED',
+    'TRAIN.DROPOUT', 'USE_GPU_NMS', 'TEST.NUM_TEST_IMAGES',
+}
+_RENAMED_KEYS = {
+    'EXAMPLE.RENAMED.KEY': 'EXAMPLE.KEY',
+    'MODEL.PS_GRID_SIZE': 'RFCN.PS_GRID_SIZE',
+    'MODEL.ROI_HEAD': 'FAST_RCNN.ROI_BOX_HEAD',
+    'MRCNN.MASK_HEAD_NAME': 'MRCNN.ROI_MASK_HEAD',
+    'TRAIN.DATASET': ('TRAIN.DATASETS',
+                      "Also convert to a tuple, e.g., 'coco_2014_train' -> ('coco_2014_train',) or "
+                      "'coco_2014_train:coco_2014_valminusminival' -> "
+                      "('coco_2014_train', 'coco_2014_valminusminival')"),
+    'TRAIN.PROPOSAL_FILE': ('TRAIN.PROPOSAL_FILES',
+                            "Also convert to a tuple, e.g., 'path/to/file' -> ('path/to/file',) or "
+                            "'path/to/file1:path/to/file2' -> ('path/to/file1', 'path/to/file2')"),
+    'TEST.SCALES': ('TEST.SCALE',
+                    "Also convert from a tuple, e.g. (600, ), to a integer, e.g. 600."),
+    'TEST.DATASET': ('TEST.DATASETS',
+                     "Also convert from a string, e.g 'coco_2014_minival', to a tuple, e.g. "
+                     "('coco_2014_minival', )."),
+    'TEST.PROPOSAL_FILE': ('TEST.PROPOSAL_FILES',
+                           "Also convert from a string, e.g. '/path/to/props.pkl', to a tuple, e.g. "
+                           "('/path/to/props.pkl', )."),
+}
+
+
+def _key_is_deprecated(full_key):
+    if full_key in _DEPRECATED_KEYS:
+        import logging
+        logging.getLogger(__name__).warning('Deprecated config key (ignoring): {}'.format(full_key))
+        return True
+    return False
+
+
+def _raise_key_rename_error(full_key):
+    new_key, msg = _RENAMED_KEYS[full_key], ''
+    if isinstance(new_key, tuple):
+        new_key, msg = new_key[0], ' Note: ' + new_key[1]
+    raise KeyError('Key {} was renamed to {}; please update your config.{}'.format(
+        full_key, new_key, msg))
+
+
 def merge_cfg_from_list(cfg_list):
-    """['TEST.NMS', 0.5, ...] — values are python literals or plain strings."""
+    """['TEST.NMS', 0.5, ...] — values are python literals or plain strings
+    (ref: config.py:1252-1273, behaviour pinned by tests/golden/reference_cfg_behaviour.json)."""
     assert len(cfg_list) % 2 == 0
     for full_key, v in zip(cfg_list[0::2], cfg_list[1::2]):
+        if _key_is_deprecated(full_key):
+            continue
+        if full_key in _RENAMED_KEYS:
+            _raise_key_rename_error(full_key)
         node = cfg
         parts = full_key.split('.')
         for sub in parts[:-1]:
@@ -254,21 +305,21 @@ def _decode(v):
 
 
 def _coerce(new, old, full_key):
-    """Accept `new` if it has the default's type, or a benign conversion of it
-    (ref: config.py:1370-1396)."""
+    """Accept `new` if it has the default's type, or one of the reference's conversions
+    (config.py:1393-1420): an ndarray default takes anything np.array accepts, a string default
+    takes str(new) of ANYTHING, tuple <-> list.  Nothing else - in particular an int for a float
+    default is a type mismatch there ('SOLVER.BASE_LR 1' fails) and therefore here."""
     t_old, t_new = type(old), type(new)
     if t_old is t_new:
         return new
     if isinstance(old, np.ndarray):
         return np.array(new, dtype=old.dtype)
-    if isinstance(old, str) and isinstance(new, str):
-        return new
-    if isinstance(old, tuple) and isinstance(new, list):
-        return tuple(new)
-    if isinstance(old, list) and isinstance(new, tuple):
+    if isinstance(old, str):
+        return str(new)
+    if isinstance(new, tuple) and isinstance(old, list):
         return list(new)
-    if isinstance(old, float) and isinstance(new, int) and not isinstance(new, bool):
-        return float(new)
+    if isinstance(new, list) and isinstance(old, tuple):
+        return tuple(new)
     raise ValueError('Type mismatch ({} vs. {}) with values ({} vs. {}) for config key: {}'.format(
         t_old, t_new, old, new, full_key))
 
@@ -277,11 +328,16 @@ def _merge(a, b, stack):
     for k, v_ in a.items():
         full_key = '.'.join(stack + [k])
         if k not in b:
+            if _key_is_deprecated(full_key):
+                continue
+            if full_key in _RENAMED_KEYS:
+                _raise_key_rename_error(full_key)
             raise KeyError('Non-existent config key: {}'.format(full_key))
         v = _decode(copy.deepcopy(v_))
         if isinstance(b[k], CfgNode):
             if not isinstance(v, dict):
-                raise ValueError('config key {} must be a mapping'.format(full_key))
+                raise ValueError('Type mismatch ({} vs. {}) with values ({} vs. {}) for config '
+                                 'key: {}'.format(type(b[k]), type(v), b[k], v, full_key))
             _merge(v, b[k], stack + [k])
         else:
             b[k] = _coerce(v, b[k], full_key)

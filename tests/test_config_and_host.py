@@ -53,8 +53,10 @@ def test_cfg_behaviour(cfgmod):
         c.merge_cfg_from_list(['SOLVER.BASE_LR', 'fast'])
     with pytest.raises(AssertionError):
         c.merge_cfg_from_list(['SOLVER.NOPE', 1])
-    c.merge_cfg_from_list(['TRAIN.SCALES', '(480, 600)', 'SOLVER.BASE_LR', 1, 'MODEL.TYPE', 'x'])
+    c.merge_cfg_from_list(['TRAIN.SCALES', '(480, 600)', 'SOLVER.BASE_LR', 1.0, 'MODEL.TYPE', 'x'])
     assert c.cfg.TRAIN.SCALES == (480, 600) and c.cfg.SOLVER.BASE_LR == 1.0
+    with pytest.raises(ValueError):          # an int is not a float in the reference's type check
+        c.merge_cfg_from_list(['SOLVER.BASE_LR', 1])
     c.assert_and_infer_cfg()
     with pytest.raises(AttributeError):
         c.cfg.NUM_GPUS = 8
@@ -559,3 +561,75 @@ def test_training_stats_reproduce_the_reference_log_lines(cfgmod, monkeypatch):
             stats.ResetIterTimer()
     assert lines == gold['lines']
     assert len(lines) == 4 and lines[1][0] == 160
+
+
+def _describe_cfg_value(v):
+    import numpy as np
+    if isinstance(v, np.ndarray):
+        return {'type': 'ndarray', 'dtype': str(v.dtype), 'value': v.tolist()}
+    if isinstance(v, tuple):
+        return {'type': 'tuple', 'value': [_describe_cfg_value(x) for x in v]}
+    if isinstance(v, list):
+        return {'type': 'list', 'value': [_describe_cfg_value(x) for x in v]}
+    if isinstance(v, dict):
+        return {'type': 'dict', 'keys': sorted(v.keys())}
+    return {'type': type(v).__name__, 'value': v}
+
+
+def test_cfg_merge_behaviour_matches_the_reference(cfgmod):
+    """tests/golden/reference_cfg_behaviour.json: 45 `merge_cfg_from_list` and 15
+    `merge_cfg_from_cfg` cases run on the imported reference (value decoding, the type check with
+    its three conversions - str(anything), tuple <-> list, ndarray -, deprecated keys ignored,
+    renamed keys refused with their pointer, unknown keys, immutability).  The mirror ends with the
+    same value and type, or raises the same exception class with the same message."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                                       'reference_cfg_behaviour.json')))
+    c = cfgmod
+
+    def lookup(full_key):
+        node = c.cfg
+        for p in full_key.split('.'):
+            node = node[p]
+        return node
+
+    def first_leaf(d, stack=()):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                return first_leaf(v, stack + (k,))
+            return '.'.join(stack + (k,))
+
+    for group, fn in (('list', c.merge_cfg_from_list), ('dict', c.merge_cfg_from_cfg)):
+        for rec in gold[group]:
+            c.reset_cfg()
+            args = rec['args']
+            key = args[0] if group == 'list' else first_leaf(args)
+            try:
+                fn(list(args) if group == 'list' else args)
+                try:
+                    got = _describe_cfg_value(lookup(key))
+                except KeyError:
+                    got = {'type': 'absent'}
+                assert 'result' in rec, (args, 'the reference raised', rec.get('error'))
+                assert got == rec['result'], (args, got, rec['result'])
+            except AssertionError as e:
+                if 'error' in rec and rec['error'][0] == 'AssertionError':
+                    assert str(e) == rec['error'][1], (args, str(e))
+                else:
+                    raise
+            except (KeyError, ValueError) as e:
+                assert 'error' in rec, (args, 'the reference accepted it', rec.get('result'), repr(e))
+                assert type(e).__name__ == rec['error'][0], (args, repr(e), rec['error'])
+                if 'AttrDict' not in rec['error'][1]:        # (a message that spells the class name)
+                    assert str(e) == rec['error'][1], (args, str(e), rec['error'][1])
+    c.reset_cfg()
+    c.assert_and_infer_cfg()
+    for stmt, err in gold['immutable']:
+        try:
+            exec(stmt, {'cfg': c.cfg})
+            raised = None
+        except BaseException as e:          # noqa: B902
+            raised = type(e).__name__
+        assert raised == err, (stmt, raised, err)
+    c.cfg.immutable(False)
