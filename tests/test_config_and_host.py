@@ -633,3 +633,56 @@ def test_cfg_merge_behaviour_matches_the_reference(cfgmod):
             raised = type(e).__name__
         assert raised == err, (stmt, raised, err)
     c.cfg.immutable(False)
+
+
+# ---- a whole minibatch against the imported reference's get_minibatch ----------------------------
+
+def _minibatch_roidb():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'minibatch_inputs', os.path.join(os.path.dirname(__file__), 'golden', 'minibatch_inputs.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize('tag,over,raw', [
+    ('default', [], True),
+    ('crop_no_distortion', ['WSL.USE_CROP', True, 'WSL.USE_DISTORTION', False], True),
+    ('single_scale', ['TRAIN.SCALES', (600,), 'TRAIN.MAX_SIZE', 1000, 'WSL.USE_CROP', False, 'WSL.USE_DISTORTION', False], False),
+    ('single_scale', ['TRAIN.SCALES', (600,), 'TRAIN.MAX_SIZE', 1000, 'WSL.USE_CROP', False, 'WSL.USE_DISTORTION', False], True),
+])
+def test_whole_minibatch_matches_the_reference_capture(tag, over, raw, monkeypatch, cfgmod):
+    """`get_minibatch` on a seeded three-image roidb against the imported reference's call
+    (tests/golden/make_golden_minibatch.py): random scale / jitter / crop draws in the same order
+    and number (the RNG's next draw afterwards is the same), the same per-image scale and resized
+    size, proposals projected into the same cropped / flipped / scaled frame, same labels."""
+    C = cfgmod
+    from detectron.roi_data import minibatch_wsl as mbw
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_minibatch.npz'))
+    gen = _minibatch_roidb()
+    C.merge_cfg_from_file(YAML)
+    C.merge_cfg_from_list(['NUM_GPUS', 1, 'TRAIN.BATCH_SIZE_PER_IM', 30] + list(over))
+    cfg = C.cfg
+    assert [str(cfg.TRAIN.SCALES), str(cfg.TRAIN.MAX_SIZE), str(cfg.WSL.USE_CROP), str(cfg.WSL.USE_DISTORTION),
+            str(cfg.WSL.CROP), str(cfg.WSL.SATURATION), str(cfg.WSL.EXPOSURE)] == list(g[tag + '__cfg'])
+    monkeypatch.setattr(mbw, '_read_image', lambda entry: gen.fake_image(entry['image']))
+    np.random.seed(77)
+    blobs, valid = mbw.get_minibatch(gen.make_roidb(), raw=raw)
+    nxt = np.random.random()
+    assert bool(valid) == bool(g[tag + '__valid'])
+    assert nxt == float(g[tag + '__next_draw'])
+    for k in ('data_ids', 'rois', 'obn_scores', 'labels_int32', 'labels_oh'):
+        want = g[tag + '__' + k]
+        got = np.asarray(blobs[k])
+        assert got.shape == want.shape and got.dtype == want.dtype, (k, got.shape, want.shape, got.dtype, want.dtype)
+        assert np.array_equal(got, want), k
+    to = g[tag + '__resized_to']
+    if raw:
+        assert [list(r['out_hw']) for r in blobs['_raw']] == to.tolist()
+        assert np.array_equal(np.array([r['scale'] for r in blobs['_raw']]), g[tag + '__im_scales'])
+        frm = g[tag + '__resized_from']
+        assert [[r['crop'][2] - r['crop'][0] + 1, r['crop'][3] - r['crop'][1] + 1]
+                for r in blobs['_raw']] == frm.tolist()
+    else:
+        assert list(blobs['data'].shape) == g[tag + '__data_shape'].tolist()
