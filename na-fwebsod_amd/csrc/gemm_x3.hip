@@ -856,6 +856,95 @@ __global__ __launch_bounds__(256) void split2h_dual_kernel(
 }
 
 
+// The same pass with 16-byte traffic on every leg (X 16-byte aligned, ld and cols multiples of 4):
+// a thread fetches four float4s of the 64 x 64 tile, and owns ONE 16-element unit per operand form
+// - (row o, K-slab s) of Pn, (column o, K-slab s) of Pt, o = lane, s = wave - so that a wave's
+// stores are one contiguous 2 KB run per plane.  Same arithmetic per element: bit-identical planes.
+__global__ __launch_bounds__(256) void split2h_dual_v4_kernel(
+    const float* __restrict__ X, int rows, int cols, int ld, long long sx,
+    const unsigned* __restrict__ rowmax, const unsigned* __restrict__ colmax,
+    const float* __restrict__ rowmul, unsigned short* __restrict__ Pn, float* __restrict__ inv_n,
+    int slabs_n, unsigned short* __restrict__ Pt, float* __restrict__ inv_t, int slabs_t, int batch,
+    const int* __restrict__ cond, int cond_value) {
+  constexpr int LDT = 68;                           // floats per tile row: 16-byte rows, banks spread
+  __shared__ __attribute__((aligned(16))) float tile[64 * LDT];
+  if (cond && *cond != cond_value) return;
+  const int bz = blockIdx.z;
+  const float* Xb = X + bz * sx;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  {
+    const int tc = (tid & 15) * 4, tr = tid >> 4;
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + i * 16 + tr, c = c0 + tc;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (r < rows && c < cols) v[i] = *reinterpret_cast<const f32x4*>(Xb + (long long)r * ld + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&tile[(i * 16 + tr) * LDT + tc]) = v[i];
+  }
+  __syncthreads();
+  const int o = tid & 63, s = tid >> 6;
+  if (Pn && r0 + o < rows && c0 / 16 + s < slabs_n) {
+    float sc, isc;
+    f16x2_scales(rowmax[(long long)bz * rows + r0 + o], sc, isc);
+    if (c0 == 0 && s == 0) inv_n[(long long)bz * rows + r0 + o] = isc;
+    const long long sp = (long long)slabs_n * 16 * rows, plane = (long long)batch * sp;
+    const long long dst = bz * sp + ((long long)(c0 / 16 + s) * rows + (r0 + o)) * 16;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&tile[o * LDT + s * 16 + hh * 8]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&tile[o * LDT + s * 16 + hh * 8 + 4]);
+      const float t[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      u32x4 hi4, lo4;
+      split2h_pack(t, sc, hi4, lo4);
+      *reinterpret_cast<u32x4*>(Pn + dst + hh * 8) = hi4;
+      *reinterpret_cast<u32x4*>(Pn + plane + dst + hh * 8) = lo4;
+    }
+  }
+  if (Pt && c0 + o < cols && r0 / 16 + s < slabs_t) {
+    float sc, isc;
+    f16x2_scales(colmax[(long long)bz * cols + c0 + o], sc, isc);
+    if (r0 == 0 && s == 0) inv_t[(long long)bz * cols + c0 + o] = isc;
+    const long long sp = (long long)slabs_t * 16 * cols, plane = (long long)batch * sp;
+    const long long dst = bz * sp + ((long long)(r0 / 16 + s) * cols + (c0 + o)) * 16;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kk = s * 16 + hh * 8 + e;
+        t[e] = tile[kk * LDT + o] * ((rowmul && r0 + kk < rows) ? rowmul[r0 + kk] : 1.f);
+      }
+      u32x4 hi4, lo4;
+      split2h_pack(t, sc, hi4, lo4);
+      *reinterpret_cast<u32x4*>(Pt + dst + hh * 8) = hi4;
+      *reinterpret_cast<u32x4*>(Pt + plane + dst + hh * 8) = lo4;
+    }
+  }
+}
+
+// The 16-byte form for the transposed planes alone, where it wins (tools/ab_split.py, 4000 x 8192:
+// 78 vs 90 us; with both forms 54 vs 50 us).  Knob "split": 1 = always scalar, 2 = 16-byte
+// whenever the operand's alignment allows.
+static void launch_split2h_dual(dim3 grid, hipStream_t s, const float* X, int rows, int cols, int ld,
+                                long long sx, const unsigned* rowmax, const unsigned* colmax,
+                                const float* rowmul, unsigned short* Pn, float* inv_n, int slabs_n,
+                                unsigned short* Pt, float* inv_t, int slabs_t, int batch,
+                                const int* cond, int cond_value) {
+  const int knob = naws_knob(NAWS_KNOB_SPLIT);
+  const bool aligned = (((uintptr_t)X & 15) == 0) && ld % 4 == 0 && cols % 4 == 0 && sx % 4 == 0;
+  if (aligned && knob != 1 && (knob == 2 || !Pn))
+    hipLaunchKernelGGL(split2h_dual_v4_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, sx, rowmax,
+                       colmax, rowmul, Pn, inv_n, slabs_n, Pt, inv_t, slabs_t, batch, cond, cond_value);
+  else
+    hipLaunchKernelGGL(split2h_dual_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, sx, rowmax,
+                       colmax, rowmul, Pn, inv_n, slabs_n, Pt, inv_t, slabs_t, batch, cond, cond_value);
+}
+
+
 }  // namespace
 
 template <int NPL>
@@ -1021,7 +1110,7 @@ extern "C" int naws_split_f16x2_dual(const float* X, int batch, int rows, int co
   const long long gy = naws_cdiv(rows, 64);
   if (batch > 65535 || gy > 65535) return NAWS_ERR_UNSUPPORTED;
   dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, batch);
-  hipLaunchKernelGGL(split2h_dual_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, rows, cols, ld,
+  launch_split2h_dual(grid, (hipStream_t)stream, X, rows, cols, ld,
                      (long long)strideX, (const unsigned*)rowmax, (const unsigned*)colmax, rowmul,
                      (unsigned short*)Pn, Pn ? scales_n + (long long)batch * rows : nullptr,
                      kpad_n / 16, (unsigned short*)Pt, Pt ? scales_t + (long long)batch * cols : nullptr,
@@ -1041,7 +1130,7 @@ extern "C" int naws_split_f16x2_rows_if(const float* X, int batch, int rows, int
   const long long gy = naws_cdiv(rows, 64);
   if (batch > 65535 || gy > 65535) return NAWS_ERR_UNSUPPORTED;
   dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, batch);
-  hipLaunchKernelGGL(split2h_dual_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, rows, cols, ld,
+  launch_split2h_dual(grid, (hipStream_t)stream, X, rows, cols, ld,
                      (long long)strideX, (const unsigned*)rowmax, (const unsigned*)nullptr,
                      (const float*)nullptr, (unsigned short*)P, inv_scale, kpad / 16,
                      (unsigned short*)nullptr, (float*)nullptr, 0, batch, (const int*)cond, cond_value);

@@ -511,6 +511,18 @@ def test_gemm_reported_maxima_and_dual_split_are_bit_identical(dev, m, n, k, seg
     for got, want in ((gn, wn), (gt, wt)):
         assert torch.equal(got.inv_scale, want.inv_scale)
         assert torch.equal(got.planes.view(torch.int16), want.planes.view(torch.int16))
+    # the scalar (1) and the 16-byte (2) form of the pass, whichever the default picked above
+    try:
+        for knob in (1, 2):
+            L.set_variant('split', knob)
+            for got, want in ((ops.split_f16x2_dual(cv, sc_n, None)[0], want_n),
+                              (ops.split_f16x2_dual(c, None, sc_t, rowmul=rowmul)[1], want_t),
+                              (ops.split_f16x2_dual(c2, sc_n2, sc_t2)[0], wn),
+                              (ops.split_f16x2_dual(c2, sc_n2, sc_t2)[1], wt)):
+                assert torch.equal(got.inv_scale, want.inv_scale), knob
+                assert torch.equal(got.planes.view(torch.int16), want.planes.view(torch.int16)), knob
+    finally:
+        L.set_variant('split', 0)
 
 
 @pytest.mark.parametrize('log2_ratio', [-20, -30, -45])
