@@ -383,6 +383,14 @@ int naws_gemm_bf16_nt(int M, int N, int K, const void* A, int a_is_bf16, int lda
 int naws_conv3x3_nhwc_bf16_fwd(const float* X, const float* Wp, const float* bias, int N, int H,
                                int W, int Cin, int Cout, int dilation, int relu, float* Y,
                                void* stream);
+/* The same operator on the wave-private halo-tile kernel (round 4; the bf16 plan's conv body):
+ * W1 = naws_to_bf16_slab of the packed weight viewed [Cout][9 * Cin] (bf16 [9 * Cin / 16][Cout][16]);
+ * Cin % 16 == 0, 9 * Cin % 64 == 0, Cout % 64 == 0, dilation 1 or 2.  pool2: the 2x2 / stride-2
+ * max-pool that follows (reference: VGG16.py:14-36 pool1..pool3) taken in the epilogue, Y is then
+ * [N][H/2][W/2][Cout] (dilation 1 only). */
+int naws_conv3x3_nhwc_bf16_wp_fwd(const float* X, const void* W1, const float* bias, int N, int H,
+                                  int W, int Cin, int Cout, int dilation, int relu, int pool2,
+                                  float* Y, void* stream);
 /* Y[b][c][r] = bf16(X[b][r][c]) for r < rows, 0 for rows <= r < rows_pad: the K-contiguous bf16
  * copies the backward FC GEMMs (dX = dY W, dW = dY^T X) take as operands. */
 int naws_transpose_to_bf16(const float* X, int batch, int rows, int cols, int ld, int rows_pad,

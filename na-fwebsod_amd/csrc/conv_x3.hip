@@ -771,10 +771,13 @@ template <int DIL> struct NawsWpGeom {
 // NPL = 3: the same kernel on the EXACT 3 x bf16 split (the strict fp32x3 plan): three planes per
 // operand, no scales, six MFMA terms per product in gemm_x3_kernel's order - replaces
 // conv_x3_halo_kernel<BN, false> (weights through LDS-DMA, one step ahead) for conv1_2 .. conv2_2.
+// NPL = 1: ONE bf16 plane per operand (fp32 activations rounded to nearest-even on their way into
+// the halo image, weights from naws_to_bf16_slab), one MFMA per product: the bf16 plan's conv body.
 template <int WR, int WC, int DIL, bool PIPE = true, int NPL = 2>
-__global__ __launch_bounds__(256, ((WC == 4 || NPL == 3) ? 2 : 3)) void conv_h2_wp_kernel(CArgs g) {
+__global__ __launch_bounds__(256, (WC == 4 || NPL == 3) ? 2 : (NPL == 1 ? 4 : 3))
+void conv_h2_wp_kernel(CArgs g) {
   static_assert(WR * WC == 4, "four waves");
-  static_assert(NPL == 2 || NPL == 3, "2 x f16 or 3 x bf16");
+  static_assert(NPL >= 1 && NPL <= 3, "bf16, 2 x f16 or 3 x bf16");
   constexpr int BN = 32 * WC, TI = 8 / WR;
   typedef typename OperandVec<NPL == 2>::type vec_t;
   constexpr int TH = 8, TW = 32, HWD = TW + 2 * DIL, HPIX = (TH + 2 * DIL) * HWD;
@@ -845,6 +848,9 @@ __global__ __launch_bounds__(256, ((WC == 4 || NPL == 3) ? 2 : 3)) void conv_h2_
       for (int e = 0; e < 8; ++e) {
         if constexpr (NPL == 3) {
           split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+        } else if constexpr (NPL == 1) {
+          const __bf16 b = (__bf16)__uint_as_float(w[e]);
+          q[0][e] = *reinterpret_cast<const unsigned short*>(&b);
         } else {
           const float t = __uint_as_float(w[e]) * scA;
           const _Float16 hi = (_Float16)t;
@@ -921,12 +927,14 @@ __global__ __launch_bounds__(256, ((WC == 4 || NPL == 3) ? 2 : 3)) void conv_h2_
   #pragma unroll
           for (int i = 0; i < TIH; ++i)
             acc[ih * TIH + i] = mfma16(a[0][i], bq[tap % 3][0], acc[ih * TIH + i]);
+          if constexpr (NPL >= 2) {
   #pragma unroll
-          for (int i = 0; i < TIH; ++i)
-            acc[ih * TIH + i] = mfma16(a[0][i], bq[tap % 3][1], acc[ih * TIH + i]);
+            for (int i = 0; i < TIH; ++i)
+              acc[ih * TIH + i] = mfma16(a[0][i], bq[tap % 3][1], acc[ih * TIH + i]);
   #pragma unroll
-          for (int i = 0; i < TIH; ++i)
-            acc[ih * TIH + i] = mfma16(a[1][i], bq[tap % 3][0], acc[ih * TIH + i]);
+            for (int i = 0; i < TIH; ++i)
+              acc[ih * TIH + i] = mfma16(a[1][i], bq[tap % 3][0], acc[ih * TIH + i]);
+          }
           if constexpr (NPL == 3) {
   #pragma unroll
             for (int i = 0; i < TIH; ++i)
@@ -968,6 +976,9 @@ __global__ __launch_bounds__(256, ((WC == 4 || NPL == 3) ? 2 : 3)) void conv_h2_
       for (int e = 0; e < 8; ++e) {
         if constexpr (NPL == 3) {
           split3(__uint_as_float(w[e]), q[0][e], q[1][e], q[2][e]);
+        } else if constexpr (NPL == 1) {
+          const __bf16 b = (__bf16)__uint_as_float(w[e]);
+          q[0][e] = *reinterpret_cast<const unsigned short*>(&b);
         } else {
           const float t = __uint_as_float(w[e]) * scA;
           const _Float16 hi = (_Float16)t;
@@ -1033,12 +1044,14 @@ __global__ __launch_bounds__(256, ((WC == 4 || NPL == 3) ? 2 : 3)) void conv_h2_
 #pragma unroll
         for (int i = 0; i < TIH; ++i)
           acc[ih * TIH + i] = mfma16(a[grp & 1][0][i], bq[tap % 3][0], acc[ih * TIH + i]);
+        if constexpr (NPL >= 2) {
 #pragma unroll
-        for (int i = 0; i < TIH; ++i)
-          acc[ih * TIH + i] = mfma16(a[grp & 1][0][i], bq[tap % 3][1], acc[ih * TIH + i]);
+          for (int i = 0; i < TIH; ++i)
+            acc[ih * TIH + i] = mfma16(a[grp & 1][0][i], bq[tap % 3][1], acc[ih * TIH + i]);
 #pragma unroll
-        for (int i = 0; i < TIH; ++i)
-          acc[ih * TIH + i] = mfma16(a[grp & 1][1][i], bq[tap % 3][0], acc[ih * TIH + i]);
+          for (int i = 0; i < TIH; ++i)
+            acc[ih * TIH + i] = mfma16(a[grp & 1][1][i], bq[tap % 3][0], acc[ih * TIH + i]);
+        }
         if constexpr (NPL == 3) {
 #pragma unroll
           for (int i = 0; i < TIH; ++i)
@@ -1174,6 +1187,42 @@ extern "C" int naws_conv3x3_nhwc_f32x3_pool_fwd(const float* X, const void* W3, 
   g.pool = 1;
   if (3 * g.planeB * 2 > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
   return launch_conv_wp_x3(g, N, (hipStream_t)stream);
+}
+
+// The bf16 plan's convolution on the wave-private halo-tile kernel (NPL = 1): W1 =
+// naws_to_bf16_slab of the packed weight viewed [Cout][9 * Cin] -> [9 * Cin / 16][Cout][16];
+// fp32 activations in and out (rounded to bf16 as MFMA operands), fp32 accumulation, bias / ReLU
+// and optionally the 2x2 / stride-2 max-pool that follows in the epilogue (dilation 1 only).
+extern "C" int naws_conv3x3_nhwc_bf16_wp_fwd(const float* X, const void* W1, const float* bias,
+                                             int N, int H, int W, int Cin, int Cout, int dilation,
+                                             int relu, int pool2, float* Y, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return NAWS_ERR_SHAPE;
+  if (dilation != 1 && dilation != 2) return NAWS_ERR_UNSUPPORTED;
+  if (dilation == 2 && pool2) return NAWS_ERR_ARG;
+  if (pool2 && (H < 2 || W < 2)) return NAWS_ERR_SHAPE;
+  if (Cin % 16 != 0 || (9 * Cin) % 64 != 0 || Cout % 64 != 0) return NAWS_ERR_UNSUPPORTED;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(W1); NAWS_REQUIRE_PTR(Y);
+  if (!bias && relu) return NAWS_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)W1) & 15) != 0) return NAWS_ERR_ARG;
+  const long long pix = (long long)N * H * W;
+  if (pix > 0x7fffffffLL || pix * Cin * 4 > 0xFFFFFF00LL) return NAWS_ERR_UNSUPPORTED;
+  CArgs g{};
+  g.X = X; g.B = (const unsigned short*)W1; g.bias = bias; g.Y = Y;
+  g.M = (int)pix; g.Cout = Cout; g.Cin = Cin; g.H = H; g.W = W; g.dil = dilation; g.relu = relu;
+  g.slabB = (long long)Cout * 16;
+  g.planeB = (long long)9 * Cin * Cout;
+  g.bytesX = (unsigned)(pix * Cin * 4);
+  g.pool = pool2 ? 1 : 0;
+  if (g.planeB * 2 > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  // 64-channel tiles (2 x 2 waves) or 128-channel tiles (1 x 4 waves: half the halo traffic per
+  // product); knob "conv_bn" = 64 / 128 forces one, 0 = the rule of the fp16x2 entry
+  bool bn64 = Cout % 128 != 0 || Cout < 512;
+  const int force_bn = naws_knob(NAWS_KNOB_CONV_BN);
+  if (force_bn && Cout % 128 == 0) bn64 = force_bn == 64;
+  if (dilation == 2)
+    return bn64 ? launch_conv_h2_wp<2, 2, 2, true, 1>(g, N, s) : launch_conv_h2_wp<1, 4, 2, true, 1>(g, N, s);
+  return bn64 ? launch_conv_h2_wp<2, 2, 1, true, 1>(g, N, s) : launch_conv_h2_wp<1, 4, 1, true, 1>(g, N, s);
 }
 
 extern "C" int naws_conv3x3_nhwc_f16x2_fwd(const float* X, const void* W2, const float* scaleW,

@@ -29,9 +29,9 @@ struct LdsSlot {
 };
 LdsSlot g_lds_slots[LDS_SLOTS];
 std::mutex g_lds_mutex;
-std::atomic<int> g_knobs[NAWS_KNOB_COUNT] = {{0}, {0}, {0}, {11}, {0}, {42}, {0}, {0}};
+std::atomic<int> g_knobs[NAWS_KNOB_COUNT] = {{0}, {0}, {0}, {11}, {0}, {42}, {0}, {0}, {0}};
 const char* const g_knob_names[NAWS_KNOB_COUNT] = {"gemm", "x3", "h2", "conv_ring", "conv_bn",
-                                                    "roi_nw", "wino", "split"};
+                                                    "roi_nw", "wino", "split", "sgd_wgs"};
 }  // namespace
 
 // Every launcher of a > 64 KB-LDS kernel passes through here, from any host thread (per-image conv

@@ -37,7 +37,8 @@ int naws_wino_col_gemm_impl(int P, int Cout, int Cin, const void* V2, const floa
 
 // Tuning knobs of the A/B tools (naws_set_variant; defaults below).  None changes a result.
 enum NawsKnob { NAWS_KNOB_GEMM = 0, NAWS_KNOB_X3, NAWS_KNOB_H2, NAWS_KNOB_CONV_RING,
-                NAWS_KNOB_CONV_BN, NAWS_KNOB_ROI_NW, NAWS_KNOB_WINO, NAWS_KNOB_SPLIT, NAWS_KNOB_COUNT };
+                NAWS_KNOB_CONV_BN, NAWS_KNOB_ROI_NW, NAWS_KNOB_WINO, NAWS_KNOB_SPLIT, NAWS_KNOB_SGD_WGS,
+                NAWS_KNOB_COUNT };
 int naws_knob(int knob);
 
 #define NAWS_REQUIRE_PTR(p) \

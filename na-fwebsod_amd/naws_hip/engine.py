@@ -365,6 +365,9 @@ class WsddnEngine(object):
                             ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
                 elif self.mfma_dtype == 'fp32x3':
                     packed = ops.split_bf16x3(packed)          # planes [3][16][Cin/16][Cout][16]
+            elif self.mfma_dtype == 'bf16' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+                # one bf16 plane [9*Cin/16][Cout][16]: the wave-private halo-tile kernel
+                packed = ops.to_bf16_slab(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
             else:
                 packed = ops.conv3x3_pack_weight(w)            # [Cout][3][3][Cin]
             self.conv[name] = (packed, b, w)
@@ -401,7 +404,8 @@ class WsddnEngine(object):
         end = len(VGG16_CONVS) if end is None else end
         # fp16x2 Winograd layers hand max|y| to the next layer (its operand scale needs an upper
         # bound of max|x|; a max-pool in between only lowers it), saving that layer's own pass
-        amax = torch.zeros((len(VGG16_CONVS) + 1,), device=self.device, dtype=torch.int32)   # one fill
+        amax = (torch.zeros((len(VGG16_CONVS) + 1,), device=self.device, dtype=torch.int32)   # one fill
+                if self.mfma_dtype == 'fp16x2' else None)
         prev, affine = None, (1.0, 0.0)  # slot holding the bound for the current x, if any
         if bound_in is not None:         # (affine_in: the bound is bound_in * mul + add, once)
             amax[-1:].copy_(bound_in)
@@ -460,6 +464,11 @@ class WsddnEngine(object):
                             x = ops.conv3x3_winograd_nhwc_f16x2(x, wp, b, d, True, out=dst,
                                                                 amax_in=bound, amax_out=word)
                         prev = li
+                    elif self.mfma_dtype == 'bf16' and wp.dtype == torch.bfloat16:
+                        fused_pool = (d == 1 and dst is None and li + 1 < len(VGG16_CONVS)
+                                      and VGG16_CONVS[li + 1][0] == 'pool')
+                        x = ops.conv3x3_nhwc_bf16_wp(x, wp, b, d, True, out=dst, pool2=fused_pool)
+                        prev = None
                     else:
                         if wp.dtype == torch.bfloat16:
                             conv = (ops.conv3x3_winograd_nhwc_f32x3 if self.conv_wino[name]
@@ -496,7 +505,8 @@ class WsddnEngine(object):
         self._roi_maps = None
         self._amax5 = (torch.empty((n if per_image else 1,), device=self.device,
                                    dtype=torch.int32) if planes else None)
-        if self._update_waiting and (not per_image or self.mfma_dtype != 'fp16x2'):
+        heads_first = self.mfma_dtype in ('fp16x2', 'bf16')
+        if self._update_waiting and (not per_image or not heads_first):
             self._launch_update(())        # no per-image conv1_1 head to put it behind
         if not per_image:
             return self._conv_chain(data, amax_final=self._amax5)
@@ -513,7 +523,8 @@ class WsddnEngine(object):
         start = main.record_event()
         while len(self._streams) < n:
             self._streams.append(torch.cuda.Stream(device=self.device))
-        split = (self._update_waiting and self.mfma_dtype == 'fp16x2')
+        split = (self._update_waiting and heads_first)
+        h2 = self.mfma_dtype == 'fp16x2'     # operand-scale bounds travel along the chain
         if split:
             # the head of every image's chain first (conv1_1: HBM-bound, 0.06 ms alone), THEN the
             # deferred parameter update, then the rest of the chains: started together, the SGD
@@ -526,7 +537,7 @@ class WsddnEngine(object):
                 with torch.cuda.stream(st):
                     wp, b, _w = self.conv['conv1_1']
                     y = ops.conv3x3_c3_nchw_to_nhwc(data[i:i + 1], wp, b, True)
-                    bound, aff = ops.amax_word(data[i:i + 1]), self._c11_bound
+                    bound, aff = (ops.amax_word(data[i:i + 1]), self._c11_bound) if h2 else (None, None)
                     heads.append((y, bound, aff))
                     evs.append(st.record_event())
             pool_done = self._pool_done

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('NAWS_LIB') or os.path.join(os.path.dirname(_HERE), 'l
 # host-side spelling of the library's A/B knobs (the library itself never reads the environment)
 _ENV_KNOBS = {'NAWS_GEMM_VARIANT': 'gemm', 'NAWS_X3_VARIANT': 'x3', 'NAWS_H2_VARIANT': 'h2',
               'NAWS_CONV_RING': 'conv_ring', 'NAWS_CONV_BN': 'conv_bn', 'NAWS_ROI_NW': 'roi_nw',
-              'NAWS_WINO_VARIANT': 'wino'}
+              'NAWS_WINO_VARIANT': 'wino', 'NAWS_SPLIT': 'split', 'NAWS_SGD_WGS': 'sgd_wgs'}
 
 OK, ERR_SHAPE, ERR_ARG, ERR_NULL, ERR_LAUNCH, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 _ERR_NAMES = {
@@ -78,6 +78,7 @@ PROTOTYPES = {
     'naws_gemm_bf16_nt': [i32, i32, i32, p, i32, i32, p, i32, i32, p, i32, i32, i64, i64, i64,
                           i32, p, i64, p, i32, f32, f32, u64, i32, p],
     'naws_conv3x3_nhwc_bf16_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
+    'naws_conv3x3_nhwc_bf16_wp_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p, p],
     'naws_transpose_to_bf16': [p, i32, i32, i32, i32, i32, p, p],
     'naws_conv3x3_nhwc_f32x3_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p],
     'naws_conv3x3_nhwc_f32x3_pool_fwd': [p, p, p, i32, i32, i32, i32, i32, i32, p, p],

@@ -389,6 +389,27 @@ def conv3x3_nhwc_bf16(x, w_packed, bias, dilation=1, relu=True, out=None):
     return y
 
 
+def conv3x3_nhwc_bf16_wp(x, w_slab, bias, dilation=1, relu=True, out=None, pool2=False):
+    """The bf16 plan's 3x3 convolution on the wave-private halo-tile kernel: w_slab =
+    to_bf16_slab(conv3x3_pack_weight(w).view(Cout, -1)) (bf16 [9*Cin/16, Cout, 16]); fp32 NHWC in
+    and out.  pool2: the 2x2 / stride-2 max-pool that follows, taken in the epilogue."""
+    _chk(x, 'x')
+    if (not w_slab.is_cuda or w_slab.dtype != torch.bfloat16 or w_slab.dim() != 3
+            or not w_slab.is_contiguous() or w_slab.shape[-1] != 16):
+        raise TypeError('w_slab must be a contiguous bf16 slab tensor [9*Cin/16, Cout, 16]')
+    n, h, w, cin = x.shape
+    cout = w_slab.shape[1]
+    if w_slab.shape[0] * 16 != 9 * cin:
+        raise ValueError('weight slab K does not match 9 * Cin')
+    shape = (n, h // 2, w // 2, cout) if pool2 else (n, h, w, cout)
+    y = out if out is not None else torch.empty(shape, device=x.device, dtype=_f32)
+    if tuple(y.shape) != shape or y.dtype != _f32 or not y.is_contiguous():
+        raise TypeError('out must be a contiguous fp32 %s tensor' % (shape,))
+    L.call('naws_conv3x3_nhwc_bf16_wp_fwd', x.data_ptr(), w_slab.data_ptr(), _ptr(bias), n, h, w,
+           cin, cout, dilation, int(relu), int(pool2), y.data_ptr(), _stream())
+    return y
+
+
 def split_bf16x3(x, transpose=False, out=None):
     """fp32 [rows, cols] or [b, rows, cols] (last dim contiguous) -> bf16 planes
     [3, (b,) K/16, outer, 16] ("K-slab-major"): outer/K = rows/cols, or cols/rows when

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--rois', type=int, default=2000)
     ap.add_argument('--mfma-dtype', default='fp16x2')
+    ap.add_argument('--fix', nargs='*', default=[], help='attr=value held for the whole run')
     ap.add_argument('--stages', action='store_true', help='per-stage times (HIP events on the main stream)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -48,6 +49,12 @@ def main():
             return int(v)
         except ValueError:
             return v
+
+    for kv in a.fix:
+        k, v = kv.split('=')
+        if not hasattr(eng, k):
+            raise SystemExit('no engine attribute %r' % k)
+        setattr(eng, k, conv(v))
 
     host = []
 

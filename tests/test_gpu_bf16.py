@@ -117,6 +117,55 @@ def test_conv3x3_bf16(dev, cin, cout, dil, h, w):
     assert np.abs(y - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('cin,cout,h,w,dil,pool', [
+    (64, 64, 37, 70, 1, True),         # conv1_2 + pool1: ragged tiles, odd height (last row dropped)
+    (64, 128, 16, 33, 1, False),       # conv2_1
+    (128, 256, 24, 40, 1, True),       # four channel tiles of 64
+    (256, 512, 19, 45, 1, False),      # 1 x 4 waves, 128-channel tiles
+    (512, 512, 21, 35, 2, False),      # conv5_x: dilation 2
+    (128, 192, 9, 31, 2, False),       # Cout % 128 != 0: 64-channel tiles, dilation 2
+])
+def test_conv3x3_bf16_wave_private(dev, cin, cout, h, w, dil, pool):
+    """The bf16 plan's conv body kernel (`naws_conv3x3_nhwc_bf16_wp_fwd`, reference op: Conv + Relu
+    (+ MaxPool) of VGG16.py:10-48): operands rounded to bf16 (nearest-even), fp32 accumulation -
+    against float64 on the rounded operands; the fused pool against pooling the unfused output
+    (bit-identical: max of the same fp32 values); both channel-tile forms agree bit for bit."""
+    from naws_hip import ops, lib as L
+    import torch.nn.functional as F
+    rng = np.random.default_rng(cin + cout + h)
+    n = 2
+    x = rng.uniform(-1, 1, (n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).bfloat16().double(),
+                          torch.from_numpy(wt).bfloat16().double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil))
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    ws = ops.to_bf16_slab(ops.conv3x3_pack_weight(_t(wt, dev)).view(cout, -1))
+    assert ws.shape == (9 * cin // 16, cout, 16)
+    y = ops.conv3x3_nhwc_bf16_wp(xd, ws, _t(b, dev), dil, True)
+    got = ops.nhwc_to_nchw(y).cpu().double()
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    if pool:
+        yp = ops.conv3x3_nhwc_bf16_wp(xd, ws, _t(b, dev), dil, True, pool2=True)
+        assert yp.shape == (n, h // 2, w // 2, cout)
+        assert torch.equal(yp, ops.maxpool2x2_nhwc(y, 2))
+    if cout % 128 == 0:
+        try:
+            outs = []
+            for bn in (64, 128):
+                L.set_variant('conv_bn', bn)
+                outs.append(ops.conv3x3_nhwc_bf16_wp(xd, ws, _t(b, dev), dil, True))
+            assert torch.equal(outs[0], outs[1])
+        finally:
+            L.set_variant('conv_bn', 0)
+    # no-ReLU / no-bias form
+    y0 = ops.conv3x3_nhwc_bf16_wp(xd, ws, None, dil, False)
+    ref0 = F.conv2d(torch.from_numpy(x).bfloat16().double(), torch.from_numpy(wt).bfloat16().double(),
+                    None, padding=dil, dilation=dil)
+    assert float((ops.nhwc_to_nchw(y0).cpu().double() - ref0).abs().max()) < 2e-5 * max(1.0, float(ref0.abs().max()))
+
+
 @pytest.mark.parametrize('m,n,k', [(256, 256, 64), (130, 72, 64), (517, 260, 1000), (64, 4000, 264),
                                    (2100, 140, 96)])
 def test_gemm_bf16_slab(dev, m, n, k):

@@ -296,8 +296,18 @@ def _planes_to_dense(f16x2, rows_per_batch):
     return d * f16x2.inv_scale.reshape(-1).double()[:, None]
 
 
+@pytest.fixture
+def sgd_walk(request):
+    """knob "sgd_wgs": 0 = the launch rule, -3 = three resident workgroups walk all tiles."""
+    from naws_hip import lib as L
+    L.set_variant('sgd_wgs', request.param)
+    yield request.param
+    L.set_variant('sgd_wgs', 0)
+
+
+@pytest.mark.parametrize('sgd_walk', [0, -3, -1], indirect=True)
 @pytest.mark.parametrize('nesterov', [0, 1])
-def test_acm_sgd_update_f16x2_writes_the_operand_planes(dev, nesterov):
+def test_acm_sgd_update_f16x2_writes_the_operand_planes(dev, nesterov, sgd_walk):
     """naws_acm_sgd_update_f16x2: parameters and momentum bit-identical to the
     plain fused update (which is held to the oracle in test_acm_sgd); rowmax = the exact row
     maxima of the updated weights; the planes it writes, times the 1/scale it reports, reproduce

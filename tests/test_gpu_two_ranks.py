@@ -55,6 +55,9 @@ def _run(eng, mb, dev):
 
 def _worker(rank, world, port, outdir, sharded=False):
     sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+    import faulthandler
+    # a rank stuck in a collective says where, then leaves (the parent's limit is 300 s)
+    faulthandler.dump_traceback_later(float(os.environ.get('NAWS_RANK_LIMIT', '240')), exit=True)
     import torch.distributed as dist
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     torch.cuda.set_device(0)
@@ -85,15 +88,29 @@ def _worker(rank, world, port, outdir, sharded=False):
     dist.destroy_process_group()
 
 
+def _run_ranks(procs, limit=300.0):
+    """Start the ranks and wait; a rank that is still alive at the limit is killed (a rank stuck in a
+    collective would otherwise keep the test session from ever exiting) and the test fails."""
+    import time
+    for p in procs:
+        p.start()
+    t0 = time.time()
+    for p in procs:
+        p.join(timeout=max(1.0, limit - (time.time() - t0)))
+    stuck = [p for p in procs if p.is_alive()]
+    for p in stuck:
+        p.kill()
+        p.join(timeout=30)
+    assert not stuck, 'ranks did not finish within %.0f s' % limit
+    for p in procs:
+        assert p.exitcode == 0
+
+
 def test_two_ranks_on_one_gpu_equal_one_rank_with_all_four_images(dev, tmp_path):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn')
     procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=600)
-        assert p.exitcode == 0
+    _run_ranks(procs)
     p0, p1 = (np.load(str(tmp_path / ('params%d.npy' % r))) for r in range(2))
     assert np.array_equal(p0, p1)          # same sums in the same order on both ranks
     # one rank, the four images as one batch: the same per-image losses, and the same update up
@@ -130,11 +147,7 @@ def test_sharded_update_two_ranks_bit_identical_to_the_allreduce_route(dev, tmp_
     for sharded in (False, True):
         s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
         procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), sharded)) for r in range(2)]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join(timeout=600)
-            assert p.exitcode == 0
+        _run_ranks(procs)
     for what in ('params', 'mom', 'planes', 'scales', 'losses'):
         ref = np.load(str(tmp_path / ('%s0.npy' % what)))
         for r in range(2):
