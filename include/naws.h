@@ -566,6 +566,19 @@ int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_t slabA, co
                            int64_t strideB, int64_t strideC, int epilogue, const float* bias,
                            int64_t strideBias, const float* aux, int ldaux, float alpha,
                            float drop_ratio, uint64_t seed, int accumulate, void* stream);
+/* naws_gemm_bf16_slab_nt with the ACM SGD update of `param` in place of the store (round 4; the
+ * bf16 plan's fc6_w gradient at one process - the reference adds its all-reduce ops only for
+ * NUM_GPUS > 1, optimizer_wsl.py:52-72, and the update operator is
+ * acm_weightdecay_momentum_sgd_op.h:48-112): the product A B^T [M x N] is the gradient of
+ * param [M][ldp] and is never written; param / momentum_buf are updated in place exactly as
+ * naws_acm_sgd_update_planes (format NAWS_PLANES_BF16) would from that gradient, and the updated
+ * rows are rounded into P, param's bf16 operand plane [N/16][prows][16] (P points at this block's
+ * first row).  N % 16 == 0, K % 64 == 0, ldp % 4 == 0. */
+int naws_gemm_bf16_slab_nt_sgd(int M, int N, int K, const void* A, int64_t slabA, const void* B,
+                               int64_t slabB, float* momentum_buf, float* param, int ldp,
+                               const float* lr, float lr_mult, float weight_decay, float momentum,
+                               int nesterov, int gpu_num, int64_t iter_count, void* P, int prows,
+                               void* stream);
 /* 3x3 / stride 1 / pad = dilation convolution, NHWC fp32 in and out, as an fp32x3 implicit GEMM
  * (same operator as naws_conv3x3_nhwc_fwd: Caffe2 Conv + Relu, reference
  * detectron/modeling/VGG16.py:37-130).  W3 = naws_split_bf16x3 (transpose = 0) of the packed

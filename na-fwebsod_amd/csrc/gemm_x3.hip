@@ -59,6 +59,16 @@ struct XArgs {
   // C receives blocks 0 + 1 + 2, C + sC2 receives blocks 1 - 2 - 3
   long long sC2;
   int col_steps;
+  // SGD form (naws_gemm_bf16_slab_nt_sgd): C is never written; the tile's products are the
+  // gradient of param[M][ldp] and go straight into the update
+  float* mom;
+  float* param;
+  int ldp;
+  const float* lr;           // device scalar: the base learning rate
+  float lr_mult, wd, momentum, gscale;
+  int nesterov, first;
+  unsigned short* P;         // param's bf16 operand plane [N/16][prows][16]
+  int prows;
 };
 
 // Operand planes are stored K-slab-major, P[plane][k/16][row][k%16]: the 16-deep K-step of a
@@ -344,9 +354,10 @@ __device__ __forceinline__ f32x4 mfma32(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int NPL, int KS, bool F16>
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL, int KS, bool F16, bool SGD = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_m16_kernel(XArgs g) {
   static_assert(KS % 2 == 0, "a 16x16x32 MFMA spans two 16-deep slabs");
+  static_assert(!SGD || (NPL == 1 && !F16), "the update epilogue: the bf16 plan's one-plane form");
   static_assert(!F16 || NPL <= 2, "f16 operands have one or two planes");
   typedef typename OperandVec<F16>::type vec_t;
   constexpr int NT = 64 * WM * WN;
@@ -530,6 +541,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   // form, which holds four rows of one column).  The epilogue therefore moves 16 bytes per lane
   // (C, aux, bias, column factors) wherever the layout allows (g.vec4), 4x fewer memory
   // instructions than the 4-byte form: the aux-reading fc7 dgrad 0.72 -> see DESIGN 0a.
+  if constexpr (SGD) {
+    // ---- the update in place of the store (one process, no gradient exchange in between;
+    // gemm_btr.hip's SGD form for the bf16 plan): the product is the gradient element, then
+    // acm_sgd_planes_kernel<2>'s element work - sgd_elem, momentum and parameter written back,
+    // the updated weight rounded to the bf16 operand plane (a lane's four columns = 8 bytes; a
+    // fragment's 16 rows x 32 bytes = one contiguous 512-byte run of the K-slab).  All of a row
+    // group's loads are issued before its arithmetic and stores.
+    const float LR = g.lr[0] * g.lr_mult;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int row = m0 + wm * WTM + i * 16 + l15;
+      const bool row_on = row < g.M;
+      const int rr = row_on ? row : g.M - 1;
+      f32x4 pw[TJ], pm[TJ];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + wn * WTN + j * 16 + kg * 4;
+        const bool on = row_on && col < g.N;
+        const long long o = (long long)rr * g.ldp + (on ? col : 0);
+        pw[j] = *reinterpret_cast<const f32x4*>(g.param + o);
+        if (!g.first) pm[j] = *reinterpret_cast<const f32x4*>(g.mom + o);
+        else pm[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + wn * WTN + j * 16 + kg * 4;
+        if (!row_on || col >= g.N) continue;          // N % 16 == 0: four columns in or out together
+        const f32x4 v = acc[i][j];
+        const long long o = (long long)row * g.ldp + col;
+        f32x4 p = pw[j], m = pm[j];
+        unsigned short q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float me = m[e], pe = p[e];
+          sgd_elem(v[e], me, pe, g.gscale, g.wd, LR, g.momentum, g.nesterov);
+          m[e] = me; p[e] = pe;
+          const __bf16 h = (__bf16)pe;
+          q[e] = *reinterpret_cast<const unsigned short*>(&h);
+        }
+        *reinterpret_cast<f32x4*>(g.mom + o) = m;
+        *reinterpret_cast<f32x4*>(g.param + o) = p;
+        const long long po = ((long long)(col >> 4) * g.prows + row) * 16 + (col & 15);
+        *reinterpret_cast<uint2*>(g.P + po) =
+            make_uint2(q[0] | ((unsigned)q[1] << 16), q[2] | ((unsigned)q[3] << 16));
+      }
+    }
+    return;
+  }
   const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
   const int epi = g.epilogue;
@@ -595,7 +654,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
     naws_tile_amax_16t<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int NPL, int KS, bool F16>
+template <int BM, int BN, int WM, int WN, int STAGES, int NPL, int KS, bool F16, bool SGD = false>
 int launch_x3_m16(XArgs& g, int batch, hipStream_t s) {
   auto a16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   g.vec4 = g.ldc % 4 == 0 && a16(g.C) && g.sC % 4 == 0 &&
@@ -605,7 +664,7 @@ int launch_x3_m16(XArgs& g, int batch, hipStream_t s) {
   g.tiles_m = (int)naws_cdiv(g.M, BM);
   g.tiles_n = (int)naws_cdiv(g.N, BN);
   const size_t lds = (size_t)STAGES * NPL * KS * (BM + BN) * 32;
-  auto kern = gemm_x3_m16_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16>;
+  auto kern = gemm_x3_m16_kernel<BM, BN, WM, WN, STAGES, NPL, KS, F16, SGD>;
   if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   g.batch = batch;
   if ((long long)g.tiles_m * g.tiles_n * batch > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
@@ -1305,6 +1364,37 @@ extern "C" int naws_amax_f32(const float* X, int64_t n, uint32_t* out, void* str
   hipLaunchKernelGGL(amax_word_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(n / 4 + 1, 256 * 8), 2048)),
                      dim3(256), 0, s, X, (long long)n, (unsigned*)out);
   return naws_check_launch();
+}
+
+// naws_gemm_bf16_slab_nt with param's SGD update in place of the store (the bf16 plan's fc6_w
+// weight gradient at one process: the product A B^T [M x N] is the gradient of param [M][ldp],
+// never written): param / momentum_buf updated in place exactly as naws_acm_sgd_update_planes
+// (format NAWS_PLANES_BF16) would from that gradient, the updated rows rounded into P, param's
+// bf16 operand plane [N/16][prows][16] (P points at this block's first row).  M: any; N % 16 == 0;
+// K % 64 == 0; ldp % 4 == 0.
+extern "C" int naws_gemm_bf16_slab_nt_sgd(int M, int N, int K, const void* A, int64_t slabA,
+                                          const void* B, int64_t slabB, float* momentum_buf,
+                                          float* param, int ldp, const float* lr, float lr_mult,
+                                          float weight_decay, float momentum, int nesterov,
+                                          int gpu_num, int64_t iter_count, void* P, int prows,
+                                          void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || gpu_num <= 0 || prows < M || ldp < N) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(A); NAWS_REQUIRE_PTR(B); NAWS_REQUIRE_PTR(momentum_buf); NAWS_REQUIRE_PTR(param);
+  NAWS_REQUIRE_PTR(lr); NAWS_REQUIRE_PTR(P);
+  if (slabA < (int64_t)M * 16 || slabB < (int64_t)N * 16) return NAWS_ERR_SHAPE;
+  if (K % 64 != 0 || N % 16 != 0 || ldp % 4 != 0 || slabA % 8 != 0 || slabB % 8 != 0) return NAWS_ERR_ARG;
+  if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)momentum_buf | (uintptr_t)param | (uintptr_t)P) & 15) != 0)
+    return NAWS_ERR_ARG;
+  if (iter_count < 0) return NAWS_ERR_ARG;
+  XArgs g{};
+  g.A = (const unsigned short*)A; g.B = (const unsigned short*)B; g.C = nullptr;
+  g.M = M; g.N = N; g.K = K; g.ldc = ldp;
+  g.slabA = slabA; g.slabB = slabB;
+  g.mom = momentum_buf; g.param = param; g.ldp = ldp; g.lr = lr; g.lr_mult = lr_mult;
+  g.wd = weight_decay; g.momentum = momentum; g.gscale = (float)(1.0 / (double)gpu_num);
+  g.nesterov = nesterov; g.first = iter_count == 0 ? 1 : 0;
+  g.P = (unsigned short*)P; g.prows = prows;
+  return launch_x3_m16<256, 256, 4, 2, 2, 1, 4, false, true>(g, 1, (hipStream_t)stream);
 }
 
 extern "C" int naws_gemm_bf16_slab_nt(int M, int N, int K, const void* A, int64_t slabA,

@@ -219,6 +219,9 @@ class WsddnEngine(object):
         # fc8's products (tiny output, long K): K in 4 slices + a deterministic second pass (58 vs
         # 97 us, tools/bench_fc8.py)
         self.FC8_KSPLIT = 4
+        # entries of VGG16_CONVS each image runs before the deferred update is queued beside the
+        # chains (1: conv1_1; 2: conv1_1 + conv1_2 with pool1)
+        self.UPDATE_AFTER = 2 if mfma_dtype == 'bf16' else 1
         self.conv_wino = {}
         self._rm_table = None
         self._fc8_ws = None
@@ -315,6 +318,10 @@ class WsddnEngine(object):
                 fmt = L.PLANES_BF16X3 if self.mfma_dtype == 'fp32x3' else L.PLANES_BF16
                 self._sgd_regions = ops.SgdPlaneRegions([
                     (o6, n6, self.k6, n6, self._wplanes['w6'], None, None, None),
+                    (o7, n6, HIDDEN, HIDDEN, self._wplanes['w7'], None, None, None)], fmt)
+                # the same table with fc6_w marked "updated elsewhere" (train_step, bf16 plan)
+                self._sgd_regions_rest = ops.SgdPlaneRegions([
+                    (o6, n6, self.k6, n6, None, None, None, None),
                     (o7, n6, HIDDEN, HIDDEN, self._wplanes['w7'], None, None, None)], fmt)
         else:
             cv(w6, out=self._wplanes['w6'])
@@ -535,9 +542,18 @@ class WsddnEngine(object):
                 st = self._streams[i]
                 st.wait_event(start)
                 with torch.cuda.stream(st):
-                    wp, b, _w = self.conv['conv1_1']
-                    y = ops.conv3x3_c3_nchw_to_nhwc(data[i:i + 1], wp, b, True)
-                    bound, aff = (ops.amax_word(data[i:i + 1]), self._c11_bound) if h2 else (None, None)
+                    if self.UPDATE_AFTER <= 1:
+                        wp, b, _w = self.conv['conv1_1']
+                        y = ops.conv3x3_c3_nchw_to_nhwc(data[i:i + 1], wp, b, True)
+                        bound, aff = ((ops.amax_word(data[i:i + 1]), self._c11_bound) if h2
+                                      else (None, None))
+                    else:
+                        # ... and conv1_2 (+ pool1): the other HBM-heavy layer of the chain
+                        bound = (torch.zeros((1,), device=self.device, dtype=torch.int32) if h2
+                                 else None)
+                        y = self._conv_chain(data[i:i + 1], first=0, end=self.UPDATE_AFTER,
+                                             amax_last=bound)
+                        aff = None
                     heads.append((y, bound, aff))
                     evs.append(st.record_event())
             pool_done = self._pool_done
@@ -550,7 +566,8 @@ class WsddnEngine(object):
                 af = None if self._amax5 is None else self._amax5[i:i + 1]
                 if split:
                     self._pool_done = pool_done
-                    self._conv_chain(None, out=out[i:i + 1], amax_final=af, first=1, x=heads[i][0],
+                    self._conv_chain(None, out=out[i:i + 1], amax_final=af,
+                                     first=max(1, self.UPDATE_AFTER), x=heads[i][0],
                                      bound_in=heads[i][1], affine_in=heads[i][2])
                 else:
                     self._conv_chain(data[i:i + 1], out=out[i:i + 1], amax_final=af)
@@ -884,6 +901,8 @@ class WsddnEngine(object):
                     ops.gemm_f32_f16x2_nt(dz6t.rows(r0, r1), xt, out=gw6[r0:r1])
             elif x3:
                 ops.gemm_f32x3_nt(dz6t[:, :, r0:r1], xt, out=gw6[r0:r1])
+            elif bf and fuse_update and self._can_fuse_wgrad_update():
+                self._wgrad_update_w6_bf16(dz6t, xt, r0, r1)
             elif bf:
                 ops.gemm_bf16_slab_nt(dz6t[:, r0:r1], xt, out=gw6[r0:r1])
             else:
@@ -921,7 +940,7 @@ class WsddnEngine(object):
 
     def _can_fuse_wgrad_update(self):
         return (self.fuse_wgrad_update and not self.reducer.active and self.iter_size == 1
-                and self.mfma_dtype == 'fp16x2' and self.fused_planes
+                and self.mfma_dtype in ('fp16x2', 'bf16') and self.fused_planes
                 and self._sgd_regions is not None and self._wplanes is not None
                 and not self._planes_dirty and self.k6 % 256 == 0)
 
@@ -952,6 +971,23 @@ class WsddnEngine(object):
             ops.split_f16x2_rows_if(w6, maxima, self._wplanes['w6'], self._wovf, tag)
             # the route is decided HERE: the deferred kernel of this step must skip fc6_w whatever
             # the toggles say by the time it runs (the table to use travels with the flag)
+            self._w6_updated = self._sgd_regions_rest
+
+    def _wgrad_update_w6_bf16(self, dz6t, xt, r0, r1):
+        """The bf16 plan's form of _wgrad_update_w6: fc6_w's rows r0..r1 updated (parameters,
+        momentum, the rounded operand plane) in the epilogue of their weight-gradient GEMM
+        (ops.gemm_bf16_slab_nt_sgd); no scales, nothing to bound or re-split."""
+        n6 = 2 * HIDDEN
+        w6 = self.arena.span(self.params, 'fc6_w', '_[noisy]_fc6_w').view(n6, self.k6)
+        m6 = self.arena.span(self.momentum_buf, 'fc6_w', '_[noisy]_fc6_w').view(n6, self.k6)
+        ends, lr_mult, wd = self._seg_host
+        o6 = self.arena.offsets['fc6_w'][0]
+        sg = next(i for i, e in enumerate(ends) if e > o6)
+        assert ends[sg] >= o6 + n6 * self.k6       # one hyper-parameter run over both branches
+        ops.gemm_bf16_slab_nt_sgd(dz6t[:, r0:r1], xt, w6, m6, self.lr, lr_mult[sg], wd[sg],
+                                  self.momentum, 0, self.gpu_num, self.sgd_iter_count,
+                                  self._wplanes['w6'], rows=(r0, r1))
+        if r1 == n6:
             self._w6_updated = self._sgd_regions_rest
 
     def train_step(self, data, rois, obn_scores, labels_oh, seg=None):
@@ -1073,10 +1109,14 @@ class WsddnEngine(object):
             # fc6_w (weights, momentum, planes) was updated by its wgrad GEMM in this step's
             # backward: the rest MUST take the plane-writing kernel with fc6_w's region skipped,
             # even if an A/B tool has flipped fused_planes since
-            if self._wplanes is None or self._sgd_regions is None or self.mfma_dtype != 'fp16x2':
+            if (self._wplanes is None or self._sgd_regions is None
+                    or self.mfma_dtype not in ('fp16x2', 'bf16')):
                 raise RuntimeError('fc6_w was updated in its wgrad epilogue but the plane state '
                                    'it belongs to is gone (engine toggles changed mid-step?)')
-            fused = planes = True
+            if self.mfma_dtype == 'bf16':
+                planes_bf = True
+            else:
+                fused = planes = True
         if fused:
             maxima = self._wscales.view(2, 2, 2 * HIDDEN)[:, 0]
             part = slice(1, 2) if w6_done else slice(0, 2)      # (fc6_w's half was handled by its wgrad)
@@ -1095,7 +1135,8 @@ class WsddnEngine(object):
         elif planes_bf:
             ops.acm_sgd_update_planes(self.grads, self.momentum_buf, self.lr, self.params,
                                       self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,
-                                      self.gpu_num, self.sgd_iter_count, self._sgd_regions)
+                                      self.gpu_num, self.sgd_iter_count,
+                                      rest if w6_done else self._sgd_regions)
         else:
             ops.acm_sgd_update(self.grads, self.momentum_buf, self.lr, self.params, self.acmgrad,
                                self.seg_end, self.seg_lr_mult, self.seg_wd, self.momentum, 0,

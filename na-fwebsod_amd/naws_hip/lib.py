@@ -90,6 +90,8 @@ PROTOTYPES = {
     'naws_min_entropy_loss_fwd': [p, p, i32, i32, p, p],
     'naws_min_entropy_loss_bwd': [p, p, p, i32, i32, p, p],
     'naws_to_bf16_slab': [p, i32, i32, i32, i32, i64, i32, i32, p, p],
+    'naws_gemm_bf16_slab_nt_sgd': [i32, i32, i32, p, i64, p, i64, p, p, i32, p, f32, f32, f32, i32, i32,
+                                   i64, p, i32, p],
     'naws_gemm_bf16_slab_nt': [i32, i32, i32, p, i64, p, i64, p, i32, i32, i64, i64, i64,
                                i32, p, i64, p, i32, f32, f32, u64, i32, p],
     'naws_split_bf16x3': [p, i32, i32, i32, i32, i64, i32, i32, p, p],

@@ -866,6 +866,31 @@ def gemm_f32_f16x2_nt_xk_sgd(a, x, param, momentum_buf, lr, lr_mult, weight_deca
            overflow.data_ptr(), int(overflow_tag), _stream())
 
 
+def gemm_bf16_slab_nt_sgd(a, b, param, momentum_buf, lr, lr_mult, weight_decay, momentum, nesterov,
+                          gpu_num, iter_count, wplane, rows=None):
+    """gemm_bf16_slab_nt whose epilogue applies the ACM SGD update to rows r0..r1 of `param` (fp32
+    [M_all, N] row-major view of the arena; `momentum_buf` likewise) instead of storing the
+    gradient a b^T, and rounds the updated rows into param's own bf16 operand plane `wplane`
+    ([N/16, M_all, 16], to_bf16_slab(param))."""
+    for t in (a, b, wplane):
+        if (not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 3 or t.shape[-1] != 16
+                or t.stride(-1) != 1 or t.stride(-2) != 16):
+            raise TypeError('operands must be unbatched bf16 slab tensors [K/16, rows, 16]')
+    mm, k = a.shape[-2], a.shape[-3] * 16
+    n = b.shape[-2]
+    r0, r1 = (0, mm) if rows is None else rows
+    if (b.shape[-3] * 16 != k or r1 - r0 != mm or param.dim() != 2 or param.shape[1] != n
+            or param.stride(1) != 1 or momentum_buf.shape != param.shape
+            or momentum_buf.stride() != param.stride() or wplane.shape[0] * 16 < n
+            or wplane.shape[1] != param.shape[0] or not wplane.is_contiguous()
+            or not 0 <= r0 < r1 <= param.shape[0]):
+        raise L.NawsError('naws_gemm_bf16_slab_nt_sgd', L.ERR_SHAPE)
+    L.call('naws_gemm_bf16_slab_nt_sgd', mm, n, k, a.data_ptr(), a.stride(-3), b.data_ptr(),
+           b.stride(-3), momentum_buf[r0:r1].data_ptr(), param[r0:r1].data_ptr(), param.stride(0),
+           lr.data_ptr(), float(lr_mult), float(weight_decay), float(momentum), int(nesterov),
+           int(gpu_num), int(iter_count), wplane[:, r0:].data_ptr(), wplane.shape[1], _stream())
+
+
 def amax_scales(batch, outer, device):
     """Zeroed scale block [2, (batch,) outer] of an F16x2 whose maxima a GEMM epilogue will report:
     [0] (viewed as int32 bit patterns: `amax_words`) is the rowmax / colmax accumulator, [1]

@@ -213,3 +213,44 @@ def test_gemm_bf16_slab_epilogues_batched(dev):
     out = torch.zeros((2, m, n), device=dev)
     ops.gemm_bf16_slab_nt(a1[:, :, :100], w1, out=out[:, :100])          # row-sliced operand
     np.testing.assert_allclose(out[:, :100].cpu().numpy(), zz[:, :100], rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize('m,n,r,it,blocks', [(256, 512, 96, 3, False),      # one tile row
+                                             (4096, 4096, 160, 0, False),    # first iteration
+                                             (512, 768, 70, 2, True)])       # ragged K, two row blocks
+def test_bf16_wgrad_with_the_update_in_its_epilogue_equals_gemm_then_sgd(dev, m, n, r, it, blocks):
+    """naws_gemm_bf16_slab_nt_sgd (the bf16 plan's fc6_w gradient at one process) against the two
+    kernels it replaces - naws_gemm_bf16_slab_nt, then naws_acm_sgd_update_planes (NAWS_PLANES_BF16):
+    parameters, momentum and the rounded operand plane bit for bit (reference: FCGradient +
+    detectron/ops/acm_weightdecay_momentum_sgd_op.h:72-109)."""
+    from naws_hip import ops, lib as L
+    g = torch.Generator(device=dev).manual_seed(5 + m)
+    dy = torch.randn((r, m), device=dev, generator=g) * 1e-3
+    x = torch.randn((r, n), device=dev, generator=g).relu_()
+    w = torch.randn((m, n), device=dev, generator=g) * 0.02
+    mom = torch.randn((m, n), device=dev, generator=g) * 1e-3
+    a, b = ops.to_bf16_slab(dy, transpose=True), ops.to_bf16_slab(x, transpose=True)
+    lr = torch.tensor([3e-3], device=dev)
+    lr_mult, wd, momentum, gpu_num = 1.0, 5e-4, 0.9, 4
+    # gradient to memory, then the plane-writing SGD kernel over an arena that is this matrix
+    w1, m1 = w.clone(), mom.clone()
+    grad = ops.gemm_bf16_slab_nt(a, b)
+    p1 = ops.to_bf16_slab(w1)
+    reg = ops.SgdPlaneRegions([(0, m, n, m, p1, None, None, None)], L.PLANES_BF16)
+    seg_end = torch.tensor([m * n], device=dev, dtype=torch.int64)
+    ops.acm_sgd_update_planes(grad.view(-1), m1.view(-1), lr, w1.view(-1), seg_end,
+                              torch.tensor([lr_mult], device=dev), torch.tensor([wd], device=dev),
+                              momentum, 0, gpu_num, it, reg)
+    # the update in the GEMM's epilogue
+    w2, m2 = w.clone(), mom.clone()
+    p2 = ops.to_bf16_slab(w2)
+    for r0, r1 in (((0, 256), (256, m)) if blocks else ((0, m),)):
+        ops.gemm_bf16_slab_nt_sgd(a[:, r0:r1], b, w2, m2, lr, lr_mult, wd, momentum, 0, gpu_num, it,
+                                  p2, rows=(r0, r1))
+    assert torch.equal(w1, w2) and torch.equal(m1, m2)
+    assert torch.equal(p1.view(torch.int16), p2.view(torch.int16))
+    assert torch.equal(p2.view(torch.int16), ops.to_bf16_slab(w2).view(torch.int16))
+    assert not torch.equal(w2, w)
+    with pytest.raises(L.NawsError):        # N not a multiple of 16
+        ops.gemm_bf16_slab_nt_sgd(a, b[:, :n - 8], w2[:, :n - 8], m2[:, :n - 8], lr, lr_mult, wd,
+                                  momentum, 0, gpu_num, it, p2)

@@ -342,6 +342,41 @@ def test_train_step_updates_fc6_in_the_wgrad_epilogue_bit_identically(dev):
     assert torch.equal(a[4], b[4]) and a[5] == b[5]
 
 
+def test_train_step_bf16_plan_updates_fc6_in_the_wgrad_epilogue_bit_identically(dev):
+    """The bf16 plan's form of the same route (ops.gemm_bf16_slab_nt_sgd): parameters, momentum and
+    the rounded operand planes after four iterations equal forward_backward() + sgd_step() bit for
+    bit, and the fused route really ran."""
+    res = []
+    for fused in (False, True):
+        eng, mb, _blobs = _setup(dev, mfma_dtype='bf16')
+        eng.fuse_wgrad_update = fused
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        eng.set_lr(1e-3)
+        gw6 = eng.arena.span(eng.grads, 'fc6_w', '_[noisy]_fc6_w')
+        for it in range(4):
+            if it == 2:
+                eng.set_lr(1e-4)
+            if it == 3:
+                eng.flush()
+                gw6.fill_(123.0)
+            out = eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+            assert eng._can_fuse_wgrad_update() == fused
+        eng.flush()
+        torch.cuda.synchronize()
+        assert bool((gw6 == 123.0).all()) == fused
+        wp = eng._wplanes
+        res.append((eng.params.clone(), eng.momentum_buf.clone(),
+                    [wp[k].view(torch.int16).clone() for k in ('w6', 'w7', 'w7t')],
+                    out['loss_cls'].clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert torch.equal(a[3], b[3])
+    w6 = eng.arena.span(eng.params, 'fc6_w', '_[noisy]_fc6_w').view(2 * 4096, -1)
+    from naws_hip import ops
+    assert torch.equal(ops.to_bf16_slab(w6).view(torch.int16), eng._wplanes['w6'].view(torch.int16))
+
+
 def test_train_step_with_an_exchange_or_other_plans_is_the_two_call_form(dev):
     """train_step() must not fuse when gradients are exchanged (reducer active) or in a plan
     without fp16x2 planes: fc6_w's gradient is written as before."""
