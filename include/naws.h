@@ -551,6 +551,16 @@ int naws_roi_pool_f_f16x2_mapped_fwd(const float* X, int N, int C, int H, int W,
  * fc6's dW = dY^T X with a scale vector of ones, provided dY is split by
  * naws_split_f16x2_kscaled with rowmul = 1/s_r. */
 int naws_f16_planes_transpose(const void* P, int R, int K, int Rpad, void* Q, void* stream);
+/* The bf16 plan's forms (round 4): RoIPoolF (+ boost) over existing block-maxima maps written as
+ * fc6's forward operand - ONE plane P[K/16][R][16] of the pooled features rounded to bf16, the
+ * layout of naws_to_bf16_slab (K = C * ph * pw, K % 64 == 0; reference operator: RoILoopPool +
+ * RoIFeatureBoost, detectron/ops/roi_loop_pool_op.cu:31-101) - and its transposition
+ * Q[Rpad/16][K][16] (Rpad = R rounded up to 64, rows >= R zero), the operand of dW = dY^T X. */
+int naws_roi_pool_f_bf16_slab_mapped_fwd(const float* X, int N, int C, int H, int W, const float* rois,
+                                         int R, const float* boost, int pooled_h, int pooled_w,
+                                         float spatial_scale, const float* M2, const float* M4,
+                                         void* P, void* stream);
+int naws_bf16_slab_transpose(const void* P, int R, int K, int Rpad, void* Q, void* stream);
 /* naws_split_f16x2 of diag(rowmul) X (rowmul[rows], shared by the batch items; nullable). */
 int naws_split_f16x2_kscaled(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
                              int transpose, int kpad, void* P, float* scales, const float* rowmul,

@@ -198,6 +198,7 @@ struct RoiPlaneOut {
   int n_words;
   long long plane;             // elements between the hi and the lo plane (= K * R)
   int R;
+  int bf16;                    // 1: ONE bf16 plane [K/16][R][16] of Y itself (the bf16 plan): no scale
 };
 
 // HIER: the window maxima are taken over precomputed block maxima instead of single pixels.
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(64 * NW) void roi_pool_nhwc_xcd_kernel(
     const int64_t img_off = (int64_t)rb.batch * H * W * C + c0 + cg * 4;
     const float* Xn = X + img_off;
     if constexpr (PLANES) {
-      if (wave < RG && lane == 0) {
+      if (wave < RG && lane == 0 && !po.bf16) {
         const float bound =
             __uint_as_float(po.amax_words[min(rb.batch, po.n_words - 1)]) * fabsf(scale);
         float sc, isc;
@@ -363,8 +364,21 @@ __global__ __launch_bounds__(64 * NW) void roi_pool_nhwc_xcd_kernel(
     for (int i = threadIdx.x; i < RG * (count / 8); i += 64 * NW) {
       const int hh = i & 1, qq = (i >> 1) % RG, j = i / (2 * RG);
       if (r0 + qq >= R) continue;
-      const float sc = s_scale[qq];
       const float* src = tiles + qq * count + j * 16 + hh * 8;
+      if (po.bf16) {                                   // (uniform over the launch)
+        unsigned short q8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 b = (__bf16)src[e];
+          q8[e] = *reinterpret_cast<const unsigned short*>(&b);
+        }
+        uint4 w;
+        w.x = q8[0] | ((unsigned)q8[1] << 16); w.y = q8[2] | ((unsigned)q8[3] << 16);
+        w.z = q8[4] | ((unsigned)q8[5] << 16); w.w = q8[6] | ((unsigned)q8[7] << 16);
+        *reinterpret_cast<uint4*>(po.P + ((long long)(slab0 + j) * po.R + r0 + qq) * 16 + hh * 8) = w;
+        continue;
+      }
+      const float sc = s_scale[qq];
       unsigned short hi[8], lo[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -586,7 +600,7 @@ extern "C" int naws_roi_pool_f_f16x2_fwd(const float* X, int N, int C, int H, in
   if ((((uintptr_t)X | (uintptr_t)planes) & 15) != 0) return NAWS_ERR_ARG;
   RoiPlaneOut po;
   po.P = (unsigned short*)planes; po.inv_scale = scales + R; po.amax_words = (const unsigned*)amax_words;
-  po.n_words = n_words; po.plane = K * R; po.R = R;
+  po.n_words = n_words; po.plane = K * R; po.R = R; po.bf16 = 0;
   hipLaunchKernelGGL(roi_pool_nhwc_xcd_kernel<true>, dim3((unsigned)(R * (C / 64))), dim3(64),
                      (size_t)(64 * pooled_h * pooled_w + 1) * sizeof(float), (hipStream_t)stream, X, C,
                      H, W, rois, R, boost, pooled_h, pooled_w, spatial_scale, C / 64, (float*)nullptr,
@@ -638,11 +652,12 @@ static int roi_pool_planes_mapped(const float* X, int N, int C, int H, int W, co
                                   int R, const float* boost, int pooled_h, int pooled_w,
                                   float spatial_scale, const uint32_t* amax_words, int n_words,
                                   const float* M2, const float* M4, void* planes, float* scales,
-                                  hipStream_t s) {
+                                  hipStream_t s, int bf16 = 0) {
   const long long K = (long long)C * pooled_h * pooled_w;
   RoiPlaneOut po;
-  po.P = (unsigned short*)planes; po.inv_scale = scales + R; po.amax_words = (const unsigned*)amax_words;
-  po.n_words = n_words; po.plane = K * R; po.R = R;
+  po.P = (unsigned short*)planes; po.inv_scale = scales ? scales + R : nullptr;
+  po.amax_words = (const unsigned*)amax_words;
+  po.n_words = n_words; po.plane = K * R; po.R = R; po.bf16 = bf16;
   const int nw = naws_knob(NAWS_KNOB_ROI_NW);       // A/B knob (tools/bench_roi.py): NW * 10 + RG
   (void)nw;
 #define NAWS_ROI_LAUNCH(NWV, RGV)                                                                    \
@@ -721,6 +736,42 @@ extern "C" int naws_roi_pool_f_f16x2_mapped_fwd(const float* X, int N, int C, in
   if ((((uintptr_t)M2 | (uintptr_t)M4) & 15) != 0) return NAWS_ERR_ARG;
   return roi_pool_planes_mapped(X, N, C, H, W, rois, R, boost, pooled_h, pooled_w, spatial_scale,
                                 amax_words, n_words, M2, M4, planes, scales, (hipStream_t)stream);
+}
+
+// RoIPoolF (+ boost) over existing block-maxima maps (naws_roi_maxmaps_fwd), written as the bf16
+// plan's fc6 operand: ONE plane P[K/16][R][16] of Y rounded to bf16 (nearest-even), K = C * ph * pw
+// (K % 64 == 0: the layout of naws_to_bf16_slab).  Same pooled values as every other form.
+extern "C" int naws_roi_pool_f_bf16_slab_mapped_fwd(const float* X, int N, int C, int H, int W,
+                                                    const float* rois, int R, const float* boost,
+                                                    int pooled_h, int pooled_w, float spatial_scale,
+                                                    const float* M2, const float* M4, void* P,
+                                                    void* stream) {
+  if (R <= 0 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0)
+    return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(rois); NAWS_REQUIRE_PTR(P);
+  NAWS_REQUIRE_PTR(M2); NAWS_REQUIRE_PTR(M4);
+  const long long K = (long long)C * pooled_h * pooled_w;
+  if (C % 64 != 0 || pooled_h * pooled_w > 256 || K % 64 != 0 || (int64_t)R * (C / 64) >= 0x7fffffffLL)
+    return NAWS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)X | (uintptr_t)P | (uintptr_t)M2 | (uintptr_t)M4) & 15) != 0) return NAWS_ERR_ARG;
+  return roi_pool_planes_mapped(X, N, C, H, W, rois, R, boost, pooled_h, pooled_w, spatial_scale,
+                                nullptr, 1, M2, M4, P, nullptr, (hipStream_t)stream, 1);
+}
+
+// Q[Rpad/16][K][16] = transposition of the bf16 slab operand P[K/16][R][16] (rows >= R zero);
+// Rpad = R rounded up to 64: the operand form of dW = dY^T X in the bf16 plan, from the forward
+// operand instead of a second pass over fp32 features.
+extern "C" int naws_bf16_slab_transpose(const void* P, int R, int K, int Rpad, void* Q, void* stream) {
+  if (R <= 0 || K <= 0) return NAWS_ERR_SHAPE;
+  if (K % 16 != 0 || Rpad != (R + 63) / 64 * 64) return NAWS_ERR_ARG;
+  NAWS_REQUIRE_PTR(P); NAWS_REQUIRE_PTR(Q);
+  if ((((uintptr_t)P | (uintptr_t)Q) & 15) != 0) return NAWS_ERR_ARG;
+  dim3 grid((unsigned)naws_cdiv(K, 256), (unsigned)(Rpad / 16), 1);
+  if (grid.y > 65535) return NAWS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(planes_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)P, R, K, (long long)K * R, (long long)Rpad * K,
+                     (unsigned short*)Q);
+  return naws_check_launch();
 }
 
 // Q[2][Rpad/16][K][16] = transposition of the f16 planes P[2][K/16][R][16]; Rpad = R rounded up to

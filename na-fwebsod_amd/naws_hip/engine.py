@@ -525,7 +525,9 @@ class WsddnEngine(object):
         else:
             h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
         out = torch.empty((n, h, w, 512), device=self.device, dtype=torch.float32)
-        self._roi_maps = (torch.empty_like(out), torch.empty_like(out)) if planes else None
+        # (bf16 plan: RoIPoolF writes fc6's one-plane operand over the same maps)
+        slab = self.mfma_dtype == 'bf16' and self.k6 % 64 == 0
+        self._roi_maps = (torch.empty_like(out), torch.empty_like(out)) if (planes or slab) else None
         main = torch.cuda.current_stream(self.device)
         start = main.record_event()
         while len(self._streams) < n:
@@ -619,6 +621,13 @@ class WsddnEngine(object):
             return ops.roi_pool_f_f16x2(conv5, rois, self._amax5, self.roi_size, self.roi_size,
                                         self.spatial_scale, boost=obn_scores.reshape(-1),
                                         hier=True, maps=maps)
+        if self.mfma_dtype == 'bf16' and self.k6 % 64 == 0 and conv5.shape[-1] % 64 == 0:
+            maps, self._roi_maps = getattr(self, '_roi_maps', None), None
+            if maps is None:
+                maps = (torch.empty_like(conv5), torch.empty_like(conv5))
+                ops.roi_maxmaps(conv5, maps[0], maps[1])
+            return ops.roi_pool_f_bf16_slab(conv5, rois, maps, self.roi_size, self.roi_size,
+                                            self.spatial_scale, boost=obn_scores.reshape(-1))
         roi_feat = ops.roi_pool_f(conv5, rois, self.roi_size, self.roi_size, self.spatial_scale,
                                   boost=obn_scores.reshape(-1), layout='NHWC', hier=True)
         return roi_feat.view(rois.shape[0], self.k6)
@@ -626,7 +635,10 @@ class WsddnEngine(object):
     def head_forward(self, roi_feat, train, both_branches=True):
         """roi_feat [Rt, k6] (or its F16x2 operand form) -> H6, H7 [Rt, nb*4096], logits L
         [Rt, nb*2C]."""
-        rt = roi_feat.planes.shape[-2] if isinstance(roi_feat, ops.F16x2) else roi_feat.shape[0]
+        f16p = isinstance(roi_feat, ops.F16x2)
+        # (the bf16 plan's operand form, written by the pooling kernel: bf16 [k6/16, Rt, 16])
+        slab_x = not f16p and roi_feat.dtype == torch.bfloat16 and roi_feat.dim() == 3
+        rt = roi_feat.planes.shape[-2] if f16p else (roi_feat.shape[1] if slab_x else roi_feat.shape[0])
         nb = 2 if both_branches else 1
         C = self.C
         w6 = self.arena.span(self.params, 'fc6_w', '_[noisy]_fc6_w').view(2 * HIDDEN, self.k6)
@@ -648,7 +660,7 @@ class WsddnEngine(object):
         elif x3:
             xp = roi_feat if roi_feat.dtype == torch.bfloat16 else ops.split_bf16x3(roi_feat)
         elif bf:
-            xp = ops.to_bf16_slab(roi_feat)
+            xp = roi_feat if slab_x else ops.to_bf16_slab(roi_feat)
         tev = getattr(self, 'timing_events', None)
         if tev is not None:     # bench.py: HIP events around the dominant kernel, same stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -879,7 +891,9 @@ class WsddnEngine(object):
             xt = ops.split_bf16x3(x, transpose=True)           # [3, Rt/16, 25088, 16]
         elif bf:
             dz6t = ops.to_bf16_slab(dz6, transpose=True)       # [Rt/16, 8192, 16]
-            xt = ops.to_bf16_slab(x, transpose=True)           # [Rt/16, 25088, 16]
+            # [Rt/16, 25088, 16]: from the pooling kernel's own operand, or a caller's fp32 features
+            xt = (ops.bf16_slab_transpose(x) if x.dtype == torch.bfloat16
+                  else ops.to_bf16_slab(x, transpose=True))
         plan = message_plan(self.arena, 2 * HIDDEN, self.allreduce_chunks, red.active)
         for kind, rows in plan[:-1]:
             r0, r1 = rows

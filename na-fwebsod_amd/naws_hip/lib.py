@@ -101,6 +101,8 @@ PROTOTYPES = {
     'naws_split_f16x2_kscaled': [p, i32, i32, i32, i32, i64, i32, i32, p, p, p, p],
     'naws_roi_pool_f_f16x2_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, i32, p, p, p],
     'naws_f16_planes_transpose': [p, i32, i32, i32, p, p],
+    'naws_bf16_slab_transpose': [p, i32, i32, i32, p, p],
+    'naws_roi_pool_f_bf16_slab_mapped_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, p, p, p],
     'naws_roi_pool_f_nhwc_hier_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, p, p],
     'naws_roi_pool_f_f16x2_hier_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, i32, p, p, p,
                                        p],

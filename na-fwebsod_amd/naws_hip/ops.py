@@ -199,6 +199,44 @@ def roi_pool_f_f16x2(x, rois, amax_words, pooled_h=7, pooled_w=7, spatial_scale=
     return out
 
 
+def roi_pool_f_bf16_slab(x, rois, maps, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None):
+    """RoIPoolF (+ boost) on NHWC features over the block-maxima maps (m2, m4) of roi_maxmaps,
+    written directly as the bf16 plan's fc6 operand: bf16 [K/16, R, 16], K = C*ph*pw (the layout
+    of to_bf16_slab; same pooled values, rounded to nearest-even)."""
+    _chk(x, 'x'); _chk(rois, 'rois')
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise L.NawsError('naws_roi_pool_f_bf16_slab_mapped_fwd', L.ERR_SHAPE)
+    n, h, w, c = x.shape
+    r = rois.shape[0]
+    k = c * pooled_h * pooled_w
+    if boost is not None:
+        _chk(boost, 'boost')
+        assert boost.numel() == r
+    m2, m4 = maps
+    _chk(m2, 'm2'); _chk(m4, 'm4')
+    if m2.shape != x.shape or m4.shape != x.shape:
+        raise TypeError('maps must have x\'s shape')
+    out = torch.empty((k // 16, r, 16), device=x.device, dtype=torch.bfloat16)
+    L.call('naws_roi_pool_f_bf16_slab_mapped_fwd', x.data_ptr(), n, c, h, w, rois.data_ptr(), r,
+           _ptr(boost), pooled_h, pooled_w, float(spatial_scale), m2.data_ptr(), m4.data_ptr(),
+           out.data_ptr(), _stream())
+    return out
+
+
+def bf16_slab_transpose(p):
+    """bf16 slab operand [K/16, R, 16] -> [Rpad/16, K, 16] (Rpad = R rounded up to 64, rows >= R
+    zero): the same matrix with the other index K-contiguous (to_bf16_slab(x, transpose=True) of
+    the matrix the slab was rounded from)."""
+    if (not p.is_cuda or p.dtype != torch.bfloat16 or p.dim() != 3 or p.shape[-1] != 16
+            or not p.is_contiguous()):
+        raise TypeError('p must be a contiguous bf16 slab tensor [K/16, R, 16]')
+    k, r = p.shape[0] * 16, p.shape[1]
+    rp = (r + 63) // 64 * 64
+    q = torch.empty((rp // 16, k, 16), device=p.device, dtype=torch.bfloat16)
+    L.call('naws_bf16_slab_transpose', p.data_ptr(), r, k, rp, q.data_ptr(), _stream())
+    return q
+
+
 def f16_planes_transpose(op):
     """F16x2 with planes [2, K/16, R, 16] -> F16x2 with planes [2, Rpad/16, K, 16] holding the same
     scaled matrix K(=rows)-contiguous (Rpad = R rounded up to 32, zero rows) and scales of ones:

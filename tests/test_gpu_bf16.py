@@ -254,3 +254,25 @@ def test_bf16_wgrad_with_the_update_in_its_epilogue_equals_gemm_then_sgd(dev, m,
     with pytest.raises(L.NawsError):        # N not a multiple of 16
         ops.gemm_bf16_slab_nt_sgd(a, b[:, :n - 8], w2[:, :n - 8], m2[:, :n - 8], lr, lr_mult, wd,
                                   momentum, 0, gpu_num, it, p2)
+
+
+@pytest.mark.parametrize('r', [37, 400])
+def test_roi_pool_writes_the_bf16_slab_operand(dev, r):
+    """naws_roi_pool_f_bf16_slab_mapped_fwd + naws_bf16_slab_transpose (the bf16 plan): the pooling
+    kernel's one-plane operand equals to_bf16_slab of the fp32 RoIPoolF output, and its transposition
+    equals the transposing conversion of the same features, bit for bit (reference operator:
+    detectron/ops/roi_loop_pool_op.cu:31-101 + RoIFeatureBoost)."""
+    from naws_hip import ops
+    from detectron.datasets import synthetic
+    mb = synthetic.make_minibatch(synthetic.make_roidb(2, (r + 1) // 2, 20, 160, 224, seed=4), 20)
+    rois = torch.from_numpy(mb['rois'][:r]).to(dev).contiguous()
+    boost = torch.from_numpy(mb['obn_scores'].reshape(-1)[:r]).to(dev).contiguous()
+    x = torch.randn((2, 20, 28, 128), device=dev).relu_()
+    want = ops.roi_pool_f(x, rois, 7, 7, 0.125, boost=boost, layout='NHWC', hier=True).view(r, -1)
+    m2, m4 = torch.empty_like(x), torch.empty_like(x)
+    ops.roi_maxmaps(x, m2, m4)
+    slab = ops.roi_pool_f_bf16_slab(x, rois, (m2, m4), 7, 7, 0.125, boost=boost)
+    assert slab.shape == (128 * 49 // 16, r, 16)
+    assert torch.equal(slab.view(torch.int16), ops.to_bf16_slab(want).view(torch.int16))
+    t = ops.bf16_slab_transpose(slab)
+    assert torch.equal(t.view(torch.int16), ops.to_bf16_slab(want, transpose=True).view(torch.int16))
