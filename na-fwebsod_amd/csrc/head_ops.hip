@@ -699,12 +699,28 @@ __device__ __forceinline__ void acm_sgd_planes_block(
   }
 }
 
-// One workgroup per tile, or (gridDim.x < blocks) a fixed number of resident workgroups walking the
-// tiles: the update then occupies a bounded share of every CU's wave slots and LDS, and the conv
-// body queued beside it keeps its own (a tile per workgroup fills the CUs with 4 x 38 KB of LDS
-// images, which the conv kernels' 43 KB workgroups cannot share).
+// One workgroup per tile (the launch in use) ...
 template <int FMT>
 __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
+    const float4* __restrict__ grad, float4* __restrict__ mom, const float* __restrict__ lr,
+    float4* __restrict__ param, const int64_t* __restrict__ seg_end,
+    const float* __restrict__ seg_lr_mult, const float* __restrict__ seg_wd, int nseg,
+    float momentum, int nesterov, float scale, int first, SgdPlaneArgs a, int* __restrict__ overflow,
+    int overflow_tag) {
+  constexpr int NPL = FMT == 0 ? 2 : (FMT == 1 ? 3 : 1);
+  __shared__ __attribute__((aligned(16))) unsigned char img[NPL * SGP_PLANE];
+  __shared__ float cmred[FMT == 0 ? 4 * 256 : 1];     // column maxima of the four waves (colmax)
+  acm_sgd_planes_block<FMT>(blockIdx.x, img, cmred, grad, mom, lr[0], param, seg_end, seg_lr_mult,
+                            seg_wd, nseg, momentum, nesterov, scale, first, a, overflow, overflow_tag);
+}
+
+// ... or a fixed number of resident workgroups walking the tiles (knob "sgd_wgs"): the update then
+// occupies a bounded share of every CU's wave slots and LDS, and the conv body queued beside it
+// keeps its own (a tile per workgroup fills the CUs with 4 x 38 KB of LDS images, which the conv
+// kernels' 43 KB workgroups cannot share).  A separate kernel: the loop costs the one-tile form
+// 34 VGPRs (96 -> 130, five -> three waves per SIMD, 0.71 -> 0.92 ms on the bench arena).
+template <int FMT>
+__global__ __launch_bounds__(TB) void acm_sgd_planes_walk_kernel(
     const float4* __restrict__ grad, float4* __restrict__ mom, const float* __restrict__ lr,
     float4* __restrict__ param, const int64_t* __restrict__ seg_end,
     const float* __restrict__ seg_lr_mult, const float* __restrict__ seg_wd, int nseg,
@@ -712,7 +728,7 @@ __global__ __launch_bounds__(TB) void acm_sgd_planes_kernel(
     int overflow_tag, int blocks) {
   constexpr int NPL = FMT == 0 ? 2 : (FMT == 1 ? 3 : 1);
   __shared__ __attribute__((aligned(16))) unsigned char img[NPL * SGP_PLANE];
-  __shared__ float cmred[FMT == 0 ? 4 * 256 : 1];     // column maxima of the four waves (colmax)
+  __shared__ float cmred[FMT == 0 ? 4 * 256 : 1];
   const float base_lr = lr[0];
   for (int bid = blockIdx.x; bid < blocks; bid += gridDim.x) {
     acm_sgd_planes_block<FMT>(bid, img, cmred, grad, mom, base_lr, param, seg_end, seg_lr_mult, seg_wd,
@@ -1007,7 +1023,7 @@ extern "C" int naws_acm_sgd_update_planes(int format, const float* grad, float* 
   // Knob "sgd_wgs" = n > 0: n x 256 resident workgroups walk the tiles instead of one workgroup per
   // tile (whose 38 / 51 KB LDS images leave the conv body beside the update no room).  In-process
   // A/B on the route with a gradient in between (tools/ab_engine.py --env sgd_wgs, one process per
-  // GPU): fp16x2 12.66 -> 12.50 ms/step, fp32x3 22.41 -> 22.27, bf16 6.97 -> 7.27.  NOT the default:
+  // GPU): fp16x2 13.01 -> 12.88 ms/step, fp32x3 21.61 -> 21.52, bf16 slower.  NOT the default:
   // with TWO processes sharing one GPU (tests/test_gpu_two_ranks.py) the ranks stopped making
   // progress with the resident form - unexplained, so the launch stays one workgroup per tile.
   const long long blocks = tiles + lin_blocks;
@@ -1015,13 +1031,19 @@ extern "C" int naws_acm_sgd_update_planes(int format, const float* grad, float* 
   const long long grid = per_cu > 0 ? std::min<long long>(blocks, (long long)per_cu * 256)
                                     : (per_cu < -1 ? std::min<long long>(blocks, -per_cu) : blocks);
 #define NAWS_SGD_PLANES(F)                                                                          \
-  hipLaunchKernelGGL(acm_sgd_planes_kernel<F>, dim3((unsigned)grid), dim3(TB), 0,                    \
-                     (hipStream_t)stream, (const float4*)grad, (float4*)momentum_buf, lr,            \
-                     (float4*)param, seg_end, seg_lr_mult, seg_wd, nseg, momentum, nesterov, scale,  \
-                     iter_count == 0 ? 1 : 0, a, overflow, overflow_tag, (int)blocks)
-  if (format == NAWS_PLANES_F16X2) NAWS_SGD_PLANES(0);
-  else if (format == NAWS_PLANES_BF16X3) NAWS_SGD_PLANES(1);
-  else NAWS_SGD_PLANES(2);
+  if (grid == blocks)                                                                               \
+    hipLaunchKernelGGL(acm_sgd_planes_kernel<F>, dim3((unsigned)blocks), dim3(TB), 0,                \
+                       (hipStream_t)stream, (const float4*)grad, (float4*)momentum_buf, lr,          \
+                       (float4*)param, seg_end, seg_lr_mult, seg_wd, nseg, momentum, nesterov,       \
+                       scale, iter_count == 0 ? 1 : 0, a, overflow, overflow_tag);                   \
+  else                                                                                              \
+    hipLaunchKernelGGL(acm_sgd_planes_walk_kernel<F>, dim3((unsigned)grid), dim3(TB), 0,             \
+                       (hipStream_t)stream, (const float4*)grad, (float4*)momentum_buf, lr,          \
+                       (float4*)param, seg_end, seg_lr_mult, seg_wd, nseg, momentum, nesterov,       \
+                       scale, iter_count == 0 ? 1 : 0, a, overflow, overflow_tag, (int)blocks)
+  if (format == NAWS_PLANES_F16X2) { NAWS_SGD_PLANES(0); }
+  else if (format == NAWS_PLANES_BF16X3) { NAWS_SGD_PLANES(1); }
+  else { NAWS_SGD_PLANES(2); }
 #undef NAWS_SGD_PLANES
   return naws_check_launch();
 }
