@@ -262,60 +262,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
   const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + bz * g.sC : nullptr;
   const int epi = g.epilogue;
-  auto write_tile = [&](f32x16 (&acc)[TI][TJ], float* C) {
-  if constexpr (F16) {
-    // undo the row scaling first (powers of two: exact).  Accumulator register e of a lane in
-    // half h is row (e&3) + 8(e>>2) + 4h of the 32x32 block: lane l fetches the factor of row l,
-    // v_readlane hands each register its row's factor (one load per block instead of 16).
-    const float* rs = g.rs + bz * g.sRs;
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      const int mine = __float_as_int(rs[min(m0 + wm * WTM + i * 32 + l31, g.M - 1)]);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int l0 = (e & 3) + 8 * (e >> 2);
-        const float r0 = __int_as_float(__builtin_amdgcn_readlane(mine, l0));
-        const float r1 = __int_as_float(__builtin_amdgcn_readlane(mine, l0 + 4));
-        const float r = h ? r1 : r0;
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j][e] *= r;
-      }
-    }
+#define NAWS_EPI_ACC acc
+#define NAWS_EPI_C C
+#include "gemm_x3_epilogue.inc"
+#undef NAWS_EPI_ACC
+#undef NAWS_EPI_C
+  if constexpr (COL2) {            // (A/B build only) the second accumulator set
+    float* C2 = C + g.sC2;
+#define NAWS_EPI_ACC acc1
+#define NAWS_EPI_C C2
+#include "gemm_x3_epilogue.inc"
+#undef NAWS_EPI_ACC
+#undef NAWS_EPI_C
   }
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const int col = n0 + wn * WTN + j * 32 + l31;
-    if (col >= g.N) continue;
-    const float bv = (bias && epi >= NAWS_EPI_BIAS && epi <= NAWS_EPI_BIAS_RELU_DROP) ? bias[col] : 0.f;
-    float cscale = 1.f;
-    if constexpr (F16) cscale = g.cs[bz * g.sCs + col];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row >= g.M) continue;
-        float v = acc[i][j][e];
-        if constexpr (F16) v *= cscale;                 // power of two: exact
-        v += bv;
-        if (epi == NAWS_EPI_BIAS_RELU || epi == NAWS_EPI_BIAS_RELU_DROP) v = fmaxf(v, 0.f);
-        if (epi == NAWS_EPI_BIAS_RELU_DROP) {
-          const unsigned long long idx =
-              (unsigned long long)bz * g.M * g.N + (unsigned long long)row * g.N + col;
-          v = naws_keep(g.seed, idx, g.drop_thr) ? v * g.drop_scale : 0.f;
-        } else if (epi == NAWS_EPI_GATE_POS) {
-          v = (aux[row * g.ldaux + col] > 0.f) ? v * g.alpha : 0.f;
-        }
-        const int idx = row * g.ldc + col;      // < 2^31, checked on the host
-        if (g.accumulate) v += C[idx];
-        C[idx] = v;
-        acc[i][j][e] = v;
-      }
-    }
-  }
-  };
-  write_tile(acc, C);
-  if constexpr (COL2) write_tile(acc1, C + g.sC2);
   if (g.am.rowmax || g.am.colmax)
     naws_tile_amax_32<TI, TJ>(acc, m0 + wm * WTM, n0 + wn * WTN, g.M, g.N, lane, g.am, bz);
 }
