@@ -122,7 +122,12 @@ def test_weights_file_roundtrip_and_alias(dev, cfgmod, tmp_path):
     assert '__preserve__/fc1000_w' in model2.preserved_blobs
 
 
-def test_train_cli_two_iterations(dev, cfgmod, tmp_path, capsys):
+@pytest.mark.parametrize('plan', [(), ('NAWS.MFMA_DTYPE', 'bf16', 'NUM_GPUS', '1', 'TRAIN.IMS_PER_BATCH', '2',
+                                       'WEBLY.BAGGING_MIXUP', 'False')])
+def test_train_cli_two_iterations(dev, cfgmod, tmp_path, capsys, plan):
+    """The training tool end to end; second case: the bf16 plan (configs[3]'s arithmetic) with two
+    images per process - per-image conv chains, RoIPoolF writing fc6's operand, fc6_w updated in its
+    wgrad epilogue, the deferred kernel for the rest."""
     import importlib.util
     cfgmod.reset_cfg()
     spec = importlib.util.spec_from_file_location(
@@ -132,7 +137,7 @@ def test_train_cli_two_iterations(dev, cfgmod, tmp_path, capsys):
     tool.main(['--cfg', YAML, '--skip-test', '--max-iter', '2', 'OUTPUT_DIR', str(tmp_path),
                'TRAIN.SCALES', '(64,)', 'TRAIN.MAX_SIZE', '96', 'TRAIN.BATCH_SIZE_PER_IM', '32',
                'WSL.USE_DISTORTION', 'False', 'DATA_LOADER.NUM_THREADS', '1',
-               'SOLVER.BASE_LR', '1e-5'])
+               'SOLVER.BASE_LR', '1e-5'] + list(plan))
     out = capsys.readouterr().out
     assert 'json_stats: {' in out and '"loss_cls"' in out
     assert 'class_weight       Stat #iter_: 1' in out
