@@ -280,6 +280,29 @@ def test_weight_planes_after_fused_update_match_fresh_split(dev):
     assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max())
 
 
+@pytest.mark.parametrize('mode', ['fp16x2', 'bf16'])
+def test_where_the_deferred_update_is_queued_does_not_change_the_result(dev, mode):
+    """engine.UPDATE_AFTER (how many layers of each image's conv chain run before the deferred
+    update is queued beside them: 1 = conv1_1, 2 = + conv1_2 / pool1, 5 = + conv2_x / pool2) only
+    moves launches between streams: parameters after three steps are bit-identical - and, in the
+    plans without operand scales, identical to one conv chain over the whole batch too."""
+    runs = {}
+    for ua, streams in ((1, True), (2, True), (5, True), (1, False)):
+        eng, mb, _blobs = _setup(dev, mfma_dtype=mode)
+        eng.UPDATE_AFTER, eng.conv_streams = ua, streams
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+        eng.set_lr(1e-3)
+        for _ in range(3):
+            out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+            eng.sgd_step()
+        eng.flush()
+        torch.cuda.synchronize()
+        runs[(ua, streams)] = (eng.params.clone(), out['loss_cls'].clone())
+    ref = runs[(1, True)]
+    for key in ((2, True), (5, True)) + (((1, False),) if mode == 'bf16' else ()):
+        assert torch.equal(runs[key][0], ref[0]) and torch.equal(runs[key][1], ref[1]), key
+
+
 @pytest.mark.parametrize('mode', ['fp32x3', 'bf16'])
 def test_weight_planes_written_by_the_update_equal_a_fresh_split(dev, mode):
     """fp32x3 / bf16 plans: the SGD kernel also writes the fc6_w / fc7_w operand planes (exact
