@@ -1020,14 +1020,16 @@ extern "C" int naws_acm_sgd_update_planes(int format, const float* grad, float* 
   a.n = nr; a.tiles = (int)tiles; a.n_lin = n_lin;
   for (int k = n_lin + 1; k < 5; ++k) a.lin_block0[k] = (int)lin_blocks;
   const float scale = (float)(1.0 / (double)gpu_num);
-  // Knob "sgd_wgs" = n > 0: n x 256 resident workgroups walk the tiles instead of one workgroup per
-  // tile (whose 38 / 51 KB LDS images leave the conv body beside the update no room).  In-process
-  // A/B on the route with a gradient in between (tools/ab_engine.py --env sgd_wgs, one process per
-  // GPU): fp16x2 13.01 -> 12.88 ms/step, fp32x3 21.61 -> 21.52, bf16 slower.  NOT the default:
-  // with TWO processes sharing one GPU (tests/test_gpu_two_ranks.py) the ranks stopped making
-  // progress with the resident form - unexplained, so the launch stays one workgroup per tile.
+  // 256 resident workgroups walk the tiles of the two- and three-plane formats instead of one
+  // workgroup per tile (whose 38 / 51 KB LDS images leave the conv body beside the update no room).
+  // In-process A/B on the route with a gradient in between (tools/ab_engine.py --env sgd_wgs):
+  // fp16x2 13.01 -> 12.88 ms/step, fp32x3 21.61 -> 21.52; the bf16 plan's 17 KB images co-reside as
+  // they are (walking: slower).  Knob "sgd_wgs": n > 0 forces n x 256 workgroups, -1 one workgroup
+  // per tile, n < -1 exactly -n workgroups (the tests walk several tiles per workgroup on small
+  // arenas).
   const long long blocks = tiles + lin_blocks;
-  const int per_cu = naws_knob(NAWS_KNOB_SGD_WGS);
+  int per_cu = naws_knob(NAWS_KNOB_SGD_WGS);
+  if (per_cu == 0) per_cu = format == NAWS_PLANES_BF16 ? -1 : 1;
   const long long grid = per_cu > 0 ? std::min<long long>(blocks, (long long)per_cu * 256)
                                     : (per_cu < -1 ? std::min<long long>(blocks, -per_cu) : blocks);
 #define NAWS_SGD_PLANES(F)                                                                          \
