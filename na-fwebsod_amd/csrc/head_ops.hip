@@ -193,9 +193,12 @@ __device__ __forceinline__ float iou_int(int ax0, int ay0, int ax1, int ay1, int
 
 constexpr int GR = 64;    // rows per workgroup
 constexpr int GJ = 64;    // j-tile staged in LDS
-constexpr int GCC = 20;   // classes accumulated per pass (registers)
+// GCC: classes accumulated per pass (registers); every pass recomputes the IoUs, so a launch takes
+// the smallest of 20 / 40 / 80 that covers C in one pass (C = 80: one pass instead of four).
+// The sums run over j in the same order whatever GCC is: results are bit-identical.
 
 // grid (ceil(max_seg/GR), nseg, JCH).  Dpart[q][r][c] = sum_{j in chunk q} J(r,j) E[j,c]
+template <int GCC>
 __global__ __launch_bounds__(GR) void gate_D_kernel(const float* __restrict__ rois,
                                                     const float* __restrict__ rois_pred,
                                                     const int32_t* __restrict__ seg_off,
@@ -861,9 +864,15 @@ extern "C" int naws_entropy_gate_fwd(const float* rois, const float* rois_pred,
   if (nseg > 65535 || C > 65535) return NAWS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int JCH = gate_chunks(max_seg_len);
-  const size_t lds = GJ * 4 * sizeof(int) + GJ * GCC * sizeof(float);
-  hipLaunchKernelGGL(gate_D_kernel, dim3((unsigned)naws_cdiv(max_seg_len, GR), nseg, JCH),
-                     dim3(GR), lds, s, rois, rois_pred, seg_off, Rt, C, JCH, workspace);
+  const dim3 dgrid((unsigned)naws_cdiv(max_seg_len, GR), nseg, JCH);
+#define NAWS_GATE_D(GCCV)                                                                          \
+  hipLaunchKernelGGL(gate_D_kernel<GCCV>, dgrid, dim3(GR),                                         \
+                     GJ * 4 * sizeof(int) + GJ * GCCV * sizeof(float), s, rois, rois_pred, seg_off, \
+                     Rt, C, JCH, workspace)
+  if (C <= 20) NAWS_GATE_D(20);
+  else if (C <= 40) NAWS_GATE_D(40);
+  else NAWS_GATE_D(80);
+#undef NAWS_GATE_D
   const int nchunk = (int)naws_cdiv(max_seg_len, GF_ROWS);
   if ((size_t)GF_ROWS * C * sizeof(float) > 64 * 1024 || nchunk > 65535) return NAWS_ERR_UNSUPPORTED;
   float* part = workspace + (int64_t)JCH * Rt * C;

@@ -185,7 +185,7 @@ def test_wsddn_outputs_fwd_bwd(dev, c):
 
 
 # ------------------------------------------------------------- entropy gate --
-@pytest.mark.parametrize('c', [20, 27])
+@pytest.mark.parametrize('c', [20, 27, 80, 93])     # one pass of 20 / 40 / 80 classes; two passes
 def test_entropy_gate(dev, c):
     from naws_hip import ops
     from oracle import oracle
