@@ -1,10 +1,13 @@
-import csv,glob,sys
+import csv,glob,os,sys
+# FC6_MIN_NS: shortest launch taken for the fc6-forward GEMM that delimits a step (3e6 for the
+# fp16x2 plan; 1.1e6 for the bf16 plan's 1.25 ms launches)
+FC6_MIN_NS=float(os.environ.get('FC6_MIN_NS','3e6'))
 f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
 rows=[r for r in csv.DictReader(open(f))]
 for r in rows:
     r['s']=int(r['Start_Timestamp']); r['e']=int(r['End_Timestamp'])
 rows.sort(key=lambda r:r['s'])
-fc6=[r for r in rows if 'gemm_x3_m16' in r['Kernel_Name'] and r['Grid_Size_X']=='262144' and (r["e"]-r["s"])>float(__import__("os").environ.get("FC6_MIN_NS","3e6"))]
+fc6=[r for r in rows if 'gemm_x3_m16' in r['Kernel_Name'] and r['Grid_Size_X']=='262144' and (r["e"]-r["s"])>FC6_MIN_NS]
 # a step from the middle of the run: the last launches of a default bench.py belong to its
 # deferred-route loop (forward_backward + sgd_step), not to the timed train_step loop
 k=len(fc6)//2 if len(sys.argv)<4 else int(sys.argv[3])
