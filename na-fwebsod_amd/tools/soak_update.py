@@ -90,6 +90,12 @@ def main():
                 fresh = ops.split_f16x2(w)
                 ratio = got.inv_scale / fresh.inv_scale
                 assert bool(((ratio == 1) | (ratio == 2)).all()), (it, key)
+            if a.fused and a.mfma_dtype in ('bf16', 'fp32x3'):
+                # no scales: the planes must BE the rounded / exactly split parameters
+                cv = ops.to_bf16_slab if a.mfma_dtype == 'bf16' else ops.split_bf16x3
+                for key, w, kw in (('w6', w6, {}), ('w7', w7, {}), ('w7t', w7, dict(transpose=True))):
+                    assert torch.equal(eng._wplanes[key].view(torch.int16),
+                                       cv(w, **kw).view(torch.int16)), (it, key)
             print('step %d: loss %.5f  max|w6| %.3f  last overflow tag %d (iter %d)  plane error / bound %.3f'
                   % (it + 1, loss, float(w6.abs().max()), ovf, eng.sgd_iter_count, worst), flush=True)
             assert np.isfinite(loss) and worst <= 1.0
