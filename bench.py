@@ -865,11 +865,21 @@ def main():
               if json.load(open(f)).get('mfma_dtype', 'fp32') == args.mfma_dtype]
         roof['traffic_measured_in_run'] = False
         if tj and headline and B == 2:
-            roof['traffic'] = json.load(open(tj[-1]))['hbm_bytes_per_launch']
+            tjd = json.load(open(tj[-1]))
+            roof['traffic'] = tjd['hbm_bytes_per_launch']
             roof['traffic_source'] = os.path.relpath(tj[-1], ROOT)
-        pmc = {'fp16x2': 'profiles/r04_default_plan_pmc.md', 'fp32x3': 'profiles/r01_x3_gemm_pmc.md'}
-        if args.mfma_dtype in pmc:
-            roof['profile_ref'] = pmc[args.mfma_dtype]
+            roof['traffic_ratio_vs_algorithmic'] = round(
+                tjd['hbm_bytes_per_launch'] / tjd['algorithmic_bytes_per_launch'], 3)
+            # the same ratio (counter bytes / algorithmic bytes per launch) for the other hot
+            # kernels of the plan, from the same PMC passes (tools/summarize_profile.py EXTRA)
+            for e in tjd.get('other_kernels', []):
+                key = e['kernel'].split(' (')[0].replace(' ', '_').replace('<', '_').replace('>', '') \
+                    .replace(',', '_').replace('+', 'and').replace('/', '_')
+                roof['traffic_ratio_' + key] = e['ratio']
+        pmc = {'fp16x2': sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_default_plan_pmc.md'))),
+               'fp32x3': [os.path.join(ROOT, 'profiles', 'r01_x3_gemm_pmc.md')]}
+        if pmc.get(args.mfma_dtype):
+            roof['profile_ref'] = os.path.relpath(pmc[args.mfma_dtype][-1], ROOT)
         cfg = {'workload': 'configs[1] flickr_voc na_wsddn_V-16-C5_1x C=%d: %d img %dx%d/GPU x %d '
                            'rois, fwd+bwd+allreduce+SGD' % (num_fg, B, args.height, args.width,
                                                             args.rois),

@@ -156,8 +156,9 @@ def _defaults():
             'SHARDED_UPDATE': False,  # NUM_GPUS > 1, fp16x2 plan: fc6_w's gradient rows are reduced to one owner
                                      # rank each, the owner updates its 8192 / N rows (fp32 master rows and momentum
                                      # live there only) and the updated rows + scale words return by all-gather:
-                                     # same bytes on the links as the all-reduce, 1 / N of the update's HBM traffic
-                                     # beside the next conv body; parameters bit-identical (tests).  A checkpoint
+                                     # same bytes on the links as the all-reduce; update traffic beside the next
+                                     # conv body 4.9 / N + 2.4 GB instead of 4.9 GB (every rank still re-splits all
+                                     # 8192 rows after the gather); parameters bit-identical (tests).  A checkpoint
                                      # then needs engine.gather_sharded_state() on every rank (the training loop
                                      # calls it).  Unmeasured on hardware: no multi-GPU node was available
             'MFMA_DTYPE': 'fp16x2',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact

@@ -135,6 +135,8 @@ class NetExecutor(object):
                 dist.broadcast(w, 0, group=self.pg)
                 dist.broadcast(b, 0, group=self.pg)
             self.engine.set_conv_blobs({k: v for k, v in self.engine.export_blobs(False).items()})
+            # engine.params was written directly: the operand planes no longer match it
+            self.engine._planes_dirty = True
         else:
             for n in self.model.params:
                 dist.broadcast(self.ws[n], 0, group=self.pg)
@@ -153,7 +155,8 @@ class NetExecutor(object):
                     ratio > cfg.SOLVER.SCALE_MOMENTUM_THRESHOLD:
                 for n in self.model.TrainableParams():
                     m = self.ws[n + '_momentum']
-                    K.unary(L.UN_SCALE, m, new_lr / cur, out=m)
+                    # a float32 quotient, as in the reference (detector.py:536-537) and the engine
+                    K.unary(L.UN_SCALE, m, float(np.float32(new_lr) / np.float32(cur)), out=m)
         return new_lr
 
     # -------------------------------------------------------------------- run

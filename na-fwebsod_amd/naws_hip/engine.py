@@ -131,9 +131,11 @@ class WsddnEngine(object):
         # each (reduce-scatter), the owner updates its 8192 / N rows (fp32 master rows + momentum
         # live there only), and the updated fp32 rows + their scale words come back by all-gather;
         # every rank then splits the rows into operand planes with the owners' scales.  Same bytes
-        # on the links as the all-reduce, 1 / N of the update's HBM traffic beside the next conv
-        # body; parameters bit-identical to the all-reduce route (tests/test_distributed_cpu.py,
-        # tests/test_gpu_two_ranks.py).  See _apply_update_sharded.
+        # on the links as the all-reduce; the update's HBM traffic beside the next conv body drops
+        # from 4.9 GB to 4.9 / N GB for the owned rows PLUS 2.4 GB for the re-split of all 8192
+        # rows after the gather (822 MB read + planes written: most of what the owner-only update
+        # saves is given back there); parameters bit-identical to the all-reduce route
+        # (tests/test_distributed_cpu.py, tests/test_gpu_two_ranks.py).  See _apply_update_sharded.
         self.sharded_update = bool(sharded_update)
         if rank is None and process_group is not None:
             import torch.distributed as dist
@@ -516,7 +518,9 @@ class WsddnEngine(object):
         if self._update_waiting and (not per_image or not heads_first):
             self._launch_update(())        # no per-image conv1_1 head to put it behind
         if not per_image:
-            return self._conv_chain(data, amax_final=self._amax5)
+            res = self._conv_chain(data, amax_final=self._amax5)
+            self._roi_maps_of = (res.data_ptr(), res._version)
+            return res
         h, w = data.shape[2], data.shape[3]
         for _ in range(3):
             h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
@@ -528,6 +532,8 @@ class WsddnEngine(object):
         # (bf16 plan: RoIPoolF writes fc6's one-plane operand over the same maps)
         slab = self.mfma_dtype == 'bf16' and self.k6 % 64 == 0
         self._roi_maps = (torch.empty_like(out), torch.empty_like(out)) if (planes or slab) else None
+        # the maps belong to THIS tensor in THIS state (_take_roi_maps)
+        self._roi_maps_of = (out.data_ptr(), out._version)
         main = torch.cuda.current_stream(self.device)
         start = main.record_event()
         while len(self._streams) < n:
@@ -613,16 +619,32 @@ class WsddnEngine(object):
     def _seed(self, layer):
         return (self.seed * 0x9E3779B1 + self.step_count * 1000003 + layer * 7919) & ((1 << 62) - 1)
 
+    def _take_roi_maps(self, conv5):
+        """The block-maxima maps conv_body() built beside the chains, if `conv5` is the very
+        tensor it returned, unmodified (same storage, same version counter); None for any other
+        tensor of the same shape - the pooling wrapper then builds maps of what it is given."""
+        maps, self._roi_maps = getattr(self, '_roi_maps', None), None
+        if maps is not None and getattr(self, '_roi_maps_of', None) != (conv5.data_ptr(), conv5._version):
+            maps = None
+        return maps
+
     def _roi_features(self, conv5, rois, obn_scores):
         """RoIPoolF + boost -> the fc6 input: fp32 [Rt, k6], or (fp16x2 plan) the GEMM operand
         planes written by the pooling kernel itself."""
         if self._amax5 is not None:
-            maps, self._roi_maps = getattr(self, '_roi_maps', None), None
+            mine = getattr(self, '_roi_maps_of', None) == (conv5.data_ptr(), conv5._version)
+            maps = self._take_roi_maps(conv5)
+            if not mine:
+                # a caller's own feature map (or conv_body's, modified): max|conv5_3| - the
+                # bound behind the operand scale of the planes - is taken from what was passed
+                self._amax5 = torch.cat([ops.amax_word(conv5[i:i + 1].contiguous())
+                                         for i in range(self._amax5.numel())]) \
+                    if self._amax5.numel() == conv5.shape[0] else ops.amax_word(conv5.contiguous())
             return ops.roi_pool_f_f16x2(conv5, rois, self._amax5, self.roi_size, self.roi_size,
                                         self.spatial_scale, boost=obn_scores.reshape(-1),
                                         hier=True, maps=maps)
         if self.mfma_dtype == 'bf16' and self.k6 % 64 == 0 and conv5.shape[-1] % 64 == 0:
-            maps, self._roi_maps = getattr(self, '_roi_maps', None), None
+            maps = self._take_roi_maps(conv5)
             if maps is None:
                 maps = (torch.empty_like(conv5), torch.empty_like(conv5))
                 ops.roi_maxmaps(conv5, maps[0], maps[1])
@@ -1202,6 +1224,17 @@ class WsddnEngine(object):
                 raise NotImplementedError('NAWS.SHARDED_UPDATE: 8192 rows do not divide into '
                                           '32-row multiples over %d ranks' % self.reducer.world_size)
             self._shard = dict(blocks=blocks)
+            if self.pg is not None:
+                import warnings
+                import torch.distributed as dist
+                if dist.get_backend(self.pg) != 'gloo':
+                    # the RCCL legs of this route (per-owner dist.reduce, in-place
+                    # all_gather_into_tensor on fp32 and int32 buffers, issued from the update
+                    # stream) have never executed - no multi-GPU node was available; only the gloo
+                    # emulation (all_reduce / broadcast) has
+                    warnings.warn('NAWS.SHARDED_UPDATE on backend %r has never run on hardware '
+                                  '(validated over gloo only); check the first steps against the '
+                                  'all-reduce route' % dist.get_backend(self.pg))
         return self._shard['blocks']
 
     def _shard_tables(self):

@@ -508,7 +508,7 @@ def emulate_exchange(src, dst, nbytes, cus, gbytes_per_sec):
     dst at the given aggregate pace on the current stream - see naws_emulate_exchange."""
     _chk(src, 'src'); _chk(dst, 'dst')
     nbytes = int(nbytes) // 16 * 16
-    if nbytes > src.numel() * 4 or nbytes > dst.numel() * 4:
+    if nbytes > src.numel() * src.element_size() or nbytes > dst.numel() * dst.element_size():
         raise ValueError('emulate_exchange: nbytes exceeds a buffer')
     L.call('naws_emulate_exchange', src.data_ptr(), dst.data_ptr(), nbytes, int(cus),
            float(gbytes_per_sec), _stream())

@@ -158,29 +158,31 @@ class EmulatedExchange(object):
     active = True
 
     def reduce_async(self, flat_slice):
+        self._phase(flat_slice, 2)         # reduce-scatter, all-gather
+
+    def _scratch_for(self, nbytes):
+        """The landing buffer of the proxy copies, at least `nbytes` long.  It is only ever
+        touched on the communication stream, so it is allocated THERE (the caching allocator
+        ties a block to the stream it was allocated on): a block that is outgrown goes back to
+        that stream's pool and cannot be handed to a main-stream tensor while proxy kernels
+        queued earlier still write into it."""
         import torch
-        from . import ops
-        n = flat_slice.numel()
+        n = (nbytes + 3) // 4
         if self._scratch is None or self._scratch.numel() < n:
-            self._scratch = torch.empty((n,), device=self.device, dtype=torch.float32)
-        part = int(n * 4 * (self.n - 1) / self.n) // 16 * 16
-        self._stream.wait_event(torch.cuda.current_stream(self.device).record_event())
-        with torch.cuda.stream(self._stream):
-            for _phase in range(2):        # reduce-scatter, all-gather
-                ops.emulate_exchange(flat_slice, self._scratch, part, self.cus, self.gbps)
-        self.total_bytes += 2 * part
+            with torch.cuda.stream(self._stream):
+                self._scratch = torch.empty((n,), device=self.device, dtype=torch.float32)
+        return self._scratch
 
     def _phase(self, flat, phases):
         import torch
         from . import ops
-        n = flat.numel()
-        if self._scratch is None or self._scratch.numel() < n:
-            self._scratch = torch.empty((n,), device=self.device, dtype=torch.float32)
-        part = int(n * 4 * (self.n - 1) / self.n) // 16 * 16
+        nbytes = flat.numel() * flat.element_size()
+        scratch = self._scratch_for(nbytes)
+        part = int(nbytes * (self.n - 1) / self.n) // 16 * 16
         self._stream.wait_event(torch.cuda.current_stream(self.device).record_event())
         with torch.cuda.stream(self._stream):
             for _phase in range(phases):
-                ops.emulate_exchange(flat, self._scratch, part, self.cus, self.gbps)
+                ops.emulate_exchange(flat, scratch, part, self.cus, self.gbps)
         self.total_bytes += phases * part
 
     # NAWS.SHARDED_UPDATE under projection: this process plays rank 0 of N - it updates rows

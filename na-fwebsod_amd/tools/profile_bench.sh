@@ -3,7 +3,7 @@
 # passes (FETCH_SIZE, WRITE_SIZE) and an SQ pass of the default plan + an SQ pass of the inference;
 # summarise with tools/summarize_profile.py / pmc_default_plan.py into profiles/.
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/prof_$R
 B="python bench.py --no-cpu-baseline --no-alt-plan --no-extra-configs --no-parity-check --no-projection"
 for P in fp16x2 fp32x3 fp32; do

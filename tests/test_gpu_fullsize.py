@@ -196,11 +196,19 @@ def test_ragged_shapes_plans_agree(dev, h, w, rois):
             bound = tol * (np.abs(r).max() if mode != 'bf16' else lscale)
             assert np.isfinite(a).all() and np.abs(a - r).max() <= bound, (mode, k)
         pa, pr = o['cls_prob'].cpu().numpy(), o32['cls_prob'].cpu().numpy()
-        # bf16: a probability is exp(logit) twice normalised, so the operands' 2^-9 rounding through
-        # 13 conv layers (conv5_3 off by 8e-3 of its maximum, old and new conv kernel alike) moves
-        # the largest one by up to ~10 % on these seeds (0.106 measured at 203 x 317); the bound is
-        # three times the loss tolerance
-        ptol = 0.15 if mode == 'bf16' else tol
-        assert np.abs(pa - pr).max() <= ptol * pr.max(), mode
+        if mode == 'bf16':
+            # bf16 (no blanket percentage): the logits carry the operands' rounding
+            # through 13 conv layers + fc6 / fc7 and are held to the plan's own logit tolerance
+            # (3e-2 of max|logit|, as in test_full_size_bf16_c80_matches_oracle); GIVEN the
+            # logits, cls_prob = sum_r softmax_c x softmax_d is a sum of positive terms each
+            # moved by at most exp(2 dz) per softmax, so its relative error is bounded by
+            # exp(4 dz) - 1 with dz the largest logit difference actually present
+            la, lr_ = o['logits'].double().cpu().numpy(), o32['logits'].double().cpu().numpy()
+            dz = float(np.abs(la - lr_).max())
+            assert dz <= 3e-2 * float(np.abs(lr_).max()), (mode, dz)
+            live = pr > 0
+            assert np.abs(pa[live] / pr[live] - 1).max() <= np.expm1(4 * dz) * (1 + 1e-3) + 1e-5, mode
+        else:
+            assert np.abs(pa - pr).max() <= tol * pr.max(), mode
         ga, gr = g.double(), g32.double()
         assert float((ga - gr).norm()) <= gtol * float(gr.norm()), mode

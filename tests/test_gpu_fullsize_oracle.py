@@ -242,7 +242,10 @@ def test_full_size_training_step_matches_oracle(dev, request, stats, mode):
     # (skewed statistics: the noise branch's fc8d gradient is ill-conditioned enough that the fp32
     # oracle itself sits at 1.8e-3 from float64; there the HIP path must be no further than it)
     for name, (e_hip, e_orc) in report.items():
-        assert e_hip <= max(5e-4, e_orc), (name, e_hip, e_orc)
+        bound = 5e-4
+        if stats == 'skewed' and name == 'noisy_fc8d_w':
+            bound = max(5e-4, e_orc)       # that one blob, that one case; 5e-4 elsewhere
+        assert e_hip <= bound, (name, e_hip, e_orc)
 
 
 def test_full_size_bf16_c80_matches_oracle(dev, ref20):

@@ -299,3 +299,26 @@ def test_min_entropy_loss_op_and_graph(dev, cfgmod):
         assert float((extra - d).abs().max()) <= 1e-4 * float(d.abs().max()) + 1e-9, k
     # the noisy branch's own logits do not see the entropy term
     assert torch.equal(res[True]['noisy_fc8c_grad'], res[False]['noisy_fc8c_grad'])
+
+
+def test_op_by_op_plan_reproduces_the_reference_momentum_correction(dev, cfgmod):
+    """NetExecutor.update_lr of the op-by-op plan against the sequence captured from the imported
+    reference (tests/golden/make_golden_lr_update.py; detector.py:509-559): same lr fed, momentum
+    of every trainable parameter scaled - or not - by the same FLOAT32 quotient, bit for bit (the
+    fused plan's form of this test is test_set_lr_reproduces_the_reference_momentum_correction)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference_lr_update.json')))
+    model, ex = _build(dev, True, True)
+    assert ex.plan == 'interpreted'
+    name = 'fc8c_w'
+    g = torch.Generator(device='cpu').manual_seed(5)
+    ref = torch.randn(ex.ws[name + '_momentum'].shape, generator=g)
+    ex.ws[name + '_momentum'].copy_(ref.to(dev))
+    want = ref.numpy().copy()
+    for case in gold['cases']:
+        assert np.float32(float(ex.lr.item())) == np.float32(case['cur_lr'])
+        got = ex.update_lr(0, case['new_lr'])
+        assert np.float32(got) == np.float32(case['returned'])
+        if case['correction'] is not None:
+            want = want * np.float32(case['correction'])
+        assert np.array_equal(ex.ws[name + '_momentum'].cpu().numpy(), want), case
