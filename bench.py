@@ -423,6 +423,7 @@ def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False):
     saved = (eng.reducer, eng.allreduce_chunks, eng.phase_events, eng.timing_events,
              eng.update_events, eng.comm_events)
     ex = EmulatedExchange(eng.device, n, cus, gbps)
+    ex.log = []
     eng.reducer, eng.allreduce_chunks = ex, (4 if n == 2 else 2)
     eng.sharded_update, eng._shard = bool(sharded), None
     eng.timing_events = eng.update_events = eng.comm_events = None
@@ -446,6 +447,7 @@ def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False):
         eng.sharded_update, eng._shard, eng._mom_synced = False, None, True
     exposed = [e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]) if n1 == 'join_update']
     return {'ms_per_step': round(ms, 3), 'cus': ex.cus, 'gbps': ex.gbps, 'chunks': 4 if n == 2 else 2,
+            'messages_per_step': ex.log[:len(ex.log) // (5 + steps)],
             'bytes_per_step': ex.total_bytes / (5 + steps),
             'exposed_ms': sum(exposed) / max(len(exposed), 1)}
 
@@ -698,6 +700,7 @@ def main():
     if pg is not None:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    eng.reducer.log = msg_log = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(True)
@@ -706,6 +709,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    eng.reducer.log = None
     rank_dt = [dt]
     if pg is not None:
         td = torch.zeros((world,), device=dev, dtype=torch.float64)
@@ -910,6 +914,20 @@ def main():
                'exposed_comm_ms': None,
                'allreduce_wait_ms': (round(sum(s.elapsed_time(e) for s, e in cev) / len(cev), 3)
                                      if cev else None)}
+        # the messages THIS rank handed to the exchange in one step, in order ("kind:elements"),
+        # and whether that is the schedule the N-rank projection of the one-GPU line plays
+        # (project_n_ranks: 4 fc6_w row chunks at 2 ranks, 2 above, then the small gradients)
+        if msg_log:
+            per = msg_log[:len(msg_log) // args.steps]
+            cfg['exchange_messages_per_step'] = ','.join('%s:%d' % (k, n) for k, n in per)
+            cfg['exchange_bytes_per_step'] = 4 * sum(n for _k, n in per)
+            if not args.sharded_update:
+                from naws_hip.reducer import message_plan, message_slice
+                plan = message_plan(eng.arena, 8192, 4 if world == 2 else 2, True)
+                want = [['all_reduce', int(message_slice(eng.arena, eng.grads, k, r, eng.k6).numel())]
+                        for k, r in plan]
+                cfg['exchange_schedule_equals_projection'] = bool(
+                    [list(m) for m in per] == want) if world > 1 else None
         for n, pr in sorted(projections.items(), key=lambda kv: str(kv[0])):
             # PROJECTIONS, not measurements of an N-GPU job: the one-rank step with the N-rank
             # schedule and a paced copy kernel in the all-reduce's place (see EmulatedExchange);
@@ -918,6 +936,7 @@ def main():
             nn = int(str(n).split('_')[0])
             cfg['projected_ms_per_step_n%s' % n] = pr['ms_per_step']
             cfg['projected_images_per_sec_n%s' % n] = round(nn * B / pr['ms_per_step'] * 1e3, 1)
+            cfg['projected_messages_n%s' % n] = ','.join('%s:%d' % (k, m) for k, m in pr['messages_per_step'])
             cfg['projected_exchange_n%s' % n] = (
                 '%d CUs x %.0f GB/s, %.2f GB per step, allreduce_chunks %d, exposed %.2f ms'
                 % (pr['cus'], pr['gbps'], pr['bytes_per_step'] / 1e9, pr['chunks'], pr['exposed_ms']))

@@ -153,6 +153,8 @@ def _defaults():
             'DEVICE_POST': True,     # inference: roi projection / dedup hash / scatter-back / TTA mean /
                                      # DETECTIONS_PER_IM cut on the GPU (csrc/infer_ops.hip): one result
                                      # download per image; False = the numpy path of the reference
+            'SYNTHETIC_TEST_IMAGES': 4,   # test engine, datasets that are not on disk: this many seeded synthetic
+                                     # images stand in (tools/test_net_wsl.py --num-images)
             'SHARDED_UPDATE': False,  # NUM_GPUS > 1, fp16x2 plan: fc6_w's gradient rows are reduced to one owner
                                      # rank each, the owner updates its 8192 / N rows (fp32 master rows and momentum
                                      # live there only) and the updated rows + scale words return by all-gather:
@@ -214,10 +216,29 @@ def get_output_dir(datasets, training=True):
     return outdir
 
 
+class _CfgLoader(yaml.SafeLoader):
+    """safe_load + the ONE python tag a reference-written cfg string carries on its mappings
+    (`!!python/object/new:detectron.utils.collections.AttrDict {dictitems, state}`, the yaml.dump
+    of the reference's AttrDict: env.py:91) and `!!python/tuple`; anything else stays refused."""
+
+
+def _construct_attrdict(loader, node):
+    m = loader.construct_mapping(node, deep=True)
+    return m.get('dictitems', {})
+
+
+_CfgLoader.add_constructor('tag:yaml.org,2002:python/object/new:detectron.utils.collections.AttrDict',
+                           _construct_attrdict)
+_CfgLoader.add_constructor('tag:yaml.org,2002:python/object/new:utils.collections.AttrDict',
+                           _construct_attrdict)
+_CfgLoader.add_constructor('tag:yaml.org,2002:python/tuple',
+                           lambda loader, node: tuple(loader.construct_sequence(node, deep=True)))
+
+
 def load_cfg(cfg_to_load):
     if hasattr(cfg_to_load, 'read'):
         cfg_to_load = cfg_to_load.read()
-    return yaml.safe_load(cfg_to_load)
+    return yaml.load(cfg_to_load, Loader=_CfgLoader)
 
 
 def merge_cfg_from_file(cfg_filename):

@@ -35,10 +35,30 @@ for _y in ('2007', '2012'):
         _DATASETS['voc_%s_%s' % (_y, _s)] = _voc(_y, _s)
 
 
+_REGISTERED = {}
+
+
 def register(name, image_directory, annotation_file, image_prefix='', devkit_directory=None):
     _DATASETS[name] = {_IM_DIR: image_directory, _ANN_FN: annotation_file, _IM_PREFIX: image_prefix}
     if devkit_directory:
         _DATASETS[name][_DEVKIT_DIR] = devkit_directory
+    _REGISTERED[name] = dict(_DATASETS[name])
+
+
+def registered():
+    """Datasets added at run time (name -> entry): what a parent hands to the children it starts
+    (detectron/utils/subprocess.py exports it as NAWS_DATASET_REGISTRY)."""
+    return dict(_REGISTERED)
+
+
+def _register_from_env():
+    import json
+    blob = os.environ.get('NAWS_DATASET_REGISTRY')
+    for name, e in (json.loads(blob) if blob else {}).items():
+        register(name, e[_IM_DIR], e[_ANN_FN], e.get(_IM_PREFIX, ''), e.get(_DEVKIT_DIR))
+
+
+_register_from_env()
 
 
 def datasets():

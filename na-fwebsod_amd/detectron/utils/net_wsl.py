@@ -86,8 +86,10 @@ def save_model_to_weights_file(weights_file, model, executor):
         unscoped = k[k.rfind('/') + 1:]
         if unscoped not in blobs:
             blobs[unscoped] = v
-    cfg_yaml = yaml.dump(_plain(cfg))
-    save_object(dict(blobs=blobs, cfg=cfg_yaml), weights_file)
+    # (the reference reads this string back as an AttrDict: net_wsl.py:64-66, :277)
+    import detectron.utils.env as envu
+    save_object(dict(blobs=blobs, cfg=envu.yaml_dump(cfg, reference_format=True),
+                     naws_cfg=envu.yaml_dump(cfg.NAWS)), weights_file)
 
 
 def _plain(node):

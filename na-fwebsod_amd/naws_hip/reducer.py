@@ -70,6 +70,13 @@ class ArenaReducer(object):
         self.world_size = int(world_size)
         self._pending = []
         self.force = False     # run the collectives even with a single rank (tests)
+        # when a list: every message handed over is appended as [kind, elements] - the schedule a
+        # run really issued (bench.py's exchange_messages_per_step, the world-8 test)
+        self.log = None
+
+    def _note(self, kind, t):
+        if self.log is not None:
+            self.log.append([kind, int(t.numel())])
 
     @property
     def active(self):
@@ -83,6 +90,7 @@ class ArenaReducer(object):
             return
         import torch.distributed as dist
         assert flat_slice.is_contiguous()
+        self._note('all_reduce', flat_slice)
         self._pending.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.pg,
                                              async_op=True))
 
@@ -105,6 +113,7 @@ class ArenaReducer(object):
             return
         import torch.distributed as dist
         assert flat_slice.is_contiguous()
+        self._note('reduce_to_owner', flat_slice)
         if self._emulated(flat_slice):
             w = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         else:
@@ -119,6 +128,7 @@ class ArenaReducer(object):
             return
         import torch.distributed as dist
         assert flat.is_contiguous() and flat.numel() % self.world_size == 0
+        self._note('gather_blocks', flat)
         n = flat.numel() // self.world_size
         if dist.get_backend(self.pg) == 'gloo':
             for o in range(self.world_size):
@@ -154,10 +164,16 @@ class EmulatedExchange(object):
         self._stream = torch.cuda.Stream(device=device)
         self._scratch = None
         self.total_bytes = 0           # moved since construction (bench: / steps)
+        self.log = None                # as ArenaReducer.log
 
     active = True
 
+    def _note(self, kind, t):
+        if self.log is not None:
+            self.log.append([kind, int(t.numel())])
+
     def reduce_async(self, flat_slice):
+        self._note('all_reduce', flat_slice)
         self._phase(flat_slice, 2)         # reduce-scatter, all-gather
 
     def _scratch_for(self, nbytes):
@@ -190,9 +206,11 @@ class EmulatedExchange(object):
     # projection run is not a training run's), the reduce-scatter and the all-gather each move
     # (N-1)/N of their message
     def reduce_to_owner_async(self, flat_slice, owner):
+        self._note('reduce_to_owner', flat_slice)
         self._phase(flat_slice, 1)
 
     def gather_blocks_async(self, flat, rank):
+        self._note('gather_blocks', flat)
         if flat.dtype.is_floating_point and flat.numel() >= 4096:
             self._phase(flat, 1)
 

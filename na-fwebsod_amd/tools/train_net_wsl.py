@@ -64,9 +64,55 @@ def main(argv=None):
     random.seed(cfg.RNG_SEED + rank)
     from detectron.utils import train_wsl
     checkpoints = train_wsl.train_model(max_iter=args.max_iter)
-    if not args.skip_test and int(os.environ.get('RANK', '0')) == 0:
-        logger.info('final checkpoint: %s (evaluation needs the VOC/COCO datasets, which are '
-                    'outside the hot path; use tools/test_net_wsl.py)', checkpoints.get('final'))
+    if world > 1:
+        # the ranks of a torchrun job end together; rank 0 alone runs the test (single process,
+        # or - with --multi-gpu-testing - as the parent of one fresh child per GPU)
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+    results = None
+    if not args.skip_test and rank == 0:
+        # Test the trained model (reference tools/train_net_wsl.py:118-160: the final checkpoint
+        # with the yaml's TTA; the per-snapshot re-tests without TTA follow)
+        results = test_model(checkpoints['final'], args.multi_gpu_testing, world)
+        print('reprint snapshot name for the result: ', checkpoints['final'])
+        _ = checkpoints.pop('final', None)
+        if checkpoints:
+            from detectron.core import config as core_config
+            core_config.cfg.immutable(False)
+            core_config.cfg.TEST.BBOX_AUG.ENABLED = False
+            core_config.cfg.VIS = False
+            core_config.cfg.immutable(True)
+            for snapshot in sorted(checkpoints.keys(), reverse=True):
+                test_model(checkpoints[snapshot], args.multi_gpu_testing, world)
+                print('reprint snapshot name for the result: ', snapshot, checkpoints[snapshot])
+    return results
+
+
+def test_model(model_file, multi_gpu_testing, num_gpus=None):
+    """Test a model (reference tools/train_net_wsl.py:163-171): every dataset of TEST.DATASETS
+    through the test engine; parameters and activations of the training run are released first."""
+    import gc
+    import torch
+    from detectron.core import test_engine_wsl
+    gc.collect()
+    torch.cuda.empty_cache()
+    if not multi_gpu_testing or num_gpus is None or num_gpus == cfg.NUM_GPUS:
+        return test_engine_wsl.run_inference(model_file, multi_gpu_testing=multi_gpu_testing)
+    # training counted NUM_GPUS = processes x images per process (the SGD normaliser); the test
+    # engine starts one child per GPU = per training process
+    from detectron.core import config as core_config
+    saved = cfg.NUM_GPUS
+    core_config.cfg.immutable(False)
+    core_config.cfg.NUM_GPUS = int(num_gpus)
+    core_config.cfg.immutable(True)
+    try:
+        return test_engine_wsl.run_inference(model_file, multi_gpu_testing=True)
+    finally:
+        core_config.cfg.immutable(False)
+        core_config.cfg.NUM_GPUS = saved
+        core_config.cfg.immutable(True)
 
 
 if __name__ == '__main__':

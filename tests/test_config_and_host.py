@@ -511,10 +511,14 @@ def test_weights_file_written_by_the_reference_loads_and_resaves(tmp_path, cfgmo
     for k, v in theirs['blobs'].items():
         assert ours['blobs'][k].dtype == v.dtype and np.array_equal(ours['blobs'][k], v), k
     # the reference dumps its AttrDict tree with python-object tags (AttrDict, numpy scalars): only
-    # its own process can rebuild that, so compare top-level section names; ours is a plain
-    # mapping, which the reference's load_cfg wraps into an AttrDict itself
+    # its own process can rebuild all of that, so compare top-level section names.  Ours carries the
+    # SAME AttrDict tag on every mapping (the reference reads the string back with its unsafe
+    # loader and uses the result as an AttrDict: net_wsl.py:64-66, :277; checked against the
+    # imported reference in tests/test_test_engine_cpu.py) and plain scalars / lists below them
     import re
-    a = yaml.safe_load(ours['cfg'])
+    from detectron.core.config import load_cfg
+    assert ours['cfg'].startswith('!!python/object/new:detectron.utils.collections.AttrDict')
+    a = load_cfg(ours['cfg'])
     b = set(re.findall(r'^  ([A-Z][A-Z0-9_]*):', theirs['cfg'], re.M))
     # (the mirror carries the sections of the hot path only, plus its own NAWS block)
     assert b and set(a) - {'NAWS'} <= b, sorted(set(a) - b)

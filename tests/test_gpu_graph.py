@@ -202,11 +202,14 @@ def _load_tool(name):
     return tool
 
 
-def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys):
+def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys, monkeypatch):
     """The whole caller chain on real files: COCO json + MCG pickle -> roidb -> loader threads
     (PNG decode) -> device-side image prep with the yaml's HSV distortion / crop / flip ->
-    training iterations -> checkpoint;  then test_net_wsl: dataset -> multi-scale + flip TTA ->
-    GPU NMS -> detections.pkl in the reference's all_boxes[cls][image] layout."""
+    training iterations -> checkpoint -> the POST-TRAINING TEST of the final checkpoint
+    (reference tools/train_net_wsl.py:118-160: test_model -> run_inference; dataset -> multi-scale
+    + flip TTA -> GPU NMS -> detections.pkl in the reference's schema);  then test_net_wsl alone,
+    in one process and with --multi-gpu-testing as a parent of two fresh children that share
+    cuda:0 (HIP_VISIBLE_DEVICES=0,0): the same detections every way."""
     from test_datasets import _toy_dataset
     from detectron.datasets import dataset_catalog
     from detectron.utils.net_wsl import load_object
@@ -216,8 +219,12 @@ def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys):
     dataset_catalog.register('toy_test', imdir, annf)
     common = ['OUTPUT_DIR', str(tmp_path), 'MODEL.NUM_CLASSES', '3', 'DATA_LOADER.NUM_THREADS', '1',
               'TRAIN.CROWD_FILTER_THRESH', '0.0']
-    _load_tool('train_net_wsl').main(
-        ['--cfg', YAML, '--skip-test', '--max-iter', '3'] + common +
+    test_opts = ['TEST.DATASETS', "('toy_test',)", 'TEST.PROPOSAL_FILES', "('%s',)" % pf,
+                 'TEST.SCALE', '64', 'TEST.MAX_SIZE', '120', 'TEST.BBOX_AUG.ENABLED', 'True',
+                 'TEST.BBOX_AUG.SCALES', '(48, 64)', 'TEST.BBOX_AUG.MAX_SIZE', '120',
+                 'TEST.BBOX_AUG.H_FLIP', 'True', 'TEST.BBOX_AUG.SCALE_H_FLIP', 'True']
+    res = _load_tool('train_net_wsl').main(
+        ['--cfg', YAML, '--max-iter', '3'] + common + test_opts +
         ['TRAIN.DATASETS', "('toy_train',)", 'TRAIN.PROPOSAL_FILES', "('%s',)" % pf,
          'TRAIN.SCALES', '(64, 80)', 'TRAIN.MAX_SIZE', '120', 'SOLVER.BASE_LR', '1e-5',
          'NAWS.DEVICE_PREP', 'True'])
@@ -229,15 +236,16 @@ def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys):
     # reference's stat_op.cu:68-74 does)
     wts = os.path.join(str(tmp_path), 'train', 'toy_train', 'generalized_wsl', 'model_final.pkl')
     assert os.path.exists(wts)
+    det_file = os.path.join(str(tmp_path), 'test', 'toy_test', 'generalized_wsl', 'detections.pkl')
+    assert 'reprint snapshot name for the result:' in out and os.path.exists(det_file)
+    assert res['toy_test']['box']['num_images'] == len(sizes)
+    post = load_object(det_file)
+    assert {'all_boxes', 'all_segms', 'all_keyps', 'cfg'} <= set(post)
+    assert post['cfg'].startswith('!!python/object/new:detectron.utils.collections.AttrDict')
+    os.remove(det_file)
     cfgmod.reset_cfg()
-    all_boxes = _load_tool('test_net_wsl').main(
-        ['--cfg', YAML] + common +
-        ['TEST.DATASETS', "('toy_test',)", 'TEST.PROPOSAL_FILES', "('%s',)" % pf, 'TEST.WEIGHTS', wts,
-         'TEST.SCALE', '64', 'TEST.MAX_SIZE', '120', 'TEST.BBOX_AUG.ENABLED', 'True',
-         'TEST.BBOX_AUG.SCALES', '(48, 64)', 'TEST.BBOX_AUG.MAX_SIZE', '120',
-         'TEST.BBOX_AUG.H_FLIP', 'True', 'TEST.BBOX_AUG.SCALE_H_FLIP', 'True'])
-    det = load_object(os.path.join(str(tmp_path), 'test', 'toy_test', 'generalized_wsl',
-                                   'detections.pkl'))
+    all_boxes = _load_tool('test_net_wsl').main(['--cfg', YAML] + common + test_opts + ['TEST.WEIGHTS', wts])
+    det = load_object(det_file)
     assert len(det['all_boxes']) == 3 and len(det['all_boxes'][1]) == len(sizes)
     n = 0
     for j in (1, 2):
@@ -245,8 +253,26 @@ def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys):
             d = np.asarray(det['all_boxes'][j][i])
             assert d.ndim == 2 and d.shape[1] == 5 and np.isfinite(d).all()
             assert np.array_equal(d, np.asarray(all_boxes[j][i]))
+            assert np.array_equal(d, np.asarray(post['all_boxes'][j][i])), (j, i)
+            assert det['all_segms'][j][i] == [] and det['all_keyps'][j][i] == []
             n += d.shape[0]
     assert n > 0
+    # --multi-gpu-testing: this process only starts the children and collates their range files
+    os.remove(det_file)
+    cfgmod.reset_cfg()
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,0')
+    multi = _load_tool('test_net_wsl').main(
+        ['--cfg', YAML, '--multi-gpu-testing'] + common + test_opts + ['TEST.WEIGHTS', wts, 'NUM_GPUS', '2'])
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    out_dir = os.path.dirname(det_file)
+    ranges = sorted(f for f in os.listdir(out_dir) if f.startswith('detection_range_') and f.endswith('.pkl'))
+    assert len(ranges) == 2, ranges
+    det2 = load_object(det_file)
+    for j in (1, 2):
+        assert len(det2['all_boxes'][j]) == len(sizes)
+        for i in range(len(sizes)):
+            assert np.array_equal(np.asarray(det2['all_boxes'][j][i]), np.asarray(det['all_boxes'][j][i])), (j, i)
+            assert np.array_equal(np.asarray(multi[j][i]), np.asarray(det['all_boxes'][j][i]))
 
 
 def test_min_entropy_loss_op_and_graph(dev, cfgmod):
