@@ -158,12 +158,11 @@ def multi_gpu_test_net_on_dataset(weights_file, dataset_name, proposal_file, num
 
 
 def save_detections(det_file, all_boxes, all_segms, all_keyps):
-    """The reference's dict (test_engine_wsl.py:189-197, :297-305).  `cfg` holds the reference's
-    own keys only - tools/reval.py merges it key by key and refuses unknown ones - and the options
-    of this implementation travel beside it."""
+    """The reference's dict, its four keys and nothing else (test_engine_wsl.py:189-197,
+    :297-305).  `cfg` holds the reference's own keys only - tools/reval.py merges it key by key
+    and refuses unknown ones - in the AttrDict-tagged yaml its loader rebuilds."""
     save_object(dict(all_boxes=all_boxes, all_segms=all_segms, all_keyps=all_keyps,
-                     cfg=envu.yaml_dump(cfg, reference_format=True),
-                     naws_cfg=envu.yaml_dump(cfg.NAWS)), det_file)
+                     cfg=envu.yaml_dump(cfg, reference_format=True)), det_file)
 
 
 def initialize_model_from_cfg(weights_file, gpu_id=0):

@@ -88,8 +88,7 @@ def save_model_to_weights_file(weights_file, model, executor):
             blobs[unscoped] = v
     # (the reference reads this string back as an AttrDict: net_wsl.py:64-66, :277)
     import detectron.utils.env as envu
-    save_object(dict(blobs=blobs, cfg=envu.yaml_dump(cfg, reference_format=True),
-                     naws_cfg=envu.yaml_dump(cfg.NAWS)), weights_file)
+    save_object(dict(blobs=blobs, cfg=envu.yaml_dump(cfg, reference_format=True)), weights_file)
 
 
 def _plain(node):

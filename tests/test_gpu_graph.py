@@ -240,7 +240,7 @@ def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys, monkeypatch):
     assert 'reprint snapshot name for the result:' in out and os.path.exists(det_file)
     assert res['toy_test']['box']['num_images'] == len(sizes)
     post = load_object(det_file)
-    assert {'all_boxes', 'all_segms', 'all_keyps', 'cfg'} <= set(post)
+    assert set(post) == {'all_boxes', 'all_segms', 'all_keyps', 'cfg'}
     assert post['cfg'].startswith('!!python/object/new:detectron.utils.collections.AttrDict')
     os.remove(det_file)
     cfgmod.reset_cfg()

@@ -614,3 +614,35 @@ def test_gemm_splitk_matches_the_one_pass_gemm(dev, ta, tb, m, n, k, batch, kspl
     assert not wide[:, :, n:].any()
     with pytest.raises(L.NawsError):
         ops.gemm_splitk(a, b, ta, tb, epilogue=L.EPI_BIAS_RELU, bias=bias, ksplit=ksplit)
+
+
+# --------- head kernels against the imported reference's graph, executed in numpy ----------
+@pytest.mark.parametrize('idx', range(5))
+def test_head_kernels_match_the_reference_graph_numeric(dev, idx):
+    """ops.wsddn_outputs (incl. cls_pred) and ops.entropy_gate against tests/golden/
+    reference_graph_numeric.npz: the reference's add_webly_outputs / add_cls_pred /
+    add_spatial_entropy_weight / add_webly_losses run op by op in numpy fp32 (R in {64, 300},
+    C in {20, 80}, p = 0 entries; case 4: a D = 0 column -> NaN, under the fixture's stated Clip
+    reading).  Same bounds as the oracle's own test of this fixture (test_graph_numeric_golden.py)."""
+    from naws_hip import ops
+    from test_graph_numeric_golden import CASES, close, logits_of
+    info, case = CASES[idx]
+    fc8c, fc8d, nc, nd = logits_of(case)
+    r = fc8c.shape[0]
+    seg = _t(np.array([0, r], np.int32), dev)
+    ac, ad, rp, cp = ops.wsddn_outputs(_t(fc8c, dev), _t(fc8d, dev), _t(nc, dev), _t(nd, dev), seg)
+    if 'out_alpha_cls' in case:
+        close(ac[0].cpu().numpy(), case['out_alpha_cls'], 2e-6)
+        close(ad[0].cpu().numpy(), case['out_alpha_det'], 2e-6, 1e-44)
+        close(ac[1].cpu().numpy(), case['out_alpha_cls_noise'], 2e-6)
+        close(ad[1].cpu().numpy(), case['out_alpha_det_noise'], 2e-6, 1e-44)
+    close(rp[0].cpu().numpy(), case['out_rois_pred'], 1e-5, 1e-44)
+    close(rp[1].cpu().numpy(), case['out_rois_pred_noise'], 1e-5, 1e-44)
+    close(cp[0].cpu().numpy(), case['out_cls_prob'], 1e-5)
+    close(cp[1].cpu().numpy(), case['out_cls_prob_noise'], 1e-5)
+    assert (rp[0].cpu().numpy()[info['p0_rows'], info['p0_class']] == 0).all()
+    outs = ops.entropy_gate(_t(case['in_rois'], dev), _t(case['out_rois_pred'], dev),
+                            _t(case['out_cls_prob'], dev), _t(case['in_labels_oh'], dev), seg, r)
+    for o, name in zip(outs, ('rois_class_weight', 'rois_class_weight_noise', 'rois_pred_hatE_sum',
+                              'rois_pred_hatE_sum_norm')):
+        close(o.cpu().numpy().reshape(1, -1), case['out_' + name], 2e-5)
