@@ -251,6 +251,11 @@ def test_cli_on_a_dataset_on_disk(dev, cfgmod, tmp_path, capsys, monkeypatch):
     for j in (1, 2):
         for i in range(len(sizes)):
             d = np.asarray(det['all_boxes'][j][i])
+            if d.size == 0 and d.ndim == 1:
+                # an image without proposals keeps the empty lists of empty_results, as in the
+                # reference (test_engine_wsl.py:234-235 `continue`s before extend_results)
+                assert det['all_boxes'][j][i] == [] and post['all_boxes'][j][i] == []
+                continue
             assert d.ndim == 2 and d.shape[1] == 5 and np.isfinite(d).all()
             assert np.array_equal(d, np.asarray(all_boxes[j][i]))
             assert np.array_equal(d, np.asarray(post['all_boxes'][j][i])), (j, i)
