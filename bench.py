@@ -14,6 +14,13 @@ import os
 import sys
 import time
 
+# The step keeps up to five HIP streams busy at once (main, one per image of the conv body, the
+# deferred update, the collective's); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
+# round-robin (default 4), and two streams that share a queue run in order - measured here as a
+# conv chain or the piece-by-piece update stuck behind a 10 ms exchange.  Must be in the
+# environment before the HIP runtime initialises; an operator's own value wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
 sys.path.insert(0, ROOT)
@@ -58,6 +65,10 @@ def parse():
     ap.add_argument('--sharded-update', action='store_true',
                     help='N > 1: NAWS.SHARDED_UPDATE - fc6_w gradient rows reduced to one owner each, '
                          'owner-only update, updated rows all-gathered (engine._apply_update_sharded)')
+    ap.add_argument('--no-pipeline-update', action='store_true',
+                    help='N > 1: wait for the whole gradient exchange and update in one launch '
+                         '(NAWS.PIPELINE_UPDATE False) instead of piece by piece with fc6 forward '
+                         'starting behind each piece')
     ap.add_argument('--no-projection', action='store_true',
                     help='skip the N-rank contention projections (profile runs: their proxy kernel '
                          'and chunked wgrad launches would otherwise sit in the kernel tables)')
@@ -486,7 +497,7 @@ def extra_configs(args, dev, B, res, cfg, roof):
         roof['tta_infer_' + {'achieved': 'whole_image_tflops'}.get(k, k)] = ti['roofline'].get(k)
 
 
-def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False):
+def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False, pipeline=True):
     """ms/step of the N-rank schedule on this one GPU with reducer.EmulatedExchange in the
     all-reduce's place (restores the engine's own reducer afterwards).  sharded: the
     NAWS.SHARDED_UPDATE schedule, this process playing rank 0 of N (it updates 1 / N of fc6_w's
@@ -495,7 +506,8 @@ def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False):
     from naws_hip.reducer import EmulatedExchange
     eng.flush()
     saved = (eng.reducer, eng.allreduce_chunks, eng.phase_events, eng.timing_events,
-             eng.update_events, eng.comm_events)
+             eng.update_events, eng.comm_events, eng.pipeline_update)
+    eng.pipeline_update = bool(pipeline)
     ex = EmulatedExchange(eng.device, n, cus, gbps)
     ex.log = []
     eng.reducer, eng.allreduce_chunks = ex, (4 if n == 2 else 2)
@@ -517,10 +529,22 @@ def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False):
     finally:
         eng.flush()
         (eng.reducer, eng.allreduce_chunks, eng.phase_events, eng.timing_events,
-         eng.update_events, eng.comm_events) = saved
+         eng.update_events, eng.comm_events, eng.pipeline_update) = saved
         eng.sharded_update, eng._shard, eng._mom_synced = False, None, True
+        eng._pipe_sent = False
     exposed = [e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]) if n1 == 'join_update']
+    # (pipelined: the head joins the update piece by piece INSIDE its forward - what is exposed
+    # there shows as a longer head_fwd stage)
+    hf = [e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]) if n1 == 'head_fwd']
+    st = {}
+    for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]):
+        if n1 != 'start':
+            st.setdefault(n1, []).append(e0.elapsed_time(e1))
+    between = [e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(pev[:-1], pev[1:]) if n1 == 'start']
     return {'ms_per_step': round(ms, 3), 'cus': ex.cus, 'gbps': ex.gbps, 'chunks': 4 if n == 2 else 2,
+            'pipelined': bool(pipeline and not sharded), 'head_fwd_ms': sum(hf) / max(len(hf), 1),
+            'stages': {k: round(sum(v) / len(v), 3) for k, v in st.items()},
+            'between_steps_ms': round(sum(between) / max(len(between), 1), 3),
             'messages_per_step': ex.log[:len(ex.log) // (5 + steps)],
             'bytes_per_step': ex.total_bytes / (5 + steps),
             'exposed_ms': sum(exposed) / max(len(exposed), 1)}
@@ -583,6 +607,7 @@ def launcher_env(environ):
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK',
                         'MASTER_ADDR', 'MASTER_PORT')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('GPU_MAX_HW_QUEUES', '8')          # (see the top of this file)
     env.setdefault('OMP_NUM_THREADS', '8')
     env['NAWS_BENCH_CHILD'] = '1'
     return env
@@ -718,7 +743,8 @@ def main():
     eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
                       weight_decay=5e-4, iter_size=1, gpu_num=world * B, seed=11,
                       process_group=pg, world_size=world, allreduce_chunks=args.allreduce_chunks,
-                      mfma_dtype=args.mfma_dtype, sharded_update=args.sharded_update, rank=rank)
+                      mfma_dtype=args.mfma_dtype, sharded_update=args.sharded_update, rank=rank,
+                      pipeline_update=False if args.no_pipeline_update else None)
     if args.force_dist:
         eng.reducer.force = True
     if args.no_conv_streams:
@@ -824,6 +850,9 @@ def main():
             [(n, 32, None) for n in (2, 4, 8)]
         for n, cus, gbps in cases:
             projections[n] = project_n_ranks(eng, t, seg, n, cus, gbps, max(20, args.steps // 3))
+            # the same schedule without the piece-by-piece update (round 4's route), for the A/B
+            projections['%d_unpipelined' % n] = project_n_ranks(
+                eng, t, seg, n, cus, gbps, max(20, args.steps // 3), pipeline=False)
         n, cus, gbps = cases[-1]
         projections['%d_sharded' % n] = project_n_ranks(eng, t, seg, n, cus, gbps,
                                                         max(20, args.steps // 3), sharded=True)
@@ -844,7 +873,7 @@ def main():
         rt = mb['rois'].shape[0]
         k6 = 512 * 49
         fc6_flops = 2.0 * rt * (2 * 4096) * k6
-        kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+        kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(args.steps, 1)    # (N > 1: two pieces per step)
         achieved = fc6_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
         # per-stage wall time on the main stream (HIP events), averaged over the timed steps
         stages, order = {}, []
@@ -969,6 +998,7 @@ def main():
                'allreduce_chunks': eng.allreduce_chunks if eng.reducer.active else 0,
                'shared_gpu': bool(args.share_gpu),
                'sharded_update': bool(eng._shard_blocks() is not None),
+               'pipelined_update': bool(eng._pipelined()),
                # where fc6_w (86 % of the parameters) is updated: 'wgrad_epilogue' = inside its
                # weight-gradient GEMM, possible only without a gradient exchange (one rank);
                # 'deferred_kernel' = gradient written, (all-reduced,) then the SGD kernel on the
@@ -997,7 +1027,7 @@ def main():
             cfg['exchange_bytes_per_step'] = 4 * sum(n for _k, n in per)
             if not args.sharded_update:
                 from naws_hip.reducer import message_plan, message_slice
-                plan = message_plan(eng.arena, 8192, 4 if world == 2 else 2, True)
+                plan = message_plan(eng.arena, 8192, 4 if world == 2 else 2, True, eng._pipelined())
                 want = [['all_reduce', int(message_slice(eng.arena, eng.grads, k, r, eng.k6).numel())]
                         for k, r in plan]
                 cfg['exchange_schedule_equals_projection'] = bool(
@@ -1010,10 +1040,15 @@ def main():
             nn = int(str(n).split('_')[0])
             cfg['projected_ms_per_step_n%s' % n] = pr['ms_per_step']
             cfg['projected_images_per_sec_n%s' % n] = round(nn * B / pr['ms_per_step'] * 1e3, 1)
+            cfg['projected_stages_n%s' % n] = ' '.join('%s %.2f' % kv for kv in pr['stages'].items()) + \
+                ' | between steps %.2f' % pr['between_steps_ms']
             cfg['projected_messages_n%s' % n] = ','.join('%s:%d' % (k, m) for k, m in pr['messages_per_step'])
             cfg['projected_exchange_n%s' % n] = (
-                '%d CUs x %.0f GB/s, %.2f GB per step, allreduce_chunks %d, exposed %.2f ms'
-                % (pr['cus'], pr['gbps'], pr['bytes_per_step'] / 1e9, pr['chunks'], pr['exposed_ms']))
+                '%d CUs x %.0f GB/s, %.2f GB per step, allreduce_chunks %d, %s, join %.2f ms, head '
+                'forward %.2f ms (%.2f without an exchange)'
+                % (pr['cus'], pr['gbps'], pr['bytes_per_step'] / 1e9, pr['chunks'],
+                   'update piece by piece' if pr['pipelined'] else 'one update launch',
+                   pr['exposed_ms'], pr['head_fwd_ms'], stage_ms.get('head_fwd', float('nan'))))
         for k, v in stage_ms.items():                 # flat: the driver's parser drops nested dicts
             cfg['stage_ms_' + k] = v
         cfg['exposed_comm_ms'] = stage_ms.get('join_update')

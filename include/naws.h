@@ -232,6 +232,16 @@ int naws_weighted_ce_fwd(const float* X, const float* L, const float* W, int N, 
                          int is_mean, int nprob, float* Y, void* stream);
 int naws_weighted_ce_bwd(const float* X, const float* L, const float* W, const float* dY,
                          int N, int C, int is_mean, int nprob, float* dX, void* stream);
+/* The same for nprob problems whose labels repeat with period lab_period (L: [lab_period,N,C];
+ * problem p is scored against L[p % lab_period]) - the loss tail of the noise-aware head runs
+ * 2 branches x nseg images against ONE labels_oh per image (webly_heads.py:167-197: both
+ * add_cross_entropy_loss calls name the same 'labels_oh' blob).  bwd: dY NULL -> every problem's
+ * upstream gradient is dy_const (the loss seed 1.0 of utils/blob.py:167-173). */
+int naws_weighted_ce_shared_fwd(const float* X, const float* L, const float* W, int N, int C,
+                                int is_mean, int nprob, int lab_period, float* Y, void* stream);
+int naws_weighted_ce_shared_bwd(const float* X, const float* L, const float* W, const float* dY,
+                                float dy_const, int N, int C, int is_mean, int nprob, int lab_period,
+                                float* dX, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * a-12  ACMWeightDecayMomentumSGDUpdate (fused), one launch per arena
@@ -324,6 +334,13 @@ int naws_acm_sgd_update_planes(int format, const float* grad, float* momentum_bu
 int naws_split_f16x2_rows_if(const float* X, int batch, int rows, int cols, int ld, int64_t strideX,
                              const uint32_t* rowmax, void* P, float* inv_scale, int kpad,
                              const int32_t* cond, int32_t cond_value, void* stream);
+/* The same for rows [row0, row0 + rows) of an unbatched [plane_rows, cols] matrix (X = its row 0;
+ * rowmax, inv_scale [plane_rows]; planes [2][kpad/16][plane_rows][16]): one row block of a weight
+ * matrix - an fc6_w piece of the pipelined N > 1 update, the rows a rank does not own under
+ * NAWS.SHARDED_UPDATE. */
+int naws_split_f16x2_row_range_if(const float* X, int plane_rows, int row0, int rows, int cols,
+                                  int ld, const uint32_t* rowmax, void* P, float* inv_scale, int kpad,
+                                  const int32_t* cond, int32_t cond_value, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * a-14  Stat accumulate   ref: detectron/ops/stat_op.cu:14-20, :24-78
@@ -463,6 +480,20 @@ int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, int64_t sla
                                 int64_t strideBias, const float* aux, int ldaux, float alpha,
                                 float drop_ratio, uint64_t seed, int accumulate, uint32_t* rowmax,
                                 int rowmax_seg_cols, uint32_t* colmax, const float* colmax_rowmul,
+                                void* stream);
+/* One COLUMN RANGE [drop_col0, drop_col0 + N) of a drop_ld-wide unbatched product: B2, scaleB, bias,
+ * colmax and C point at the range's first weight row / output column, rowmax at the words of the
+ * rowmax segment the range lies in; the Dropout counters are those of the full-width launch
+ * (element (m, n) draws counter m * drop_ld + drop_col0 + n), so the ranges of one activation can be
+ * produced by separate launches with bit-identical results.  Used by the pipelined N > 1 step: fc6
+ * forward is cut along the weight rows and each piece starts as soon as ITS rows of fc6_w have
+ * been exchanged and updated (reference: the FC op of wsl_heads.py:674-679 after the per-blob
+ * all-reduce + update of optimizer_wsl.py:52-137 - same values, earlier start). */
+int naws_gemm_f32_f16x2_nt_cols(int M, int N, int K, const void* A2, int64_t slabA, int64_t planeA,
+                                const float* scaleA, const void* B2, int64_t slabB, int64_t planeB,
+                                const float* scaleB, float* C, int ldc, int epilogue,
+                                const float* bias, float drop_ratio, uint64_t seed, uint32_t* rowmax,
+                                int rowmax_seg_cols, uint32_t* colmax, int drop_ld, int drop_col0,
                                 void* stream);
 int naws_gemm_f32_amax(int transA, int transB, int M, int N, int K, const float* A, int lda,
                        const float* B, int ldb, float* C, int ldc, int batch, int64_t strideA,

@@ -69,6 +69,10 @@ struct XArgs {
   int nesterov, first;
   unsigned short* P;         // param's bf16 operand plane [N/16][prows][16]
   int prows;
+  // Dropout counter of element (row, col) = row * drop_ld + drop_c0 + col (0 / 0: the launch's own
+  // N and column 0).  A launch that produces a COLUMN RANGE of a wider activation (fc6 forward
+  // cut along the weight rows, naws_gemm_f32_f16x2_nt_cols) draws the masks of the full-width launch.
+  int drop_ld, drop_c0;
 };
 
 // Operand planes are stored K-slab-major, P[plane][k/16][row][k%16]: the 16-deep K-step of a
@@ -589,8 +593,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 1 : 2)) void gemm_x3_
           t += bv[e];
           if (epi == NAWS_EPI_BIAS_RELU || epi == NAWS_EPI_BIAS_RELU_DROP) t = fmaxf(t, 0.f);
           if (epi == NAWS_EPI_BIAS_RELU_DROP) {
+            const unsigned long long dld = g.drop_ld ? g.drop_ld : g.N;
             const unsigned long long idx =
-                (unsigned long long)bz * g.M * g.N + (unsigned long long)row * g.N + (col + e);
+                (unsigned long long)bz * g.M * dld + (unsigned long long)row * dld + (g.drop_c0 + col + e);
             t = naws_keep(g.seed, idx, g.drop_thr) ? t * g.drop_scale : 0.f;
           } else if (epi == NAWS_EPI_GATE_POS) {
             t = (ax[e] > 0.f) ? t * g.alpha : 0.f;
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(256) void split2h_dual_kernel(
     const unsigned* __restrict__ rowmax, const unsigned* __restrict__ colmax,
     const float* __restrict__ rowmul, unsigned short* __restrict__ Pn, float* __restrict__ inv_n,
     int slabs_n, unsigned short* __restrict__ Pt, float* __restrict__ inv_t, int slabs_t, int batch,
-    const int* __restrict__ cond, int cond_value) {
+    const int* __restrict__ cond, int cond_value, int prows_n) {
   __shared__ float tile[64][65];
   if (cond && *cond != cond_value) return;          // (naws_split_f16x2_rows_if)
   const int bz = blockIdx.z;
@@ -848,8 +853,9 @@ __global__ __launch_bounds__(256) void split2h_dual_kernel(
       for (int e = 0; e < 8; ++e) t[e] = tile[o][s * 16 + hh * 8 + e];
       u32x4 hi4, lo4;
       split2h_pack(t, sc, hi4, lo4);
-      const long long sp = (long long)slabs_n * 16 * rows, plane = (long long)batch * sp;
-      const long long dst = bz * sp + ((long long)(c0 / 16 + s) * rows + (r0 + o)) * 16 + hh * 8;
+      // (prows_n: the planes' own row count - a launch may cover a row range of them)
+      const long long sp = (long long)slabs_n * 16 * prows_n, plane = (long long)batch * sp;
+      const long long dst = bz * sp + ((long long)(c0 / 16 + s) * prows_n + (r0 + o)) * 16 + hh * 8;
       *reinterpret_cast<u32x4*>(Pn + dst) = hi4;
       *reinterpret_cast<u32x4*>(Pn + plane + dst) = lo4;
     }
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(256) void split2h_dual_v4_kernel(
     const unsigned* __restrict__ rowmax, const unsigned* __restrict__ colmax,
     const float* __restrict__ rowmul, unsigned short* __restrict__ Pn, float* __restrict__ inv_n,
     int slabs_n, unsigned short* __restrict__ Pt, float* __restrict__ inv_t, int slabs_t, int batch,
-    const int* __restrict__ cond, int cond_value) {
+    const int* __restrict__ cond, int cond_value, int prows_n) {
   constexpr int LDT = 68;                           // floats per tile row: 16-byte rows, banks spread
   __shared__ __attribute__((aligned(16))) float tile[64 * LDT];
   if (cond && *cond != cond_value) return;
@@ -909,8 +915,8 @@ __global__ __launch_bounds__(256) void split2h_dual_v4_kernel(
     float sc, isc;
     f16x2_scales(rowmax[(long long)bz * rows + r0 + o], sc, isc);
     if (c0 == 0 && s == 0) inv_n[(long long)bz * rows + r0 + o] = isc;
-    const long long sp = (long long)slabs_n * 16 * rows, plane = (long long)batch * sp;
-    const long long dst = bz * sp + ((long long)(c0 / 16 + s) * rows + (r0 + o)) * 16;
+    const long long sp = (long long)slabs_n * 16 * prows_n, plane = (long long)batch * sp;
+    const long long dst = bz * sp + ((long long)(c0 / 16 + s) * prows_n + (r0 + o)) * 16;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(&tile[o * LDT + s * 16 + hh * 8]);
@@ -951,15 +957,18 @@ static void launch_split2h_dual(dim3 grid, hipStream_t s, const float* X, int ro
                                 long long sx, const unsigned* rowmax, const unsigned* colmax,
                                 const float* rowmul, unsigned short* Pn, float* inv_n, int slabs_n,
                                 unsigned short* Pt, float* inv_t, int slabs_t, int batch,
-                                const int* cond, int cond_value) {
+                                const int* cond, int cond_value, int prows_n = 0) {
+  if (prows_n <= 0) prows_n = rows;
   const int knob = naws_knob(NAWS_KNOB_SPLIT);
   const bool aligned = (((uintptr_t)X & 15) == 0) && ld % 4 == 0 && cols % 4 == 0 && sx % 4 == 0;
   if (aligned && knob != 1 && (knob == 2 || !Pn))
     hipLaunchKernelGGL(split2h_dual_v4_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, sx, rowmax,
-                       colmax, rowmul, Pn, inv_n, slabs_n, Pt, inv_t, slabs_t, batch, cond, cond_value);
+                       colmax, rowmul, Pn, inv_n, slabs_n, Pt, inv_t, slabs_t, batch, cond, cond_value,
+                       prows_n);
   else
     hipLaunchKernelGGL(split2h_dual_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, sx, rowmax,
-                       colmax, rowmul, Pn, inv_n, slabs_n, Pt, inv_t, slabs_t, batch, cond, cond_value);
+                       colmax, rowmul, Pn, inv_n, slabs_n, Pt, inv_t, slabs_t, batch, cond, cond_value,
+                       prows_n);
 }
 
 
@@ -1155,6 +1164,29 @@ extern "C" int naws_split_f16x2_rows_if(const float* X, int batch, int rows, int
   return naws_check_launch();
 }
 
+// The same for rows [row0, row0 + rows) of an unbatched [plane_rows, cols] matrix whose planes
+// P[2][kpad/16][plane_rows][16], maxima and 1/scale vectors are indexed by the matrix row: the
+// conditional re-split of ONE row block (an fc6_w piece of the pipelined N > 1 update, the rows a
+// rank does not own under NAWS.SHARDED_UPDATE).  X points at row 0 of the matrix.
+extern "C" int naws_split_f16x2_row_range_if(const float* X, int plane_rows, int row0, int rows,
+                                             int cols, int ld, const uint32_t* rowmax, void* P,
+                                             float* inv_scale, int kpad, const int32_t* cond,
+                                             int32_t cond_value, void* stream) {
+  if (plane_rows <= 0 || rows <= 0 || cols <= 0 || ld < cols) return NAWS_ERR_SHAPE;
+  if (row0 < 0 || row0 + rows > plane_rows) return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(rowmax); NAWS_REQUIRE_PTR(P); NAWS_REQUIRE_PTR(inv_scale);
+  if (kpad != (cols + 31) / 32 * 32 || ((uintptr_t)P & 15) != 0) return NAWS_ERR_ARG;
+  const long long gy = naws_cdiv(rows, 64);
+  if (gy > 65535) return NAWS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)naws_cdiv(cols, 64), (unsigned)gy, 1);
+  launch_split2h_dual(grid, (hipStream_t)stream, X + (long long)row0 * ld, rows, cols, ld, 0LL,
+                     (const unsigned*)rowmax + row0, (const unsigned*)nullptr, (const float*)nullptr,
+                     (unsigned short*)P + (long long)row0 * 16, inv_scale + row0, kpad / 16,
+                     (unsigned short*)nullptr, (float*)nullptr, 0, 1, (const int*)cond, cond_value,
+                     plane_rows);
+  return naws_check_launch();
+}
+
 extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, int ld,
                                 int64_t strideX, int transpose, int kpad, void* P, float* scales,
                                 void* stream) {
@@ -1164,18 +1196,20 @@ extern "C" int naws_split_f16x2(const float* X, int batch, int rows, int cols, i
 
 #define g_h2_variant naws_knob(NAWS_KNOB_H2)
 
-extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, int64_t slabA,
-                                           int64_t planeA, const float* scaleA, const void* B2,
-                                           int64_t slabB, int64_t planeB, const float* scaleB,
-                                           float* C, int ldc, int batch, int64_t strideA,
-                                           int64_t strideB, int64_t strideC, int64_t strideScaleA,
-                                           int64_t strideScaleB, int epilogue, const float* bias,
-                                           int64_t strideBias, const float* aux, int ldaux,
-                                           float alpha, float drop_ratio, uint64_t seed,
-                                           int accumulate, uint32_t* rowmax, int rowmax_seg_cols,
-                                           uint32_t* colmax, const float* colmax_rowmul,
-                                           void* stream) {
+static int gemm_f32_f16x2_nt_impl(int M, int N, int K, const void* A2, int64_t slabA,
+                                  int64_t planeA, const float* scaleA, const void* B2,
+                                  int64_t slabB, int64_t planeB, const float* scaleB,
+                                  float* C, int ldc, int batch, int64_t strideA,
+                                  int64_t strideB, int64_t strideC, int64_t strideScaleA,
+                                  int64_t strideScaleB, int epilogue, const float* bias,
+                                  int64_t strideBias, const float* aux, int ldaux,
+                                  float alpha, float drop_ratio, uint64_t seed,
+                                  int accumulate, uint32_t* rowmax, int rowmax_seg_cols,
+                                  uint32_t* colmax, const float* colmax_rowmul,
+                                  int drop_ld, int drop_col0, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return NAWS_ERR_SHAPE;
+  if (drop_ld < 0 || drop_col0 < 0 || (drop_ld > 0 && drop_col0 + N > drop_ld)) return NAWS_ERR_ARG;
+  if (drop_ld > 0 && batch != 1) return NAWS_ERR_UNSUPPORTED;
   NAWS_REQUIRE_PTR(A2); NAWS_REQUIRE_PTR(B2); NAWS_REQUIRE_PTR(C);
   NAWS_REQUIRE_PTR(scaleA); NAWS_REQUIRE_PTR(scaleB);
   if (epilogue < NAWS_EPI_NONE || epilogue > NAWS_EPI_GATE_POS) return NAWS_ERR_ARG;
@@ -1199,6 +1233,7 @@ extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, 
   g.drop_thr = naws_drop_threshold(drop_ratio);
   g.drop_scale = (float)(1.0 / (1.0 - (double)drop_ratio));
   g.seed = seed; g.epilogue = epilogue; g.accumulate = accumulate;
+  g.drop_ld = drop_ld; g.drop_c0 = drop_col0;
   g.rs = scaleA; g.cs = scaleB; g.sRs = strideScaleA; g.sCs = strideScaleB;
   if (rowmax || colmax) {
     // a wave's columns must lie in one rowmax segment: segments are multiples of the widest tile
@@ -1210,9 +1245,12 @@ extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, 
     g.am.sRow = (long long)nseg * M; g.am.sCol = N;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (N <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+  // (a column range of a wider product takes the kernel the full-width launch would take: the
+  // pieces are then bit-identical to it at every size, not only where both land on one form)
+  const int Nd = drop_ld > 0 ? drop_ld : N;
+  if (Nd <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
   // fewer 256x256 tiles than CUs (the column remainder of a wgrad split into whole waves)
-  if (naws_cdiv(M, 256) * naws_cdiv(N, 256) * batch < 256 && g_h2_variant != 5)
+  if (naws_cdiv(M, 256) * naws_cdiv(Nd, 256) * batch < 256 && g_h2_variant != 5)
     return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
   // short K (the Winograd batch GEMMs): two 4-wave workgroups per CU overlap one's prologue /
   // epilogue with the other's K loop
@@ -1243,6 +1281,43 @@ extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, 
     // in the power-limited long-K GEMMs (tools/ab_h2.py, interleaved: fc6 fwd 3.62 vs 3.83 ms)
     default: return launch_x3_m16<256, 256, 4, 2, 2, 2, 2, true>(g, batch, s);
   }
+}
+
+extern "C" int naws_gemm_f32_f16x2_nt_amax(int M, int N, int K, const void* A2, int64_t slabA,
+                                           int64_t planeA, const float* scaleA, const void* B2,
+                                           int64_t slabB, int64_t planeB, const float* scaleB,
+                                           float* C, int ldc, int batch, int64_t strideA,
+                                           int64_t strideB, int64_t strideC, int64_t strideScaleA,
+                                           int64_t strideScaleB, int epilogue, const float* bias,
+                                           int64_t strideBias, const float* aux, int ldaux,
+                                           float alpha, float drop_ratio, uint64_t seed,
+                                           int accumulate, uint32_t* rowmax, int rowmax_seg_cols,
+                                           uint32_t* colmax, const float* colmax_rowmul,
+                                           void* stream) {
+  return gemm_f32_f16x2_nt_impl(M, N, K, A2, slabA, planeA, scaleA, B2, slabB, planeB, scaleB, C, ldc,
+                                batch, strideA, strideB, strideC, strideScaleA, strideScaleB,
+                                epilogue, bias, strideBias, aux, ldaux, alpha, drop_ratio, seed,
+                                accumulate, rowmax, rowmax_seg_cols, colmax, colmax_rowmul, 0, 0,
+                                stream);
+}
+
+// One COLUMN RANGE [drop_col0, drop_col0 + N) of a drop_ld-wide product (unbatched): B2, scaleB,
+// bias, colmax and C point at the range's first weight row / column; the dropout counters are
+// those of the full-width launch, so the ranges of one activation may be produced by separate
+// launches (fc6 forward cut along the weight rows: each piece starts as soon as ITS rows of
+// fc6_w have been exchanged and updated - the pipelined N > 1 step) with bit-identical results.
+extern "C" int naws_gemm_f32_f16x2_nt_cols(int M, int N, int K, const void* A2, int64_t slabA,
+                                           int64_t planeA, const float* scaleA, const void* B2,
+                                           int64_t slabB, int64_t planeB, const float* scaleB,
+                                           float* C, int ldc, int epilogue, const float* bias,
+                                           float drop_ratio, uint64_t seed, uint32_t* rowmax,
+                                           int rowmax_seg_cols, uint32_t* colmax, int drop_ld,
+                                           int drop_col0, void* stream) {
+  if (drop_ld <= 0) return NAWS_ERR_ARG;
+  return gemm_f32_f16x2_nt_impl(M, N, K, A2, slabA, planeA, scaleA, B2, slabB, planeB, scaleB, C, ldc,
+                                1, 0, 0, 0, 0, 0, epilogue, bias, 0, nullptr, 0, 1.f, drop_ratio, seed,
+                                0, rowmax, rowmax_seg_cols, colmax, nullptr, drop_ld, drop_col0,
+                                stream);
 }
 
 #ifdef NAWS_AB   // Winograd frequency-column batch GEMM: A/B build only (tools/ab_wino_col.py)

@@ -338,12 +338,14 @@ __global__ __launch_bounds__(TB) void gate_finish_kernel(
 }
 
 // ---- (weighted) cross entropy: one lane per problem, serial in index order -
+// (lab_period: problem p reads the labels of problem p % lab_period - the two branches of the
+// noise-aware head share one labels_oh per image, so no [2, nseg, C] copy of it is ever made)
 __global__ void wce_fwd_kernel(const float* __restrict__ X, const float* __restrict__ L,
                                const float* __restrict__ W, int N, int C, int is_mean,
-                               float* __restrict__ Y) {
+                               float* __restrict__ Y, int lab_period) {
   if (threadIdx.x != 0) return;
   const int n = N * C;
-  X += (int64_t)blockIdx.x * n; L += (int64_t)blockIdx.x * n;
+  X += (int64_t)blockIdx.x * n; L += (int64_t)(blockIdx.x % lab_period) * n;
   if (W) W += (int64_t)blockIdx.x * n;
   Y += blockIdx.x;
   const float norm = is_mean ? (float)C : 1.0f;
@@ -361,15 +363,17 @@ __global__ void wce_fwd_kernel(const float* __restrict__ X, const float* __restr
 
 __global__ void wce_bwd_kernel(const float* __restrict__ X, const float* __restrict__ L,
                                const float* __restrict__ W, const float* __restrict__ dY, int N,
-                               int C, int is_mean, float* __restrict__ dX) {
+                               int C, int is_mean, float* __restrict__ dX, int lab_period,
+                               float dy_const) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N * C) return;
   const int64_t i = (int64_t)blockIdx.y * N * C + e;
+  const float lab = L[(int64_t)(blockIdx.y % lab_period) * N * C + e];
   const float norm = is_mean ? (float)C : 1.0f;
-  const float grad = dY[blockIdx.y];
+  const float grad = dY ? dY[blockIdx.y] : dy_const;     // (dY NULL: the loss seed, one constant)
   const float prob = fmaxf(X[i], 1e-20f);
   const float one_prob = fmaxf(1.0f - X[i], 1e-20f);
-  float v = fminf(grad * (-1.0f * L[i] / prob - (-1.0f) * (1.0f - L[i]) / one_prob) / norm, 1e4f);
+  float v = fminf(grad * (-1.0f * lab / prob - (-1.0f) * (1.0f - lab) / one_prob) / norm, 1e4f);
   if (W) v *= W[i];
   dX[i] = v * (float)(1.0 / N);
 }
@@ -892,7 +896,34 @@ extern "C" int naws_weighted_ce_fwd(const float* X, const float* L, const float*
   if (N <= 0 || C <= 0 || nprob <= 0 || nprob > 65535) return NAWS_ERR_SHAPE;
   NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(L); NAWS_REQUIRE_PTR(Y);
   hipLaunchKernelGGL(wce_fwd_kernel, dim3(nprob), dim3(64), 0, (hipStream_t)stream, X, L, W, N, C,
-                     is_mean, Y);
+                     is_mean, Y, nprob);
+  return naws_check_launch();
+}
+
+// nprob problems whose labels repeat with period lab_period (L: [lab_period, N, C]): problem p is
+// scored against L[p % lab_period].  The loss tail of the noise-aware head: 2 branches x nseg
+// images, one labels_oh per image.
+extern "C" int naws_weighted_ce_shared_fwd(const float* X, const float* L, const float* W, int N, int C,
+                                           int is_mean, int nprob, int lab_period, float* Y,
+                                           void* stream) {
+  if (N <= 0 || C <= 0 || nprob <= 0 || nprob > 65535 || lab_period <= 0 || nprob % lab_period != 0)
+    return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(L); NAWS_REQUIRE_PTR(Y);
+  hipLaunchKernelGGL(wce_fwd_kernel, dim3(nprob), dim3(64), 0, (hipStream_t)stream, X, L, W, N, C,
+                     is_mean, Y, lab_period);
+  return naws_check_launch();
+}
+
+// ... and its gradient; dY NULL: every problem's upstream gradient is dy_const (the loss seed 1.0
+// of blob.py:167-173 without a tensor of ones).
+extern "C" int naws_weighted_ce_shared_bwd(const float* X, const float* L, const float* W,
+                                           const float* dY, float dy_const, int N, int C, int is_mean,
+                                           int nprob, int lab_period, float* dX, void* stream) {
+  if (N <= 0 || C <= 0 || nprob <= 0 || nprob > 65535 || lab_period <= 0 || nprob % lab_period != 0)
+    return NAWS_ERR_SHAPE;
+  NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(L); NAWS_REQUIRE_PTR(dX);
+  hipLaunchKernelGGL(wce_bwd_kernel, dim3((unsigned)naws_cdiv((int64_t)N * C, 64), nprob), dim3(64), 0,
+                     (hipStream_t)stream, X, L, W, dY, N, C, is_mean, dX, lab_period, dy_const);
   return naws_check_launch();
 }
 
@@ -902,7 +933,7 @@ extern "C" int naws_weighted_ce_bwd(const float* X, const float* L, const float*
   if (N <= 0 || C <= 0 || nprob <= 0 || nprob > 65535) return NAWS_ERR_SHAPE;
   NAWS_REQUIRE_PTR(X); NAWS_REQUIRE_PTR(L); NAWS_REQUIRE_PTR(dY); NAWS_REQUIRE_PTR(dX);
   hipLaunchKernelGGL(wce_bwd_kernel, dim3((unsigned)naws_cdiv((int64_t)N * C, 64), nprob), dim3(64), 0,
-                     (hipStream_t)stream, X, L, W, dY, N, C, is_mean, dX);
+                     (hipStream_t)stream, X, L, W, dY, N, C, is_mean, dX, nprob, 1.0f);
   return naws_check_launch();
 }
 

@@ -153,14 +153,19 @@ def _defaults():
             'DEVICE_POST': True,     # inference: roi projection / dedup hash / scatter-back / TTA mean /
                                      # DETECTIONS_PER_IM cut on the GPU (csrc/infer_ops.hip): one result
                                      # download per image; False = the numpy path of the reference
+            'PIPELINE_UPDATE': True,  # NUM_GPUS > 1, fp16x2 plan: the deferred update runs piece by piece as the
+                                     # gradient messages arrive (fc6 biases, fc6_w in two row pieces, the rest) and
+                                     # the next iteration's fc6 forward starts each piece behind ITS update, so the
+                                     # tail of the exchange hides under fc6 forward as well (2 ranks: projected
+                                     # 19.2 -> see DESIGN 5); bit-identical parameters (tests/test_gpu_two_ranks.py)
             'SYNTHETIC_TEST_IMAGES': 4,   # test engine, datasets that are not on disk: this many seeded synthetic
                                      # images stand in (tools/test_net_wsl.py --num-images)
             'SHARDED_UPDATE': False,  # NUM_GPUS > 1, fp16x2 plan: fc6_w's gradient rows are reduced to one owner
                                      # rank each, the owner updates its 8192 / N rows (fp32 master rows and momentum
                                      # live there only) and the updated rows + scale words return by all-gather:
                                      # same bytes on the links as the all-reduce; update traffic beside the next
-                                     # conv body 4.9 / N + 2.4 GB instead of 4.9 GB (every rank still re-splits all
-                                     # 8192 rows after the gather); parameters bit-identical (tests).  A checkpoint
+                                     # conv body 4.9 / N + 1.6 (N-1)/N GB instead of 4.9 GB (a rank splits only the
+                                     # rows it does not own after the gather); parameters bit-identical (tests).  A checkpoint
                                      # then needs engine.gather_sharded_state() on every rank (the training loop
                                      # calls it).  Unmeasured on hardware: no multi-GPU node was available
             'MFMA_DTYPE': 'fp16x2',  # 'fp32': fp32 MFMA everywhere; 'fp32x3': fc6/fc7 GEMMs as exact

@@ -86,7 +86,8 @@ class NetExecutor(object):
                 world_size=world_size, allreduce_chunks=cfg.NAWS.ALLREDUCE_CHUNKS,
                 mfma_dtype=cfg.NAWS.MFMA_DTYPE, scale_momentum=cfg.SOLVER.SCALE_MOMENTUM,
                 scale_momentum_threshold=cfg.SOLVER.SCALE_MOMENTUM_THRESHOLD,
-                sharded_update=cfg.NAWS.SHARDED_UPDATE, rank=self.rank)
+                sharded_update=cfg.NAWS.SHARDED_UPDATE, rank=self.rank,
+                pipeline_update=cfg.NAWS.PIPELINE_UPDATE)
         else:
             if self.ims != 1:
                 raise NotImplementedError('the op-by-op plan follows the reference: one image '

@@ -90,7 +90,7 @@ class WsddnEngine(object):
                  momentum=0.9, weight_decay=5e-4, iter_size=1, gpu_num=1, seed=11,
                  process_group=None, world_size=1, allreduce_chunks=0, freeze_conv_body=True,
                  mfma_dtype='fp16x2', scale_momentum=True, scale_momentum_threshold=1.1,
-                 sharded_update=False, rank=None):
+                 sharded_update=False, rank=None, pipeline_update=None):
         if not freeze_conv_body:
             raise NotImplementedError('only TRAIN.FREEZE_CONV_BODY: True is on the hot path '
                                       '(SURVEY.md fact 2): the conv body has no backward')
@@ -132,11 +132,20 @@ class WsddnEngine(object):
         # live there only), and the updated fp32 rows + their scale words come back by all-gather;
         # every rank then splits the rows into operand planes with the owners' scales.  Same bytes
         # on the links as the all-reduce; the update's HBM traffic beside the next conv body drops
-        # from 4.9 GB to 4.9 / N GB for the owned rows PLUS 2.4 GB for the re-split of all 8192
-        # rows after the gather (822 MB read + planes written: most of what the owner-only update
-        # saves is given back there); parameters bit-identical to the all-reduce route
+        # from 4.9 GB to 4.9 / N GB for the owned rows plus 1.6 (N-1)/N GB for the planes of the
+        # rows the other ranks own (their fp32 rows read once after the gather, planes written);
+        # parameters bit-identical to the all-reduce route
         # (tests/test_distributed_cpu.py, tests/test_gpu_two_ranks.py).  See _apply_update_sharded.
         self.sharded_update = bool(sharded_update)
+        # NAWS.PIPELINE_UPDATE (N > 1, fp16x2 plan; None = on whenever there is an exchange): the
+        # deferred update runs PIECE BY PIECE - fc6's biases, then fc6_w in two 4096-row pieces,
+        # each as soon as the messages covering it have arrived, then the rest - and the next
+        # iteration's fc6 forward starts each piece behind ITS update (naws_gemm_f32_f16x2_nt_cols),
+        # so the tail of the exchange hides under fc6 forward too instead of stalling the head
+        # (2 ranks: the one xGMI link needs ~10 ms for the 958 MB, the conv body + RoIPool hide 3).
+        # Same sums, same update arithmetic, same Dropout masks: parameters bit-identical to the
+        # unpipelined route (tests/test_gpu_two_ranks.py).  See _apply_update_pipelined.
+        self.pipeline_update = pipeline_update
         if rank is None and process_group is not None:
             import torch.distributed as dist
             rank = dist.get_rank(process_group)
@@ -238,6 +247,8 @@ class WsddnEngine(object):
         self._update_waiting = False
         self._upd_stream = None
         self._upd_event = None
+        self._piece_events = None    # pipelined update: [(r0, r1, event)] of the step being joined
+        self._pipe = None            # its tables (built on first use)
         self._wplanes = None         # split planes of fc6_w / fc7_w / fc7_w^T (16-bit MFMA plans)
         self._planes_dirty = True
 
@@ -654,9 +665,9 @@ class WsddnEngine(object):
                                   boost=obn_scores.reshape(-1), layout='NHWC', hier=True)
         return roi_feat.view(rois.shape[0], self.k6)
 
-    def head_forward(self, roi_feat, train, both_branches=True):
+    def head_forward(self, roi_feat, train, both_branches=True, pieces=None):
         """roi_feat [Rt, k6] (or its F16x2 operand form) -> H6, H7 [Rt, nb*4096], logits L
-        [Rt, nb*2C]."""
+        [Rt, nb*2C].  pieces: see _join_update_for_head (the pipelined update's events)."""
         f16p = isinstance(roi_feat, ops.F16x2)
         # (the bf16 plan's operand form, written by the pooling kernel: bf16 [k6/16, Rt, 16])
         slab_x = not f16p and roi_feat.dtype == torch.bfloat16 and roi_feat.dim() == 3
@@ -674,6 +685,9 @@ class WsddnEngine(object):
         bf = self.mfma_dtype == 'bf16'
         x3 = self.mfma_dtype == 'fp32x3'
         h2 = self.mfma_dtype == 'fp16x2'
+        if pieces is not None and not (h2 and nb == 2):
+            self._finish_pieces(pieces)      # (a caller's own plan: join the whole update first)
+            pieces = None
         if self.mfma_dtype != 'fp32' and self._planes_dirty:
             self._refresh_weight_planes()
         # the activation operand in the plan's form (its own kernels, outside the timed launch)
@@ -684,10 +698,38 @@ class WsddnEngine(object):
         elif bf:
             xp = roi_feat if slab_x else ops.to_bf16_slab(roi_feat)
         tev = getattr(self, 'timing_events', None)
-        if tev is not None:     # bench.py: HIP events around the dominant kernel, same stream
+        if tev is not None and pieces is None:   # bench.py: HIP events around the dominant kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if h2:
+        if h2 and pieces is not None:
+            # fc6 forward piece by piece: piece (r0, r1) = weight rows / h6 columns r0..r1 of one
+            # branch, launched behind the event of ITS update; same kernel, same K order, same
+            # Dropout counters as the one launch below (naws_gemm_f32_f16x2_nt_cols)
+            self._new_amax_arena(rt, nb)
+            sc6n = self._scales(nb, rt)
+            sc6t = self._scales(nb, HIDDEN) if train else None
+            h6 = torch.empty((rt, nb * HIDDEN), device=self.device, dtype=torch.float32)
+            main = torch.cuda.current_stream(self.device)
+            rowwords = ops.amax_words(sc6n)                       # [nb, Rt]
+            colwords = None if sc6t is None else ops.amax_words(sc6t).view(-1)
+            for r0, r1, ev in pieces['fc6']:
+                main.wait_event(ev)
+                if r0 // HIDDEN != (r1 - 1) // HIDDEN:
+                    raise RuntimeError('a forward piece must lie inside one branch')
+                if tev is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                ops.gemm_f32_f16x2_nt_cols(
+                    xp, self._wplanes['w6'].rows(r0, r1), h6[:, r0:r1], r0, nb * HIDDEN,
+                    epilogue=epi, bias=b6[r0:r1], drop_ratio=self.dropout if drop else 0.0,
+                    seed=self._seed(6), rowmax=rowwords[r0 // HIDDEN], rowmax_seg=HIDDEN,
+                    colmax=None if colwords is None else colwords[r0:r1])
+                if tev is not None:
+                    e1.record()
+                    tev.append((e0, e1))
+            self._finish_pieces(pieces)          # fc7 / fc8 read the rest of the update
+            tev = None
+        elif h2:
             # the GEMM epilogue reports max|h6| per row of each branch (fc7's operand scale) and,
             # in training, per column (fc7 wgrad's): no pass over h6 for the maxima
             self._new_amax_arena(rt, nb)
@@ -806,18 +848,23 @@ class WsddnEngine(object):
         x = self._roi_features(conv5, rois, obn_scores)
         del conv5
         mark('roi_pool')
-        self.flush()                 # previous iteration's all-reduce + SGD, now overlapped
+        # previous iteration's all-reduce + SGD, now overlapped: joined here as a whole, or - the
+        # pipelined N > 1 update - piece by piece inside the head forward
+        pieces = self._join_update_for_head()
         mark('join_update')
-        h6, h7, lg = self.head_forward(x, train=True)
+        h6, h7, lg = self.head_forward(x, train=True, pieces=pieces)
         mark('head_fwd')
         ld8 = self.ld8
         cols = [0, C, ld8, ld8 + C]                          # fc8c, fc8d, noisy_fc8c, noisy_fc8d
         lv = [lg[:, o:o + C] for o in cols]
         ac, ad, rp, cp = ops.wsddn_outputs(lv[0], lv[1], lv[2], lv[3], seg_off)
         cw, cwn, hs, hsn = ops.entropy_gate(rois, rp[0], cp[0], labels_oh, seg_off, max_seg)
-        wts = torch.stack([cw, cwn])                           # [2, nseg, C]
-        lab2 = labels_oh.unsqueeze(0).expand(2, n_img, C).contiguous()
-        losses = ops.weighted_ce(cp, lab2, wts, self.is_mean, 2 * n_img)   # [2*nseg]
+        # [class_weight | class_weight_noise] as one [2, nseg, C] view of the gate's output buffer;
+        # both branches score against the same labels_oh (no stack / expand / ones kernels: the
+        # loss tail is the hand-written kernels only)
+        wts = cw._base[:2] if cw._base is not None and cw._base.dim() == 3 else torch.stack([cw, cwn])
+        lab = labels_oh if labels_oh.is_contiguous() else labels_oh.contiguous()
+        losses = ops.weighted_ce_shared(cp, lab, wts, self.is_mean)        # [2*nseg]
         out = dict(loss_cls=losses[:n_img], loss_cls_noise=losses[n_img:], cls_prob=cp[0],
                    cls_prob_noise=cp[1], class_weight=cw, class_weight_noise=cwn,
                    hatE_sum=hs, hatE_sum_norm=hsn, rois_pred=rp[0],
@@ -827,8 +874,7 @@ class WsddnEngine(object):
         if not compute_grads:
             return out
         # ---- backward (loss gradient seed 1.0 per loss, blob.py:167-173)
-        ones = torch.ones((2 * n_img,), device=self.device, dtype=torch.float32)
-        g = ops.weighted_ce_grad(cp, lab2, wts, ones, self.is_mean, 2 * n_img)
+        g = ops.weighted_ce_shared_grad(cp, lab, wts, self.is_mean, dy_const=1.0)
         dl = (torch.zeros if ld8 != 2 * C else torch.empty)((rt, 2 * ld8), device=self.device,
                                                             dtype=torch.float32)
         ops.wsddn_outputs_grad(ac, ad, rp, cp, g, seg_off, out=dl, col_offsets=cols)
@@ -916,7 +962,15 @@ class WsddnEngine(object):
             # [Rt/16, 25088, 16]: from the pooling kernel's own operand, or a caller's fp32 features
             xt = (ops.bf16_slab_transpose(x) if x.dtype == torch.bfloat16
                   else ops.to_bf16_slab(x, transpose=True))
-        plan = message_plan(self.arena, 2 * HIDDEN, self.allreduce_chunks, red.active)
+        pipelined = self._pipelined()
+        plan = message_plan(self.arena, 2 * HIDDEN, self.allreduce_chunks, red.active, pipelined)
+        self._pipe_sent = pipelined
+        if pipelined:
+            # fc6's bias gradients first (the first forward piece of the next iteration needs the
+            # updated biases): a column sum of dZ6, known before the weight gradient
+            ops.colsum(dz6, out=gb6)
+            red.reduce_async(message_slice(self.arena, G, 'fc6_b', None, self.k6))
+            plan = plan[1:]
         for kind, rows in plan[:-1]:
             r0, r1 = rows
             if h2:
@@ -951,7 +1005,8 @@ class WsddnEngine(object):
                     red.reduce_to_owner_async(gw6[p0:p1].reshape(-1), o)
         # 3. the small gradients (under the fc6_w exchange): fc6 db; fc7 dW = dZ7^T H6, db;
         # fc8 dW = dL^T H7, db
-        ops.colsum(dz6, out=gb6)
+        if not pipelined:
+            ops.colsum(dz6, out=gb6)
         if h2:
             ops.gemm_f32_f16x2_nt(dz7t, self._h6t, out=gw7)
             self._h6t = None
@@ -1098,6 +1153,7 @@ class WsddnEngine(object):
         self._upd_stream.wait_event(self._grads_ready)
         for e in after:
             self._upd_stream.wait_event(e)
+        self._piece_events = None
         with torch.cuda.stream(self._upd_stream):
             self._apply_update()
             self._upd_event = self._upd_stream.record_event()
@@ -1107,9 +1163,41 @@ class WsddnEngine(object):
             if self._update_waiting:
                 self._launch_update(())
             self._update_pending = False
+            self._piece_events = None
             torch.cuda.current_stream(self.device).wait_event(self._upd_event)
 
+    def _join_update_for_head(self):
+        """Before the head reads the parameters: join the deferred update - entirely (-> None), or,
+        when it ran piece by piece (_apply_update_pipelined), hand the pieces' events to
+        head_forward, which waits for each one right before the launch that needs it."""
+        if not self._update_pending:
+            return None
+        if self._update_waiting:
+            self._launch_update(())
+        if self._piece_events is None:
+            self.flush()
+            return None
+        pieces, self._piece_events = self._piece_events, None
+        return pieces
+
+    def _finish_pieces(self, pieces):
+        """The main stream joins what is left of a pipelined update (everything after fc6_w)."""
+        self._update_pending = False
+        torch.cuda.current_stream(self.device).wait_event(pieces['done'])
+
+    def _pipelined(self):
+        """True when this process's updates run piece by piece (NAWS.PIPELINE_UPDATE)."""
+        want = self.pipeline_update
+        if want is None:
+            want = True
+        return bool(want and self.reducer.active and hasattr(self.reducer, 'wait_first')
+                    and self.mfma_dtype == 'fp16x2'
+                    and not self.sharded_update and self.iter_size == 1 and self.k6 % 256 == 0
+                    and self.fused_planes and (self.defer_update is None or self.defer_update))
+
     def _apply_update(self):
+        if self._pipe_ready():
+            return self._apply_update_pipelined()      # (waits message by message itself)
         cev = getattr(self, 'comm_events', None)   # bench.py: how long this stream, with this
         if cev is not None and self.reducer.active:  # rank's gradients complete, waits for the exchange
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1209,6 +1297,145 @@ class WsddnEngine(object):
             self._planes_dirty = False
         elif self.mfma_dtype != 'fp32' and self._wplanes is not None:
             self._refresh_weight_planes()
+
+    # ------------------------------------------------- NAWS.PIPELINE_UPDATE
+    FWD_PIECES = ((0, HIDDEN), (HIDDEN, 2 * HIDDEN))      # one branch each: 16 x 16 tiles of 256 x 256
+                                                          # at R = 4000 = one round of the 256 CUs
+
+    def _pipe_ready(self):
+        """The messages of this step went out in the pipelined order AND the plane-writing kernel
+        can run on them (planes valid, one hyper-parameter run per weight matrix); otherwise the
+        update waits for everything and takes the one-launch route - any message order is fine
+        for that."""
+        return (getattr(self, '_pipe_sent', False) and self._wplanes is not None
+                and self._sgd_regions is not None and not self._planes_dirty
+                and self._upd_stream is not None
+                and torch.cuda.current_stream(self.device) == self._upd_stream)
+
+    def _seg_tables(self, start, count):
+        """(seg_end, seg_lr_mult, seg_wd) device tensors of the arena range [start, start + count),
+        ends relative to `start` (the SGD kernels take a base pointer + per-run hyper-parameters)."""
+        ends, lr_mult, wd = self._seg_host
+        e2, l2, w2 = [], [], []
+        for e, l, w in zip(ends, lr_mult, wd):
+            if e <= start:
+                continue
+            e2.append(min(e, start + count) - start)
+            l2.append(l)
+            w2.append(w)
+            if e >= start + count:
+                break
+        return (torch.tensor(e2, dtype=torch.int64, device=self.device),
+                torch.tensor(l2, dtype=torch.float32, device=self.device),
+                torch.tensor(w2, dtype=torch.float32, device=self.device))
+
+    def _pipe_tables(self):
+        if self._pipe is None:
+            n6 = 2 * HIDDEN
+            o6, ob, o7 = (self.arena.offsets[k][0] for k in ('fc6_w', 'fc6_b', 'fc7_w'))
+            sc = self._wscales.view(2, 2, n6)                # [operand][maxima | 1/scale][rows]
+            p6, p7 = self._wplanes['w6'], self._wplanes['w7']
+            cm7 = self._wplanes['w7t'].scales[0].view(torch.int32)
+            pieces = []
+            for r0, r1 in self.FWD_PIECES:
+                regs = ops.SgdPlaneRegions([(0, r1 - r0, self.k6, n6, (p6.planes, r0),
+                                             self._wbound[r0:r1], sc[0, 0].view(torch.int32)[r0:r1],
+                                             sc[0, 1][r0:r1])])
+                pieces.append(dict(rows=(r0, r1), start=o6 + r0 * self.k6, count=(r1 - r0) * self.k6,
+                                   regions=regs, seg=self._seg_tables(o6 + r0 * self.k6,
+                                                                      (r1 - r0) * self.k6)))
+            tail = ops.SgdPlaneRegions([(0, n6, HIDDEN, HIDDEN, p7.planes, self._wbound[n6:],
+                                         sc[1, 0].view(torch.int32), sc[1, 1], cm7)])
+            self._pipe = dict(pieces=pieces, bias=dict(start=ob, count=o7 - ob,
+                                                       seg=self._seg_tables(ob, o7 - ob)),
+                              tail=dict(start=o7, count=self.arena.total - o7, regions=tail,
+                                        seg=self._seg_tables(o7, self.arena.total - o7)),
+                              ovf=torch.zeros((len(self.FWD_PIECES) + 1,), device=self.device,
+                                              dtype=torch.int32))
+        return self._pipe
+
+    def _apply_update_pipelined(self):
+        """The deferred update of an N > 1 step, piece by piece (update stream).  Messages arrive
+        in the order backward handed them over: [fc6 biases][fc6_w row chunks ...][the rest].
+          1. fc6's biases (element-wise kernel on their 8192 floats);
+          2. per forward piece (FWD_PIECES: fc6_w rows of one branch): wait for the chunks that
+             cover it, run the plane-writing SGD kernel on exactly those rows (arena slice, row
+             block of the operand planes), queue the conditional exact re-split of those rows,
+             record the piece's event - the next iteration's fc6 forward launches that piece
+             behind it (head_forward) while the later messages are still on the links;
+          3. the rest (fc7_w with planes + column maxima, fc8, biases), fc7_w's transposed planes,
+             the final event.
+        Per element the arithmetic is the one-launch route's (same kernels on slices: parameters,
+        momentum, planes and scales bit-identical, tests/test_gpu_two_ranks.py); the one difference:
+        the "a row outgrew twice its previous maximum" word is kept PER PIECE, so the exact
+        re-split that answers it covers that piece's rows instead of all of fc6_w / fc7_w - the
+        other rows keep their (equally valid) bound-derived scales."""
+        red, n6 = self.reducer, 2 * HIDDEN
+        tb = self._pipe_tables()
+        sc = self._wscales.view(2, 2, n6)
+        max6, max7 = sc[0, 0].view(torch.int32), sc[1, 0].view(torch.int32)
+        tag = self.sgd_iter_count + 1
+        w6, w7 = self._weight_views()
+        wp = self._wplanes
+        cev = getattr(self, 'comm_events', None)
+        uev = getattr(self, 'update_events', None)
+        if cev is not None:
+            c0 = torch.cuda.Event(enable_timing=True)
+            c0.record()
+        if uev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def sl(flat, t):
+            return flat[t['start']:t['start'] + t['count']]
+        # 1. fc6's biases
+        red.wait_first(1)
+        if uev is not None:
+            e0.record()
+        b = tb['bias']
+        ops.acm_sgd_update(sl(self.grads, b), sl(self.momentum_buf, b), self.lr, sl(self.params, b),
+                           None, b['seg'][0], b['seg'][1], b['seg'][2], self.momentum, 0, 1,
+                           self.gpu_num, self.sgd_iter_count)
+        # 2. fc6_w, one forward piece at a time
+        chunks = [rows for kind, rows in message_plan(self.arena, n6, self.allreduce_chunks, True, True)
+                  if kind == 'fc6_w']
+        arrived, events = 0, []
+        for i, pc in enumerate(tb['pieces']):
+            r0, r1 = pc['rows']
+            need = sum(1 for c0_, _c1 in chunks if c0_ < r1)        # chunks that start below r1
+            red.wait_first(need - arrived)
+            arrived = need
+            self._wbound[r0:r1].copy_(max6[r0:r1])
+            max6[r0:r1].zero_()
+            ovf = tb['ovf'][i:i + 1]
+            ops.acm_sgd_update_f16x2(sl(self.grads, pc), sl(self.momentum_buf, pc), self.lr,
+                                     sl(self.params, pc), pc['seg'][0], pc['seg'][1], pc['seg'][2],
+                                     self.momentum, 0, self.gpu_num, self.sgd_iter_count,
+                                     pc['regions'], ovf, tag)
+            ops.split_f16x2_row_range_if(w6, max6, wp['w6'], r0, r1, cond=ovf, cond_value=tag)
+            events.append((r0, r1, self._upd_stream.record_event()))
+        # 3. the rest
+        red.wait()
+        if cev is not None:
+            c1 = torch.cuda.Event(enable_timing=True)
+            c1.record()
+            cev.append((c0, c1))
+        t = tb['tail']
+        self._wbound[n6:].copy_(max7)
+        max7.zero_()
+        wp['w7t'].scales[0].zero_()
+        ovf = tb['ovf'][-1:]
+        ops.acm_sgd_update_f16x2(sl(self.grads, t), sl(self.momentum_buf, t), self.lr,
+                                 sl(self.params, t), t['seg'][0], t['seg'][1], t['seg'][2],
+                                 self.momentum, 0, self.gpu_num, self.sgd_iter_count,
+                                 t['regions'], ovf, tag)
+        if uev is not None:
+            e1.record()
+            uev.append((e0, e1))
+        self.sgd_iter_count += 1
+        ops.split_f16x2_rows_if(w7, max7, wp['w7'], ovf, tag)
+        ops.split_f16x2_dual(w7, None, wp['w7t'].scales, out_t=wp['w7t'])
+        self._planes_dirty = False
+        self._piece_events = dict(fc6=events, done=self._upd_stream.record_event())
 
     # ------------------------------------------------- NAWS.SHARDED_UPDATE
     def _shard_blocks(self):
@@ -1325,7 +1552,15 @@ class WsddnEngine(object):
         eff = torch.where(raised, rowmax, bound_scale)     # 1/scale = 2^(e-14)  ->  a maximum 2^e
         self._wovf.copy_(torch.where(raised, torch.full_like(self._wovf, tag), self._wovf))
         wp = self._wplanes
-        ops.split_f16x2_rows_if(w6, eff, wp['w6'], None, 0)
+        # the rows this rank does NOT own: planes from the owners' scales (always); its own rows
+        # already carry the planes its SGD kernel wrote with exactly those scales - they are redone
+        # (from the exact maxima) only if some owner raised the overflow word (the full
+        # re-split gave back most of what the owner-only update saves)
+        if b0 > 0:
+            ops.split_f16x2_row_range_if(w6, eff, wp['w6'], 0, b0)
+        if b1 < n6:
+            ops.split_f16x2_row_range_if(w6, eff, wp['w6'], b1, n6)
+        ops.split_f16x2_row_range_if(w6, eff, wp['w6'], b0, b1, cond=self._wovf, cond_value=tag)
         ops.split_f16x2_rows_if(w7, max7, wp['w7'], self._wovf, tag)
         ops.split_f16x2_dual(w7, None, wp['w7t'].scales, out_t=wp['w7t'])
         self._planes_dirty = False

@@ -54,12 +54,15 @@ PROTOTYPES = {
     'naws_entropy_gate_fwd': [p, p, p, p, p, i32, i32, i32, i32, p, p, p, p, p, p],
     'naws_weighted_ce_fwd': [p, p, p, i32, i32, i32, i32, p, p],
     'naws_weighted_ce_bwd': [p, p, p, p, i32, i32, i32, i32, p, p],
+    'naws_weighted_ce_shared_fwd': [p, p, p, i32, i32, i32, i32, i32, p, p],
+    'naws_weighted_ce_shared_bwd': [p, p, p, p, f32, i32, i32, i32, i32, i32, p, p],
     'naws_acm_sgd_update': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p],
     'naws_acm_sgd_update_rowmax': [p, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i32, i64, p, p,
                                    i32, p],
     'naws_acm_sgd_update_planes': [i32, p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i64, p, i32, p, i32, p],
     'naws_acm_sgd_update_f16x2': [p, p, p, p, i64, p, p, p, i32, f32, i32, i32, i64, p, i32, p, i32, p],
     'naws_split_f16x2_rows_if': [p, i32, i32, i32, i32, i64, p, p, p, i32, p, i32, p],
+    'naws_split_f16x2_row_range_if': [p, i32, i32, i32, i32, i32, p, p, p, i32, p, i32, p],
     'naws_roi_label_fwd': [p, p, p, p, i32, i32, i32, f32, f32, f32, i32, i32, i32, p, p, p, p, p],
     'naws_softmax_with_loss_n_fwd': [p, p, p, i32, i32, f32, p, p, p, p],
     'naws_softmax_with_loss_n_bwd': [p, p, p, p, i32, i32, f32, p, p, p],
@@ -126,6 +129,8 @@ PROTOTYPES = {
     'naws_gemm_f32_f16x2_nt_amax': [i32, i32, i32, p, i64, i64, p, p, i64, i64, p, p, i32, i32,
                                     i64, i64, i64, i64, i64, i32, p, i64, p, i32, f32, f32, u64, i32,
                                     p, i32, p, p, p],
+    'naws_gemm_f32_f16x2_nt_cols': [i32, i32, i32, p, i64, i64, p, p, i64, i64, p, p, i32, i32, p, f32,
+                                    u64, p, i32, p, i32, i32, p],
     'naws_gemm_f32_amax': [i32, i32, i32, i32, i32, p, i32, p, i32, p, i32, i32, i64, i64, i64,
                            i32, p, i64, p, i32, f32, f32, u64, i32, p, i32, p, p, p],
     'naws_split_f16x2_dual': [p, i32, i32, i32, i32, i64, p, p, p, p, p, i32, p, p, i32, p],

@@ -840,6 +840,31 @@ def gemm_f32_f16x2_nt(a, b, out=None, epilogue=L.EPI_NONE, bias=None, aux=None, 
     return out
 
 
+def gemm_f32_f16x2_nt_cols(a, b, out, col0, width, epilogue=L.EPI_NONE, bias=None, drop_ratio=0.0,
+                           seed=0, rowmax=None, rowmax_seg=0, colmax=None):
+    """Columns [col0, col0 + n) of the `width`-wide product A B_all^T, with b = the rows
+    col0 .. col0 + n of B_all's operand (`.rows(col0, col0 + n)`), `out` = that column range of the
+    [M, width] result (a row-strided view), bias / colmax = the range's entries, rowmax = the words
+    of the range's rowmax segment.  Element (m, c) draws the Dropout counter m * width + col0 + c,
+    as the full-width gemm_f32_f16x2_nt does: the pieces of one activation are bit-identical to
+    the single launch (naws_gemm_f32_f16x2_nt_cols)."""
+    a3, b3 = a.planes, b.planes
+    for t in (a3, b3):
+        if (not t.is_cuda or t.dtype != torch.float16 or t.dim() != 4 or t.shape[0] != 2
+                or t.shape[-1] != 16 or t.stride(-1) != 1 or t.stride(-2) != 16):
+            raise TypeError('operands must be unbatched f16 split planes [2, K/16, rows, 16]')
+    sa, sb = a.inv_scale, b.inv_scale
+    mm, k = a3.shape[-2], a3.shape[-3] * 16
+    nn = b3.shape[-2]
+    if k != b3.shape[-3] * 16 or out.shape != (mm, nn) or out.stride(1) != 1:
+        raise L.NawsError('naws_gemm_f32_f16x2_nt_cols', L.ERR_SHAPE)
+    L.call('naws_gemm_f32_f16x2_nt_cols', mm, nn, k, a3.data_ptr(), a3.stride(-3), a3.stride(0),
+           sa.data_ptr(), b3.data_ptr(), b3.stride(-3), b3.stride(0), sb.data_ptr(), out.data_ptr(),
+           out.stride(0), epilogue, _ptr(bias), float(drop_ratio), int(seed) & 0xFFFFFFFFFFFFFFFF,
+           *_amax_args(rowmax, rowmax_seg, colmax, None)[:3], int(width), int(col0), _stream())
+    return out
+
+
 def gemm_f32_f16x2_nt_xk(a, x, out=None, ncols=None, scale_x=None):
     """C[M, N] = sum_k A[k][m] X[k][n]: a = F16x2 with planes [2, K/16, M, 16] (a transposing split:
     K = the source's rows, zero beyond x's row count), x = F16x2 with planes [2, N/16, R, 16] - the
@@ -1049,12 +1074,40 @@ def entropy_gate(rois, rois_pred, cls_prob, labels_oh, seg_off, max_seg_len):
     dev = rois.device
     nws = L.load().naws_entropy_gate_workspace_floats(rt, c, nseg, max_seg_len)
     ws = torch.empty((max(nws, 1),), device=dev, dtype=_f32)
-    outs = [torch.empty((nseg, c), device=dev, dtype=_f32) for _ in range(4)]
+    # one buffer: [class_weight | class_weight_noise] is then the [2, nseg, C] weight operand of the
+    # two branches' cross entropy as it stands (no stack)
+    buf = torch.empty((4, nseg, c), device=dev, dtype=_f32)
+    outs = [buf[i] for i in range(4)]
     L.call('naws_entropy_gate_fwd', rois.data_ptr(), rois_pred.data_ptr(), cls_prob.data_ptr(),
            labels_oh.data_ptr(), seg_off.data_ptr(), nseg, rt, c, max_seg_len, ws.data_ptr(),
            outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
            _stream())
     return tuple(outs)
+
+
+def weighted_ce_shared(x, l, w, is_mean):
+    """x, w: [nb, nseg, C] (nb branches), l: [nseg, C] shared by the branches -> losses [nb * nseg]
+    (naws_weighted_ce_shared_fwd, N = 1 row per problem)."""
+    _chk(x, 'X'); _chk(l, 'L'); _chk(w, 'W')
+    nb, nseg, c = x.shape
+    if l.shape != (nseg, c) or w.shape != x.shape:
+        raise L.NawsError('naws_weighted_ce_shared_fwd', L.ERR_SHAPE)
+    y = torch.empty((nb * nseg,), device=x.device, dtype=_f32)
+    L.call('naws_weighted_ce_shared_fwd', x.data_ptr(), l.data_ptr(), w.data_ptr(), 1, c, int(is_mean),
+           nb * nseg, nseg, y.data_ptr(), _stream())
+    return y
+
+
+def weighted_ce_shared_grad(x, l, w, is_mean, dy=None, dy_const=1.0):
+    """Gradient of weighted_ce_shared w.r.t. x; dy None: the constant loss seed dy_const."""
+    _chk(x, 'X'); _chk(l, 'L'); _chk(w, 'W')
+    nb, nseg, c = x.shape
+    if l.shape != (nseg, c) or w.shape != x.shape or (dy is not None and dy.numel() != nb * nseg):
+        raise L.NawsError('naws_weighted_ce_shared_bwd', L.ERR_SHAPE)
+    dx = torch.empty_like(x)
+    L.call('naws_weighted_ce_shared_bwd', x.data_ptr(), l.data_ptr(), w.data_ptr(), _ptr(dy),
+           float(dy_const), 1, c, int(is_mean), nb * nseg, nseg, dx.data_ptr(), _stream())
+    return dx
 
 
 def weighted_ce(x, l, w, is_mean, nprob=1):
@@ -1188,6 +1241,19 @@ def split_f16x2_rows_if(x, rowmax, out, cond, cond_value):
     L.call('naws_split_f16x2_rows_if', x.data_ptr(), batch, rows, cols, x2.stride(0),
            (x.stride(0) if batched else 0), rowmax.data_ptr(), out.planes.data_ptr(),
            out.inv_scale.data_ptr(), (cols + 31) // 32 * 32, _ptr(cond), int(cond_value), _stream())
+    return out
+
+
+def split_f16x2_row_range_if(x, rowmax, out, row0, row1, cond=None, cond_value=0):
+    """split_f16x2_rows_if for rows row0..row1 of an unbatched fp32 [rows, cols] matrix x: rowmax /
+    out's planes and scales are those of the WHOLE matrix, only the range's entries are read /
+    written."""
+    if x.dim() != 2 or x.stride(1) != 1 or out.planes.dim() != 4:
+        raise TypeError('split_f16x2_row_range_if: an unbatched matrix and its planes')
+    rows, cols = x.shape
+    L.call('naws_split_f16x2_row_range_if', x.data_ptr(), rows, int(row0), int(row1 - row0), cols,
+           x.stride(0), rowmax.data_ptr(), out.planes.data_ptr(), out.inv_scale.data_ptr(),
+           (cols + 31) // 32 * 32, _ptr(cond), int(cond_value), _stream())
     return out
 
 

@@ -22,14 +22,21 @@ def row_chunks(rows, n_chunks, align=128):
     return out
 
 
-def message_plan(arena, rows6, allreduce_chunks, active):
+def message_plan(arena, rows6, allreduce_chunks, active, pipelined=False):
     """The gradient messages of one iteration, in the order backward produces and hands them to
     the collective: fc6_w's gradient (86 % of the bytes) in row chunks - each chunk is reduced as
     soon as its wgrad GEMM is queued - then ONE message with every other gradient (fc6 / fc7
     biases, fc7_w, fc8*: contiguous in the arena).  -> [('fc6_w', (r0, r1)), ..., ('small', None)].
+    pipelined (the N > 1 step whose fc6 forward starts piece by piece, engine._apply_update_pipelined):
+    fc6's two bias vectors (32 KB, known before the weight gradient: a column sum of dZ6) travel
+    FIRST as a message of their own, because the first forward piece of the next iteration needs
+    them, and the last message holds the rest: [('fc6_b', None), ('fc6_w', (r0, r1)), ...,
+    ('rest', None)].  Same bytes, same sums.
     The engine walks this list (engine._head_backward); tests/test_distributed_cpu.py replays it
     on a CPU arena over gloo."""
     plan = [('fc6_w', rc) for rc in row_chunks(rows6, allreduce_chunks if active else 1)]
+    if pipelined:
+        return [('fc6_b', None)] + plan + [('rest', None)]
     plan.append(('small', None))
     return plan
 
@@ -39,6 +46,10 @@ def message_slice(arena, grads, kind, rows, k6):
     if kind == 'fc6_w':
         o6 = arena.offsets['fc6_w'][0]
         return grads[o6 + rows[0] * k6:o6 + rows[1] * k6]
+    if kind == 'fc6_b':
+        return arena.span(grads, 'fc6_b', '_[noisy]_fc6_b')
+    if kind == 'rest':
+        return arena.span(grads, 'fc7_w', 'noisy_fc8d_b')
     return arena.span(grads, 'fc6_b', 'noisy_fc8d_b')
 
 
@@ -98,6 +109,16 @@ class ArenaReducer(object):
         for w in self._pending:
             w.wait()
         self._pending = []
+
+    def wait_first(self, n):
+        """Wait for the `n` oldest messages still in flight only (hand-over order): the pipelined
+        update consumes fc6_w's chunks one by one while the later ones are still on the links."""
+        for w in self._pending[:n]:
+            w.wait()
+        del self._pending[:n]
+
+    def in_flight(self):
+        return len(self._pending)
 
     # ---- NAWS.SHARDED_UPDATE: gradient rows to their owner, updated rows back to everybody ----
     def _emulated(self, t):
@@ -161,12 +182,22 @@ class EmulatedExchange(object):
         self.gbps = float(gbytes_per_sec) if gbytes_per_sec else 0.6 * 153.0 * min(self.n - 1, 7)
         self.world_size = self.n       # (only NAWS.SHARDED_UPDATE's ownership reads it; the
         self.force = True              #  update's 1/gpu_num is the caller's business)
-        self._stream = torch.cuda.Stream(device=device)
+        # ONE communication stream per device for every instance: a process that builds several
+        # exchanges one after another (bench.py's projections) would otherwise keep drawing new
+        # streams, and HIP maps streams onto a handful of hardware queues round-robin
+        # (GPU_MAX_HW_QUEUES) - two streams on one queue run in order, which serialises exactly
+        # the overlap this class exists to measure
+        key = str(device)
+        if key not in EmulatedExchange._streams:
+            EmulatedExchange._streams[key] = torch.cuda.Stream(device=device)
+        self._stream = EmulatedExchange._streams[key]
         self._scratch = None
+        self._events = []              # one per message in flight, recorded behind its proxy kernels
         self.total_bytes = 0           # moved since construction (bench: / steps)
         self.log = None                # as ArenaReducer.log
 
     active = True
+    _streams = {}
 
     def _note(self, kind, t):
         if self.log is not None:
@@ -199,6 +230,7 @@ class EmulatedExchange(object):
         with torch.cuda.stream(self._stream):
             for _phase in range(phases):
                 ops.emulate_exchange(flat, scratch, part, self.cus, self.gbps)
+            self._events.append(self._stream.record_event())
         self.total_bytes += phases * part
 
     # NAWS.SHARDED_UPDATE under projection: this process plays rank 0 of N - it updates rows
@@ -217,3 +249,14 @@ class EmulatedExchange(object):
     def wait(self):
         import torch
         torch.cuda.current_stream(self.device).wait_event(self._stream.record_event())
+        self._events = []
+
+    def wait_first(self, n):
+        import torch
+        if n > 0 and self._events:
+            n = min(n, len(self._events))
+            torch.cuda.current_stream(self.device).wait_event(self._events[n - 1])
+            del self._events[:n]
+
+    def in_flight(self):
+        return len(self._events)

@@ -652,3 +652,60 @@ def test_conv_f16x2_dark_region_against_the_documented_floor(dev, path, log2_dar
         # 2^-30: elements keep 2^-9 relative; the sum of K = 1152 such terms is still bounded
         # by the absolute floor checked above, which here is ~1e-3 of the dark half's maximum
         assert rel_dark <= 2e-2, rel_dark
+
+
+@pytest.mark.parametrize('m', [96, 2000, 4000])
+def test_column_pieces_of_a_product_are_bit_identical_to_the_one_launch(dev, m):
+    """naws_gemm_f32_f16x2_nt_cols (the pipelined N > 1 step's fc6 forward): the two 4096-column
+    pieces of h6 = Dropout(ReLU(x W^T + b)) - each its own launch on its own weight rows - equal the
+    single 8192-column launch bit for bit: values, Dropout masks, row maxima per branch, column
+    maxima; at sizes that take the 128 x 128 form, and the 256 x 256 form with and without a
+    partial row tile."""
+    from naws_hip import lib as L
+    from naws_hip import ops
+    g = torch.Generator(device='cpu').manual_seed(7)
+    k, n = 512, 8192
+    x = torch.randn((m, k), generator=g).to(dev)
+    w = (torch.randn((n, k), generator=g) * 0.05).to(dev)
+    b = torch.randn((n,), generator=g).to(dev)
+    xp, wpl = ops.split_f16x2(x), ops.split_f16x2(w)
+
+    def words(*shape):
+        return torch.zeros(shape, device=dev, dtype=torch.int32)
+    rm, cm = words(2, m), words(n)
+    full = ops.gemm_f32_f16x2_nt(xp, wpl, epilogue=L.EPI_BIAS_RELU_DROP, bias=b, drop_ratio=0.5,
+                                 seed=1234567, rowmax=rm, rowmax_seg=4096, colmax=cm)
+    out = torch.full((m, n), float('nan'), device=dev)
+    rm2, cm2 = words(2, m), words(n)
+    for r0, r1 in ((4096, 8192), (0, 4096)):          # any order
+        ops.gemm_f32_f16x2_nt_cols(xp, wpl.rows(r0, r1), out[:, r0:r1], r0, n,
+                                   epilogue=L.EPI_BIAS_RELU_DROP, bias=b[r0:r1], drop_ratio=0.5,
+                                   seed=1234567, rowmax=rm2[r0 // 4096], rowmax_seg=4096,
+                                   colmax=cm2[r0:r1])
+    assert torch.equal(out, full)
+    assert float((full == 0).float().mean()) > 0.4          # (the masks are really there)
+    assert torch.equal(rm2, rm) and torch.equal(cm2, cm)
+
+
+def test_row_range_resplit_equals_the_whole_matrix_resplit(dev):
+    """naws_split_f16x2_row_range_if: redoing rows [r0, r1) of a matrix's planes from given maxima
+    writes exactly what naws_split_f16x2_rows_if writes for those rows and leaves every other row's
+    planes and scales alone; a false condition leaves everything alone."""
+    from naws_hip import ops
+    g = torch.Generator(device='cpu').manual_seed(9)
+    rows, cols = 1024, 768
+    x = (torch.randn((rows, cols), generator=g) * torch.logspace(-3, 3, rows).view(-1, 1)).to(dev)
+    ref = ops.split_f16x2(x)
+    maxima = x.abs().amax(dim=1).view(torch.int32).contiguous()
+    whole = ops.F16x2(torch.zeros_like(ref.planes), torch.zeros_like(ref.scales))
+    ops.split_f16x2_rows_if(x, maxima, whole, None, 0)
+    assert torch.equal(whole.planes, ref.planes) and torch.equal(whole.inv_scale, ref.inv_scale)
+    part = ops.F16x2(torch.full_like(ref.planes, 7.0), torch.full_like(ref.scales, 7.0))
+    cond = torch.tensor([5], device=dev, dtype=torch.int32)
+    ops.split_f16x2_row_range_if(x, maxima, part, 96, 672, cond=cond, cond_value=4)      # not taken
+    assert float((part.planes != 7).sum()) == 0
+    ops.split_f16x2_row_range_if(x, maxima, part, 96, 672, cond=cond, cond_value=5)
+    assert torch.equal(part.planes[:, :, 96:672], ref.planes[:, :, 96:672])
+    assert torch.equal(part.inv_scale[96:672], ref.inv_scale[96:672])
+    assert float((part.planes[:, :, :96] != 7).sum()) == 0 and float((part.planes[:, :, 672:] != 7).sum()) == 0
+    assert float((part.inv_scale[:96] != 7).sum()) == 0 and float((part.inv_scale[672:] != 7).sum()) == 0

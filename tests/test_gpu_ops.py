@@ -646,3 +646,35 @@ def test_head_kernels_match_the_reference_graph_numeric(dev, idx):
     for o, name in zip(outs, ('rois_class_weight', 'rois_class_weight_noise', 'rois_pred_hatE_sum',
                               'rois_pred_hatE_sum_norm')):
         close(o.cpu().numpy().reshape(1, -1), case['out_' + name], 2e-5)
+
+
+@pytest.mark.parametrize('is_mean', [True, False])
+def test_weighted_ce_shared_labels(dev, is_mean):
+    """naws_weighted_ce_shared_fwd / _bwd (2 branches x nseg images scored against ONE labels_oh per
+    image; gradient seeded by a constant instead of a tensor of ones) == the per-problem operator
+    on expanded labels, bit for bit, and == the oracle (cross_entropy_wsl_op.cc:87-180)."""
+    from naws_hip import ops
+    from oracle import oracle
+    rng = np.random.default_rng(15)
+    for c, nseg in ((20, 3), (80, 2)):
+        x = rng.uniform(0, 1, (2, nseg, c)).astype(np.float32)
+        x[0, 0, :4] = [0.0, 1.0, 1e-30, 0.9999999]
+        l = (rng.uniform(0, 1, (nseg, c)) > 0.8).astype(np.float32)
+        l[0, 2] = 0.37
+        w = rng.uniform(0, 1, (2, nseg, c)).astype(np.float32)
+        xd, ld, wd = _t(x, dev), _t(l, dev), _t(w, dev)
+        y = ops.weighted_ce_shared(xd, ld, wd, is_mean)
+        dx = ops.weighted_ce_shared_grad(xd, ld, wd, is_mean, dy_const=1.0)
+        l2 = ld.unsqueeze(0).expand(2, nseg, c).contiguous()
+        ones = torch.ones((2 * nseg,), device=dev)
+        assert torch.equal(y, ops.weighted_ce(xd, l2, wd, is_mean, 2 * nseg))
+        assert torch.equal(dx, ops.weighted_ce_grad(xd, l2, wd, ones, is_mean, 2 * nseg))
+        dy = _t(rng.uniform(0.5, 2, 2 * nseg).astype(np.float32), dev)
+        assert torch.equal(ops.weighted_ce_shared_grad(xd, ld, wd, is_mean, dy=dy),
+                           ops.weighted_ce_grad(xd, l2, wd, dy, is_mean, 2 * nseg))
+        for b in range(2):
+            for s in range(nseg):
+                _close(y[b * nseg + s], oracle.weighted_ce(x[b, s:s + 1], l[s:s + 1], w[b, s:s + 1], is_mean),
+                       rtol=1e-6)
+                _close(dx[b, s], oracle.weighted_ce_grad(x[b, s:s + 1], l[s:s + 1], w[b, s:s + 1],
+                                                         np.ones((1,), np.float32), is_mean)[0], rtol=1e-6)

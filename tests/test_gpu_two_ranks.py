@@ -27,11 +27,12 @@ def _batches(world=2):
     return roidb, halves
 
 
-def _engine(dev, gpu_num, pg=None, world=1, sharded=False, chunks=4):
+def _engine(dev, gpu_num, pg=None, world=1, sharded=False, chunks=4, pipeline=None, dropout=0.0):
     from detectron.datasets import synthetic
     from naws_hip.engine import WsddnEngine
-    eng = WsddnEngine(C + 1, dev, dropout=0.0, gpu_num=gpu_num, seed=5, process_group=pg,
-                      world_size=world, allreduce_chunks=chunks, sharded_update=sharded)
+    eng = WsddnEngine(C + 1, dev, dropout=dropout, gpu_num=gpu_num, seed=5, process_group=pg,
+                      world_size=world, allreduce_chunks=chunks, sharded_update=sharded,
+                      pipeline_update=pipeline)
     blobs = synthetic.init_blobs(C, seed=5)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)
@@ -53,7 +54,7 @@ def _run(eng, mb, dev):
     return np.stack(losses)
 
 
-def _worker(rank, world, port, outdir, sharded=False):
+def _worker(rank, world, port, outdir, sharded=False, pipeline=None, dropout=0.0, tag=None):
     sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
     import faulthandler
     # a rank stuck in a collective says where, then leaves (the parent's limit is 300 s)
@@ -66,8 +67,10 @@ def _worker(rank, world, port, outdir, sharded=False):
     _roidb, halves = _batches(world)
     # world 2: four explicit chunks; world 8: the engine's own auto choice ("2 above 2 ranks")
     eng = _engine(dev, world * B, dist.group.WORLD, world, sharded=sharded,
-                  chunks=4 if world == 2 else 0)
+                  chunks=4 if world == 2 else 0, pipeline=pipeline, dropout=dropout)
     assert eng.reducer.active and (eng._shard_blocks() is not None) == sharded
+    # the update runs piece by piece by default whenever there is an exchange (not when sharded)
+    assert eng._pipelined() == (not sharded and pipeline is not False)
     assert eng.gpu_num == world * B
     if world == 8:
         assert eng.allreduce_chunks == 2
@@ -77,9 +80,12 @@ def _worker(rank, world, port, outdir, sharded=False):
     losses = _run(eng, halves[rank], dev)
     if rank == 0:
         import json
-        with open(os.path.join(outdir, 'messages%s.json' % ('s' if sharded else '')), 'w') as f:
+        with open(os.path.join(outdir, 'messages%s.json' % (tag if tag is not None else
+                                                             ('s' if sharded else ''))), 'w') as f:
             json.dump(log, f)
-    tag = 's' if sharded else ''
+    tag = tag if tag is not None else ('s' if sharded else '')
+    if eng._pipelined():
+        assert log[0][0] == 'all_reduce' and log[0][1] == 8192          # fc6's biases travel first
     if sharded:
         # momentum rows live with their owner until a checkpoint gathers them
         try:
@@ -263,8 +269,9 @@ def test_eight_ranks_on_one_gpu_allreduce_and_sharded_routes(dev, tmp_path):
     # same chunks + small + the two gathers (sharded route)
     msgs = json.load(open(str(tmp_path / 'messages.json')))
     per_step = len(msgs) // STEPS
-    assert per_step == 3 and [m[1] for m in msgs[:3]] == [4096 * 25088, 4096 * 25088, msgs[2][1]]
-    assert msgs[2][1] == ref['params'].size - 8192 * 25088
+    # (the pipelined order: fc6's biases, 2 fc6_w row chunks, the rest)
+    assert per_step == 4 and [m[1] for m in msgs[:4]] == [8192, 4096 * 25088, 4096 * 25088, msgs[3][1]]
+    assert msgs[3][1] == ref['params'].size - 8192 * 25088 - 8192
     smsgs = json.load(open(str(tmp_path / 'messagess.json')))
     kinds = [m[0] for m in smsgs[:len(smsgs) // STEPS]]
     assert kinds.count('reduce_to_owner') == 8 and kinds.count('gather_blocks') == 2
@@ -306,3 +313,29 @@ def test_eight_ranks_on_one_gpu_allreduce_and_sharded_routes(dev, tmp_path):
     assert np.allclose(got_losses, one_losses, rtol=2e-4, atol=1e-6)
     d1 = np.abs(ref['params'] - eng.params.cpu().numpy()).max()
     assert d1 <= 1e-3 * step + 1e-9, (d1, step)
+
+
+def test_pipelined_update_bit_identical_to_the_unpipelined_route(dev, tmp_path):
+    """NAWS.PIPELINE_UPDATE on hardware (two ranks on one GPU over gloo), Dropout ON: fc6's biases
+    as the first message, fc6_w updated in two row pieces as its chunks arrive, the next
+    iteration's fc6 forward launched piece by piece behind them with the full launch's Dropout
+    counters.  After three training steps the losses of every step, the parameters, the momentum,
+    fc6_w's operand planes and their scales are bit-identical to the route that waits for the whole
+    exchange and updates in one launch, on both ranks."""
+    ctx = mp.get_context('spawn')
+    for pipeline, tag in ((False, 'u'), (True, 'p')):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), False, pipeline, 0.5, tag))
+                 for r in range(2)]
+        _run_ranks(procs)
+    import json
+    mu = json.load(open(str(tmp_path / 'messagesu.json')))
+    mp_ = json.load(open(str(tmp_path / 'messagesp.json')))
+    assert len(mu) // STEPS == 5 and len(mp_) // STEPS == 6          # 4 chunks + small | + the biases
+    assert sum(m[1] for m in mu) == sum(m[1] for m in mp_)           # same bytes
+    for what in ('params', 'mom', 'planes', 'scales', 'losses'):
+        for r in range(2):
+            a = np.load(str(tmp_path / ('%su%d.npy' % (what, r))))
+            b = np.load(str(tmp_path / ('%sp%d.npy' % (what, r))))
+            assert np.array_equal(a, b), (what, r)
+    assert np.isfinite(np.load(str(tmp_path / 'lossesp0.npy'))).all()
