@@ -857,6 +857,7 @@ def main():
         projections['%d_sharded' % n] = project_n_ranks(eng, t, seg, n, cus, gbps,
                                                         max(20, args.steps // 3), sharded=True)
     conv_alone_ms = None
+    roipool_alone_ms = None
     if rank == 0:
         eng.timing_events = eng.phase_events = eng.update_events = eng.comm_events = None
         eng.conv_body(t['data'])
@@ -868,6 +869,25 @@ def main():
         c1.record()
         torch.cuda.synchronize()
         conv_alone_ms = c0.elapsed_time(c1) / 10
+        # RoIPoolF + boost alone (one launch over all proposals, maps given): inside a step each
+        # image's proposals are pooled at the tail of that image's conv chain, so the step has no
+        # RoIPool stage of its own to time
+        if args.mfma_dtype == 'fp16x2' and eng._amax5 is not None:
+            from naws_hip import ops as _ops
+            conv5 = eng.conv_body(t['data'])
+            maps = eng._roi_maps
+            torch.cuda.synchronize()
+            if maps is not None:
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(10):
+                    _ops.roi_pool_f_f16x2(conv5, t['rois'], eng._amax5, eng.roi_size, eng.roi_size,
+                                          eng.spatial_scale, boost=t['obn_scores'].reshape(-1),
+                                          hier=True, maps=maps)
+                c1.record()
+                torch.cuda.synchronize()
+                roipool_alone_ms = c0.elapsed_time(c1) / 10
+            del conv5, maps
 
     if rank == 0:
         rt = mb['rois'].shape[0]
@@ -956,7 +976,14 @@ def main():
                 roof['conv_stack_frac_vs_bf16_mfma_peak'] = round(tf / BF16_MFMA_PEAK_TFLOPS, 3)
             else:
                 roof['conv_stack_frac_vs_fp32_mfma_peak'] = round(tf / FP32_MFMA_PEAK_TFLOPS, 3)
-        if roipool_bytes and stage_ms.get('roi_pool'):
+        if roipool_bytes and roipool_alone_ms:
+            # (pooled per image on the conv streams inside a step: `stage_ms_roi_pool` is what is
+            # left on the main stream - the join -, `stage_ms_conv_body` includes the pooling)
+            gbs = roipool_bytes / roipool_alone_ms / 1e6
+            roof.update(roipool_ms=round(roipool_alone_ms, 4), roipool_GBps=round(gbs, 1),
+                        roipool_frac_vs_hbm_6300=round(gbs / HBM_ACHIEVABLE_GBPS, 3),
+                        roipool_measured='alone, one launch over all proposals, after the timed steps')
+        elif roipool_bytes and stage_ms.get('roi_pool'):
             gbs = roipool_bytes / stage_ms['roi_pool'] / 1e6
             roof.update(roipool_ms=stage_ms['roi_pool'], roipool_GBps=round(gbs, 1),
                         roipool_frac_vs_hbm_6300=round(gbs / HBM_ACHIEVABLE_GBPS, 3))

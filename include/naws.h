@@ -577,6 +577,16 @@ int naws_roi_pool_f_f16x2_mapped_fwd(const float* X, int N, int C, int H, int W,
                                      float spatial_scale, const uint32_t* amax_words, int n_words,
                                      const float* M2, const float* M4, void* planes, float* scales,
                                      void* stream);
+/* ... for rois [r_first, r_first + count) of R_total only (rois, boost, planes, scales: those of all
+ * R_total rois): one image's proposals, pooled on that image's stream at the tail of its conv
+ * chain.  Launches over disjoint ranges write disjoint rows of the planes; together they equal
+ * the one launch bit for bit. */
+int naws_roi_pool_f_f16x2_mapped_range_fwd(const float* X, int N, int C, int H, int W,
+                                           const float* rois, int R_total, int r_first, int count,
+                                           const float* boost, int pooled_h, int pooled_w,
+                                           float spatial_scale, const uint32_t* amax_words,
+                                           int n_words, const float* M2, const float* M4,
+                                           void* planes, float* scales, void* stream);
 /* Q f16 [2][Rpad/16][K][16] = transposition of P f16 [2][K/16][R][16] (Rpad = R rounded up to 32,
  * rows >= R zero): the K(=rois)-contiguous form of the same scaled matrix, B operand of
  * fc6's dW = dY^T X with a scale vector of ones, provided dY is split by

@@ -652,12 +652,18 @@ static int roi_pool_planes_mapped(const float* X, int N, int C, int H, int W, co
                                   int R, const float* boost, int pooled_h, int pooled_w,
                                   float spatial_scale, const uint32_t* amax_words, int n_words,
                                   const float* M2, const float* M4, void* planes, float* scales,
-                                  hipStream_t s, int bf16 = 0) {
+                                  hipStream_t s, int bf16 = 0, int R_total = 0, int r_first = 0) {
   const long long K = (long long)C * pooled_h * pooled_w;
+  // (R_total > 0: this launch pools rois [r_first, r_first + R) of R_total - one image's
+  // proposals on that image's stream; planes / scales / rois / boost describe all R_total rois)
+  if (R_total <= 0) { R_total = R; r_first = 0; }
+  rois += (long long)r_first * 5;
+  if (boost) boost += r_first;
   RoiPlaneOut po;
-  po.P = (unsigned short*)planes; po.inv_scale = scales ? scales + R : nullptr;
+  po.P = (unsigned short*)planes + (long long)r_first * 16;
+  po.inv_scale = scales ? scales + R_total + r_first : nullptr;
   po.amax_words = (const unsigned*)amax_words;
-  po.n_words = n_words; po.plane = K * R; po.R = R; po.bf16 = bf16;
+  po.n_words = n_words; po.plane = K * R_total; po.R = R_total; po.bf16 = bf16;
   const int nw = naws_knob(NAWS_KNOB_ROI_NW);       // A/B knob (tools/bench_roi.py): NW * 10 + RG
   (void)nw;
 #define NAWS_ROI_LAUNCH(NWV, RGV)                                                                    \
@@ -736,6 +742,28 @@ extern "C" int naws_roi_pool_f_f16x2_mapped_fwd(const float* X, int N, int C, in
   if ((((uintptr_t)M2 | (uintptr_t)M4) & 15) != 0) return NAWS_ERR_ARG;
   return roi_pool_planes_mapped(X, N, C, H, W, rois, R, boost, pooled_h, pooled_w, spatial_scale,
                                 amax_words, n_words, M2, M4, planes, scales, (hipStream_t)stream);
+}
+
+// The same for rois [r_first, r_first + count) of R_total only (rois, boost, planes and scales are
+// those of ALL R_total rois): the engine pools each image's proposals at the tail of that image's
+// conv chain, on its stream, beside the other image's last layers.
+extern "C" int naws_roi_pool_f_f16x2_mapped_range_fwd(const float* X, int N, int C, int H, int W,
+                                                      const float* rois, int R_total, int r_first,
+                                                      int count, const float* boost, int pooled_h,
+                                                      int pooled_w, float spatial_scale,
+                                                      const uint32_t* amax_words, int n_words,
+                                                      const float* M2, const float* M4, void* planes,
+                                                      float* scales, void* stream) {
+  const int rc = roi_pool_planes_check(X, N, C, H, W, rois, R_total, pooled_h, pooled_w, amax_words,
+                                       n_words, planes, scales);
+  if (rc != NAWS_OK) return rc;
+  if (r_first < 0 || count < 0 || r_first + count > R_total) return NAWS_ERR_SHAPE;
+  if (count == 0) return NAWS_OK;
+  NAWS_REQUIRE_PTR(M2); NAWS_REQUIRE_PTR(M4);
+  if ((((uintptr_t)M2 | (uintptr_t)M4) & 15) != 0) return NAWS_ERR_ARG;
+  return roi_pool_planes_mapped(X, N, C, H, W, rois, count, boost, pooled_h, pooled_w, spatial_scale,
+                                amax_words, n_words, M2, M4, planes, scales, (hipStream_t)stream, 0,
+                                R_total, r_first);
 }
 
 // RoIPoolF (+ boost) over existing block-maxima maps (naws_roi_maxmaps_fwd), written as the bf16

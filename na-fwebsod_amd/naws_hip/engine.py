@@ -233,6 +233,8 @@ class WsddnEngine(object):
         # entries of VGG16_CONVS each image runs before the deferred update is queued beside the
         # chains (1: conv1_1; 2: conv1_1 + conv1_2 with pool1)
         self.UPDATE_AFTER = 2 if mfma_dtype == 'bf16' else 1
+        # fp16x2 plan: each image's proposals are pooled on that image's conv stream (conv_body)
+        self.ROI_POOL_ON_CHAINS = True
         self.conv_wino = {}
         self._rm_table = None
         self._fc8_ws = None
@@ -509,8 +511,13 @@ class WsddnEngine(object):
         self._pool_done = fused_pool     # a range that ends on a fused pool: the next one skips it
         return x
 
-    def conv_body(self, data):
+    def conv_body(self, data, roi_job=None):
         """data NCHW [B,3,H,W] -> conv5_3 NHWC [B,H/8-1,W/8-1,512].
+
+        roi_job = (rois, obn_scores, seg) (fp16x2 plan, one chain per image): every image's
+        proposals are pooled at the tail of ITS chain, on its stream, beside the other images'
+        last layers - RoIPoolF + boost straight into fc6's operand planes, rows seg[i]..seg[i+1];
+        the finished operand is then in self._roi_operand (consumed by _roi_features).
 
         The 13 layers of one image are a dependent chain, and the deep layers have only a
         couple of workgroup-tiles per CU, so every layer ends on a partially filled chip.
@@ -523,6 +530,7 @@ class WsddnEngine(object):
         per_image = n > 1 and self.conv_streams
         self._pool_done = False
         self._roi_maps = None
+        self._roi_operand = None
         self._amax5 = (torch.empty((n if per_image else 1,), device=self.device,
                                    dtype=torch.int32) if planes else None)
         heads_first = self.mfma_dtype in ('fp16x2', 'bf16')
@@ -545,6 +553,10 @@ class WsddnEngine(object):
         self._roi_maps = (torch.empty_like(out), torch.empty_like(out)) if (planes or slab) else None
         # the maps belong to THIS tensor in THIS state (_take_roi_maps)
         self._roi_maps_of = (out.data_ptr(), out._version)
+        pooled = None
+        if (roi_job is not None and planes and self.ROI_POOL_ON_CHAINS
+                and roi_job[0].shape[0] > 0 and len(roi_job[2]) == n + 1):
+            pooled = ops.roi_pool_operand(roi_job[0].shape[0], self.k6, self.device)
         main = torch.cuda.current_stream(self.device)
         start = main.record_event()
         while len(self._streams) < n:
@@ -593,8 +605,17 @@ class WsddnEngine(object):
                 if self._roi_maps is not None:
                     # RoIPoolF's block-maxima maps of this image, beside the other image's tail
                     ops.roi_maxmaps(out[i:i + 1], self._roi_maps[0][i:i + 1], self._roi_maps[1][i:i + 1])
+                    if pooled is not None and roi_job[2][i + 1] > roi_job[2][i]:
+                        # ... and its proposals pooled right behind them (batch index i: the maps
+                        # and conv5_3 of the other images are not touched)
+                        ops.roi_pool_f_f16x2_range(out, roi_job[0], self._amax5, pooled, roi_job[2][i],
+                                                   roi_job[2][i + 1], self._roi_maps, self.roi_size,
+                                                   self.roi_size, self.spatial_scale,
+                                                   boost=roi_job[1].reshape(-1))
                 done = st.record_event()
             main.wait_event(done)
+        if pooled is not None:
+            self._roi_operand = (pooled, out.data_ptr(), roi_job[0].data_ptr())
         return out
 
     def _seg_to_device(self, seg):
@@ -642,6 +663,12 @@ class WsddnEngine(object):
     def _roi_features(self, conv5, rois, obn_scores):
         """RoIPoolF + boost -> the fc6 input: fp32 [Rt, k6], or (fp16x2 plan) the GEMM operand
         planes written by the pooling kernel itself."""
+        done = getattr(self, '_roi_operand', None)
+        self._roi_operand = None
+        if done is not None and done[1] == conv5.data_ptr() and done[2] == rois.data_ptr() \
+                and getattr(self, '_roi_maps_of', None) == (conv5.data_ptr(), conv5._version):
+            self._roi_maps = None
+            return done[0]                    # pooled per image at the tails of the conv chains
         if self._amax5 is not None:
             mine = getattr(self, '_roi_maps_of', None) == (conv5.data_ptr(), conv5._version)
             maps = self._take_roi_maps(conv5)
@@ -843,7 +870,7 @@ class WsddnEngine(object):
                 e.record()
                 pev.append((name, e))
         mark('start')
-        conv5 = self.conv_body(data)
+        conv5 = self.conv_body(data, roi_job=(rois, obn_scores, seg))
         mark('conv_body')
         x = self._roi_features(conv5, rois, obn_scores)
         del conv5

@@ -112,6 +112,8 @@ PROTOTYPES = {
     'naws_roi_maxmaps_fwd': [p, i32, i32, i32, i32, p, p, p],
     'naws_roi_pool_f_f16x2_mapped_fwd': [p, i32, i32, i32, i32, p, i32, p, i32, i32, f32, p, i32, p, p, p,
                                          p, p],
+    'naws_roi_pool_f_f16x2_mapped_range_fwd': [p, i32, i32, i32, i32, p, i32, i32, i32, p, i32, i32, f32, p,
+                                               i32, p, p, p, p, p],
     'naws_conv3x3_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, f32, f32, p, i32,
                                     i32, p],
     'naws_amax_f32': [p, i64, p, p],

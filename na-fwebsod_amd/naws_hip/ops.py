@@ -157,6 +157,33 @@ def roi_maxmaps(x, m2, m4):
     L.call('naws_roi_maxmaps_fwd', x.data_ptr(), n, c, h, w, m2.data_ptr(), m4.data_ptr(), _stream())
 
 
+def roi_pool_operand(r, k, device):
+    """An empty fp16x2 fc6 operand for r rois x k features (what roi_pool_f_f16x2 fills)."""
+    return F16x2(torch.empty((2, k // 16, r, 16), device=device, dtype=torch.float16),
+                 torch.empty((2, r), device=device, dtype=_f32))
+
+
+def roi_pool_f_f16x2_range(x, rois, amax_words, out, r0, r1, maps, pooled_h=7, pooled_w=7,
+                           spatial_scale=0.125, boost=None):
+    """roi_pool_f_f16x2 over existing block-maxima maps for rois r0..r1 only, into rows r0..r1 of
+    `out` (roi_pool_operand for ALL of rois): one image's proposals on that image's stream."""
+    _chk(x, 'x'); _chk(rois, 'rois')
+    n, h, w, c = x.shape
+    r = rois.shape[0]
+    m2, m4 = maps
+    _chk(m2, 'm2'); _chk(m4, 'm4')
+    if boost is not None:
+        _chk(boost, 'boost')
+        assert boost.numel() == r
+    if out.planes.shape != (2, c * pooled_h * pooled_w // 16, r, 16) or m2.shape != x.shape:
+        raise L.NawsError('naws_roi_pool_f_f16x2_mapped_range_fwd', L.ERR_SHAPE)
+    L.call('naws_roi_pool_f_f16x2_mapped_range_fwd', x.data_ptr(), n, c, h, w, rois.data_ptr(), r,
+           int(r0), int(r1 - r0), _ptr(boost), pooled_h, pooled_w, float(spatial_scale),
+           amax_words.data_ptr(), amax_words.numel(), m2.data_ptr(), m4.data_ptr(),
+           out.planes.data_ptr(), out.scales.data_ptr(), _stream())
+    return out
+
+
 def roi_pool_f_f16x2(x, rois, amax_words, pooled_h=7, pooled_w=7, spatial_scale=0.125, boost=None,
                      hier=True, maps=None):
     """RoIPoolF (+ boost) on NHWC features, written directly as the fp16x2 operand of the fc6

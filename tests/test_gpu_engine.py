@@ -524,3 +524,38 @@ def test_cross_plan_soak_short(dev):
     print('\n' + '\n'.join(lines))
     assert ok
     assert sc.horizon(traj['fp16x2'], traj['fp32'], 1e-3)[0] >= 8
+
+
+def test_per_image_pooling_on_the_conv_streams_is_bit_identical(dev):
+    """engine.conv_body(roi_job=...) pools each image's proposals at the tail of that image's conv
+    chain (naws_roi_pool_f_f16x2_mapped_range_fwd on the image's stream): fc6's operand planes and
+    scales, the losses and every gradient equal the one-launch-after-the-join route bit for bit;
+    ragged proposal counts, one image without proposals of its own in the middle of the batch."""
+    from detectron.datasets import synthetic
+    from naws_hip.engine import WsddnEngine
+    c = 20
+    blobs = synthetic.init_blobs(c, seed=3)
+    roidb = synthetic.make_roidb(3, 40, c, 64, 96, seed=4)
+    for e, r in zip(roidb, (37, 5, 40)):
+        for k in ('boxes', 'obn_scores', 'gt_classes'):
+            e[k] = e[k][:r]
+    mb = synthetic.make_minibatch(roidb, c)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
+    seg = [0, 37, 42, 82]
+    res = []
+    for on in (True, False):
+        eng = WsddnEngine(c + 1, dev, dropout=0.5, gpu_num=3, seed=3, mfma_dtype='fp16x2')
+        eng.ROI_POOL_ON_CHAINS = on
+        eng.set_conv_blobs(blobs)
+        eng.set_head_blobs(blobs)
+        conv5 = eng.conv_body(t['data'], roi_job=(t['rois'], t['obn_scores'], seg))
+        assert (eng._roi_operand is not None) == on
+        x = eng._roi_features(conv5, t['rois'], t['obn_scores'])
+        planes, scales = x.planes.clone(), x.inv_scale.clone()
+        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+        torch.cuda.synchronize()
+        res.append((planes, scales, out['loss_cls'].clone(), out['loss_cls_noise'].clone(),
+                    eng.grads.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[0][2]).all()
