@@ -10,9 +10,21 @@ import sys
 
 HOT = ('gemm_x3', 'gemm_h2_btr', 'conv_h2', 'conv_x3', 'roi_pool', 'acm_sgd', 'split2h_dual', 'gemm_smallk', 'wino_',
        'conv_c3')
-LABEL = {('gemm_h2_btr_kernel<256, 256, 4, 2, true>', '1572864', 399): 'fc6 wgrad + SGD epilogue',
-         ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>', '262144', 493): 'fc6 fwd (M=4000 N=8192 K=25088)',
-         ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true>', '1572864', 472): 'fc6 wgrad (M=8192 N=24576 K=4000)'}
+# (template prefix, grid, MFMA-busy cycles / 1e7) -> what the launch is; prefixes, because template
+# argument lists grow (round 4 appended one and every exact-name label stopped matching)
+LABEL = {('gemm_h2_btr_kernel<256, 256, 4, 2, true', '1572864', None): 'fc6 wgrad + SGD epilogue',
+         ('gemm_h2_btr_kernel<256, 256, 4, 2, false', '1572864', None): 'fc6 wgrad, gradient written (deferred route)',
+         ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true', '262144', 493): 'fc6 fwd (M=4000 N=8192 K=25088)',
+         ('gemm_x3_kernel<128, 128, 2, 2, 3, 2, 1, true', '311296', None): 'Winograd batch GEMM (16 x [2344 tiles x 512 x 512])',
+         ('roi_pool_nhwc_xcd_kernel<true, true', None, None): 'RoIPoolF + boost -> fc6 operand planes'}
+
+
+def label_of(key):
+    for (pre, grid, work), text in LABEL.items():
+        if key[0].startswith(pre) and (grid is None or key[1] == grid) and \
+                (work is None or abs(key[2] - work) <= 0.06 * work):
+            return text
+    return None
 
 
 def main():
@@ -56,8 +68,8 @@ def main():
         n = len(v)
         avg = [sum(x[i] for x in v) / n for i in range(6)]
         name = key[0] + ' (' + key[1] + ')'
-        if key in LABEL:
-            name += ' = ' + LABEL[key]
+        if label_of(key):
+            name += ' = ' + label_of(key)
         lines.append('| %s | %d | %.3f | %.2f | %.0f %% | %.0f %% | %.0f %% | %d |' % (
             name, n, avg[0], avg[1], 100 * avg[2], 100 * avg[3], 100 * avg[4], avg[5]))
     tail = sys.argv[3] if len(sys.argv) > 3 else None
