@@ -14,13 +14,6 @@ import os
 import sys
 import time
 
-# The step keeps up to five HIP streams busy at once (main, one per image of the conv body, the
-# deferred update, the collective's); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
-# round-robin (default 4), and two streams that share a queue run in order - measured here as a
-# conv chain or the piece-by-piece update stuck behind a 10 ms exchange.  Must be in the
-# environment before the HIP runtime initialises; an operator's own value wins.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
 sys.path.insert(0, ROOT)
@@ -607,7 +600,6 @@ def launcher_env(environ):
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK',
                         'MASTER_ADDR', 'MASTER_PORT')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    env.setdefault('GPU_MAX_HW_QUEUES', '8')          # (see the top of this file)
     env.setdefault('OMP_NUM_THREADS', '8')
     env['NAWS_BENCH_CHILD'] = '1'
     return env

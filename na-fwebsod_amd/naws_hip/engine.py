@@ -41,6 +41,23 @@ VGG16_CONVS = [
 
 HIDDEN = 4096
 
+# The side streams of every engine of a process, by (device, role): 'conv0', 'conv1', ... (one
+# chain per image) and 'update'.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues
+# round-robin as they are first used, and two streams on one queue run in order; a process that
+# builds several engines one after another (bench.py's plans, the test suite) would otherwise
+# keep drawing new streams from torch's pool until the image chains of one engine share a queue
+# with each other or with the main stream (measured: the bf16 plan inside the default bench line
+# at 242 instead of 280 img/s).  Shared streams keep the process at main + B + 2 streams; engines
+# that are driven one at a time - the only way they are used - lose nothing.
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, role):
+    key = (str(device), role)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
 
 def head_param_specs(num_fg_classes, dim_in=512, roi_size=7):
     """Arena order.  Adjacent pairs form the fused GEMM operands."""
@@ -560,7 +577,7 @@ class WsddnEngine(object):
         main = torch.cuda.current_stream(self.device)
         start = main.record_event()
         while len(self._streams) < n:
-            self._streams.append(torch.cuda.Stream(device=self.device))
+            self._streams.append(side_stream(self.device, 'conv%d' % len(self._streams)))
         split = (self._update_waiting and heads_first)
         h2 = self.mfma_dtype == 'fp16x2'     # operand-scale bounds travel along the chain
         if split:
@@ -1166,7 +1183,7 @@ class WsddnEngine(object):
         if self._upd_stream is None:
             # an ordinary stream: a low-priority one, or one confined to a subset of the compute
             # units, measured worse in every form (docs/history: 13.7-23 vs 13.5 ms per step)
-            self._upd_stream = torch.cuda.Stream(device=self.device)
+            self._upd_stream = side_stream(self.device, 'update')
         self._grads_ready = main.record_event()
         # launched by the next conv body behind conv1_1 of every image (or by flush): started at
         # once, the SGD kernel's workgroups fill the CUs and the two conv1_1 launches at the head

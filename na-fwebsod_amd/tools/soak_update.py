@@ -31,11 +31,25 @@ def main():
                     help='1: engine.train_step (one rank: fc6_w updated in its wgrad GEMM); 0: forward_backward + sgd_step')
     ap.add_argument('--mfma-dtype', default='fp16x2')
     ap.add_argument('--trace', type=int, default=0, help='print the loss every N steps')
+    ap.add_argument('--exchange', type=int, default=0,
+                    help='N > 1: the N-rank schedule with reducer.EmulatedExchange in the all-reduce\'s '
+                         'place (gradients untouched): the deferred update runs piece by piece '
+                         '(NAWS.PIPELINE_UPDATE) unless --pipeline 0')
+    ap.add_argument('--pipeline', type=int, default=1)
+    ap.add_argument('--digest', action='store_true',
+                    help='print a digest of the parameters / momentum / fc6_w planes at every check '
+                         '(two runs that must be bit-identical print the same lines)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     c, B = 20, 2
     eng = WsddnEngine(c + 1, dev, gpu_num=B, seed=11, mfma_dtype=a.mfma_dtype)
     eng.fused_planes = bool(a.fused)
+    if a.exchange > 1:
+        from naws_hip.reducer import EmulatedExchange
+        eng.reducer = EmulatedExchange(dev, a.exchange)
+        eng.allreduce_chunks = 4 if a.exchange == 2 else 2
+        eng.pipeline_update = bool(a.pipeline)
+        print('exchange emulated for %d ranks; update piece by piece: %s' % (a.exchange, eng._pipelined()))
     blobs = synthetic.init_blobs(c, seed=11)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)
@@ -98,6 +112,12 @@ def main():
                                        cv(w, **kw).view(torch.int16)), (it, key)
             print('step %d: loss %.5f  max|w6| %.3f  last overflow tag %d (iter %d)  plane error / bound %.3f'
                   % (it + 1, loss, float(w6.abs().max()), ovf, eng.sgd_iter_count, worst), flush=True)
+            if a.digest:
+                import hashlib
+                dg = [hashlib.blake2b(x.contiguous().view(torch.uint8).cpu().numpy(), digest_size=8).hexdigest()
+                      for x in (eng.params, eng.momentum_buf, eng._wplanes['w6'].planes.view(torch.int16)
+                                if a.mfma_dtype == 'fp16x2' and eng._wplanes else eng.params[:4])]
+                print('   digest params %s momentum %s planes %s' % tuple(dg), flush=True)
             assert np.isfinite(loss) and worst <= 1.0
     print('soak ok: %d steps, overflow re-splits seen at %d checkpoints' % (a.steps, tags))
 

@@ -16,10 +16,6 @@ import pprint
 import sys
 import time
 
-# main + per-image conv chains + deferred update + the collective's stream: more concurrent HIP
-# streams than ROCm's default four hardware queues (two streams on one queue run in order); set
-# before the HIP runtime starts, an operator's own value wins (bench.py has the measurement)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 
 from detectron.core.config import (assert_and_infer_cfg, cfg, merge_cfg_from_file,  # noqa: E402

@@ -16,10 +16,6 @@ import pprint
 import random
 import sys
 
-# main + per-image conv chains + deferred update + the collective's stream: more concurrent HIP
-# streams than ROCm's default four hardware queues (two streams on one queue run in order); set
-# before the HIP runtime starts, an operator's own value wins (bench.py has the measurement)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 
 import numpy as np  # noqa: E402
