@@ -514,8 +514,13 @@ def project_n_ranks(eng, t, seg, n, cus, gbps, steps, sharded=False, pipeline=Tr
                 torch.cuda.synchronize()
                 eng.phase_events = pev
                 t0 = time.perf_counter()
-            eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
-            eng.sgd_step()
+            if pipeline and not sharded:
+                # (as the training loop does: train_step queues the update's parts from inside
+                # backward, each right behind the message it waits for)
+                eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            else:
+                eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+                eng.sgd_step()
         eng.flush()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3

@@ -1009,12 +1009,31 @@ class WsddnEngine(object):
         pipelined = self._pipelined()
         plan = message_plan(self.arena, 2 * HIDDEN, self.allreduce_chunks, red.active, pipelined)
         self._pipe_sent = pipelined
+        # train_step() (fuse_update): each part of the piece-by-piece update is queued on the
+        # update stream RIGHT BEHIND the message it waits for, from here, instead of after the
+        # whole backward - fc6_w, its planes and fc6's biases are not read again once the forward
+        # has run.  In queue order the update's parts then sit between the messages, so the
+        # pipeline also holds where HIP puts the update stream and the collective's stream on one
+        # hardware queue (two streams on one queue run in order; measured with ROCm's default
+        # queue count: queued after backward, every part waited behind the whole exchange).
+        eager = bool(pipelined and fuse_update and self._pipe_planes_ok())
+        if eager:
+            if self._upd_stream is None:
+                self._upd_stream = side_stream(self.device, 'update')
+            self.flush()                 # (nothing can be pending here: the head joined it)
+            with torch.cuda.stream(self._upd_stream):
+                self._pipe_begin()
+        self._pipe_eager = eager
         if pipelined:
             # fc6's bias gradients first (the first forward piece of the next iteration needs the
             # updated biases): a column sum of dZ6, known before the weight gradient
             ops.colsum(dz6, out=gb6)
             red.reduce_async(message_slice(self.arena, G, 'fc6_b', None, self.k6))
             plan = plan[1:]
+            if eager:
+                with torch.cuda.stream(self._upd_stream):
+                    self._pipe_enqueue_bias()
+        next_piece = 0
         for kind, rows in plan[:-1]:
             r0, r1 = rows
             if h2:
@@ -1047,6 +1066,10 @@ class WsddnEngine(object):
             else:      # each owner's rows of this chunk go to that owner only
                 for o, p0, p1 in owner_pieces(r0, r1, blocks):
                     red.reduce_to_owner_async(gw6[p0:p1].reshape(-1), o)
+            while eager and next_piece < len(self.FWD_PIECES) and self.FWD_PIECES[next_piece][1] <= r1:
+                with torch.cuda.stream(self._upd_stream):       # every chunk of this piece is out
+                    self._pipe_enqueue_piece(next_piece)
+                next_piece += 1
         # 3. the small gradients (under the fc6_w exchange): fc6 db; fc7 dW = dZ7^T H6, db;
         # fc8 dW = dL^T H7, db
         if not pipelined:
@@ -1072,6 +1095,11 @@ class WsddnEngine(object):
             self._fc8_gemm(dlv, h7v, True, False, gw8)
             ops.colsum(dl, out=gb8)
         red.reduce_async(message_slice(self.arena, G, *plan[-1], self.k6))
+        if eager:
+            with torch.cuda.stream(self._upd_stream):
+                self._pipe_enqueue_tail()
+                self._upd_event = self._upd_stream.record_event()
+            self._update_pending, self._update_waiting = True, False
 
     def _can_fuse_wgrad_update(self):
         return (self.fuse_wgrad_update and not self.reducer.active and self.iter_size == 1
@@ -1175,6 +1203,9 @@ class WsddnEngine(object):
         for the gradient all-reduce and runs the (HBM-bound) fused SGD kernel while the main
         stream already runs the next iteration's (MFMA-bound, parameter-free) conv body + RoIPool;
         `flush()` — called before the head touches the parameters — joins the two streams."""
+        if getattr(self, '_pipe_eager', False):
+            self._pipe_eager = False      # train_step: backward has queued the update already
+            return
         defer = True if self.defer_update is None else self.defer_update
         if not defer:
             self._apply_update()
@@ -1351,10 +1382,13 @@ class WsddnEngine(object):
         can run on them (planes valid, one hyper-parameter run per weight matrix); otherwise the
         update waits for everything and takes the one-launch route - any message order is fine
         for that."""
-        return (getattr(self, '_pipe_sent', False) and self._wplanes is not None
-                and self._sgd_regions is not None and not self._planes_dirty
+        return (getattr(self, '_pipe_sent', False) and self._pipe_planes_ok()
                 and self._upd_stream is not None
                 and torch.cuda.current_stream(self.device) == self._upd_stream)
+
+    def _pipe_planes_ok(self):
+        return (self._wplanes is not None and self._sgd_regions is not None
+                and not self._planes_dirty)
 
     def _seg_tables(self, start, count):
         """(seg_end, seg_lr_mult, seg_wd) device tensors of the arena range [start, start + count),
@@ -1413,73 +1447,96 @@ class WsddnEngine(object):
         momentum, planes and scales bit-identical, tests/test_gpu_two_ranks.py); the one difference:
         the "a row outgrew twice its previous maximum" word is kept PER PIECE, so the exact
         re-split that answers it covers that piece's rows instead of all of fc6_w / fc7_w - the
-        other rows keep their (equally valid) bound-derived scales."""
-        red, n6 = self.reducer, 2 * HIDDEN
-        tb = self._pipe_tables()
-        sc = self._wscales.view(2, 2, n6)
-        max6, max7 = sc[0, 0].view(torch.int32), sc[1, 0].view(torch.int32)
-        tag = self.sgd_iter_count + 1
-        w6, w7 = self._weight_views()
-        wp = self._wplanes
+        other rows keep their (equally valid) bound-derived scales.
+
+        This is the form sgd_step() queues after a plain forward_backward().  train_step() queues
+        the same three parts EARLIER, from inside backward, each right behind the message it
+        waits for (_pipe_enqueue_*): fc6_w is not read again once its forward has run, so its rows
+        may be updated while the rest of backward is still computing."""
+        self._pipe_begin()
+        self._pipe_enqueue_bias()
+        for i in range(len(self.FWD_PIECES)):
+            self._pipe_enqueue_piece(i)
+        self._pipe_enqueue_tail()
+
+    def _pipe_slice(self, flat, t):
+        return flat[t['start']:t['start'] + t['count']]
+
+    def _pipe_begin(self):
+        """Start of one step's piece-by-piece update (current stream = the update stream)."""
+        self._pipe_tables()
+        self._pipe_state = dict(arrived=0, events=[], tag=self.sgd_iter_count + 1, cev=None)
         cev = getattr(self, 'comm_events', None)
-        uev = getattr(self, 'update_events', None)
         if cev is not None:
             c0 = torch.cuda.Event(enable_timing=True)
             c0.record()
-        if uev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._pipe_state['cev'] = c0
 
-        def sl(flat, t):
-            return flat[t['start']:t['start'] + t['count']]
-        # 1. fc6's biases
-        red.wait_first(1)
-        if uev is not None:
-            e0.record()
-        b = tb['bias']
-        ops.acm_sgd_update(sl(self.grads, b), sl(self.momentum_buf, b), self.lr, sl(self.params, b),
-                           None, b['seg'][0], b['seg'][1], b['seg'][2], self.momentum, 0, 1,
-                           self.gpu_num, self.sgd_iter_count)
-        # 2. fc6_w, one forward piece at a time
-        chunks = [rows for kind, rows in message_plan(self.arena, n6, self.allreduce_chunks, True, True)
-                  if kind == 'fc6_w']
-        arrived, events = 0, []
-        for i, pc in enumerate(tb['pieces']):
-            r0, r1 = pc['rows']
-            need = sum(1 for c0_, _c1 in chunks if c0_ < r1)        # chunks that start below r1
-            red.wait_first(need - arrived)
-            arrived = need
-            self._wbound[r0:r1].copy_(max6[r0:r1])
-            max6[r0:r1].zero_()
-            ovf = tb['ovf'][i:i + 1]
-            ops.acm_sgd_update_f16x2(sl(self.grads, pc), sl(self.momentum_buf, pc), self.lr,
-                                     sl(self.params, pc), pc['seg'][0], pc['seg'][1], pc['seg'][2],
-                                     self.momentum, 0, self.gpu_num, self.sgd_iter_count,
-                                     pc['regions'], ovf, tag)
-            ops.split_f16x2_row_range_if(w6, max6, wp['w6'], r0, r1, cond=ovf, cond_value=tag)
-            events.append((r0, r1, self._upd_stream.record_event()))
-        # 3. the rest
-        red.wait()
-        if cev is not None:
+    def _pipe_enqueue_bias(self):
+        tb, b = self._pipe, self._pipe['bias']
+        self.reducer.wait_first(1)
+        ops.acm_sgd_update(self._pipe_slice(self.grads, b), self._pipe_slice(self.momentum_buf, b),
+                           self.lr, self._pipe_slice(self.params, b), None, b['seg'][0], b['seg'][1],
+                           b['seg'][2], self.momentum, 0, 1, self.gpu_num, self.sgd_iter_count)
+
+    def _pipe_chunks_below(self, row):
+        """How many fc6_w messages start below `row` (= must have arrived before rows < row are
+        complete)."""
+        return sum(1 for kind, rows in message_plan(self.arena, 2 * HIDDEN, self.allreduce_chunks, True, True)
+                   if kind == 'fc6_w' and rows[0] < row)
+
+    def _pipe_enqueue_piece(self, i):
+        n6 = 2 * HIDDEN
+        st, pc = self._pipe_state, self._pipe['pieces'][i]
+        r0, r1 = pc['rows']
+        need = self._pipe_chunks_below(r1)
+        self.reducer.wait_first(need - st['arrived'])
+        st['arrived'] = need
+        sc = self._wscales.view(2, 2, n6)
+        max6 = sc[0, 0].view(torch.int32)
+        self._wbound[r0:r1].copy_(max6[r0:r1])
+        max6[r0:r1].zero_()
+        ovf = self._pipe['ovf'][i:i + 1]
+        w6, _w7 = self._weight_views()
+        ops.acm_sgd_update_f16x2(self._pipe_slice(self.grads, pc), self._pipe_slice(self.momentum_buf, pc),
+                                 self.lr, self._pipe_slice(self.params, pc), pc['seg'][0], pc['seg'][1],
+                                 pc['seg'][2], self.momentum, 0, self.gpu_num, self.sgd_iter_count,
+                                 pc['regions'], ovf, st['tag'])
+        ops.split_f16x2_row_range_if(w6, max6, self._wplanes['w6'], r0, r1, cond=ovf, cond_value=st['tag'])
+        st['events'].append((r0, r1, self._upd_stream.record_event()))
+
+    def _pipe_enqueue_tail(self):
+        n6 = 2 * HIDDEN
+        st, t, wp = self._pipe_state, self._pipe['tail'], self._wplanes
+        self.reducer.wait()
+        if st['cev'] is not None:
             c1 = torch.cuda.Event(enable_timing=True)
             c1.record()
-            cev.append((c0, c1))
-        t = tb['tail']
+            self.comm_events.append((st['cev'], c1))
+        uev = getattr(self, 'update_events', None)
+        if uev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        sc = self._wscales.view(2, 2, n6)
+        max7 = sc[1, 0].view(torch.int32)
         self._wbound[n6:].copy_(max7)
         max7.zero_()
         wp['w7t'].scales[0].zero_()
-        ovf = tb['ovf'][-1:]
-        ops.acm_sgd_update_f16x2(sl(self.grads, t), sl(self.momentum_buf, t), self.lr,
-                                 sl(self.params, t), t['seg'][0], t['seg'][1], t['seg'][2],
-                                 self.momentum, 0, self.gpu_num, self.sgd_iter_count,
-                                 t['regions'], ovf, tag)
+        ovf = self._pipe['ovf'][-1:]
+        _w6, w7 = self._weight_views()
+        ops.acm_sgd_update_f16x2(self._pipe_slice(self.grads, t), self._pipe_slice(self.momentum_buf, t),
+                                 self.lr, self._pipe_slice(self.params, t), t['seg'][0], t['seg'][1],
+                                 t['seg'][2], self.momentum, 0, self.gpu_num, self.sgd_iter_count,
+                                 t['regions'], ovf, st['tag'])
         if uev is not None:
             e1.record()
             uev.append((e0, e1))
         self.sgd_iter_count += 1
-        ops.split_f16x2_rows_if(w7, max7, wp['w7'], ovf, tag)
+        ops.split_f16x2_rows_if(w7, max7, wp['w7'], ovf, st['tag'])
         ops.split_f16x2_dual(w7, None, wp['w7t'].scales, out_t=wp['w7t'])
         self._planes_dirty = False
-        self._piece_events = dict(fc6=events, done=self._upd_stream.record_event())
+        self._piece_events = dict(fc6=st['events'], done=self._upd_stream.record_event())
+        self._pipe_state = None
 
     # ------------------------------------------------- NAWS.SHARDED_UPDATE
     def _shard_blocks(self):

@@ -34,7 +34,8 @@ def main():
     ap.add_argument('--exchange', type=int, default=0,
                     help='N > 1: the N-rank schedule with reducer.EmulatedExchange in the all-reduce\'s '
                          'place (gradients untouched): the deferred update runs piece by piece '
-                         '(NAWS.PIPELINE_UPDATE) unless --pipeline 0')
+                         '(NAWS.PIPELINE_UPDATE) unless --pipeline 0; with --train-step 1 its parts are '
+                         'queued from inside backward, as the training loop does')
     ap.add_argument('--pipeline', type=int, default=1)
     ap.add_argument('--digest', action='store_true',
                     help='print a digest of the parameters / momentum / fc6_w planes at every check '

@@ -40,14 +40,16 @@ DOMINANT = {
 # Other kernels of the default plan whose measured-to-algorithmic traffic ratio goes into the
 # bench line.  (template prefix, Grid_Size or None, label, algorithmic MB per
 # launch at BASELINE configs[1]: 2 images 600 x 1000, R = 2000 each, C = 20).
-#   roi_pool: 2 x 2000 x 25088 x 4 B of operand planes written + 2 x 18.8 MB of conv5_3 read
+#   roi_pool: 2 x 2000 x 25088 x 4 B of operand planes written + 2 x 18.8 MB of conv5_3 read (half of
+#     it per image: since round 5 the engine pools each image on its own conv stream)
 #   fc6 wgrad + SGD: dZ6^T planes 131 MB + x planes 401 MB read; w, momentum read and written
 #     (4 x 822 MB) + the 4-byte planes (822 MB)
 #   conv_h2_wp (one image per launch): fp32 NHWC input + (pooled) output; a grid is shared by the
 #     layers of one resolution, the figure is their mean: conv1_2 153.6 + 38.4; conv2_1 38.4 +
 #     76.8, conv2_2 76.8 + 19.2; conv3_1 19.2 + 38.4, conv3_2 38.4 + 38.4, conv3_3 38.4 + 9.6
 EXTRA = [
-    ('roi_pool_nhwc_xcd_kernel<true, true', None, 'roi_pool_nhwc_xcd (RoIPoolF + boost -> fc6 planes)', 439.0),
+    ('roi_pool_nhwc_xcd_kernel<true, true', '4096000', 'roi_pool_nhwc_xcd (RoIPoolF + boost -> fc6 planes), all 4000 proposals in one launch', 439.0),
+    ('roi_pool_nhwc_xcd_kernel<true, true', '2048000', 'roi_pool_nhwc_xcd, one image (2000 proposals) per launch on its conv stream', 219.5),
     ('gemm_h2_btr_kernel<256, 256, 4, 2, true', None, 'gemm_h2_btr<256,256,SGD> (fc6 wgrad + update)', 4642.0),
     ('gemm_h2_btr_kernel<256, 256, 4, 2, false', None, 'gemm_h2_btr<256,256> (fc6 wgrad, gradient written)', 1354.0),
     ('conv_h2_wp_kernel<2, 2, 1, true, 2', '614400', 'conv_h2_wp conv1_2 + pool1 (one image)', 192.0),

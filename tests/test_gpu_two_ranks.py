@@ -40,21 +40,25 @@ def _engine(dev, gpu_num, pg=None, world=1, sharded=False, chunks=4, pipeline=No
     return eng
 
 
-def _run(eng, mb, dev):
+def _run(eng, mb, dev, train_step=False):
     t = {k: torch.from_numpy(v).to(dev) for k, v in mb.items()}
     n = int(mb['data'].shape[0])
     seg = [0] + np.cumsum(np.bincount(mb['rois'][:, 0].astype(np.int64), minlength=n)).tolist()
     losses = []
     for _ in range(STEPS):
-        out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
-        eng.sgd_step()
+        if train_step:     # (the training loop's call: the update's parts are queued from inside backward)
+            out = eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+        else:
+            out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
+            eng.sgd_step()
         losses.append(out['loss_cls'].cpu().numpy().copy())
     eng.flush()
     torch.cuda.synchronize()
     return np.stack(losses)
 
 
-def _worker(rank, world, port, outdir, sharded=False, pipeline=None, dropout=0.0, tag=None):
+def _worker(rank, world, port, outdir, sharded=False, pipeline=None, dropout=0.0, tag=None,
+            train_step=False):
     sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
     import faulthandler
     # a rank stuck in a collective says where, then leaves (the parent's limit is 300 s)
@@ -77,7 +81,7 @@ def _worker(rank, world, port, outdir, sharded=False, pipeline=None, dropout=0.0
         if sharded:
             assert eng._shard_blocks() == [(r * 1024, (r + 1) * 1024) for r in range(8)]
     eng.reducer.log = log = []
-    losses = _run(eng, halves[rank], dev)
+    losses = _run(eng, halves[rank], dev, train_step=train_step)
     if rank == 0:
         import json
         with open(os.path.join(outdir, 'messages%s.json' % (tag if tag is not None else
@@ -323,9 +327,11 @@ def test_pipelined_update_bit_identical_to_the_unpipelined_route(dev, tmp_path):
     fc6_w's operand planes and their scales are bit-identical to the route that waits for the whole
     exchange and updates in one launch, on both ranks."""
     ctx = mp.get_context('spawn')
-    for pipeline, tag in ((False, 'u'), (True, 'p')):
+    # 'u': one update launch after the whole exchange; 'p': piece by piece, queued by sgd_step();
+    # 'e': piece by piece, queued from inside backward (train_step, what the training loop calls)
+    for pipeline, tag, ts in ((False, 'u', False), (True, 'p', False), (True, 'e', True)):
         s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), False, pipeline, 0.5, tag))
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), False, pipeline, 0.5, tag, ts))
                  for r in range(2)]
         _run_ranks(procs)
     import json
@@ -333,9 +339,11 @@ def test_pipelined_update_bit_identical_to_the_unpipelined_route(dev, tmp_path):
     mp_ = json.load(open(str(tmp_path / 'messagesp.json')))
     assert len(mu) // STEPS == 5 and len(mp_) // STEPS == 6          # 4 chunks + small | + the biases
     assert sum(m[1] for m in mu) == sum(m[1] for m in mp_)           # same bytes
+    assert json.load(open(str(tmp_path / 'messagese.json'))) == mp_   # same messages, same order
     for what in ('params', 'mom', 'planes', 'scales', 'losses'):
         for r in range(2):
             a = np.load(str(tmp_path / ('%su%d.npy' % (what, r))))
-            b = np.load(str(tmp_path / ('%sp%d.npy' % (what, r))))
-            assert np.array_equal(a, b), (what, r)
+            for t in ('p', 'e'):
+                b = np.load(str(tmp_path / ('%s%s%d.npy' % (what, t, r))))
+                assert np.array_equal(a, b), (what, t, r)
     assert np.isfinite(np.load(str(tmp_path / 'lossesp0.npy'))).all()

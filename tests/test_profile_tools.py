@@ -47,7 +47,7 @@ def test_summary_has_the_fc6_row_and_the_traffic_file(tmp_path):
     assert 3e9 < tj['hbm_bytes_per_launch'] < 8e9
     assert tj['ratio_vs_algorithmic'] == pytest.approx(tj['hbm_bytes_per_launch'] / 1.354e9, rel=1e-3)
     labels = [e['kernel'] for e in tj['other_kernels']]
-    for want in ('roi_pool_nhwc_xcd', 'gemm_h2_btr<256,256,SGD>', 'conv_h2_wp conv1_2'):
+    for want in ('roi_pool_nhwc_xcd', 'gemm_h2_btr<256,256,SGD>', 'conv_h2_wp conv1_2'):      # (r04 excerpt: one RoIPool launch per step)
         assert any(want in l for l in labels), (want, labels)
     assert all(e['ratio'] > 0.9 for e in tj['other_kernels'])
     assert os.path.exists(out + '_kernel_stats.csv')
