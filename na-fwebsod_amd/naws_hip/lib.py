@@ -180,6 +180,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch's bundled HIP runtime has to be in the process BEFORE this library is opened: opened
+    # first, libnaws_hip.so binds /opt/rocm's libamdhip64 and a process that then touches the GPU
+    # through torch holds two runtimes (the library's first launch fails with hipErrorNoDevice)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             'libnaws_hip.so not found at %s — build it with `make -C na-fwebsod_amd/csrc` '

@@ -35,16 +35,16 @@ def main():
         kv = dict(x.split('=') for x in c.split(',') if x)
         cases.append(kv)
         for k in kv:
-            if not k.isupper():
+            if hasattr(eng, k):            # (engine attributes may be upper-case too: DIRECT_MIN_TILES)
                 base.setdefault(k, getattr(eng, k))
 
     def apply(kv):
         for k, v in base.items():
             setattr(eng, k, v)
-        for k in [k for c in cases for k in c if k.isupper()]:
+        for k in [k for c in cases for k in c if k.isupper() and not hasattr(eng, k)]:
             L.set_variant(L._ENV_KNOBS[k], {'NAWS_CONV_RING': 11, 'NAWS_ROI_NW': 42}.get(k, 0))
         for k, v in kv.items():
-            if k.isupper():
+            if k.isupper() and not hasattr(eng, k):
                 L.set_variant(L._ENV_KNOBS[k], int(v))
             else:
                 setattr(eng, k, type(base[k])(int(v)))
