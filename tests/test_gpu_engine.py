@@ -210,7 +210,10 @@ def test_rccl_chunked_allreduce_single_rank(dev):
         created = True
     try:
         res = []
-        for forced in (False, True):
+        # plain run; RCCL with the update queued by sgd_step(); RCCL with train_step(), which queues
+        # the piece-by-piece update's parts from inside backward (round 5) - real NCCL work handles
+        # waited for on the update stream while backward is still being enqueued
+        for forced, train_step in ((False, False), (True, False), (True, True)):
             eng = WsddnEngine(c + 1, dev, dropout=0.5, gpu_num=2, seed=3,
                               process_group=dist.group.WORLD if forced else None, world_size=1,
                               allreduce_chunks=4)
@@ -218,15 +221,20 @@ def test_rccl_chunked_allreduce_single_rank(dev):
             eng.set_conv_blobs(blobs)
             eng.set_head_blobs(blobs)
             eng.set_lr(1e-4)
-            for _ in range(2):
-                eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
-                eng.sgd_step()
+            for _ in range(3):
+                if train_step:
+                    eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+                else:
+                    eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'])
+                    eng.sgd_step()
             eng.flush()
             torch.cuda.synchronize()
-            res.append((eng.grads.clone(), eng.params.clone()))
-            assert eng.reducer.active == forced
+            res.append((eng.grads.clone(), eng.params.clone(), eng.momentum_buf.clone()))
+            assert eng.reducer.active == forced and eng._pipelined() == forced
             del eng
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert torch.equal(a, b)
     finally:
         if created:
             dist.destroy_process_group()
