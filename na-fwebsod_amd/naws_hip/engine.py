@@ -1096,6 +1096,7 @@ class WsddnEngine(object):
             ops.colsum(dl, out=gb8)
         red.reduce_async(message_slice(self.arena, G, *plan[-1], self.k6))
         if eager:
+            self._pipe_state['grads_ready'] = torch.cuda.current_stream(self.device).record_event()
             with torch.cuda.stream(self._upd_stream):
                 self._pipe_enqueue_tail()
                 self._upd_event = self._upd_stream.record_event()
@@ -1465,12 +1466,7 @@ class WsddnEngine(object):
     def _pipe_begin(self):
         """Start of one step's piece-by-piece update (current stream = the update stream)."""
         self._pipe_tables()
-        self._pipe_state = dict(arrived=0, events=[], tag=self.sgd_iter_count + 1, cev=None)
-        cev = getattr(self, 'comm_events', None)
-        if cev is not None:
-            c0 = torch.cuda.Event(enable_timing=True)
-            c0.record()
-            self._pipe_state['cev'] = c0
+        self._pipe_state = dict(arrived=0, events=[], tag=self.sgd_iter_count + 1, grads_ready=None)
 
     def _pipe_enqueue_bias(self):
         tb, b = self._pipe, self._pipe['bias']
@@ -1508,11 +1504,19 @@ class WsddnEngine(object):
     def _pipe_enqueue_tail(self):
         n6 = 2 * HIDDEN
         st, t, wp = self._pipe_state, self._pipe['tail'], self._wplanes
+        # bench.py (comm_events): how long this stream, with this rank's gradients complete, still
+        # waits for the exchange (queued from inside backward: `grads_ready` = the main stream's
+        # position behind the last gradient kernel)
+        cev = getattr(self, 'comm_events', None)
+        if cev is not None:
+            if st['grads_ready'] is not None:
+                self._upd_stream.wait_event(st['grads_ready'])
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
         self.reducer.wait()
-        if st['cev'] is not None:
-            c1 = torch.cuda.Event(enable_timing=True)
+        if cev is not None:
             c1.record()
-            self.comm_events.append((st['cev'], c1))
+            cev.append((c0, c1))
         uev = getattr(self, 'update_events', None)
         if uev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
