@@ -8,9 +8,10 @@ for r in rows:
     r['s']=int(r['Start_Timestamp']); r['e']=int(r['End_Timestamp'])
 rows.sort(key=lambda r:r['s'])
 fc6=[r for r in rows if 'gemm_x3_m16' in r['Kernel_Name'] and r['Grid_Size_X']=='262144' and (r["e"]-r["s"])>FC6_MIN_NS]
-# a step from the middle of the run: the last launches of a default bench.py belong to its
-# deferred-route loop (forward_backward + sgd_step), not to the timed train_step loop
-k=len(fc6)//2 if len(sys.argv)<4 else int(sys.argv[3])
+# a step from the middle of the TIMED loop: the second half of a default bench.py's fc6-forward
+# launches belongs to its deferred-route loop (forward_backward + sgd_step: the wgrad GEMM without
+# the SGD epilogue, the whole-arena update kernel), not to the train_step loop the headline times
+k=len(fc6)//4 if len(sys.argv)<4 else int(sys.argv[3])
 t0=fc6[k]['s']; t1=fc6[k+1]['s']
 win=[r for r in rows if r['s']>=t0 and r['s']<t1]
 def nm(r): return r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').split('(')[0][:50]
