@@ -386,3 +386,73 @@ def test_unlagged_loader_failure_stops_both_ranks_in_the_same_iteration():
     assert b['error'] == 'roi_data_loader failed'
     assert a['collectives'] == b['collectives']
     assert [i for i, _ in a['ran']] == [i for i, _ in b['ran']] == [0, 1, 2]
+
+
+def _pipelined_replay_worker(rank, world, port, q):
+    """As _replay_worker with the PIPELINED message order (round 5: fc6's biases first, fc6_w row
+    chunks, the rest) and the update's waits in the order engine._apply_update_pipelined issues
+    them: wait_first(1) for the biases, wait_first(chunks below each forward piece), wait() for
+    the rest - every wait_first must leave exactly the later messages in flight."""
+    sys.path.insert(0, os.path.join(ROOT, 'na-fwebsod_amd'))
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from naws_hip.reducer import ArenaReducer, message_plan, message_slice
+    arena, params, grads_of, k6, rows6, sgd = _replay_setup()
+    B = 2
+    g = grads_of(rank)
+    red = ArenaReducer(dist.group.WORLD, world)
+    red.log = log = []
+    plan = message_plan(arena, rows6, 4, red.active, pipelined=True)
+    covered = torch.zeros((arena.total,), dtype=torch.int32)
+    base = g.data_ptr()
+    for kind, rows in plan:
+        sl = message_slice(arena, g, kind, rows, k6)
+        o = (sl.data_ptr() - base) // 4
+        covered[o:o + sl.numel()] += 1
+        red.reduce_async(sl)
+    in_flight = [red.in_flight()]
+    red.wait_first(1)                               # the biases
+    in_flight.append(red.in_flight())
+    chunks = [rows for kind, rows in plan if kind == 'fc6_w']
+    arrived = 0
+    for piece_end in (rows6 // 2, rows6):           # the two forward pieces
+        need = sum(1 for r0, _r1 in chunks if r0 < piece_end)
+        red.wait_first(need - arrived)
+        arrived = need
+        in_flight.append(red.in_flight())
+    red.wait()
+    in_flight.append(red.in_flight())
+    p, m = sgd(params.clone(), g, gpu_num=world * B)
+    q.put((rank, p.numpy(), m.numpy(), [k for k, _ in plan], in_flight,
+           bool((covered == 1).all()), [n for _k, n in log]))
+    dist.destroy_process_group()
+
+
+def test_pipelined_message_order_over_gloo_equals_the_plain_order():
+    """The pipelined plan covers the gradient arena exactly once, starts with fc6's two bias
+    vectors, and - summed over gloo at world 2 and updated - gives bit for bit the parameters and
+    momentum of the plain order (a + b = b + a: cutting the small message in two changes nothing)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    res = {}
+    for target, tag in ((_replay_worker, 'plain'), (_pipelined_replay_worker, 'pipe')):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=target, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        out = [q.get(timeout=240) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        res[tag] = {o[0]: o for o in out}
+    for r in range(2):
+        plain, pipe = res['plain'][r], res['pipe'][r]
+        assert pipe[3] == ['fc6_b', 'fc6_w', 'fc6_w', 'fc6_w', 'fc6_w', 'rest']
+        assert pipe[4] == [6, 5, 3, 1, 0]            # in flight after each wait of the update
+        assert pipe[5]                                # every gradient element in exactly one message
+        assert pipe[6][0] == 2 * (4096 // 16) and sum(pipe[6]) == sum(plain[4])
+        assert np.array_equal(pipe[1], plain[1]) and np.array_equal(pipe[2], plain[2])
+    assert np.array_equal(res['pipe'][0][1], res['pipe'][1][1])
