@@ -1693,7 +1693,7 @@ class WsddnEngine(object):
         if seg is None:
             seg = self.segments(rois, n_img)
         seg_off = self._seg_to_device(seg)
-        conv5 = self.conv_body(data)
+        conv5 = self.conv_body(data, roi_job=(rois, obn_scores, seg))
         x = self._roi_features(conv5, rois, obn_scores)
         _h6, _h7, lg = self.head_forward(x, train=False, both_branches=False)
         C = self.C
