@@ -93,11 +93,22 @@ def extend_results(index, all_res, im_res):
         all_res[cls_idx][index] = im_res[cls_idx]
 
 
+def check_weights_file(weights_file):
+    """A non-empty TEST.WEIGHTS that does not exist is an error, as in the reference (its
+    initialize_gpu_from_weights_file opens the file, utils/net_wsl.py:64-66): evaluating the
+    randomly initialised model instead would write detections.pkl and exit 0.  Only
+    TEST.WEIGHTS == '' selects the no-weights synthetic smoke path."""
+    if weights_file and not os.path.exists(weights_file):
+        raise FileNotFoundError('TEST.WEIGHTS {!r} does not exist (an empty TEST.WEIGHTS runs the '
+                                'randomly initialised model on purpose)'.format(weights_file))
+
+
 def run_inference(weights_file, ind_range=None, multi_gpu_testing=False, gpu_id=0,
                   check_expected_results=False):
     """Parent (ind_range None): every dataset of TEST.DATASETS, in this process or - with
     multi_gpu_testing - through one child per GPU.  Child (ind_range given): that range of the
     single dataset named on its command line (reference :70-122)."""
+    check_weights_file(weights_file)         # before any child is started or any model is built
     is_parent = ind_range is None
     if is_parent:
         all_results = {}
@@ -171,12 +182,14 @@ def initialize_model_from_cfg(weights_file, gpu_id=0):
     from detectron.core.executor import NetExecutor
     import detectron.modeling.model_builder_wsl as model_builder
     import detectron.utils.net_wsl as nu
+    check_weights_file(weights_file)
     device = torch.device('cuda', int(gpu_id))
     torch.cuda.set_device(device)
     model = model_builder.create(cfg.MODEL.TYPE, train=False)
     ex = NetExecutor(model, device)
     ex.init_params()
-    if weights_file and os.path.exists(weights_file):
+    check_weights_file(weights_file)
+    if weights_file:
         nu.initialize_from_weights_file(model, weights_file, ex, broadcast=False)
     return model, ex
 

@@ -22,16 +22,27 @@ _RANK_VARS = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RAN
 
 
 def visible_gpu_inds(environ, num_gpus):
-    """The GPU index of every child (reference :57-65 reads CUDA_VISIBLE_DEVICES, else counts
-    down from NUM_GPUS - 1).  On ROCm the list is HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is
-    honoured as its alias); an index may repeat - two children on one GPU - which is how the
-    one-GPU box exercises this path."""
+    """The visible-device token of every child (reference :57-65 reads CUDA_VISIBLE_DEVICES, else
+    counts down from NUM_GPUS - 1).  On ROCm the list is HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES
+    is honoured as its alias; ROCR_VISIBLE_DEVICES, which renumbers the devices HIP sees, is
+    consulted when neither is set - then the children get HIP indices 0..n-1 of that renumbered
+    set).  Tokens are passed through as STRINGS: an entry may be an index or a `GPU-<uuid>`.  An
+    index may repeat - two children on one GPU - which is how the one-GPU box exercises this path.
+    A list shorter than NUM_GPUS starts fewer children, with a warning."""
     vis = environ.get('HIP_VISIBLE_DEVICES') or environ.get('CUDA_VISIBLE_DEVICES')
     if vis:
-        inds = [int(x) for x in vis.split(',')]
-        assert -1 not in inds, 'Hiding GPU indices using the \'-1\' index is not supported'
-        return inds[:num_gpus] if len(inds) >= num_gpus else inds
-    return list(reversed(range(num_gpus)))
+        inds = [x.strip() for x in vis.split(',') if x.strip()]
+        assert '-1' not in inds, 'Hiding GPU indices using the \'-1\' index is not supported'
+        inds = [int(x) if x.isdigit() else x for x in inds]
+    elif environ.get('ROCR_VISIBLE_DEVICES'):
+        n = len([x for x in environ['ROCR_VISIBLE_DEVICES'].split(',') if x.strip()])
+        inds = list(reversed(range(min(n, num_gpus))))
+    else:
+        return list(reversed(range(num_gpus)))
+    if len(inds) < num_gpus:
+        logger.warning('NUM_GPUS is %d but only %d device(s) are visible (%s): starting %d '
+                       'child(ren)', num_gpus, len(inds), ','.join(str(i) for i in inds), len(inds))
+    return inds[:num_gpus]
 
 
 def split_ranges(total_range_size, parts):
@@ -80,31 +91,71 @@ def process_in_parallel(tag, total_range_size, binary, output_dir, opts=()):
                       bufsize=1, universal_newlines=True)
         processes.append((i, p, start, end, out))
     outputs = []
-    for i, p, start, end, out in processes:
-        log_subprocess_output(i, p, output_dir, tag, start, end)
-        if i > 0:
-            out.close()
-        range_file = os.path.join(output_dir, '%s_range_%s_%s.pkl' % (tag, start, end))
-        outputs.append(load_object(range_file))
+    try:
+        for i, p, start, end, out in processes:
+            log_subprocess_output(i, p, output_dir, tag, start, end,
+                                  others=[q for _j, q, _s, _e, _o in processes if q is not p])
+            if i > 0:
+                out.close()
+            range_file = os.path.join(output_dir, '%s_range_%s_%s.pkl' % (tag, start, end))
+            outputs.append(load_object(range_file))
+    except BaseException:
+        # a failed child (or an interrupt): no sibling is left running on its GPU
+        terminate_all([p for _i, p, _s, _e, _o in processes])
+        raise
     return outputs
 
 
-def log_subprocess_output(i, p, output_dir, tag, start, end):
+def terminate_all(procs, grace=10.0):
+    """terminate(), then kill() whatever has not exited after `grace` seconds."""
+    import time
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        p.terminate()
+    t0 = time.time()
+    for p in live:
+        try:
+            p.wait(timeout=max(0.1, grace - (time.time() - t0)))
+        except _sp.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
+def first_failed(procs):
+    for p in procs:
+        rc = p.poll()
+        if rc is not None and rc != 0:
+            return rc
+    return None
+
+
+def log_subprocess_output(i, p, output_dir, tag, start, end, others=()):
     """The first child's output in real time, the others' once they have finished, in order
-    (reference :110-136).  A child that fails stops the parent."""
+    (reference :110-136).  A child that fails stops the parent - also a LATER child while an
+    earlier one is still running (`others` are polled while this one is waited for)."""
     outfile = os.path.join(output_dir, '%s_range_%s_%s.stdout' % (tag, start, end))
     logger.info('# ' + '-' * 76 + ' #')
     logger.info('stdout of subprocess %s with range [%s, %s]' % (i, start + 1, end))
     logger.info('# ' + '-' * 76 + ' #')
+
+    def check_others():
+        rc = first_failed(others)
+        assert rc is None, 'Range subprocess failed (exit code: {})'.format(rc)
     if i == 0:
         with open(outfile, 'w') as f:
             for line in iter(p.stdout.readline, ''):
                 print(line.rstrip())
                 f.write(line)
+                check_others()
         p.stdout.close()
         ret = p.wait()
     else:
-        ret = p.wait()
+        while True:
+            try:
+                ret = p.wait(timeout=1.0)
+                break
+            except _sp.TimeoutExpired:
+                check_others()
         with open(outfile, 'r') as f:
             print(''.join(f.readlines()))
     sys.stdout.flush()

@@ -573,6 +573,7 @@ class WsddnEngine(object):
         pooled = None
         if (roi_job is not None and planes and self.ROI_POOL_ON_CHAINS
                 and roi_job[0].shape[0] > 0 and len(roi_job[2]) == n + 1):
+            self._check_rows_grouped_by_image(roi_job[0], roi_job[2])
             pooled = ops.roi_pool_operand(roi_job[0].shape[0], self.k6, self.device)
         main = torch.cuda.current_stream(self.device)
         start = main.record_event()
@@ -632,8 +633,27 @@ class WsddnEngine(object):
                 done = st.record_event()
             main.wait_event(done)
         if pooled is not None:
-            self._roi_operand = (pooled, out.data_ptr(), roi_job[0].data_ptr())
+            # the operand belongs to exactly these tensors in exactly this state (_roi_features)
+            self._roi_operand = (pooled, out.data_ptr(), self._roi_job_key(roi_job[0], roi_job[1]))
         return out
+
+    @staticmethod
+    def _roi_job_key(rois, obn_scores):
+        return (rois.data_ptr(), rois._version, obn_scores.data_ptr(), obn_scores._version)
+
+    def _check_rows_grouped_by_image(self, rois, seg):
+        """Precondition of the per-image pooling on the conv streams: rows seg[i]..seg[i+1] of
+        `rois` carry batch index i (the kernel takes the image from rois[:,0], the stream from
+        seg).  Checked on the device, with a host sync, under NAWS_DEBUG_CHECKS=1 only."""
+        import os
+        if os.environ.get('NAWS_DEBUG_CHECKS') != '1':
+            return
+        want = torch.repeat_interleave(
+            torch.arange(len(seg) - 1, device=rois.device, dtype=rois.dtype),
+            torch.tensor([seg[i + 1] - seg[i] for i in range(len(seg) - 1)], device=rois.device))
+        if want.numel() != rois.shape[0] or not bool((rois[:, 0] == want).all().item()):
+            raise ValueError('rois must be grouped by image in order: rows seg[i]..seg[i+1] must '
+                             'carry batch index i (seg = %r)' % (list(seg),))
 
     def _seg_to_device(self, seg):
         """Per-image row offsets -> int32 device tensor WITHOUT stalling the host: a copy from
@@ -682,7 +702,8 @@ class WsddnEngine(object):
         planes written by the pooling kernel itself."""
         done = getattr(self, '_roi_operand', None)
         self._roi_operand = None
-        if done is not None and done[1] == conv5.data_ptr() and done[2] == rois.data_ptr() \
+        if done is not None and done[1] == conv5.data_ptr() \
+                and done[2] == self._roi_job_key(rois, obn_scores) \
                 and getattr(self, '_roi_maps_of', None) == (conv5.data_ptr(), conv5._version):
             self._roi_maps = None
             return done[0]                    # pooled per image at the tails of the conv chains
@@ -1266,10 +1287,27 @@ class WsddnEngine(object):
         want = self.pipeline_update
         if want is None:
             want = True
-        return bool(want and self.reducer.active and hasattr(self.reducer, 'wait_first')
-                    and self.mfma_dtype == 'fp16x2'
-                    and not self.sharded_update and self.iter_size == 1 and self.k6 % 256 == 0
-                    and self.fused_planes and (self.defer_update is None or self.defer_update))
+        on = bool(want and self.reducer.active and hasattr(self.reducer, 'wait_first')
+                  and self.mfma_dtype == 'fp16x2'
+                  and not self.sharded_update and self.iter_size == 1 and self.k6 % 256 == 0
+                  and self.fused_planes and (self.defer_update is None or self.defer_update))
+        if on and not getattr(self, '_pipe_warned', False):
+            self._pipe_warned = True
+            if self.pg is not None and self.world_size > 1:
+                import torch.distributed as dist
+                if dist.get_backend(self.pg) != 'gloo':
+                    # per-message Work.wait() on the update stream from inside backward,
+                    # SGD pieces between collectives still in flight, fc6 forward pieces gated on
+                    # per-piece events - validated over gloo (2 and 8 ranks on one GPU) and with
+                    # one-rank RCCL only; no multi-GPU node was ever available
+                    import warnings
+                    warnings.warn('NAWS.PIPELINE_UPDATE on backend %r with %d ranks has never run '
+                                  'on hardware (validated over gloo and one-rank RCCL only); '
+                                  'NAWS.PIPELINE_UPDATE False is the fallback: the one-launch update '
+                                  'behind the whole exchange.  bench.py checks the ranks\' state '
+                                  'digests after warm-up and falls back by itself on a stall'
+                                  % (dist.get_backend(self.pg), self.world_size))
+        return on
 
     def _apply_update(self):
         if self._pipe_ready():

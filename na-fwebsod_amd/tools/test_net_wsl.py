@@ -56,6 +56,9 @@ def main(argv=None):
         logger.info('Waiting for \'{}\' to exist...'.format(cfg.TEST.WEIGHTS))
         time.sleep(10)
         waited += 10
+    # still missing (no --wait, or the hour is over): an error, not a run on random weights
+    from detectron.core.test_engine_wsl import check_weights_file
+    check_weights_file(cfg.TEST.WEIGHTS)
     from detectron.core import test_engine_wsl
     res = test_engine_wsl.run_inference(cfg.TEST.WEIGHTS, ind_range=args.range,
                                         multi_gpu_testing=args.multi_gpu_testing,

@@ -75,7 +75,11 @@ def main(argv=None):
     if not args.skip_test and rank == 0:
         # Test the trained model (reference tools/train_net_wsl.py:118-160: the final checkpoint
         # with the yaml's TTA; the per-snapshot re-tests without TTA follow)
-        results = test_model(checkpoints['final'], args.multi_gpu_testing, world)
+        # N ranks trained: test through one fresh child per GPU by default, so that all N GPUs
+        # work and no test shares this process's HIP context and cached memory (rank 0 is only
+        # the children's parent; its engine / executor are gone once train_model has returned)
+        multi = args.multi_gpu_testing or world > 1
+        results = test_model(checkpoints['final'], multi, world)
         print('reprint snapshot name for the result: ', checkpoints['final'])
         _ = checkpoints.pop('final', None)
         if checkpoints:
@@ -85,7 +89,7 @@ def main(argv=None):
             core_config.cfg.VIS = False
             core_config.cfg.immutable(True)
             for snapshot in sorted(checkpoints.keys(), reverse=True):
-                test_model(checkpoints[snapshot], args.multi_gpu_testing, world)
+                test_model(checkpoints[snapshot], multi, world)
                 print('reprint snapshot name for the result: ', snapshot, checkpoints[snapshot])
     return results
 

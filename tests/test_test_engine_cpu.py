@@ -55,6 +55,12 @@ def test_split_ranges_and_gpu_inds():
     assert su.visible_gpu_inds({'CUDA_VISIBLE_DEVICES': '0,0'}, 2) == [0, 0]
     with pytest.raises(AssertionError):
         su.visible_gpu_inds({'HIP_VISIBLE_DEVICES': '0,-1'}, 2)
+    # UUID-style tokens pass through as strings; a short list starts fewer children
+    # (with a warning); ROCR_VISIBLE_DEVICES is consulted when the HIP list is unset
+    assert su.visible_gpu_inds({'HIP_VISIBLE_DEVICES': 'GPU-1a2b,3'}, 2) == ['GPU-1a2b', 3]
+    assert su.visible_gpu_inds({'HIP_VISIBLE_DEVICES': '4'}, 8) == [4]
+    assert su.visible_gpu_inds({'ROCR_VISIBLE_DEVICES': '2,3'}, 8) == [1, 0]
+    assert su.child_env({'PATH': '/bin'}, 'GPU-1a2b')['HIP_VISIBLE_DEVICES'] == 'GPU-1a2b'
 
 
 def test_child_command_and_environment(cfgmod):
@@ -95,16 +101,18 @@ def test_two_ranges_collate_to_the_single_run(cfgmod, tmp_path, monkeypatch):
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1')
     monkeypatch.setenv('RANK', '0')               # the parent of a torchrun job: must not leak
     monkeypatch.setenv('WORLD_SIZE', '2')
+    weights = tmp_path / 'model_final.pkl'       # (the fake children never open it)
+    weights.write_bytes(b'')
     # one "child" over everything = the single run
     _cfg(cfgmod, tmp_path / 'single', 5, 1)
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0')
-    res1 = te.run_inference('/nonexistent/model_final.pkl', multi_gpu_testing=True)
+    res1 = te.run_inference(str(weights), multi_gpu_testing=True)
     single = pickle.load(open(os.path.join(str(tmp_path / 'single'), 'test', 'synthetic',
                                            'generalized_wsl', 'detections.pkl'), 'rb'))
     # two children, ranges [0, 3) and [3, 5)
     _cfg(cfgmod, tmp_path / 'double', 5, 2)
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1')
-    res2 = te.run_inference('/nonexistent/model_final.pkl', multi_gpu_testing=True)
+    res2 = te.run_inference(str(weights), multi_gpu_testing=True)
     out = os.path.join(str(tmp_path / 'double'), 'test', 'synthetic', 'generalized_wsl')
     assert sorted(f for f in os.listdir(out) if f.endswith('.pkl')) == \
         ['detection_range_0_3.pkl', 'detection_range_3_5.pkl', 'detections.pkl']
@@ -176,6 +184,63 @@ def test_failed_child_stops_the_parent(cfgmod, tmp_path, monkeypatch):
     _cfg(cfgmod, tmp_path, 4, 2)
     with pytest.raises(AssertionError, match='Range subprocess failed'):
         te.run_inference('', multi_gpu_testing=True)
+
+
+def test_failed_later_child_terminates_its_siblings(cfgmod, tmp_path, monkeypatch):
+    """child 1 fails while child 0 is still running - the parent notices without
+    waiting for child 0 to finish, and no child is left behind."""
+    import time
+    from detectron.core import test_engine_wsl as te
+    import detectron.utils.env as envu
+    fake_dir = tmp_path / 'tools'
+    fake_dir.mkdir()
+    (fake_dir / 'test_net_wsl.py').write_text(textwrap.dedent('''
+        import os, sys, time
+        a = sys.argv
+        start = int(a[a.index('--range') + 1])
+        if start > 0:
+            sys.exit(7)
+        open(os.path.join(%r, 'child0.pid'), 'w').write(str(os.getpid()))
+        for _ in range(600):
+            print('still running', flush=True)
+            time.sleep(0.1)
+    ''') % str(tmp_path))
+    monkeypatch.setattr(envu, 'get_runtime_dir', lambda: str(fake_dir))
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1')
+    _cfg(cfgmod, tmp_path, 4, 2)
+    t0 = time.time()
+    with pytest.raises(AssertionError, match='Range subprocess failed'):
+        te.run_inference('', multi_gpu_testing=True)
+    assert time.time() - t0 < 30            # (child 0 alone would run for a minute)
+    pid = int(open(str(tmp_path / 'child0.pid')).read())
+    time.sleep(0.2)
+    with pytest.raises(OSError):
+        os.kill(pid, 0)                     # terminated and reaped
+
+
+def test_missing_weights_file_is_an_error(cfgmod, tmp_path):
+    """ADVICE r5 (medium): a non-empty TEST.WEIGHTS that does not exist must not fall through to
+    the randomly initialised model - neither in the parent (before any child starts), nor in a
+    child / single process, nor in the CLI after its --wait loop gave up."""
+    from detectron.core import test_engine_wsl as te
+    _cfg(cfgmod, tmp_path, 2, 1)
+    missing = str(tmp_path / 'model_final.pkl')
+    with pytest.raises(FileNotFoundError, match='TEST.WEIGHTS'):
+        te.run_inference(missing)
+    with pytest.raises(FileNotFoundError):
+        te.run_inference(missing, multi_gpu_testing=True)
+    with pytest.raises(FileNotFoundError):
+        te.run_inference(missing, ind_range=(0, 1))
+    with pytest.raises(FileNotFoundError):
+        te.initialize_model_from_cfg(missing)
+    te.check_weights_file('')               # the synthetic smoke path stays available
+    # the CLI: no --wait -> immediately
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'na-fwebsod_amd', 'tools', 'test_net_wsl.py'),
+                        '--cfg', YAML, '--wait', '', 'OUTPUT_DIR', str(tmp_path), 'TEST.WEIGHTS', missing],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and 'FileNotFoundError' in r.stderr, r.stderr[-1500:]
+    assert not any(f.endswith('.pkl') for _d, _s, fs in os.walk(str(tmp_path)) for f in fs)
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/detectron'),
