@@ -11,6 +11,20 @@ for p in (ROOT, os.path.join(ROOT, 'na-fwebsod_amd')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run on the GPU box)')
+    config.addinivalue_line('markers', 'ab: checks a kernel form that LOST its A/B and exists only in '
+                                       'the A/B build (make AB=1 -> libnaws_hip_ab.so); collected '
+                                       'only when NAWS_LIB points at that library')
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests of A/B-only kernel forms are not part of the product suite: deselected (not skipped)
+    unless the run is pointed at the A/B library, so `-m gpu` reports no skips for them."""
+    if 'libnaws_hip_ab' in os.environ.get('NAWS_LIB', ''):
+        return
+    drop = [it for it in items if it.get_closest_marker('ab') is not None]
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = [it for it in items if it.get_closest_marker('ab') is None]
 
 
 @pytest.fixture(scope='session')

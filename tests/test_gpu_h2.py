@@ -244,6 +244,7 @@ def test_conv3x3_winograd_f16x2(dev, cin, cout, dil, h, w, amp):
     assert np.abs(ops.nhwc_to_nchw(y4).cpu().numpy() - ref).max() < 1e-5 * scale
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize('cin,cout,dil,h,w,amp', [(512, 512, 1, 75, 125, 3.0), (512, 512, 2, 74, 124, 0.02),
                                                    (64, 128, 1, 37, 41, 50.0), (256, 512, 2, 19, 23, 1.0)])
 def test_conv3x3_winograd_f16x2_frequency_columns(dev, cin, cout, dil, h, w, amp):
