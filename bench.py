@@ -62,6 +62,17 @@ def parse():
                     help='N > 1: wait for the whole gradient exchange and update in one launch '
                          '(NAWS.PIPELINE_UPDATE False) instead of piece by piece with fc6 forward '
                          'starting behind each piece')
+    ap.add_argument('--drop-sharded-update', action='store_true',
+                    help='cancels --sharded-update (the supervisor\'s fallback attempts append flags '
+                         'to the original command line)')
+    ap.add_argument('--no-supervisor', action='store_true',
+                    help='N > 1: run the rank in THIS process instead of as a watched child of a '
+                         'per-rank supervisor (naws_hip/supervise.py: per-phase watchdog, fresh '
+                         'workers on the unpipelined route after a stall, a death or a rank-digest '
+                         'mismatch)')
+    ap.add_argument('--no-route-ab', action='store_true',
+                    help='N > 1: skip the in-run A/B of the update routes after the timed region '
+                         '(value_unpipelined / value_pipelined, value_sharded)')
     ap.add_argument('--no-projection', action='store_true',
                     help='skip the N-rank contention projections (profile runs: their proxy kernel '
                          'and chunked wgrad launches would otherwise sit in the kernel tables)')
@@ -589,6 +600,336 @@ X3_KERNEL_NAME = ('gemm_x3_m16_kernel<256,128,4x2 waves,2 stages,3 planes x 2 K-
                   'v_mfma_f32_16x16x32_bf16 per fp32 product')
 
 
+# ---------------------------------------------------------------------------------------------
+# N > 1 hardening: the same five functions serve the GPU job (EngineJob) and
+# the --dry-run job on CPU tensors over gloo (DryJob), so the CPU tests exercise the very code
+# the first multi-GPU RCCL run will execute.
+# ---------------------------------------------------------------------------------------------
+def state_digest(tensors):
+    """int64 [2 * len(tensors)]: per buffer (sum of its words, position-weighted sum of its
+    words), both exact integer sums of the raw bit patterns - equal on two ranks iff (up to a 2^-64
+    accident) the buffers are bit-identical.  Chunked: the 957.7 MB arenas are never widened to
+    int64 as a whole."""
+    import torch
+    out = []
+    weights = {}
+    for t in tensors:
+        v = t.detach().contiguous().view(-1)
+        v = v.view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[v.element_size()])
+        s1 = torch.zeros((), dtype=torch.int64, device=v.device)
+        s2 = torch.zeros((), dtype=torch.int64, device=v.device)
+        step = 1 << 24
+        for o in range(0, v.numel(), step):
+            c = v[o:o + step].to(torch.int64)
+            key = (c.numel(), str(v.device))
+            if key not in weights:
+                weights[key] = torch.arange(c.numel(), device=v.device, dtype=torch.int64) % 8191 + 1
+            s1 += c.sum()
+            s2 += (c * weights[key]).sum() + (o // step) * 7 * c.sum()
+        out += [s1, s2]
+    return torch.stack(out)
+
+
+def ranks_agree(job, pg, rank, world):
+    """(True when every rank holds bit-identical state, [names of the buffers that differ]).
+    COLLECTIVE.  One all-reduce of a [world, 2 * buffers] int64 table."""
+    import torch
+    import torch.distributed as dist
+    names, tensors = zip(*sorted(job.state_tensors().items()))
+    dig = state_digest(tensors)
+    table = torch.zeros((world, dig.numel()), dtype=torch.int64, device=dig.device)
+    table[rank] = dig
+    dist.all_reduce(table, group=pg)
+    same = (table == table[0:1]).all(dim=0).cpu().tolist()
+    bad = sorted({names[i // 2] for i, ok in enumerate(same) if not ok})
+    return not bad, bad
+
+
+def bare_allreduce(job, pg, world, iters=5, warm=2):
+    """The gradient exchange ALONE: the step's own messages (job.message_slices(): fc6_w's
+    gradient in its row chunks, then the small gradients - the same slices of the same arena),
+    handed to the collective back to back with no compute beside them.  -> (ms per exchange,
+    bus bandwidth in GB/s = 2 (N-1)/N x bytes / time, bytes)."""
+    import torch.distributed as dist
+    slices = job.message_slices()
+    nbytes = sum(int(x.numel()) * x.element_size() for x in slices)
+
+    def once():
+        works = [dist.all_reduce(x, group=pg, async_op=True) for x in slices]
+        for w in works:
+            w.wait()
+        job.sync()
+    for _ in range(warm):
+        once()
+    dist.barrier(group=pg)
+    job.sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        once()
+    dist.barrier(group=pg)
+    job.sync()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    bus = 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9 if world > 1 else 0.0
+    for x in slices:
+        x.zero_()                   # (sums of zeros stay zeros; a dry-run arena is reset too)
+    return ms, bus, nbytes
+
+
+def timed_steps(job, pg, rank, world, steps, warm=0):
+    """`warm` untimed + `steps` timed steps of the job's CURRENT route between barrier + device
+    sync on both sides; -> (seconds of the slowest rank, [seconds per rank]).  COLLECTIVE."""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warm):
+        job.step(False)
+    job.flush()
+    if pg is not None:
+        dist.barrier(group=pg)
+    job.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step(True)
+    job.flush()          # the last iteration's (deferred) all-reduce + SGD belongs to the K steps
+    if pg is not None:
+        dist.barrier(group=pg)
+    job.sync()
+    dt = time.perf_counter() - t0
+    rank_dt = [dt]
+    if pg is not None:
+        td = torch.zeros((world,), device=job.device, dtype=torch.float64)
+        td[rank] = dt
+        dist.all_reduce(td, group=pg)
+        rank_dt = td.cpu().tolist()
+    return max(rank_dt), rank_dt
+
+
+def route_ab(job, pg, rank, world, steps, hb, images_per_step):
+    """After the timed region, in the SAME job: K steps of the other update routes, each between
+    its own barriers, each followed by the rank-digest check.  -> flat keys for the line.
+    `value` stays the default route's; a leg that cannot run says why."""
+    from naws_hip.reducer import owner_blocks
+    out = {}
+    was = job.route()
+    legs = []
+    if was['sharded']:
+        legs = [('unpipelined', dict(pipeline_update=False, sharded_update=False))]
+    else:
+        other = not was['pipelined']
+        legs.append(('pipelined' if other else 'unpipelined',
+                     dict(pipeline_update=None if other else False, sharded_update=False)))
+        if owner_blocks(job.rows6, world) is not None and job.can_shard:
+            legs.append(('sharded', dict(pipeline_update=False, sharded_update=True)))
+        else:
+            out['value_sharded'] = None
+            out['sharded_skipped'] = 'fc6_w rows do not divide into 32-row blocks over %d ranks' % world
+    for name, route in legs:
+        hb.phase('ab_' + name, steps=steps + 3)
+        job.set_route(**route)
+        got = job.route()
+        if (name == 'pipelined') != got['pipelined'] or (name == 'sharded') != got['sharded']:
+            out['value_' + name] = None          # (the plan cannot take that route: said, not faked)
+            out[name + '_skipped'] = 'route not available on this plan'
+            continue
+        dt, _ = timed_steps(job, pg, rank, world, steps, warm=3)
+        out['value_' + name] = round(world * images_per_step * steps / dt, 3)
+        out['ms_per_step_' + name] = round(dt / steps * 1e3, 3)
+        ok, bad = ranks_agree(job_after_gather(job), pg, rank, world)
+        out['rank_digest_equal_' + name] = bool(ok)
+        if not ok:
+            out['rank_digest_differs_' + name] = ','.join(bad)
+    job.set_route(pipeline_update=None if was['pipelined'] else False, sharded_update=was['sharded'])
+    return out
+
+
+def job_after_gather(job):
+    job.gather_sharded_state()       # (COLLECTIVE; no-op off the sharded route)
+    return job
+
+
+class EngineJob(object):
+    """WsddnEngine + its resident inputs behind the few calls the N > 1 skeleton needs."""
+
+    def __init__(self, eng, t, seg, two_call=False):
+        self.eng, self.t, self.seg, self.two_call = eng, t, seg, two_call
+        self.device = eng.device
+        self.rows6 = 8192
+        self.can_shard = eng.mfma_dtype == 'fp16x2' and eng.iter_size == 1
+        self.timed_hooks = None       # (ev, pev, uev, cev) lists while the headline region runs
+        self.last = None
+        self.probe_fn, self.first_probe = None, None
+
+    def step(self, timed):
+        e, t = self.eng, self.t
+        hooks = self.timed_hooks if timed and self.timed_hooks else (None, None, None, None)
+        e.timing_events, e.phase_events, e.update_events, e.comm_events = hooks
+        if self.two_call:
+            out = e.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=self.seg)
+            e.sgd_step()
+        else:       # the same two calls; without a gradient exchange fc6_w is updated by its wgrad GEMM
+            out = e.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=self.seg)
+        self.last = out
+        if self.first_probe is None and self.probe_fn is not None:
+            self.first_probe = self.probe_fn(out)
+        return out
+
+    def flush(self):
+        self.eng.flush()
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def state_tensors(self):
+        return self.eng.state_tensors()
+
+    def gather_sharded_state(self):
+        self.eng.gather_sharded_state()
+
+    def broadcast_parameters(self):
+        self.eng.broadcast_parameters(0)
+
+    def message_slices(self):
+        from naws_hip.reducer import message_plan, message_slice
+        e = self.eng
+        plan = message_plan(e.arena, 2 * 4096, e.allreduce_chunks, True, False)
+        return [message_slice(e.arena, e.grads, k, r, e.k6) for k, r in plan]
+
+    def route(self):
+        e = self.eng
+        return dict(pipelined=bool(e._pipelined()), sharded=bool(e._shard_blocks() is not None))
+
+    def set_route(self, pipeline_update=None, sharded_update=False):
+        self.eng.set_update_route(pipeline_update, sharded_update)
+
+
+class DryJob(object):
+    """--dry-run: the N > 1 skeleton on a small CPU parameter arena over gloo - real message
+    plans, the real ArenaReducer, a trivial deterministic 'gradient' - so that broadcast, rank
+    digests, the bare exchange, the route A/B and the supervisor's fallbacks run on a CPU box."""
+
+    def __init__(self, pg, rank, world, pipelined, sharded, chunks):
+        import torch
+        from naws_hip.engine import ParamArena
+        from naws_hip.reducer import ArenaReducer
+        self.device = torch.device('cpu')
+        self.pg, self.rank, self.world = pg, rank, world
+        self.rows6, self.k6, self.can_shard = 256, 48, True
+        h, c = 128, 5
+        specs = [('fc6_w', (h, self.k6)), ('_[noisy]_fc6_w', (h, self.k6)), ('fc6_b', (h,)),
+                 ('_[noisy]_fc6_b', (h,)), ('fc7_w', (h, h)), ('_[noisy]_fc7_w', (h, h)),
+                 ('fc7_b', (h,)), ('_[noisy]_fc7_b', (h,)), ('fc8c_w', (c, h)), ('fc8d_w', (c, h)),
+                 ('noisy_fc8c_w', (c, h)), ('noisy_fc8d_w', (c, h)), ('fc8c_b', (c,)),
+                 ('fc8d_b', (c,)), ('noisy_fc8c_b', (c,)), ('noisy_fc8d_b', (c,))]
+        self.arena = ParamArena(specs, self.device)
+        g = torch.Generator().manual_seed(11 + 100 * rank)   # every rank starts DIFFERENT
+        self.params = torch.randn((self.arena.total,), generator=g)
+        self.momentum = torch.randn((self.arena.total,), generator=g)
+        self.grads = torch.zeros((self.arena.total,))
+        self.reducer = ArenaReducer(pg, world)
+        self.reducer.force = pg is not None
+        self.pipelined, self.sharded, self.chunks = bool(pipelined), bool(sharded), int(chunks)
+        self.it = 0
+        self.inject = os.environ.get('NAWS_BENCH_INJECT', '')
+
+    def _inject(self, what):
+        """NAWS_BENCH_INJECT='<what>:<route>:<rank>[:<step>]' - the tests' stall / death / divergence
+        on one rank of one route (what in stall, die, diverge)."""
+        p = self.inject.split(':')
+        if len(p) < 3 or p[0] != what or int(p[2]) != self.rank:
+            return False
+        route = 'sharded' if self.sharded else 'pipelined' if self.pipelined else 'unpipelined'
+        return p[1] in (route, 'any') and self.it >= int(p[3] if len(p) > 3 else 0)
+
+    def step(self, timed):
+        import torch
+        from naws_hip.reducer import message_plan, message_slice, owner_blocks, owner_pieces
+        if self._inject('stall'):
+            time.sleep(3600)
+        if self._inject('die'):
+            os._exit(9)
+        time.sleep(0.001)
+        g = torch.Generator().manual_seed(1000 * self.it + self.rank)
+        self.grads.copy_(torch.randint(-8, 9, (self.arena.total,), generator=g).float() / 64.0)
+        if self._inject('diverge'):
+            self.grads[0] += 1.0
+        blocks = owner_blocks(self.rows6, self.world) if self.sharded else None
+        o6 = self.arena.offsets['fc6_w'][0]
+        for kind, rows in message_plan(self.arena, self.rows6, self.chunks, True, self.pipelined):
+            sl = message_slice(self.arena, self.grads, kind, rows, self.k6)
+            if blocks is not None and kind == 'fc6_w':
+                for o, p0, p1 in owner_pieces(rows[0], rows[1], blocks):
+                    self.reducer.reduce_to_owner_async(
+                        self.grads[o6 + p0 * self.k6:o6 + p1 * self.k6], o)
+            else:
+                self.reducer.reduce_async(sl)
+        self.reducer.wait()
+        if self._inject('diverge'):
+            self.grads[0] += float(self.rank + 1)     # AFTER the sum: this rank's state walks off
+        lr = 1.0 / 1024
+        if blocks is None:
+            self.momentum.mul_(0.5).add_(self.grads, alpha=lr / self.world)
+            self.params.sub_(self.momentum)
+        else:       # owner-only update of fc6_w's rows, everything else everywhere, rows gathered
+            b0, b1 = blocks[self.rank]
+            mine = slice(o6 + b0 * self.k6, o6 + b1 * self.k6)
+            rest = slice(o6 + self.rows6 * self.k6, self.arena.total)
+            for s_ in (mine, rest):
+                self.momentum[s_].mul_(0.5).add_(self.grads[s_], alpha=lr / self.world)
+                self.params[s_].sub_(self.momentum[s_])
+            self.reducer.gather_blocks_async(self.params[o6:o6 + self.rows6 * self.k6], self.rank)
+            self.reducer.wait()
+            self._mom_local = True
+        self.it += 1
+
+    def flush(self):
+        pass
+
+    def sync(self):
+        pass
+
+    def state_tensors(self):
+        return dict(params=self.params, momentum=self.momentum)
+
+    def gather_sharded_state(self):
+        if getattr(self, '_mom_local', False):
+            o6 = self.arena.offsets['fc6_w'][0]
+            self.reducer.gather_blocks_async(self.momentum[o6:o6 + self.rows6 * self.k6], self.rank)
+            self.reducer.wait()
+            self._mom_local = False
+
+    def broadcast_parameters(self):
+        import torch.distributed as dist
+        dist.broadcast(self.params, 0, group=self.pg)
+        dist.broadcast(self.momentum, 0, group=self.pg)
+
+    def message_slices(self):
+        from naws_hip.reducer import message_plan, message_slice
+        return [message_slice(self.arena, self.grads, k, r, self.k6)
+                for k, r in message_plan(self.arena, self.rows6, self.chunks, True, False)]
+
+    def route(self):
+        return dict(pipelined=self.pipelined and not self.sharded, sharded=self.sharded)
+
+    def set_route(self, pipeline_update=None, sharded_update=False):
+        self.gather_sharded_state()
+        self.pipelined = pipeline_update is None or bool(pipeline_update)
+        self.sharded = bool(sharded_update)
+
+
+def init_process_group(backend, rank, world, dev=None):
+    """env:// rendezvous (the launcher's store) on the first attempt; a supervisor's fallback
+    attempt rendezvouses through a FileStore of its own (NAWS_BENCH_STORE): the launcher's TCP
+    store still holds the keys of the attempt that was killed."""
+    import torch.distributed as dist
+    kw = {}
+    if os.environ.get('NAWS_BENCH_STORE'):
+        kw['init_method'] = 'file://' + os.environ['NAWS_BENCH_STORE']
+    if dev is not None:
+        kw['device_id'] = dev
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist.group.WORLD
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -678,45 +1019,124 @@ def emit(res):
     print(json.dumps(res), flush=True)
 
 
+def n_rank_prologue(job, pg, rank, world, args, hb):
+    """What every N > 1 job does before its first step: rank 0's parameters to every rank
+    (reference: utils/net_wsl.py:183-207 - the ranks are seeded DIFFERENTLY on purpose, so the
+    check below fails without the broadcast), then the gradient exchange alone.  -> keys."""
+    out = {}
+    hb.phase('setup')
+    same_before, _ = ranks_agree(job, pg, rank, world)
+    job.broadcast_parameters()
+    same_after, bad = ranks_agree(job, pg, rank, world)
+    out['params_broadcast_from_rank0'] = True
+    out['ranks_equal_before_broadcast'] = bool(same_before)
+    if not same_after:
+        print('bench.py: ranks differ AFTER the parameter broadcast: %s' % ','.join(bad),
+              file=sys.stderr, flush=True)
+        sys.exit(EXIT_DIGEST_MISMATCH)
+    hb.phase('allreduce_alone')
+    share = getattr(args, 'share_gpu', False)
+    ms, bus, nbytes = bare_allreduce(job, pg, world, iters=2 if share else 5, warm=1 if share else 2)
+    out.update(allreduce_alone_ms=round(ms, 3), allreduce_busbw_GBps=round(bus, 2),
+               allreduce_bytes=nbytes)
+    return out
+
+
+EXIT_DIGEST_MISMATCH = 4        # (= naws_hip.supervise.EXIT_DIGEST_MISMATCH)
+
+
+def check_rank_digests(job, pg, rank, world, hb, where):
+    """COLLECTIVE.  Exit code 4 on every rank when the ranks' states differ (under the
+    supervisor: fresh workers on the next route of the ladder)."""
+    hb.phase('digest')
+    ok, bad = ranks_agree(job_after_gather(job), pg, rank, world)
+    if not ok:
+        if rank == 0:
+            print('bench.py: the ranks hold DIFFERENT state %s: %s (route %s)'
+                  % (where, ','.join(bad), json.dumps(job.route())), file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(EXIT_DIGEST_MISMATCH)      # (no teardown: a diverged job's collectives may not match)
+    return True
+
+
+def save_main_line(res):
+    """Rank 0, as soon as the headline exists: the supervisor prints this file if a LATER leg
+    (route A/B, extras) stalls or dies."""
+    path = os.environ.get('NAWS_BENCH_MAINLINE')
+    if path:
+        with open(path + '.tmp', 'w') as f:
+            json.dump(res, f)
+        os.replace(path + '.tmp', path)
+
+
+def fallback_keys():
+    fb = os.environ.get('NAWS_BENCH_FALLBACK')
+    return dict(route_fallback=fb, route_attempt=int(os.environ.get('NAWS_BENCH_ATTEMPT', '0')),
+                route_of_attempt=os.environ.get('NAWS_BENCH_ROUTE', 'as launched'),
+                supervised=os.environ.get('NAWS_BENCH_WORKER') == '1')
+
+
 def dry_run(args, rank, world):
-    """The rank skeleton of main() without a GPU (tests/test_bench_launcher.py)."""
-    import torch
+    """The rank skeleton of main() without a GPU (tests/test_bench_launcher.py): rendezvous over
+    gloo, parameter broadcast, bare exchange, warm-up, rank-digest check, K timed steps between
+    barriers, max over ranks, the route A/B legs, ONE JSON line - on DryJob's CPU arena."""
     import torch.distributed as dist
+    from naws_hip.supervise import Heartbeat
+    hb = Heartbeat()
+    hb.phase('init')
     if os.environ.get('NAWS_DRY_RUN_FAIL_RANK') == str(rank):
         sys.exit(3)                      # the launcher test's failing rank
+    pg = None
     if world > 1 or args.force_dist:
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        pg = init_process_group('gloo', rank, world)
+    job = DryJob(pg, rank, world, pipelined=not args.no_pipeline_update and not args.sharded_update,
+                 sharded=args.sharded_update, chunks=args.allreduce_chunks or (4 if world == 2 else 2))
+    extra = {}
+    if pg is not None:
+        extra.update(n_rank_prologue(job, pg, rank, world, args, hb))
+    hb.phase('warmup', steps=args.warmup)
     for _ in range(args.warmup):
-        time.sleep(0.001)
-    if dist.is_initialized():
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(0.001 * (1 + rank))
-    if dist.is_initialized():
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    rank_dt = [dt]
-    if dist.is_initialized():
-        td = torch.zeros((world,), dtype=torch.float64)
-        td[rank] = dt
-        dist.all_reduce(td)
-        rank_dt = td.tolist()
-        dt = max(rank_dt)
+        job.step(False)
+    if pg is not None:
+        extra['rank_digest_equal'] = check_rank_digests(job, pg, rank, world, hb, 'after warm-up')
+    hb.phase('timed', steps=args.steps)
+    dt, rank_dt = timed_steps(job, pg, rank, world, args.steps)
+    if pg is not None:
+        check_rank_digests(job, pg, rank, world, hb, 'after the timed steps')
+    res = None
+    if rank == 0:
+        res = {'metric': 'dry-run (no GPU work; launcher / rendezvous / N-rank skeleton check only)',
+               'value': None, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none',
+               'data': 'none',
+               'config': {'workload': 'dry-run', 'parallelism': 'dp%d' % world,
+                          'rccl_world_size': world,
+                          'pipelined_update': job.route()['pipelined'],
+                          'sharded_update': job.route()['sharded'],
+                          'ms_per_step_rank_min': round(min(rank_dt) / args.steps * 1e3, 3),
+                          'ms_per_step_rank_max': round(max(rank_dt) / args.steps * 1e3, 3),
+                          'launched_by_bench': os.environ.get('NAWS_BENCH_CHILD') == '1'}}
+        res.update(extra)
+        res.update(fallback_keys())
+        res['config'].update({k: v for k, v in res.items()
+                              if k in extra or k.startswith('route_') or k == 'supervised'})
+        save_main_line(res)
+    hb.phase('main_done')
+    if pg is not None and not args.no_route_ab:
+        legs = route_ab(job, pg, rank, world, args.steps, hb, 1)
+        if rank == 0:
+            res.update(legs)
+            res['config'].update(legs)
+    hb.phase('emit')
+    if pg is not None:
         dist.destroy_process_group()
     if rank == 0:
         print('rank 0: some library banner after which the line must still come last')
-        emit({'metric': 'dry-run (no GPU work; launcher / rendezvous check only)', 'value': None,
-              'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-              'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-              'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'none',
-              'config': {'workload': 'dry-run', 'parallelism': 'dp%d' % world,
-                         'rccl_world_size': world,
-                         'ms_per_step_rank_min': round(min(rank_dt) / args.steps * 1e3, 3),
-                         'ms_per_step_rank_max': round(max(rank_dt) / args.steps * 1e3, 3),
-                         'launched_by_bench': os.environ.get('NAWS_BENCH_CHILD') == '1'}})
+        emit(res)
     else:
         print('rank %d: noise on stdout' % rank, flush=True)
+    hb.phase('done', printed=True)
 
 
 def main():
@@ -728,7 +1148,6 @@ def main():
         # a bare `python bench.py --gpus N`: this process becomes the launcher (before anything
         # here has touched the GPU) and the ranks run as its children
         return self_launch(args, sys.argv[1:])
-    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world:
         sys.exit('bench.py: --gpus %d inside a %d-rank job (WORLD_SIZE=%d): launch it with '
@@ -736,27 +1155,39 @@ def main():
                  'own ranks' % (args.gpus, world, world, args.gpus, args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.drop_sharded_update:
+        args.sharded_update = False
+    if world > 1 and not args.no_supervisor and os.environ.get('NAWS_BENCH_WORKER') != '1':
+        # A rank of an N > 1 job: THIS process stays a supervisor (it has not touched the GPU and
+        # never will) and runs the rank as a watched child - per-phase watchdog; after a stall, a
+        # death or a rank-digest mismatch every rank's supervisor starts a FRESH worker on the
+        # next route of the ladder (naws_hip/supervise.py)
+        from naws_hip.supervise import supervise_rank
+        sys.exit(supervise_rank(os.path.abspath(__file__), sys.argv[1:]))
     if args.dry_run:
         return dry_run(args, rank, world)
+    from naws_hip.supervise import Heartbeat
+    hb = Heartbeat()
+    hb.phase('init')
+    import torch
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
     if world > 1 or args.force_dist:
-        import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         if args.share_gpu:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+            pg = init_process_group('gloo', rank, world)
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        pg = dist.group.WORLD
+            pg = init_process_group('nccl', rank, world, dev)
     from detectron.datasets import synthetic
     from naws_hip.engine import WsddnEngine
 
     num_fg = args.classes
     B = args.images_per_gpu
+    hb.phase('setup')
     eng = WsddnEngine(num_fg + 1, dev, dilation=2, dropout=0.5, is_mean=True, momentum=0.9,
                       weight_decay=5e-4, iter_size=1, gpu_num=world * B, seed=11,
                       process_group=pg, world_size=world, allreduce_chunks=args.allreduce_chunks,
@@ -766,7 +1197,10 @@ def main():
         eng.reducer.force = True
     if args.no_conv_streams:
         eng.conv_streams = False
-    blobs = synthetic.init_blobs(num_fg, seed=11)     # identical on every rank (= broadcast)
+    # Rank 0 holds the seeded initial weights; every other rank starts from a DIFFERENT seed and
+    # receives rank 0's blobs by broadcast (reference: utils/net_wsl.py:183-207 copies GPU 0's
+    # blobs to the other GPUs) - identical seeds on every rank would hide a broken broadcast
+    blobs = synthetic.init_blobs(num_fg, seed=11 if rank == 0 else 1000 + rank)
     eng.set_conv_blobs(blobs)
     eng.set_head_blobs(blobs)
     del blobs
@@ -777,6 +1211,10 @@ def main():
     counts = np.bincount(mb['rois'][:, 0].astype(np.int64), minlength=B)
     seg = [0] + np.cumsum(counts).tolist()        # per-image row offsets, known on the host
     eng.set_lr(args.lr)
+    job = EngineJob(eng, t, seg, two_call=args.no_fused_update)
+    nrank = {}
+    if pg is not None:
+        nrank.update(n_rank_prologue(job, pg, rank, world, args, hb))
 
     # live timing of the dominant kernel (fc6 forward GEMM, N = 8192) with HIP events on
     # the launch stream
@@ -785,55 +1223,35 @@ def main():
     uev = []     # the fused SGD kernel, on the update stream
     cev = []     # update stream: from "gradients complete" to "all-reduce complete"
 
-    probe0 = []
+    job.timed_hooks = (ev, pev, uev, cev)
+    inject = os.environ.get('NAWS_BENCH_INJECT', '').split(':')   # tests: 'stall:<route>:<rank>'
 
-    def step(timed):
-        out = _step(timed)
-        if not probe0:
-            probe0.append(step0_probe(out))
-        return out
+    def injected_stall():
+        if len(inject) >= 3 and inject[0] == 'stall' and int(inject[2]) == rank:
+            r = job.route()
+            name = 'sharded' if r['sharded'] else 'pipelined' if r['pipelined'] else 'unpipelined'
+            if inject[1] in (name, 'any'):
+                time.sleep(3600)           # (host-side: the other ranks wait in their collectives)
 
-    def _step(timed):
-        if timed:
-            eng.timing_events = ev
-            eng.phase_events = pev
-            eng.update_events = uev
-            eng.comm_events = cev
-        else:
-            eng.timing_events = None
-            eng.phase_events = None
-            eng.update_events = None
-            eng.comm_events = None
-        if args.no_fused_update:
-            out = eng.forward_backward(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
-            eng.sgd_step()
-        else:       # the same two calls; without a gradient exchange fc6_w is updated by its wgrad GEMM
-            out = eng.train_step(t['data'], t['rois'], t['obn_scores'], t['labels_oh'], seg=seg)
-        return out
-
-    for _ in range(args.warmup):
-        out = step(False)
+    hb.phase('warmup', steps=args.warmup)
+    job.probe_fn = step0_probe          # the in-run parity check compares every plan's FIRST step
+    for i in range(args.warmup):
+        job.step(False)
     eng.flush()
     if pg is not None:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
+        # every rank must hold bit-identical parameters, momentum, operand planes and scales
+        # after W real updates - BEFORE anything is timed (exit 4 otherwise)
+        nrank['rank_digest_equal'] = check_rank_digests(job, pg, rank, world, hb, 'after warm-up')
+    hb.phase('timed', steps=args.steps)
+    injected_stall()
     eng.reducer.log = msg_log = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
-    eng.flush()          # the last iteration's (deferred) all-reduce + SGD belongs to the K steps
-    if pg is not None:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, rank_dt = timed_steps(job, pg, rank, world, args.steps)
     eng.reducer.log = None
-    rank_dt = [dt]
+    out = job.last
+    probe0 = [job.first_probe]
     if pg is not None:
-        td = torch.zeros((world,), device=dev, dtype=torch.float64)
-        td[rank] = dt
-        torch.distributed.all_reduce(td, op=torch.distributed.ReduceOp.SUM)
-        rank_dt = td.cpu().tolist()
-        dt = max(rank_dt)               # the job's time is its slowest rank's
+        check_rank_digests(job, pg, rank, world, hb, 'after the timed steps')
+    hb.phase('extras')
     loss = float(out['loss_cls'].sum().item() + out['loss_cls_noise'].sum().item())
 
     # after the timed steps: the conv body alone (nothing else on the device).  Inside a step it
@@ -1137,6 +1555,22 @@ def main():
                 extra_configs(args, dev, B, res, cfg, roof)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, num_fg)
+        # N > 1 (or --force-dist): the broadcast / bare-exchange / rank-digest keys, flat in the
+        # line and in config (the driver's parser keeps flat keys), and what the supervisor did
+        res.update(nrank)
+        res.update(fallback_keys())
+        cfg.update(nrank)
+        cfg.update(fallback_keys())
+        save_main_line(res)
+    hb.phase('main_done')
+    if pg is not None and not args.no_route_ab and args.mfma_dtype == 'fp16x2':
+        # the other update routes, K steps each, in this same job (value stays the default route's)
+        job.timed_hooks = None
+        legs = route_ab(job, pg, rank, world, args.steps, hb, B)
+        if rank == 0:
+            res.update(legs)
+            res['config'].update(legs)
+    hb.phase('emit')
     if pg is not None:
         torch.distributed.destroy_process_group()
     if rank == 0:
@@ -1144,6 +1578,7 @@ def main():
         if res.get('parity_in_run', {}).get('ok') is False:
             sys.exit('bench.py: the headline plan disagrees with the fp32 plans beyond the stated '
                      'tolerances: %s' % json.dumps(res['parity_in_run']))
+    hb.phase('done', printed=True)
 
 
 if __name__ == '__main__':

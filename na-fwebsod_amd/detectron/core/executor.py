@@ -131,13 +131,7 @@ class NetExecutor(object):
             return
         import torch.distributed as dist
         if self.engine is not None:
-            dist.broadcast(self.engine.params, 0, group=self.pg)
-            for _wp, b, w in self.engine.conv.values():
-                dist.broadcast(w, 0, group=self.pg)
-                dist.broadcast(b, 0, group=self.pg)
-            self.engine.set_conv_blobs({k: v for k, v in self.engine.export_blobs(False).items()})
-            # engine.params was written directly: the operand planes no longer match it
-            self.engine._planes_dirty = True
+            self.engine.broadcast_parameters(0)
         else:
             for n in self.model.params:
                 dist.broadcast(self.ws[n], 0, group=self.pg)

@@ -417,6 +417,57 @@ class WsddnEngine(object):
             if name in blobs:
                 self.blob(name).copy_(blobs[name].to(self.device, torch.float32).view(shape))
 
+    def broadcast_parameters(self, src=0):
+        """COLLECTIVE (every rank): rank `src`'s parameters, momentum and conv body to every rank
+        (reference: utils/net_wsl.py:183-207 copies GPU 0's blobs to the other GPUs through the
+        host; here one RCCL broadcast per buffer).  The conv weights are re-packed from what
+        arrived, the operand planes re-split on the next forward.  No-op without a process group."""
+        if self.pg is None:
+            return
+        import torch.distributed as dist
+        self.flush()
+        root = dist.get_global_rank(self.pg, src)
+        dist.broadcast(self.params, root, group=self.pg)
+        dist.broadcast(self.momentum_buf, root, group=self.pg)
+        if self.conv:
+            for _wp, b, w in self.conv.values():
+                dist.broadcast(w, root, group=self.pg)
+                dist.broadcast(b, root, group=self.pg)
+            self.set_conv_blobs({k: v for k, v in self.export_blobs(False).items()
+                                 if k.startswith('conv')})
+        # self.params was written directly: the operand planes no longer match it
+        self._planes_dirty = True
+
+    def state_tensors(self):
+        """Every buffer that must be bit-identical on all ranks of a data-parallel job after an
+        update: parameters, momentum, and (16-bit MFMA plans) the operand planes of fc6_w / fc7_w /
+        fc7_w^T with their scale words.  The pending update is joined first; under
+        NAWS.SHARDED_UPDATE call gather_sharded_state() (collective) before comparing momentum."""
+        self.flush()
+        out = dict(params=self.params, momentum=self.momentum_buf)
+        if self._wplanes is not None and not self._planes_dirty:
+            for k, v in self._wplanes.items():
+                if isinstance(v, ops.F16x2):
+                    out['planes_' + k], out['scales_' + k] = v.planes, v.scales
+                else:
+                    out['planes_' + k] = v
+        return out
+
+    def set_update_route(self, pipeline_update=None, sharded_update=False):
+        """COLLECTIVE when leaving the sharded route (the owners' momentum rows are gathered
+        first).  Switch how the deferred update of an N > 1 step runs, at a step boundary:
+        pipeline_update None = the default (piece by piece whenever there is an exchange), False =
+        one launch behind the whole exchange; sharded_update = NAWS.SHARDED_UPDATE.  All three
+        routes hold bit-identical state across the ranks, so a job may change route mid-run
+        (bench.py's in-run A/B, the fallback of a training job)."""
+        self.flush()
+        if self._shard_blocks() is not None:
+            self.gather_sharded_state()
+        self.pipeline_update = pipeline_update
+        self.sharded_update = bool(sharded_update)
+        self._shard, self._mom_synced = None, True
+        self._pipe_sent = False
+
     def export_blobs(self, with_momentum=True):
         self.flush()
         if with_momentum and not self._mom_synced:
