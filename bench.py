@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense v_mfma_f32_32x32x16_bf16 / _f16
 HBM_ACHIEVABLE_GBPS = 6300.0    # same guide: ~6.3 TB/s achievable of the 8 TB/s HBM3E spec
+LINK_GBPS = 153.0               # same guide: one xGMI link, per direction; 7 links per GPU
 
 
 def parse():
@@ -1280,17 +1281,23 @@ def main():
     if world == 1 and args.mfma_dtype == 'fp16x2' and not args.share_gpu and not args.force_dist \
             and not args.no_projection:
         spec = [x for x in args.emulate_exchange.split(',') if x]
+        # Two paces per rank count: the links delivering 0.6 of their
+        # 153 GB/s per direction (the optimistic point of rounds 4-5) and 0.3 of it (RCCL's bus
+        # bandwidth on ~1 GB messages is commonly well below the link rate) - key suffix _pace03
         cases = [(int(spec[0]), int(spec[1]) if len(spec) > 1 else 32,
-                  float(spec[2]) if len(spec) > 2 else None)] if spec else \
-            [(n, 32, None) for n in (2, 4, 8)]
-        for n, cus, gbps in cases:
-            projections[n] = project_n_ranks(eng, t, seg, n, cus, gbps, max(20, args.steps // 3))
+                  float(spec[2]) if len(spec) > 2 else None, '')] if spec else \
+            [(n, 32, frac * LINK_GBPS * min(n - 1, 7), tag)
+             for frac, tag in ((0.6, ''), (0.3, '_pace03')) for n in (2, 4, 8)]
+        psteps = max(20, args.steps // 3)
+        for n, cus, gbps, tag in cases:
+            projections['%d%s' % (n, tag)] = project_n_ranks(eng, t, seg, n, cus, gbps, psteps)
             # the same schedule without the piece-by-piece update (round 4's route), for the A/B
-            projections['%d_unpipelined' % n] = project_n_ranks(
-                eng, t, seg, n, cus, gbps, max(20, args.steps // 3), pipeline=False)
-        n, cus, gbps = cases[-1]
-        projections['%d_sharded' % n] = project_n_ranks(eng, t, seg, n, cus, gbps,
-                                                        max(20, args.steps // 3), sharded=True)
+            projections['%d_unpipelined%s' % (n, tag)] = project_n_ranks(
+                eng, t, seg, n, cus, gbps, psteps, pipeline=False)
+        for n, cus, gbps, tag in cases:
+            if n == cases[-1][0]:
+                projections['%d_sharded%s' % (n, tag)] = project_n_ranks(eng, t, seg, n, cus, gbps,
+                                                                        psteps, sharded=True)
     conv_alone_ms = None
     roipool_alone_ms = None
     if rank == 0:
@@ -1494,6 +1501,22 @@ def main():
                         for k, r in plan]
                 cfg['exchange_schedule_equals_projection'] = bool(
                     [list(m) for m in per] == want) if world > 1 else None
+        # which route the two-pace projection favours at every (rank count, pace): the route that
+        # never loses by more than 0.3 ms anywhere is the one an N > 1 job should default to
+        verdict, worst = [], {'pipelined': 0.0, 'unpipelined': 0.0}
+        for key in sorted(k for k in projections if '_' not in str(k).replace('_pace03', '')):
+            n_, tag = str(key).replace('_pace03', ''), ('_pace03' if 'pace03' in str(key) else '')
+            a = projections[key]['ms_per_step']
+            b = projections.get('%s_unpipelined%s' % (n_, tag), {}).get('ms_per_step')
+            if b is None:
+                continue
+            verdict.append('n%s%s %+.2f' % (n_, tag, a - b))
+            worst['pipelined'] = max(worst['pipelined'], a - b)
+            worst['unpipelined'] = max(worst['unpipelined'], b - a)
+        if verdict:
+            cfg['projected_pipelined_minus_unpipelined_ms'] = ' '.join(verdict)
+            cfg['projected_worst_loss_ms_pipelined'] = round(worst['pipelined'], 3)
+            cfg['projected_worst_loss_ms_unpipelined'] = round(worst['unpipelined'], 3)
         for n, pr in sorted(projections.items(), key=lambda kv: str(kv[0])):
             # PROJECTIONS, not measurements of an N-GPU job: the one-rank step with the N-rank
             # schedule and a paced copy kernel in the all-reduce's place (see EmulatedExchange);
