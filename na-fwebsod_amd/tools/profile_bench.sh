@@ -16,6 +16,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/infer_stats -o st -- 
 tail -1 $O.infer.log | cut -c1-300
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fp16x2_fetch -o pf -- $B --steps 2 --warmup 1 > $O.fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/fp16x2_write -o pw -- $B --steps 2 --warmup 1 > $O.write.log 2>&1
+# the bf16 / C = 80 plan's fc6 forward (its roofline had traffic: null)
+BB="$B --mfma-dtype bf16 --classes 80"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/bf16_fetch -o pf -- $BB --steps 2 --warmup 1 > $O.bf16fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/bf16_write -o pw -- $BB --steps 2 --warmup 1 > $O.bf16write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/fp16x2_sq -o ps -- $B --steps 3 --warmup 1 > $O.sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/infer_sq -o ps -- python bench.py --infer --steps 8 --warmup 4 > $O.infersq.log 2>&1
 ls $O

@@ -10,7 +10,7 @@ mkdir -p $P
 bash $T/profile_bench.sh $R
 for M in fp16x2 fp32x3 fp32 bf16; do
   F=$O/${M}_stats; W=$O/${M}_stats
-  if [ $M = fp16x2 ]; then F=$O/fp16x2_fetch; W=$O/fp16x2_write; fi
+  if [ $M = fp16x2 ] || [ $M = bf16 ]; then F=$O/${M}_fetch; W=$O/${M}_write; fi
   python $T/summarize_profile.py $O/${M}_stats $F $W $P/${R}_bench_$M $M > /dev/null
 done
 python $T/summarize_profile.py $O/infer_stats $O/infer_stats $O/infer_stats $P/${R}_infer fp16x2 --allow-missing > /dev/null
