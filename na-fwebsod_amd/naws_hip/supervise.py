@@ -126,6 +126,16 @@ def shared_dir(environ):
     return d
 
 
+def _die_with_parent():
+    """preexec of the worker: SIGKILL it when this supervisor dies without a chance to clean up
+    (the launcher's SIGKILL after its SIGTERM grace) - no orphan is left holding a GPU."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).prctl(1, signal.SIGKILL)       # PR_SET_PDEATHSIG
+    except Exception:                                    # noqa: BLE001 - best effort, Linux only
+        pass
+
+
 def _kill(proc, grace=5.0):
     """SIGTERM to the worker's process group, SIGKILL after `grace` seconds."""
     if proc.poll() is not None:
@@ -192,7 +202,7 @@ def supervise_rank(script, argv, environ=None, ladder=None, poll=0.2, log=None):
         if k > 0:
             log('attempt %d (%s): %s' % (k, name, ' '.join(extra)))
         started = time.time()
-        proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+        proc = subprocess.Popen(cmd, env=env, start_new_session=True, preexec_fn=_die_with_parent)
         current['proc'] = proc
         verdict = None                       # ('ok' | 'fail' | 'post_main', reason)
         while verdict is None:
@@ -229,8 +239,9 @@ def supervise_rank(script, argv, environ=None, ladder=None, poll=0.2, log=None):
             return 0
         log('%s' % verdict[1])
         if verdict[0] == 'post_main':
-            # the headline exists: report it, say which leg did not finish
-            if rank == 0:
+            # the headline exists: report it, say which leg did not finish (unless the worker
+            # printed its line itself and only hung on its way out)
+            if rank == 0 and not last_heartbeat(hb, started).get('printed'):
                 try:
                     res = json.load(open(mainline))
                 except (OSError, ValueError):
