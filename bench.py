@@ -738,6 +738,9 @@ def route_ab(job, pg, rank, world, steps, hb, images_per_step):
         other = not was['pipelined']
         legs.append(('pipelined' if other else 'unpipelined',
                      dict(pipeline_update=None if other else False, sharded_update=False)))
+        # the plainest exchange there is - fc6_w's gradient as ONE message behind the whole wgrad,
+        # one update launch - as the yardstick of what chunking + pipelining buy on real links
+        legs.append(('one_message', dict(pipeline_update=False, sharded_update=False, chunks=1)))
         if owner_blocks(job.rows6, world) is not None and job.can_shard:
             legs.append(('sharded', dict(pipeline_update=False, sharded_update=True)))
         else:
@@ -747,6 +750,8 @@ def route_ab(job, pg, rank, world, steps, hb, images_per_step):
         hb.phase('ab_' + name, steps=steps + 3)
         job.set_route(**route)
         got = job.route()
+        if route.get('chunks'):
+            out['chunks_' + name] = got['chunks']
         if (name == 'pipelined') != got['pipelined'] or (name == 'sharded') != got['sharded']:
             out['value_' + name] = None          # (the plan cannot take that route: said, not faked)
             out[name + '_skipped'] = 'route not available on this plan'
@@ -758,7 +763,8 @@ def route_ab(job, pg, rank, world, steps, hb, images_per_step):
         out['rank_digest_equal_' + name] = bool(ok)
         if not ok:
             out['rank_digest_differs_' + name] = ','.join(bad)
-    job.set_route(pipeline_update=None if was['pipelined'] else False, sharded_update=was['sharded'])
+    job.set_route(pipeline_update=None if was['pipelined'] else False, sharded_update=was['sharded'],
+                  chunks=was['chunks'])
     return out
 
 
@@ -817,10 +823,13 @@ class EngineJob(object):
 
     def route(self):
         e = self.eng
-        return dict(pipelined=bool(e._pipelined()), sharded=bool(e._shard_blocks() is not None))
+        return dict(pipelined=bool(e._pipelined()), sharded=bool(e._shard_blocks() is not None),
+                    chunks=int(e.allreduce_chunks))
 
-    def set_route(self, pipeline_update=None, sharded_update=False):
+    def set_route(self, pipeline_update=None, sharded_update=False, chunks=None):
         self.eng.set_update_route(pipeline_update, sharded_update)
+        if chunks:
+            self.eng.allreduce_chunks = int(chunks)     # (read per backward: engine.message_plan)
 
 
 class DryJob(object):
@@ -929,12 +938,15 @@ class DryJob(object):
                 for k, r in message_plan(self.arena, self.rows6, self.chunks, True, False)]
 
     def route(self):
-        return dict(pipelined=self.pipelined and not self.sharded, sharded=self.sharded)
+        return dict(pipelined=self.pipelined and not self.sharded, sharded=self.sharded,
+                    chunks=self.chunks)
 
-    def set_route(self, pipeline_update=None, sharded_update=False):
+    def set_route(self, pipeline_update=None, sharded_update=False, chunks=None):
         self.gather_sharded_state()
         self.pipelined = pipeline_update is None or bool(pipeline_update)
         self.sharded = bool(sharded_update)
+        if chunks:
+            self.chunks = int(chunks)
 
 
 def init_process_group(backend, rank, world, dev=None):

@@ -48,11 +48,13 @@ DEADLINES = {
     'ab_unpipelined': (120.0, 1.5),
     'ab_pipelined': (120.0, 1.5),
     'ab_sharded': (120.0, 1.5),
+    'ab_one_message': (120.0, 1.5),
     'extras': (900.0, 0.0),          # rank 0's conv-alone / RoIPool-alone timings
     'emit': (120.0, 0.0),
     'done': (120.0, 0.0),            # destroy_process_group, interpreter exit
 }
-POST_MAIN = ('main_done', 'ab_unpipelined', 'ab_pipelined', 'ab_sharded', 'extras', 'emit', 'done')
+POST_MAIN = ('main_done', 'ab_unpipelined', 'ab_pipelined', 'ab_sharded', 'ab_one_message', 'extras',
+             'emit', 'done')
 EXIT_DIGEST_MISMATCH = 4
 
 

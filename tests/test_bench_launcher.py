@@ -106,6 +106,8 @@ def test_two_ranks_broadcast_digest_bare_exchange_and_route_ab():
     assert res['config']['pipelined_update'] is True
     assert res['value_unpipelined'] > 0 and res['rank_digest_equal_unpipelined'] is True
     assert res['value_sharded'] > 0 and res['rank_digest_equal_sharded'] is True
+    assert res['value_one_message'] > 0 and res['chunks_one_message'] == 1
+    assert res['rank_digest_equal_one_message'] is True
     assert res['route_fallback'] is None and res['supervised'] is True
     # flat copies inside config too (the driver's parser keeps flat keys)
     for k in ('value_unpipelined', 'value_sharded', 'rank_digest_equal', 'allreduce_busbw_GBps'):

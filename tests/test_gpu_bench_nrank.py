@@ -45,12 +45,14 @@ def test_two_ranks_on_one_gpu_broadcast_digests_bare_exchange_and_route_ab(dev):
     assert res['config']['exchange_schedule_equals_projection'] is True
     assert res['value_unpipelined'] > 0 and res['rank_digest_equal_unpipelined'] is True
     assert res['value_sharded'] > 0 and res['rank_digest_equal_sharded'] is True
+    assert res['value_one_message'] > 0 and res['chunks_one_message'] == 1
+    assert res['rank_digest_equal_one_message'] is True
     assert 'ab_failed' not in res
 
 
 def test_a_stalled_rank_on_the_pipelined_route_ends_in_fresh_workers_on_the_unpipelined_route(dev):
     r, res = _bench('--gpus', '2', '--share-gpu', '--no-route-ab', *SMALL,
-                    env=dict(NAWS_BENCH_INJECT='stall:pipelined:1', NAWS_BENCH_DEADLINE_SCALE='0.3'))
+                    env=dict(NAWS_BENCH_INJECT='stall:pipelined:1', NAWS_BENCH_DEADLINE_SCALE='0.15'))
     assert r.returncode == 0 and res is not None, r.stderr[-4000:]
     assert res['route_attempt'] == 1 and res['route_of_attempt'] == 'unpipelined'
     assert 'no progress' in res['route_fallback'] and 'phase timed' in res['route_fallback']
