@@ -626,44 +626,11 @@ X3_KERNEL_NAME = ('gemm_x3_m16_kernel<256,128,4x2 waves,2 stages,3 planes x 2 K-
 # the --dry-run job on CPU tensors over gloo (DryJob), so the CPU tests exercise the very code
 # the first multi-GPU RCCL run will execute.
 # ---------------------------------------------------------------------------------------------
-def state_digest(tensors):
-    """int64 [2 * len(tensors)]: per buffer (sum of its words, position-weighted sum of its
-    words), both exact integer sums of the raw bit patterns - equal on two ranks iff (up to a 2^-64
-    accident) the buffers are bit-identical.  Chunked: the 957.7 MB arenas are never widened to
-    int64 as a whole."""
-    import torch
-    out = []
-    weights = {}
-    for t in tensors:
-        v = t.detach().contiguous().view(-1)
-        v = v.view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[v.element_size()])
-        s1 = torch.zeros((), dtype=torch.int64, device=v.device)
-        s2 = torch.zeros((), dtype=torch.int64, device=v.device)
-        step = 1 << 24
-        for o in range(0, v.numel(), step):
-            c = v[o:o + step].to(torch.int64)
-            key = (c.numel(), str(v.device))
-            if key not in weights:
-                weights[key] = torch.arange(c.numel(), device=v.device, dtype=torch.int64) % 8191 + 1
-            s1 += c.sum()
-            s2 += (c * weights[key]).sum() + (o // step) * 7 * c.sum()
-        out += [s1, s2]
-    return torch.stack(out)
-
-
 def ranks_agree(job, pg, rank, world):
     """(True when every rank holds bit-identical state, [names of the buffers that differ]).
-    COLLECTIVE.  One all-reduce of a [world, 2 * buffers] int64 table."""
-    import torch
-    import torch.distributed as dist
-    names, tensors = zip(*sorted(job.state_tensors().items()))
-    dig = state_digest(tensors)
-    table = torch.zeros((world, dig.numel()), dtype=torch.int64, device=dig.device)
-    table[rank] = dig
-    dist.all_reduce(table, group=pg)
-    same = (table == table[0:1]).all(dim=0).cpu().tolist()
-    bad = sorted({names[i // 2] for i, ok in enumerate(same) if not ok})
-    return not bad, bad
+    COLLECTIVE: naws_hip.reducer.ranks_agree over the job's state buffers."""
+    from naws_hip.reducer import ranks_agree as _agree
+    return _agree(job.state_tensors(), pg, rank, world)
 
 
 def bare_allreduce(job, pg, world, iters=5, warm=2):

@@ -89,6 +89,17 @@ def train_model(roidb=None, max_iter=None, printer=print):
         stats.IterToc()
         if (cur_iter + 1) % period == 0 and cur_iter > start_iter and executor.engine is not None:
             executor.engine.gather_sharded_state()    # collective under NAWS.SHARDED_UPDATE, else a no-op
+            if pg is not None and world > 1:
+                # every snapshot: the ranks must hold bit-identical parameters, momentum, operand
+                # planes and scales (collective; one small all-reduce of exact digests) - a rank
+                # that walked away would otherwise train on silently
+                from naws_hip.reducer import ranks_agree
+                same, bad = ranks_agree(executor.engine.state_tensors(), pg, rank, world)
+                if not same:
+                    handle_critical_error(model, 'ranks hold different state at iteration %d: %s '
+                                          '(NAWS.PIPELINE_UPDATE False / NAWS.SHARDED_UPDATE False '
+                                          'select the one-launch all-reduce route)'
+                                          % (cur_iter, ','.join(bad)))
         if (cur_iter + 1) % period == 0 and cur_iter > start_iter and rank == 0:
             checkpoints[cur_iter] = os.path.join(output_dir, 'model_iter{}.pkl'.format(cur_iter))
             nu.save_model_to_weights_file(checkpoints[cur_iter], model, executor)

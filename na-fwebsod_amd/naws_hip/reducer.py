@@ -75,6 +75,51 @@ def owner_pieces(r0, r1, blocks):
     return out
 
 
+def state_digest(tensors):
+    """int64 [2 * len(tensors)]: per buffer (sum of its words, position-weighted sum of its
+    words), both exact integer sums of the raw bit patterns - equal on two ranks iff (up to a 2^-64
+    accident) the buffers are bit-identical.  Chunked: the 957.7 MB arenas are never widened to
+    int64 as a whole.  (Checkpoint-time / bench-time bookkeeping in plain torch ops: not on the
+    step's path.)"""
+    import torch
+    out = []
+    weights = {}
+    for t in tensors:
+        v = t.detach().contiguous().view(-1)
+        v = v.view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[v.element_size()])
+        s1 = torch.zeros((), dtype=torch.int64, device=v.device)
+        s2 = torch.zeros((), dtype=torch.int64, device=v.device)
+        step = 1 << 24
+        for o in range(0, v.numel(), step):
+            c = v[o:o + step].to(torch.int64)
+            key = (c.numel(), str(v.device))
+            if key not in weights:
+                weights[key] = torch.arange(c.numel(), device=v.device, dtype=torch.int64) % 8191 + 1
+            s1 += c.sum()
+            s2 += (c * weights[key]).sum() + (o // step) * 7 * c.sum()
+        out += [s1, s2]
+    return torch.stack(out)
+
+
+def ranks_agree(state, process_group, rank, world_size):
+    """COLLECTIVE.  state: {name: tensor} (engine.state_tensors()) -> (True when every rank holds
+    bit-identical buffers, [names of the buffers that differ]).  One all-reduce of a
+    [world, 2 * buffers] int64 table.  The reference's ranks are GPUs of one process that start
+    from broadcast blobs and apply the same all-reduced gradients (optimizer_wsl.py:52-72): equal
+    by construction; here that property is CHECKED - after warm-up in bench.py, at every snapshot
+    in the training loop."""
+    import torch
+    import torch.distributed as dist
+    names, tensors = zip(*sorted(state.items()))
+    dig = state_digest(tensors)
+    table = torch.zeros((int(world_size), dig.numel()), dtype=torch.int64, device=dig.device)
+    table[int(rank)] = dig
+    dist.all_reduce(table, group=process_group)
+    same = (table == table[0:1]).all(dim=0).cpu().tolist()
+    bad = sorted({names[i // 2] for i, ok in enumerate(same) if not ok})
+    return not bad, bad
+
+
 class ArenaReducer(object):
     def __init__(self, process_group=None, world_size=1):
         self.pg = process_group

@@ -456,3 +456,45 @@ def test_pipelined_message_order_over_gloo_equals_the_plain_order():
         assert pipe[6][0] == 2 * (4096 // 16) and sum(pipe[6]) == sum(plain[4])
         assert np.array_equal(pipe[1], plain[1]) and np.array_equal(pipe[2], plain[2])
     assert np.array_equal(res['pipe'][0][1], res['pipe'][1][1])
+
+
+def _digest_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from naws_hip.reducer import ranks_agree, state_digest
+    g = torch.Generator().manual_seed(3)
+    state = dict(params=torch.randn((70000,), generator=g), momentum=torch.randn((513,), generator=g),
+                 planes=torch.randint(-30000, 30000, (4, 33, 16), generator=g, dtype=torch.int16),
+                 words=torch.randint(0, 1 << 30, (129,), generator=g, dtype=torch.int32))
+    same0, bad0 = ranks_agree(state, dist.group.WORLD, rank, world)
+    # one bit of one float on the last rank; two swapped elements elsewhere (same plain sum)
+    if rank == world - 1:
+        state['momentum'].view(torch.int32)[7] ^= 1
+        p = state['planes'].view(-1)
+        p[5], p[900] = p[900].clone(), p[5].clone()
+    same1, bad1 = ranks_agree(state, dist.group.WORLD, rank, world)
+    d = state_digest([state['planes']])
+    q.put((rank, same0, bad0, same1, bad1, d.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_digests_detect_one_flipped_bit_and_a_permutation():
+    """naws_hip.reducer.ranks_agree (bench.py's check after warm-up, the training loop's at every
+    snapshot): equal buffers agree; one flipped mantissa bit on one rank and a swap of two
+    elements (which leaves the plain sum unchanged) are both reported, by buffer name, on EVERY rank."""
+    world = 3
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_digest_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same0, bad0, same1, bad1, _d in got:
+        assert same0 is True and bad0 == []
+        assert same1 is False and bad1 == ['momentum', 'planes']
+    assert got[0][5] == got[1][5] and got[0][5][0] == got[2][5][0] and got[0][5][1] != got[2][5][1]
