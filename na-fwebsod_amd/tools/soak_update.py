@@ -37,6 +37,10 @@ def main():
                          '(NAWS.PIPELINE_UPDATE) unless --pipeline 0; with --train-step 1 its parts are '
                          'queued from inside backward, as the training loop does')
     ap.add_argument('--pipeline', type=int, default=1)
+    ap.add_argument('--switch-route', action='store_true',
+                    help='with --exchange: change the update route at every check through '
+                         'engine.set_update_route (piece by piece -> one launch -> piece by piece ...): '
+                         'the digests must equal a run that stays on one route')
     ap.add_argument('--digest', action='store_true',
                     help='print a digest of the parameters / momentum / fc6_w planes at every check '
                          '(two runs that must be bit-identical print the same lines)')
@@ -120,6 +124,10 @@ def main():
                                 if a.mfma_dtype == 'fp16x2' and eng._wplanes else eng.params[:4])]
                 print('   digest params %s momentum %s planes %s' % tuple(dg), flush=True)
             assert np.isfinite(loss) and worst <= 1.0
+            if a.switch_route and a.exchange > 1:
+                now = eng._pipelined()
+                eng.set_update_route(pipeline_update=False if now else None)
+                print('   route switched: update piece by piece %s -> %s' % (now, eng._pipelined()), flush=True)
     print('soak ok: %d steps, overflow re-splits seen at %d checkpoints' % (a.steps, tags))
 
 
