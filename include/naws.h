@@ -519,6 +519,23 @@ int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const f
                                          const float* bias, int N, int H, int W, int Cin, int Cout,
                                          int dilation, int relu, float* workspace, float* Y,
                                          const uint32_t* amax_in, uint32_t* amax_out, void* stream);
+/* Winograd F(4x4,3x3) form of the same operator (csrc/winograd4.hip; reference
+ * detectron/modeling/VGG16.py:33-46, conv4_x / conv5_x): 36 batched GEMMs over 6x6 input tiles,
+ * 4x fewer MFMA flops than the direct sum and 0.56 of F(2x2)'s transform-domain bytes.  The
+ * transforms run in fp32; the input transform scales by one power of two per tensor
+ * (|B^T d B| <= 100 max|x|) and writes the f16 hi / lo planes itself.
+ * naws_winograd4_weight_transform: U[36][Cout][Cin] = G g G^T of W_oihw, taken in double and
+ * rounded once.  U2 / scaleU: naws_split_f16x2 of U viewed as batch 36 of [Cout][Cin] (scaleU = its
+ * scales[1], [36][Cout]).  Cin % 32 == 0, Cout % 4 == 0.  amax_in (required): device word holding
+ * the bit pattern of an upper bound of max|X| (naws_amax_f32, or the amax_out of the producing
+ * layer).  amax_out (nullable, != amax_in): receives the bit pattern of max|Y|.  workspace:
+ * naws_winograd4_f16x2_workspace_floats(...) floats, 16-byte aligned. */
+int naws_winograd4_weight_transform(const float* W_oihw, int Cout, int Cin, float* U, void* stream);
+int64_t naws_winograd4_f16x2_workspace_floats(int N, int H, int W, int Cin, int Cout, int dilation);
+int naws_conv3x3_winograd4_nhwc_f16x2_fwd(const float* X, const void* U2, const float* scaleU,
+                                          const float* bias, int N, int H, int W, int Cin, int Cout,
+                                          int dilation, int relu, float* workspace, float* Y,
+                                          const uint32_t* amax_in, uint32_t* amax_out, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution of the shallow VGG layers (conv1_2 .. conv2_2; reference
  * detectron/modeling/VGG16.py:12-22) in the 2 x f16 split: as naws_conv3x3_nhwc_f32x3_fwd's
  * halo-tile kernel with 3 MFMA terms.  W2 / scaleW: naws_split_f16x2 of the packed weight

@@ -1249,8 +1249,10 @@ static int gemm_f32_f16x2_nt_impl(int M, int N, int K, const void* A2, int64_t s
   // pieces are then bit-identical to it at every size, not only where both land on one form)
   const int Nd = drop_ld > 0 ? drop_ld : N;
   if (Nd <= 64 || M <= 128) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
-  // fewer 256x256 tiles than CUs (the column remainder of a wgrad split into whole waves)
-  if (naws_cdiv(M, 256) * naws_cdiv(Nd, 256) * batch < 256 && g_h2_variant != 5)
+  // fewer 256x256 tiles than CUs (the column remainder of a wgrad split into whole waves); the
+  // batched short-K products (Winograd: 16 or 36 frequencies) choose among the forms below
+  if (naws_cdiv(M, 256) * naws_cdiv(Nd, 256) * batch < 256 && g_h2_variant != 5 &&
+      !(batch >= 16 && K <= 1024))
     return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
   // short K (the Winograd batch GEMMs): two 4-wave workgroups per CU overlap one's prologue /
   // epilogue with the other's K loop

@@ -113,28 +113,6 @@ __global__ __launch_bounds__(256) void amax_all_kernel(const float* __restrict__
   }
 }
 
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void put_h2(float4 v, float sc, unsigned short* __restrict__ hi,
-                                       unsigned short* __restrict__ lo) {
-  const float t[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-  unsigned short h[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const _Float16 a = (_Float16)t[e];
-    float r = t[e] - (float)a;
-    if (!(fabsf(t[e]) <= 65504.f)) r = 0.f;
-    const _Float16 b = (_Float16)r;
-    h[e] = *reinterpret_cast<const unsigned short*>(&a);
-    l[e] = *reinterpret_cast<const unsigned short*>(&b);
-  }
-  u32x2 wh, wl;
-  wh.x = h[0] | ((unsigned)h[1] << 16); wh.y = h[2] | ((unsigned)h[3] << 16);
-  wl.x = l[0] | ((unsigned)l[1] << 16); wl.y = l[2] | ((unsigned)l[3] << 16);
-  *reinterpret_cast<u32x2*>(hi) = wh;
-  *reinterpret_cast<u32x2*>(lo) = wl;
-}
-
 // V planes P[2][16][Cin/16][tiles][16] f16 = split of (B^T d B) * s, s = one power of two for the
 // whole tensor: |B^T d B| <= 4 max|x|, so s = 2^(12 - floor(log2 max|x|)) keeps it below 2^15.
 // One lane = one tile x 4 channels; lane order (4 channel groups of a 16-channel slab, then tiles):

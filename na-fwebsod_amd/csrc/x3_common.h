@@ -43,6 +43,30 @@ __device__ __forceinline__ void split3(float a, unsigned short& p1, unsigned sho
   p3 = *reinterpret_cast<const unsigned short*>(&h3);
 }
 
+// Four fp32 values -> scaled f16 hi / lo planes (8 bytes each): the element step of every
+// transform that writes fp16x2 operand planes itself (winograd.hip, winograd4.hip).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void put_h2(float4 v, float sc, unsigned short* __restrict__ hi,
+                                       unsigned short* __restrict__ lo) {
+  const float t[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+  unsigned short h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 a = (_Float16)t[e];
+    float r = t[e] - (float)a;
+    if (!(fabsf(t[e]) <= 65504.f)) r = 0.f;
+    const _Float16 b = (_Float16)r;
+    h[e] = *reinterpret_cast<const unsigned short*>(&a);
+    l[e] = *reinterpret_cast<const unsigned short*>(&b);
+  }
+  u32x2 wh, wl;
+  wh.x = h[0] | ((unsigned)h[1] << 16); wh.y = h[2] | ((unsigned)h[3] << 16);
+  wl.x = l[0] | ((unsigned)l[1] << 16); wl.y = l[2] | ((unsigned)l[3] << 16);
+  *reinterpret_cast<u32x2*>(hi) = wh;
+  *reinterpret_cast<u32x2*>(lo) = wl;
+}
+
 __device__ __forceinline__ void f16x2_scales(unsigned amax_bits, float& s, float& inv) {
   naws_f16x2_scales(amax_bits, s, inv);      // naws_common.h
 }

@@ -242,6 +242,9 @@ class WsddnEngine(object):
         # TTA scales) take the direct kernel: 512 / 1024 / never measured 45.3 / 47.5 / 47.4 vs 44.6
         # ms per TTA image
         self.DIRECT_MIN_TILES = 256
+        # fp16x2 plan: Winograd F(4x4,3x3) (csrc/winograd4.hip) for the layers with at least this
+        # many input channels (conv4_2..conv5_3), F(2x2) below (conv4_1: the fused kernel); 0 = never
+        self.WINO_F4_MIN_CIN = 512
         # fp32x3: up to this many output channels the direct 3-plane kernel, Winograd above
         self.X3_DIRECT_MAX_COUT = 256
         # fc8's products (tiny output, long K): K in 4 slices + a deterministic second pass (58 vs
@@ -394,7 +397,10 @@ class WsddnEngine(object):
                 # weight planes [3][9*Cin/16][Cout][16] of the packed [Cout][3][3][Cin] weight
                 packed = ops.split_bf16x3(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
             elif use_wino:
-                packed = ops.winograd_weight_transform(w)      # [16][Cout][Cin]
+                f4 = (self.mfma_dtype == 'fp16x2' and 0 < self.WINO_F4_MIN_CIN <= w.shape[1]
+                      and w.shape[1] % 32 == 0)
+                packed = (ops.winograd4_weight_transform(w) if f4          # [36][Cout][Cin]
+                          else ops.winograd_weight_transform(w))           # [16][Cout][Cin]
                 if self.mfma_dtype == 'fp16x2':
                     packed = ops.split_f16x2(packed)           # F16x2, planes [2][16][Cin/16][Cout][16]
                     if w.shape[0] % 128 == 0 and \

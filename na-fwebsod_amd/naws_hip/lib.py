@@ -128,6 +128,8 @@ PROTOTYPES = {
     'naws_gemm_f32_f16x2_nt_xk_sgd': [i32, i32, i32, p, i64, i64, p, p, i64, i64, i32, p, p, p, i32, p,
                                       f32, f32, f32, i32, i32, i64, p, i64, i32, p, p, p, p, i32, p],
     'naws_conv3x3_winograd_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p],
+    'naws_winograd4_weight_transform': [p, i32, i32, p, p],
+    'naws_conv3x3_winograd4_nhwc_f16x2_fwd': [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p],
     'naws_gemm_f32_f16x2_nt_amax': [i32, i32, i32, p, i64, i64, p, p, i64, i64, p, p, i32, i32,
                                     i64, i64, i64, i64, i64, i32, p, i64, p, i32, f32, f32, u64, i32,
                                     p, i32, p, p, p],
@@ -150,6 +152,7 @@ SPECIAL = {
     'naws_roi_pool_workspace_floats': ([i32, i32, i32, i32], i64),
     'naws_winograd_f32x3_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
     'naws_winograd_f16x2_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
+    'naws_winograd4_f16x2_workspace_floats': ([i32, i32, i32, i32, i32, i32], i64),
     'naws_gemm_f32_splitk_workspace_floats': ([i32, i32, i32, i32], i64),
 }
 ALL_SYMBOLS = sorted(list(PROTOTYPES) + list(SPECIAL))

@@ -72,6 +72,15 @@ def winograd_weight_transform(w_oihw):
     return u
 
 
+def winograd4_weight_transform(w_oihw):
+    """U [36, Cout, Cin] = G g G^T of F(4x4, 3x3) (csrc/winograd4.hip), frequency 6 i + j."""
+    _chk(w_oihw, 'w')
+    cout, cin = w_oihw.shape[:2]
+    u = torch.empty((36, cout, cin), device=w_oihw.device, dtype=_f32)
+    L.call('naws_winograd4_weight_transform', w_oihw.data_ptr(), cout, cin, u.data_ptr(), _stream())
+    return u
+
+
 def conv3x3_winograd_nhwc(x, u, bias, dilation=1, relu=True, out=None):
     _chk(x, 'x'); _chk(u, 'U')
     n, h, w, cin = x.shape
@@ -586,17 +595,27 @@ def winograd_weight_columns(u):
 def conv3x3_winograd_nhwc_f16x2(x, u2, bias, dilation=1, relu=True, out=None, amax_in=None,
                                 amax_out=None):
     """Winograd F(2x2,3x3) with fp16x2 GEMMs; u2 = split_f16x2(winograd_weight_transform(w))
-    (F16x2: planes [2, 16, Cin/16, Cout, 16], scales [2, 16, Cout]).  amax_in / amax_out: optional
+    (F16x2: planes [2, 16, Cin/16, Cout, 16], scales [2, 16, Cout]) - or F(4x4,3x3) when u2 =
+    split_f16x2(winograd4_weight_transform(w)) (planes [2, 36, Cin/16, Cout, 16]).  amax_in / amax_out: optional
     one-element int32 tensors (bit pattern of an upper bound of max|x| / receives that of max|y|)."""
     _chk(x, 'x')
     n, h, w, cin = x.shape
     cout = u2.planes.shape[-2]
     col = tuple(u2.planes.shape[:3]) == (2, 4, 4 * cin // 16)     # winograd_weight_columns
     if u2.planes.dtype != torch.float16 or not (
-            col or tuple(u2.planes.shape[:3]) == (2, 16, cin // 16)):
+            col or tuple(u2.planes.shape[:3]) in ((2, 16, cin // 16), (2, 36, cin // 16))):
         raise TypeError('u2 must hold the f16 planes [2, 16, Cin/16, Cout, 16] of U (or the '
                         'column form [2, 4, 4 Cin/16, Cout, 16])')
     y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=_f32)
+    if tuple(u2.planes.shape[:3]) == (2, 36, cin // 16):          # winograd4_weight_transform
+        nws = L.load().naws_winograd4_f16x2_workspace_floats(n, h, w, cin, cout, dilation)
+        ws = torch.empty((nws,), device=x.device, dtype=_f32)
+        if amax_in is None:
+            amax_in = amax_word(x)
+        L.call('naws_conv3x3_winograd4_nhwc_f16x2_fwd', x.data_ptr(), u2.planes.data_ptr(),
+               u2.inv_scale.data_ptr(), _ptr(bias), n, h, w, cin, cout, dilation, int(relu),
+               ws.data_ptr(), y.data_ptr(), _ptr(amax_in), _ptr(amax_out), _stream())
+        return y
     nws = L.load().naws_winograd_f16x2_workspace_floats(n, h, w, cin, cout, dilation)
     ws = torch.empty((nws,), device=x.device, dtype=_f32)
     if col and not hasattr(L.load(), 'naws_conv3x3_winograd_nhwc_f16x2_col_fwd'):

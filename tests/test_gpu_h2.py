@@ -244,6 +244,66 @@ def test_conv3x3_winograd_f16x2(dev, cin, cout, dil, h, w, amp):
     assert np.abs(ops.nhwc_to_nchw(y4).cpu().numpy() - ref).max() < 1e-5 * scale
 
 
+@pytest.mark.parametrize('cin,cout,dil,h,w,amp', [(128, 256, 1, 19, 23, 1.0), (512, 512, 2, 20, 31, 1.0),
+                                                  (256, 256, 1, 38, 63, 300.0), (512, 512, 1, 75, 125, 1e-3),
+                                                  (512, 512, 2, 74, 124, 5.0), (64, 64, 3, 9, 5, 1.0)])
+def test_conv3x3_winograd4_f16x2(dev, cin, cout, dil, h, w, amp):
+    """Winograd F(4x4,3x3) (csrc/winograd4.hip: 6x6 input tiles, 36 batched GEMMs on the f16 MFMA,
+    operand planes written by the input transform) against a float64 convolution: within 2e-5 of
+    max|y| on spatially WHITE inputs - the form's worst case: independent pixels put as much
+    energy into the high frequencies, which B^T weighs by up to 10 and A^T cancels again, as
+    into the low ones (measured 4e-6 .. 1.3e-5, 10-25x the fp32 F(2x2) path; on the network's own
+    activations the whole chain of five F(4x4) layers costs 2x, tests/test_gpu_fullsize_oracle.py)
+    - at activation magnitudes from 1e-3 to 300; edge tiles (sizes that are not multiples of 4), dilation 1 / 2 / 3, bias / ReLU on and off,
+    an all-zero input, and the operand-scale bound handed over instead of measured."""
+    from naws_hip import ops
+    import torch.nn.functional as F
+    rng = np.random.default_rng(148)
+    n = 2
+    x = (np.maximum(rng.standard_normal((n, cin, h, w)), 0) * amp).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.uniform(-0.5, 0.5, cout) * amp).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(),
+                          torch.from_numpy(b).double(), padding=dil, dilation=dil)).numpy()
+    xd = ops.nchw_to_nhwc(_t(x, dev))
+    u = ops.winograd_weight_transform(_t(wt, dev))
+    y32 = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc(xd, u, _t(b, dev), dil, True)).cpu().numpy()
+    u4 = ops.split_f16x2(ops.winograd4_weight_transform(_t(wt, dev)))
+    assert tuple(u4.planes.shape) == (2, 36, cin // 16, cout, 16)
+    y = ops.nhwc_to_nchw(ops.conv3x3_winograd_nhwc_f16x2(xd, u4, _t(b, dev), dil, True)).cpu().numpy()
+    scale = np.abs(ref).max()
+    e4, e2 = np.abs(y - ref).max(), np.abs(y32 - ref).max()
+    print('\n[F(4x4) %d->%d d%d %dx%d] max error / max|y|: %.1e (fp32 F(2x2): %.1e)'
+          % (cin, cout, dil, h, w, e4 / scale, e2 / scale))
+    assert e4 < 2e-5 * scale
+    y2 = ops.conv3x3_winograd_nhwc_f16x2(xd, u4, None, dil, False)
+    r2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, padding=dil,
+                  dilation=dil).numpy()
+    assert np.abs(ops.nhwc_to_nchw(y2).cpu().numpy() - r2).max() < 2e-5 * np.abs(r2).max()
+    assert not ops.conv3x3_winograd_nhwc_f16x2(torch.zeros_like(xd), u4, None, dil, False).any()
+    am = torch.zeros((2,), device=dev, dtype=torch.int32)
+    am[0] = int(np.float32(np.abs(x).max()).view(np.int32))
+    y3 = ops.conv3x3_winograd_nhwc_f16x2(xd, u4, _t(b, dev), dil, True, amax_in=am[0:1],
+                                         amax_out=am[1:2])
+    assert np.array_equal(ops.nhwc_to_nchw(y3).cpu().numpy(), y)
+    assert np.int32(am[1].item()).view(np.float32) == np.float32(y.max())
+    am[0] = int(np.float32(3.0 * np.abs(x).max()).view(np.int32))
+    y4 = ops.conv3x3_winograd_nhwc_f16x2(xd, u4, _t(b, dev), dil, True, amax_in=am[0:1])
+    assert np.abs(ops.nhwc_to_nchw(y4).cpu().numpy() - ref).max() < 2e-5 * scale
+
+
+def test_winograd4_weight_transform_matches_float64(dev):
+    """U = G g G^T of F(4x4,3x3): the kernel takes it in double and rounds once."""
+    from naws_hip import ops
+    rng = np.random.default_rng(149)
+    wt = rng.standard_normal((32, 48, 3, 3)).astype(np.float32)
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+                  [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], np.float64)
+    want = np.einsum('ai,ocij,bj->aboc', G, wt.astype(np.float64), G).reshape(36, 32, 48)
+    got = ops.winograd4_weight_transform(_t(wt, dev)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1.2e-7, atol=1e-12)
+
+
 @pytest.mark.ab
 @pytest.mark.parametrize('cin,cout,dil,h,w,amp', [(512, 512, 1, 75, 125, 3.0), (512, 512, 2, 74, 124, 0.02),
                                                    (64, 128, 1, 37, 41, 50.0), (256, 512, 2, 19, 23, 1.0)])
