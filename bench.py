@@ -1397,11 +1397,19 @@ def main():
                             conv_stack_alone_tflops=round(conv_gflop / conv_alone_ms, 1))
             # THE fraction: what the stack EXECUTES on its matrix pipe against that pipe's peak.
             # Split plans: npass passes over the direct layers (conv1_2..conv3_3: 221.0 of the
-            # 463.7 algorithmic GFLOP per image) and over Winograd F(2x2,3x3)'s 1/2.25 of
-            # conv4_1..conv5_3 (242.7 GFLOP); conv1_1 runs on the vector unit.
+            # 463.7 algorithmic GFLOP per image) and over Winograd's share of conv4_1..conv5_3
+            # (242.7 GFLOP: 1/2.25 of it under F(2x2,3x3), 1/4 under F(4x4,3x3)); conv1_1 runs on
+            # the vector unit.
             if h2 or x3:
                 npass = 3 if h2 else 6
-                ex_gflop = conv_gflop / 463.7 * npass * (221.0 + 242.7 / 2.25)
+                # fp16x2: F(4x4,3x3) from WINO_F4_MIN_CIN input channels (conv4_2..conv5_3, 220.6 of
+                # the deep layers' 242.7 GFLOP; executed with the tile padding: 19 x 32 tiles of
+                # 4 x 4 for 75 x 125 outputs = 1.038 x), F(2x2) for the rest of them
+                f4 = (220.6 if 0 < getattr(eng, 'WINO_F4_MIN_CIN', 0) <= 512 else 0.0) if h2 else 0.0
+                if h2 and 0 < getattr(eng, 'WINO_F4_MIN_CIN', 0) <= 256:
+                    f4 = 242.7
+                ex_gflop = conv_gflop / 463.7 * npass * (221.0 + (242.7 - f4) / 2.25 + 1.038 * f4 / 4.0)
+                roof['conv_stack_winograd_f4_gflop_of_463_7'] = f4
                 tag = 'f16' if h2 else 'bf16'
                 roof['conv_stack_executed_%s_tflops' % tag] = round(ex_gflop / stage_ms['conv_body'], 1)
                 roof['conv_stack_frac_vs_%s_mfma_peak' % tag] = round(

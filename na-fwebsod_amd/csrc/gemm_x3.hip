@@ -1264,6 +1264,9 @@ static int gemm_f32_f16x2_nt_impl(int M, int N, int K, const void* A2, int64_t s
     if (g_h2_variant == 15) return launch_x3_m16<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
 #endif
     if (g_h2_variant == 17) return launch_x3<128, 128, 2, 2, 2, 2, 2, true>(g, batch, s);
+    // (round 6, the 36-frequency products of F(4x4), kernel trace of tools/ab_wino4.py: this form
+    // 51.1 us, the 16x16x32 shape on 2 x 32-deep stages 52.1, 2 x 32 of this shape 62; at
+    // 150 x 250 tiles 186 vs 191)
     // 16-deep K-steps on a ring of 3 stages (48 KB: still two workgroups per CU): the DMA runs two
     // steps ahead instead of one, which is what a 16..32-step tile needs (tools/ab_h2.py, the
     // Winograd batch GEMM of conv4_2: 0.101 vs 0.114 ms with 32-deep steps and 2 stages)

@@ -93,10 +93,62 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&s)[4]) {
 }
 
 // V planes = split of (B^T d B) * s, s = one power of two for the whole tensor: max|x| * s < 2^9,
-// |B^T d B| * s <= 100 * 2^9 < 65504.  One lane = one tile x 4 channels; lane order (4 channel
-// quads of a 16-channel slab, then tiles, then slabs): a wave writes 16 tiles x 32 B = 512
-// contiguous bytes per (xi, plane) and reads 64-byte pieces of 16 pixels per tap.
-__global__ __launch_bounds__(256) void wino4_input_h2_kernel(const float* __restrict__ X, Wino4Geom g,
+// |B^T d B| * s <= 100 * 2^9 < 65504.  One lane = one tile x 4 channels x TWO of the six rows of
+// the transform-domain tile; lane order (4 channel quads of a 16-channel slab, then tiles, then
+// slabs): a wave writes 16 tiles x 32 B = 512 contiguous bytes per (xi, plane) and reads 64-byte
+// pieces of 16 pixels per tap.  The three waves of a workgroup take the row pairs {1, 2}, {3, 4}
+// and {0, 5} of the same 64 (tile, quad) items: the pairs share their sub-expressions of B^T, the
+// first two need input rows 1..4 only, the taps the waves have in common are L1 hits - and the
+// launch has three times the waves of a one-lane-per-tile form (912 workgroups at 75 x 125 x 512,
+// 12 instead of 36 transform-domain values live per lane: 21 -> see DESIGN 3 for the timing).
+template <int RP>
+__device__ __forceinline__ void wino4_input_rows(const float* __restrict__ X, const Wino4Geom& g,
+                                                 int Cin, int c, int n, int py, int px, int ty,
+                                                 int tx, float sc, unsigned short* __restrict__ hi,
+                                                 unsigned short* __restrict__ lo,
+                                                 long long xi_stride) {
+  constexpr int R0 = RP == 0 ? 1 : RP == 1 ? 3 : 0, R1 = RP == 0 ? 2 : RP == 1 ? 4 : 5;
+  constexpr int I0 = RP == 2 ? 0 : 1, I1 = RP == 2 ? 6 : 5;       // input rows the pair needs
+  float4 t0[6], t1[6];                  // (B^T d)[R0][.], (B^T d)[R1][.]
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int xs = 4 * tx - 1 + j;
+    const int x = xs * g.d + px;
+    float4 dd[6];
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+      const int ys = 4 * ty - 1 + i;
+      const int y = ys * g.d + py;
+      const bool ok = ys >= 0 && xs >= 0 && y < g.H && x < g.W;
+      dd[i] = ok ? *reinterpret_cast<const float4*>(
+                       X + (((long long)n * g.H + y) * g.W + x) * Cin + c)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (RP == 0) {
+      const float4 e = f4fma(-4.f, dd[2], dd[4]), f = f4fma(-4.f, dd[1], dd[3]);
+      t0[j] = f4add4(e, f);
+      t1[j] = f4sub4(e, f);
+    } else if constexpr (RP == 1) {
+      const float4 p = f4sub4(dd[4], dd[2]), q = f4sub4(dd[3], dd[1]);
+      t0[j] = f4fma(2.f, q, p);
+      t1[j] = f4fma(-2.f, q, p);
+    } else {
+      t0[j] = f4fma(4.f, dd[0], f4fma(-5.f, dd[2], dd[4]));
+      t1[j] = f4fma(4.f, dd[1], f4fma(-5.f, dd[3], dd[5]));
+    }
+  }
+  float4 oo[6];
+  bt6(t0, oo);                          // (.) B
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    put_h2(oo[j], sc, hi + (R0 * 6 + j) * xi_stride, lo + (R0 * 6 + j) * xi_stride);
+  bt6(t1, oo);
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    put_h2(oo[j], sc, hi + (R1 * 6 + j) * xi_stride, lo + (R1 * 6 + j) * xi_stride);
+}
+
+__global__ __launch_bounds__(192) void wino4_input_h2_kernel(const float* __restrict__ X, Wino4Geom g,
                                                              int Cin, const unsigned* __restrict__ amax,
                                                              float* __restrict__ inv_scale,
                                                              unsigned short* __restrict__ Vp,
@@ -111,45 +163,21 @@ __global__ __launch_bounds__(256) void wino4_input_h2_kernel(const float* __rest
   const long long total = g.P * (Cin / 4);
   const long long xi_stride = (long long)Cin * g.P;                 // elements between the 36 xi
   const long long plane = 36 * xi_stride;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
-       t += (long long)gridDim.x * 256) {
+  const int rp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (long long t = (long long)blockIdx.x * 64 + (threadIdx.x & 63); t < total;
+       t += (long long)gridDim.x * 64) {
     const int cq = (int)(t & 3);
     const long long p = (t >> 2) % g.P;
     const int s = (int)((t >> 2) / g.P);
     const int c = s * 16 + cq * 4;
-    if (s == 0 && cq == 0) inv_scale[p] = isc;
+    if (s == 0 && cq == 0 && rp == 0) inv_scale[p] = isc;
     int n, py, px, ty, tx;
     tile4_coords(g, p, n, py, px, ty, tx);
-    // column stage first: for each of the six input columns j, the six rows -> (B^T d)[.][j]
-    float4 tt[6][6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int xs = 4 * tx - 1 + j;
-      const int x = xs * g.d + px;
-      float4 dd[6], oo[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int ys = 4 * ty - 1 + i;
-        const int y = ys * g.d + py;
-        const bool ok = ys >= 0 && xs >= 0 && y < g.H && x < g.W;
-        dd[i] = ok ? *reinterpret_cast<const float4*>(
-                         X + (((long long)n * g.H + y) * g.W + x) * Cin + c)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      bt6(dd, oo);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) tt[i][j] = oo[i];
-    }
     unsigned short* hi = Vp + ((long long)s * g.P + p) * 16 + cq * 4;
     unsigned short* lo = hi + plane;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {       // (.) B
-      float4 oo[6];
-      bt6(tt[i], oo);
-#pragma unroll
-      for (int j = 0; j < 6; ++j)
-        put_h2(oo[j], sc, hi + (i * 6 + j) * xi_stride, lo + (i * 6 + j) * xi_stride);
-    }
+    if (rp == 0) wino4_input_rows<0>(X, g, Cin, c, n, py, px, ty, tx, sc, hi, lo, xi_stride);
+    else if (rp == 1) wino4_input_rows<1>(X, g, Cin, c, n, py, px, ty, tx, sc, hi, lo, xi_stride);
+    else wino4_input_rows<2>(X, g, Cin, c, n, py, px, ty, tx, sc, hi, lo, xi_stride);
   }
 }
 
@@ -289,8 +317,8 @@ extern "C" int naws_conv3x3_winograd4_nhwc_f16x2_fwd(const float* X, const void*
   float* invA = Mb + 36 * slabM;                                     // P floats
   {
     const long long total = g.P * (Cin / 4);
-    hipLaunchKernelGGL(wino4_input_h2_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 256), 256 * 16)),
-                       dim3(256), 0, s, X, g, Cin, (const unsigned*)amax_in, invA, Vp, (unsigned*)amax_out);
+    hipLaunchKernelGGL(wino4_input_h2_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 64), 256 * 32)),
+                       dim3(192), 0, s, X, g, Cin, (const unsigned*)amax_in, invA, Vp, (unsigned*)amax_out);
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
   }

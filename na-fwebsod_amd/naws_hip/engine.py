@@ -242,9 +242,10 @@ class WsddnEngine(object):
         # TTA scales) take the direct kernel: 512 / 1024 / never measured 45.3 / 47.5 / 47.4 vs 44.6
         # ms per TTA image
         self.DIRECT_MIN_TILES = 256
-        # fp16x2 plan: Winograd F(4x4,3x3) (csrc/winograd4.hip) for the layers with at least this
-        # many input channels (conv4_2..conv5_3), F(2x2) below (conv4_1: the fused kernel); 0 = never
-        self.WINO_F4_MIN_CIN = 512
+        # fp16x2 plan: Winograd F(4x4,3x3) (csrc/winograd4.hip) for the Winograd layers with at
+        # least this many input channels (256: conv4_1..conv5_3; 512 leaves conv4_1 to F(2x2)'s
+        # fused kernel: conv body 2.099 vs 2.082 ms, tools/ab_wino4.py); 0 = F(2x2) everywhere
+        self.WINO_F4_MIN_CIN = 256
         # fp32x3: up to this many output channels the direct 3-plane kernel, Winograd above
         self.X3_DIRECT_MAX_COUT = 256
         # fc8's products (tiny output, long K): K in 4 slices + a deterministic second pass (58 vs
