@@ -23,6 +23,8 @@ Blob names, shapes and update rule follow the reference:
   detectron/ops/acm_weightdecay_momentum_sgd_op.h:48-112.
 """
 
+import os
+
 import numpy as np
 import torch
 
@@ -237,7 +239,7 @@ class WsddnEngine(object):
         # streams (before the head, checkpoints, lr changes, end of run).
         self.defer_update = None     # None/True -> side stream; False -> inline on the main stream
         # ---- fixed choices, named where the code branches on them ------------------------------
-        # Winograd F(2x2,3x3) for conv4_1..conv5_3 (and conv3_x in the fp32 plan); the layers with
+        # Winograd for conv4_1..conv5_3 (and conv3_x in the fp32 plan); under F(2x2) the layers with
         # >= 256 halo tiles per launch (conv1_2..conv3_3 at 600x1000, the deep layers of the larger
         # TTA scales) take the direct kernel: 512 / 1024 / never measured 45.3 / 47.5 / 47.4 vs 44.6
         # ms per TTA image
@@ -274,6 +276,14 @@ class WsddnEngine(object):
         self._pipe = None            # its tables (built on first use)
         self._wplanes = None         # split planes of fc6_w / fc7_w / fc7_w^T (16-bit MFMA plans)
         self._planes_dirty = True
+        # MEASUREMENT AID: NAWS_ENGINE_SET="DIRECT_MIN_TILES=100000,WINO_F4_MIN_CIN=0" overrides the
+        # upper-case integer choices above for every engine of the process (A/B runs of entry points
+        # that build their engine themselves: bench.py --infer, the CLIs)
+        for kv in filter(None, os.environ.get('NAWS_ENGINE_SET', '').split(',')):
+            k, v = kv.split('=')
+            if not (k.isupper() and isinstance(getattr(self, k, None), int)):
+                raise ValueError('NAWS_ENGINE_SET: %r is not an integer engine choice' % k)
+            setattr(self, k, int(v))
 
     # ------------------------------------------------------------------ params
     def blob(self, name):
@@ -404,7 +414,9 @@ class WsddnEngine(object):
                           else ops.winograd_weight_transform(w))           # [16][Cout][Cin]
                 if self.mfma_dtype == 'fp16x2':
                     packed = ops.split_f16x2(packed)           # F16x2, planes [2][16][Cin/16][Cout][16]
-                    if w.shape[0] % 128 == 0 and \
+                    # (F(4x4) layers never switch: 42.4 vs 43.5 ms per TTA image with the direct
+                    # form taking over at the large scales, 44.5 for F(2x2) with it)
+                    if not f4 and w.shape[0] % 128 == 0 and \
                             (dil == 1 or (dil is None and self.dilation in (1, 2))):
                         # also the direct form: chosen per input size in _conv_chain
                         self.conv_direct_h2[name] = ops.split_f16x2(
