@@ -13,7 +13,7 @@
 // matrix cores in the hi / lo split with fp32 accumulation (gemm_x3.hip, as F(2x2)).  |B^T d B| <=
 // 100 max|x| (row sums of |B^T| are 10), so the tensor-wide power of two maps max|x| below 2^9
 // (F(2x2): 2^13) and the f16 pair keeps >= 22 significand bits down to 2^-20 of the maximum.
-// tools/wino_error_study.py (CPU, fp32 emulation of both forms through conv4_1 .. conv5_3 at
+// tests/wino_error_study.py (CPU, fp32 emulation of both forms through conv4_1 .. conv5_3 at
 // 600 x 1000, Kaiming and skewed statistics): per-channel error of conv5_3 / channel RMS against
 // the fp32 direct oracle 3.6e-5 .. 4.1e-5 for F(4x4) vs 2.1e-5 .. 2.3e-5 for F(2x2) (the direct fp32
 // sum is itself 1.6e-5 .. 1.9e-5 from float64); tests/test_gpu_fullsize_oracle.py holds the plan

@@ -69,17 +69,18 @@ def _worker(rank, world, port, outdir, sharded=False, pipeline=None, dropout=0.0
     dev = torch.device('cuda', 0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     _roidb, halves = _batches(world)
-    # world 2: four explicit chunks; world 8: the engine's own auto choice ("2 above 2 ranks")
+    # world 2: four explicit chunks; above: the engine's own auto choice ("2 above 2 ranks")
     eng = _engine(dev, world * B, dist.group.WORLD, world, sharded=sharded,
                   chunks=4 if world == 2 else 0, pipeline=pipeline, dropout=dropout)
     assert eng.reducer.active and (eng._shard_blocks() is not None) == sharded
     # the update runs piece by piece by default whenever there is an exchange (not when sharded)
     assert eng._pipelined() == (not sharded and pipeline is not False)
     assert eng.gpu_num == world * B
-    if world == 8:
+    if world > 2:
         assert eng.allreduce_chunks == 2
         if sharded:
-            assert eng._shard_blocks() == [(r * 1024, (r + 1) * 1024) for r in range(8)]
+            rows = 8192 // world
+            assert eng._shard_blocks() == [(r * rows, (r + 1) * rows) for r in range(world)]
     eng.reducer.log = log = []
     losses = _run(eng, halves[rank], dev, train_step=train_step)
     if rank == 0:
@@ -106,7 +107,7 @@ def _worker(rank, world, port, outdir, sharded=False, pipeline=None, dropout=0.0
     if world == 2 or rank == 0:
         for k, v in arrays.items():
             np.save(os.path.join(outdir, '%s%s%d.npy' % (k, tag, rank)), v)
-    # (world 8: 2.7 GB per rank - the other ranks leave a digest of every array instead)
+    # (world > 2: 2.7 GB per rank - the other ranks leave a digest of every array instead)
     import hashlib
     import json
     with open(os.path.join(outdir, 'digest%s%d.json' % (tag, rank)), 'w') as f:
@@ -189,7 +190,11 @@ def test_sharded_update_two_ranks_bit_identical_to_the_allreduce_route(dev, tmp_
 
 
 # ------------------------------------------------------------------------------------------
-# World size 8 (BASELINE configs[2]: 8 ranks x 2 images, gpu_num = 16) on the one GPU of the box
+# configs[2]'s N-rank schedule (N ranks x 2 images, gpu_num = 2 N) on the one GPU of the box.  The
+# box's process guard allows six processes on the GPU at once - this session + at most five ranks -,
+# so the hardware run is world 4 (rounds 4-5 ran world 8 here before the guard existed; the world-8
+# message plan and owner blocks are covered on CPU: tests/test_distributed_cpu.py, test_bench_launcher.py)
+MANY = 4
 # ------------------------------------------------------------------------------------------
 def _spawn(world, outdir, sharded):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
@@ -230,23 +235,23 @@ def _sequential_reference(dev, world):
     return eng, np.stack(losses)
 
 
-def test_eight_ranks_on_one_gpu_allreduce_and_sharded_routes(dev, tmp_path):
-    """configs[2]'s schedule at world = 8: eight processes share cuda:0 and
-    exchange over gloo, 2 images each, gpu_num = 16, the engine's own auto chunk count (2),
-    perm-style image shards, owner blocks of 8192 / 8 = 1024 fc6_w rows on the sharded route.
+def test_many_ranks_on_one_gpu_allreduce_and_sharded_routes(dev, tmp_path):
+    """configs[2]'s schedule above two ranks: MANY processes share cuda:0 and
+    exchange over gloo, 2 images each, gpu_num = 2 MANY, the engine's own auto chunk count (2),
+    perm-style image shards, owner blocks of 8192 / MANY fc6_w rows on the sharded route.
       * every rank ends with bit-identical parameters (both routes);
       * the sharded route is bit-identical to the all-reduce route: parameters, momentum (once
         gathered), fc6_w's operand planes and their scales, on every rank;
-      * against ONE process that plays the 8 ranks in turn and sums their gradients itself
-        (gpu_num = 16): first-step losses equal, parameters after 3 steps within the fp32
+      * against ONE process that plays the ranks in turn and sums their gradients itself
+        (gpu_num = 2 MANY): first-step losses equal, parameters after 3 steps within the fp32
         summation-order slack of the exchange (1e-3 of the total parameter movement);
-      * against one process fed the 16 images as ONE batch (gpu_num = 16): the same within the
+      * against one process fed all the images as ONE batch (gpu_num = 2 MANY): the same within the
         order in which the proposals of a batch are summed.
     Bit-identity between N ranks and one process is not a property of the algorithm (nor of the
     reference: NCCL's ring adds the ranks' fp32 gradients in a rank-rotated order per chunk,
     optimizer_wsl.py:52-72), so the single-process comparisons carry a stated tolerance."""
     import json
-    world = 8
+    world = MANY
     for sharded in (False, True):
         _spawn(world, str(tmp_path), sharded)
     ref = {w: np.load(str(tmp_path / ('%s0.npy' % w))) for w in ('params', 'mom', 'planes', 'scales')}
@@ -261,9 +266,9 @@ def test_eight_ranks_on_one_gpu_allreduce_and_sharded_routes(dev, tmp_path):
         assert dig[('s', r)] == dig[('s', 0)], r
     # ... and against the all-reduce route: the first step's losses are equal, the parameters
     # agree within the summation-order slack.  (At world 2 the two routes are bit-identical -
-    # a + b = b + a - and the two-rank test asserts that; with 8 addends the ring's order of
+    # a + b = b + a - and the two-rank test asserts that; with more addends the ring's order of
     # additions depends on where an element sits in its message, and the two routes cut
-    # fc6_w's gradient into different messages: 2 row chunks vs 8 owner pieces.)
+    # fc6_w's gradient into different messages: 2 row chunks vs one piece per owner.)
     for r in range(world):
         ls, la = (np.load(str(tmp_path / ('losses%s%d.npy' % (t, r)))) for t in ('s', ''))
         assert np.array_equal(ls[0], la[0]), r
@@ -278,9 +283,9 @@ def test_eight_ranks_on_one_gpu_allreduce_and_sharded_routes(dev, tmp_path):
     assert msgs[3][1] == ref['params'].size - 8192 * 25088 - 8192
     smsgs = json.load(open(str(tmp_path / 'messagess.json')))
     kinds = [m[0] for m in smsgs[:len(smsgs) // STEPS]]
-    assert kinds.count('reduce_to_owner') == 8 and kinds.count('gather_blocks') == 2
+    assert kinds.count('reduce_to_owner') == world and kinds.count('gather_blocks') == 2
     assert sum(m[1] for m in smsgs[:len(smsgs) // STEPS] if m[0] == 'reduce_to_owner') == 8192 * 25088
-    # ---- one process playing the 8 ranks in turn
+    # ---- one process playing the ranks in turn
     eng, seq_losses = _sequential_reference(dev, world)
     got_losses = np.concatenate([np.load(str(tmp_path / ('losses%d.npy' % r))) for r in range(world)], 1)
     assert np.array_equal(got_losses[0], seq_losses[0])              # same kernels, same inputs
@@ -291,8 +296,8 @@ def test_eight_ranks_on_one_gpu_allreduce_and_sharded_routes(dev, tmp_path):
     d = np.abs(ref['params'] - seq).max()
     ds = np.abs(sref['params'] - seq).max()
     dr = np.abs(sref['params'] - ref['params']).max()
-    print('\n[world 8] max |params - sequential reference|: all-reduce route %.3e, sharded route '
-          '%.3e; sharded vs all-reduce %.3e (total movement %.3e)' % (d, ds, dr, step))
+    print('\n[world %d] max |params - sequential reference|: all-reduce route %.3e, sharded route '
+          '%.3e; sharded vs all-reduce %.3e (total movement %.3e)' % (world, d, ds, dr, step))
     assert d <= 1e-3 * step + 1e-9, (d, step)
     assert ds <= 1e-3 * step + 1e-9, (ds, step)
     assert dr <= 1e-3 * step + 1e-9, (dr, step)
@@ -301,14 +306,14 @@ def test_eight_ranks_on_one_gpu_allreduce_and_sharded_routes(dev, tmp_path):
     n6, k6 = 8192, 25088
     w6 = sref['params'][:n6 * k6].reshape(n6, k6)
     pl = sref['planes'].view(np.float16).astype(np.float32)           # [2, k6/16, n6, 16]
-    rows = np.arange(0, n6, 1024 // 4)                                # every owner's block sampled
+    rows = np.arange(0, n6, n6 // world // 4)                         # every owner's block sampled
     rebuilt = (pl[0][:, rows] + pl[1][:, rows]).transpose(1, 0, 2).reshape(len(rows), k6) \
         * sref['scales'][rows, None]
     err = np.abs(rebuilt - w6[rows]).max(axis=1) / np.abs(w6[rows]).max(axis=1)
     assert err.max() <= 2.0 ** -20, err.max()
     del eng
     torch.cuda.empty_cache()
-    # ---- one process, the 16 images as one batch
+    # ---- one process, all the images as one batch
     from detectron.datasets import synthetic
     roidb, _shares = _batches(world)
     eng = _engine(dev, world * B)

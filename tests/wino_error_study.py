@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""CPU study behind csrc/winograd4.hip (no GPU; uses the ORACLE's conv body, so it is a tool, not
-product code): the per-channel error of conv5_3 when conv4_1..conv5_3 run as Winograd F(2x2,3x3) or
+"""CPU study behind csrc/winograd4.hip (no GPU; it imports the ORACLE's layer table, so it lives under
+tests/, not in the product package): the per-channel error of conv5_3 when conv4_1..conv5_3 run as Winograd F(2x2,3x3) or
 F(4x4,3x3) emulated in numpy fp32 (transforms fp32, products by fp32 BLAS; split=1 also rounds V
 under one power-of-two scale per tensor and U under one per (frequency, output channel) to the
 f16 hi + lo pair), against the torch fp32 direct convolution (the oracle) and a float64 one.
 Yardstick = tests/test_gpu_fullsize_oracle.py's: max error per channel / the channel's
 pre-activation RMS; plus max error / max|conv5_3| and the dark-third measure.
 
-    python tools/wino_error_study.py 600 1000 kaiming|skewed
+    python tests/wino_error_study.py 600 1000 kaiming|skewed
 
 Measured (600 x 1000): F(2x2) 2.1e-5 / 2.1e-5, F(4x4) 3.8e-5 / 3.6e-5 (kaiming / skewed, split=1);
 the fp32 direct sum itself is 1.6e-5 / 1.9e-5 from float64."""
@@ -15,7 +15,7 @@ import sys, time
 import numpy as np, torch, torch.nn.functional as F
 import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(_HERE, '..', '..')); sys.path.insert(0, os.path.join(_HERE, '..'))
+sys.path.insert(0, os.path.join(_HERE, '..')); sys.path.insert(0, os.path.join(_HERE, '..', 'na-fwebsod_amd'))
 from detectron.datasets import synthetic
 from oracle import oracle
 
