@@ -9,13 +9,14 @@ import glob
 import sys
 
 HOT = ('gemm_x3', 'gemm_h2_btr', 'conv_h2', 'conv_x3', 'roi_pool', 'acm_sgd', 'split2h_dual', 'gemm_smallk', 'wino_',
-       'conv_c3')
+       'wino4_', 'conv_c3')
 # (template prefix, grid, MFMA-busy cycles / 1e7) -> what the launch is; prefixes, because template
 # argument lists grow (round 4 appended one and every exact-name label stopped matching)
 LABEL = {('gemm_h2_btr_kernel<256, 256, 4, 2, true', '1572864', None): 'fc6 wgrad + SGD epilogue',
          ('gemm_h2_btr_kernel<256, 256, 4, 2, false', '1572864', None): 'fc6 wgrad, gradient written (deferred route)',
          ('gemm_x3_m16_kernel<256, 256, 4, 2, 2, 2, 2, true', '262144', 493): 'fc6 fwd (M=4000 N=8192 K=25088)',
-         ('gemm_x3_kernel<128, 128, 2, 2, 3, 2, 1, true', '311296', None): 'Winograd batch GEMM (16 x [2344 tiles x 512 x 512])',
+         ('gemm_x3_kernel<128, 128, 2, 2, 3, 2, 1, true', '311296', None): 'Winograd F(2x2) batch GEMM (16 x [2344 tiles x 512 x 512])',
+         ('gemm_x3_kernel<128, 128, 2, 2, 3, 2, 1, true', '184320', None): 'Winograd F(4x4) batch GEMM (36 x [608 or 640 tiles x 512 x Cin])',
          ('roi_pool_nhwc_xcd_kernel<true, true', None, None): 'RoIPoolF + boost -> fc6 operand planes'}
 
 

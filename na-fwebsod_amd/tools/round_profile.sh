@@ -20,8 +20,9 @@ python $T/pmc_default_plan.py $O/infer_sq $P/${R}_infer_pmc.md > /dev/null
 python $T/step_timeline.py $O/fp16x2_stats full > $P/${R}_step_timeline.txt 2>&1
 python bench.py > $P/${R}_bench_line.json 2> $P/${R}_bench_line.err
 python bench.py --infer > $P/${R}_infer_line.json 2>/dev/null
-# configs[2]'s schedule with eight ranks on this one GPU over gloo (a diagnostic, not a rate)
-python bench.py --gpus 8 --share-gpu --steps 6 --warmup 2 2>/dev/null | tail -1 > $P/${R}_share_gpu8_line.json
+# configs[2]'s schedule with four ranks on this one GPU over gloo (a diagnostic, not a rate; the
+# box's process guard allows six processes on the GPU: rounds 4-5 ran eight ranks here)
+python bench.py --gpus 4 --share-gpu --steps 6 --warmup 2 2>/dev/null | tail -1 > $P/${R}_share_gpu4_line.json
 # kernel timelines of one step of the 2-rank projection, update piece by piece / in one launch
 rocprofv3 --kernel-trace --output-format csv -d $O/n2_trace -o tr -- python bench.py --no-cpu-baseline --no-alt-plan --no-extra-configs --no-parity-check --emulate-exchange 2 --steps 20 --warmup 5 > $O.n2.log 2>&1
 python $T/exchange_timeline.py $O/n2_trace pipelined 100 > $P/${R}_n2_projection_timeline_pipelined.txt 2>&1
