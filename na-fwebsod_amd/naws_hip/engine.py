@@ -258,13 +258,6 @@ class WsddnEngine(object):
         self.UPDATE_AFTER = 2 if mfma_dtype == 'bf16' else 1
         # fp16x2 plan: each image's proposals are pooled on that image's conv stream (conv_body)
         self.ROI_POOL_ON_CHAINS = True
-        # The per-image chains start STAGGERED: image i + 1 enters its MFMA-bound direct layers
-        # (entries STAGGER_FROM .. STAGGER_AT - 1 of VGG16_CONVS: conv1_2 .. pool3) when image i leaves
-        # them for its Winograd layers (L2 / HBM-bound transforms and short-K GEMMs) - started
-        # together, both images sit in the same phase and halve the same resource
-        self.STAGGER_CHAINS = 1 if mfma_dtype == 'fp16x2' else 0
-        self.STAGGER_FROM = 1
-        self.STAGGER_AT = 10
         self.conv_wino = {}
         self._rm_table = None
         self._fc8_ws = None
@@ -415,8 +408,11 @@ class WsddnEngine(object):
                 # weight planes [3][9*Cin/16][Cout][16] of the packed [Cout][3][3][Cin] weight
                 packed = ops.split_bf16x3(ops.conv3x3_pack_weight(w).view(w.shape[0], -1))
             elif use_wino:
+                # (conv3_2 / conv3_3, 256 -> 256 at 150 x 250, stay on the direct kernel: as F(4x4)
+                # their V and M are 88 MB each way for a quarter of conv4_2's products - 0.24 vs
+                # 0.19 ms per layer-image inside a step)
                 f4 = (self.mfma_dtype == 'fp16x2' and 0 < self.WINO_F4_MIN_CIN <= w.shape[1]
-                      and w.shape[1] % 32 == 0)
+                      and w.shape[1] % 32 == 0 and w.shape[0] >= 512)
                 packed = (ops.winograd4_weight_transform(w) if f4          # [36][Cout][Cin]
                           else ops.winograd_weight_transform(w))           # [16][Cout][Cin]
                 if self.mfma_dtype == 'fp16x2':
@@ -510,15 +506,12 @@ class WsddnEngine(object):
 
     # ---------------------------------------------------------------- forward
     def _conv_chain(self, data, out=None, amax_final=None, first=0, end=None, x=None,
-                    bound_in=None, amax_last=None, affine_in=None, stagger=None):
+                    bound_in=None, amax_last=None, affine_in=None):
         """data NCHW [b,3,H,W] -> conv5_3 NHWC, on the current stream.  amax_final (int32 [1],
         fp16x2 plan): receives the bit pattern of max|conv5_3| for the RoIPool operand scale.
         first / end: run only VGG16_CONVS[first:end] (x = the input of layer `first`, bound_in = the
         word holding an upper bound of max|x|); amax_last: a pre-zeroed word that the LAST layer of
-        the range max-es its max|y| into (shared by the per-image chains).
-        stagger = (event or None, list): STAGGER_CHAINS (conv_body) - the current stream waits for
-        the event before entry max(first, STAGGER_FROM) of VGG16_CONVS is queued, and an event
-        recorded right in front of entry STAGGER_AT (the first Winograd layer) is appended to the list."""
+        the range max-es its max|y| into (shared by the per-image chains)."""
         last = VGG16_CONVS[-1][0]
         end = len(VGG16_CONVS) if end is None else end
         # fp16x2 Winograd layers hand max|y| to the next layer (its operand scale needs an upper
@@ -537,12 +530,6 @@ class WsddnEngine(object):
         for li, item in enumerate(VGG16_CONVS):
             if li < first or li >= end:
                 continue
-            if stagger is not None:
-                cur = torch.cuda.current_stream(self.device)
-                if li == max(first, self.STAGGER_FROM) and stagger[0] is not None:
-                    cur.wait_event(stagger[0])           # the previous image has left its direct layers
-                if li == self.STAGGER_AT:
-                    stagger[1].append(cur.record_event())
             if item[0] == 'pool':
                 if not fused_pool and not (li == first and self._pool_done):
                     x = ops.maxpool2x2_nhwc(x, 2)
@@ -693,23 +680,19 @@ class WsddnEngine(object):
                     evs.append(st.record_event())
             pool_done = self._pool_done
             self._launch_update(evs)
-        left_direct = None               # STAGGER_CHAINS: the previous image is past pool3
         for i in range(n):
             st = self._streams[i]
             if not split:
                 st.wait_event(start)
             with torch.cuda.stream(st):
                 af = None if self._amax5 is None else self._amax5[i:i + 1]
-                stg = (left_direct, []) if self.STAGGER_CHAINS else None
                 if split:
                     self._pool_done = pool_done
                     self._conv_chain(None, out=out[i:i + 1], amax_final=af,
                                      first=max(1, self.UPDATE_AFTER), x=heads[i][0],
-                                     bound_in=heads[i][1], affine_in=heads[i][2], stagger=stg)
+                                     bound_in=heads[i][1], affine_in=heads[i][2])
                 else:
-                    self._conv_chain(data[i:i + 1], out=out[i:i + 1], amax_final=af, stagger=stg)
-                if stg is not None and stg[1]:
-                    left_direct = stg[1][0]
+                    self._conv_chain(data[i:i + 1], out=out[i:i + 1], amax_final=af)
                 if self._roi_maps is not None:
                     # RoIPoolF's block-maxima maps of this image, beside the other image's tail
                     ops.roi_maxmaps(out[i:i + 1], self._roi_maps[0][i:i + 1], self._roi_maps[1][i:i + 1])

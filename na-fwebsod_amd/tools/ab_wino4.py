@@ -92,33 +92,6 @@ def body(a, dev):
                 outs[label] = y.clone()
             else:
                 times[label].append(s.elapsed_time(e) / a.iters)
-    # the staggered start of the per-image chains (engine.STAGGER_CHAINS), on the default engine
-    eng = engines['F(4x4) from Cin 256']
-    for label, kv in (('chains start together', dict(STAGGER_CHAINS=0)),
-                      ('staggered: conv1_2 behind pool3', dict(STAGGER_CHAINS=1, STAGGER_FROM=1, STAGGER_AT=10)),
-                      ('staggered: conv1_1 behind pool3', dict(STAGGER_CHAINS=1, STAGGER_FROM=0, STAGGER_AT=10)),
-                      ('staggered: conv2_1 behind pool3', dict(STAGGER_CHAINS=1, STAGGER_FROM=3, STAGGER_AT=10)),
-                      ('staggered: conv1_2 behind pool2', dict(STAGGER_CHAINS=1, STAGGER_FROM=1, STAGGER_AT=6))):
-        times[label] = []
-        engines[label] = (eng, kv)
-    for r in range(a.rounds + 1):
-        for label, ek in engines.items():
-            if not isinstance(ek, tuple):
-                continue
-            for k, v in ek[1].items():
-                setattr(eng, k, v)
-            y = eng.conv_body(data)
-            torch.cuda.synchronize()
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(a.iters):
-                y = eng.conv_body(data)
-            e.record()
-            torch.cuda.synchronize()
-            if r == 0:
-                outs[label] = y.clone()
-            else:
-                times[label].append(s.elapsed_time(e) / a.iters)
     first = next(iter(outs))
     for label in engines:
         ts = sorted(times[label])
