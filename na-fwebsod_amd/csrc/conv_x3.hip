@@ -1138,8 +1138,7 @@ int launch_conv_h2_wp(CArgs& g, int N, hipStream_t s) {
   g.tiles_n = (int)naws_cdiv(g.Cout, BN);
   const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
   if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
-  size_t lds = (size_t)2 * NPL * 2 * NawsWpGeom<DIL>::A_HALF;
-  if (naws_knob(NAWS_KNOB_CONV_RING) == 20) lds += 24 * 1024;      // EXPERIMENT: two workgroups per CU
+  const size_t lds = (size_t)2 * NPL * 2 * NawsWpGeom<DIL>::A_HALF;
   auto kern = conv_h2_wp_kernel<WR, WC, DIL, PIPE, NPL>;
   if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
