@@ -57,6 +57,15 @@ EXTRA = [
     ('conv_h2_wp_kernel<2, 2, 1, true, 2', '614400', 'conv_h2_wp conv1_2 + pool1 (one image)', 192.0),
     ('conv_h2_wp_kernel<2, 2, 1, true, 2', '311296', 'conv_h2_wp conv2_1 / conv2_2 + pool2 (mean)', 105.6),
     ('conv_h2_wp_kernel<2, 2, 1, true, 2', '155648', 'conv_h2_wp conv3_1 / 3_2 / 3_3 + pool3 (mean)', 60.8),
+    # Winograd F(4x4,3x3), one image per launch (round 6): input transform = fp32 NHWC input read + the
+    # two f16 V planes written (36 x tiles x Cin x 4 B); batch GEMM = V + U planes read + M written;
+    # output transform = M read + NHWC output written.  608 tiles at 75 x 125, 640 at 74 x 124 dilated.
+    ('wino4_input_h2_kernel', '233472', 'wino4_input conv4_2 conv4_3 (19.2 MB in, 44.8 MB of V planes out)', 64.0),
+    ('wino4_input_h2_kernel', '245760', 'wino4_input conv5_x (18.8 MB in, 47.2 MB out)', 66.0),
+    ('gemm_x3_kernel<128, 128, 2, 2, 3, 2, 1, true', '184320',
+     'gemm_x3 winograd4 batch GEMM 36 frequencies (gemm_x3_kernel<128,128,3 stages>; mean of conv4_1 86.1, conv4_2/3 127.3, conv5_x 132.1)', 122.8),
+    ('wino4_output_kernel', '77824', 'wino4_output conv4_x (44.8 MB of M in, 19.2 MB out)', 64.0),
+    ('wino4_output_kernel', '81920', 'wino4_output conv5_x (47.2 MB in, 18.8 MB out)', 66.0),
 ]
 
 
