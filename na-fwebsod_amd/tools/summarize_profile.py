@@ -76,8 +76,8 @@ def short(name):
 
 def template_match(prefix, kernel_name):
     """True when `kernel_name` is an instance of the template prefix: the prefix must be followed
-    by `,` (more template arguments) or `>` (none)."""
-    return re.search(re.escape(prefix) + r'\s*[,>]', kernel_name) is not None
+    by `,` (more template arguments), `>` (none) or `(` (the kernel is not a template)."""
+    return re.search(re.escape(prefix) + r'\s*[,>(]', kernel_name) is not None
 
 
 def _find(d, pat):
