@@ -99,8 +99,9 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&s)[4]) {
 // pieces of 16 pixels per tap.  The three waves of a workgroup take the row pairs {1, 2}, {3, 4}
 // and {0, 5} of the same 64 (tile, quad) items: the pairs share their sub-expressions of B^T, the
 // first two need input rows 1..4 only, the taps the waves have in common are L1 hits - and the
-// launch has three times the waves of a one-lane-per-tile form (912 workgroups at 75 x 125 x 512,
-// 12 instead of 36 transform-domain values live per lane: 21 -> see DESIGN 3 for the timing).
+// launch has three times the waves of a one-lane-per-tile form (12 instead of 36 transform-domain
+// values live per lane; the two forms time alike: 21.7 vs 21.0 us at 75 x 125 x 512, 75 vs 79 at
+// 150 x 250).
 template <int RP>
 __device__ __forceinline__ void wino4_input_rows(const float* __restrict__ X, const Wino4Geom& g,
                                                  int Cin, int c, int n, int py, int px, int ty,
@@ -148,11 +149,14 @@ __device__ __forceinline__ void wino4_input_rows(const float* __restrict__ X, co
     put_h2(oo[j], sc, hi + (R1 * 6 + j) * xi_stride, lo + (R1 * 6 + j) * xi_stride);
 }
 
-__global__ __launch_bounds__(192) void wino4_input_h2_kernel(const float* __restrict__ X, Wino4Geom g,
-                                                             int Cin, const unsigned* __restrict__ amax,
-                                                             float* __restrict__ inv_scale,
-                                                             unsigned short* __restrict__ Vp,
-                                                             unsigned* __restrict__ amax_out) {
+// SLABS = 2: six waves per workgroup - the three row pairs of TWO neighbouring 16-channel slabs of
+// the same 16 tiles, so that both 64-byte halves of every 128-byte line of X are read on one CU.
+template <int SLABS>
+__global__ __launch_bounds__(192 * SLABS) void wino4_input_h2_kernel(const float* __restrict__ X, Wino4Geom g,
+                                                                     int Cin, const unsigned* __restrict__ amax,
+                                                                     float* __restrict__ inv_scale,
+                                                                     unsigned short* __restrict__ Vp,
+                                                                     unsigned* __restrict__ amax_out) {
   // this layer's output maximum is accumulated by wino4_output_kernel, stream-ordered after this
   if (amax_out && blockIdx.x == 0 && threadIdx.x == 0) *amax_out = 0u;
   int e = (int)((*amax >> 23) & 0xff);
@@ -160,15 +164,16 @@ __global__ __launch_bounds__(192) void wino4_input_h2_kernel(const float* __rest
   e = min(max(e, 40), 250);
   const float sc = __uint_as_float((unsigned)(262 - e) << 23);      // 2^(8 - (e - 127))
   const float isc = __uint_as_float((unsigned)(e - 8) << 23);
-  const long long total = g.P * (Cin / 4);
+  const long long total = g.P * (Cin / 4) / SLABS;                  // (tile, quad, slab group) items
   const long long xi_stride = (long long)Cin * g.P;                 // elements between the 36 xi
   const long long plane = 36 * xi_stride;
-  const int rp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rp = wv % 3, ss = wv / 3;
   for (long long t = (long long)blockIdx.x * 64 + (threadIdx.x & 63); t < total;
        t += (long long)gridDim.x * 64) {
     const int cq = (int)(t & 3);
     const long long p = (t >> 2) % g.P;
-    const int s = (int)((t >> 2) / g.P);
+    const int s = (int)((t >> 2) / g.P) * SLABS + ss;
     const int c = s * 16 + cq * 4;
     if (s == 0 && cq == 0 && rp == 0) inv_scale[p] = isc;
     int n, py, px, ty, tx;
@@ -317,8 +322,9 @@ extern "C" int naws_conv3x3_winograd4_nhwc_f16x2_fwd(const float* X, const void*
   float* invA = Mb + 36 * slabM;                                     // P floats
   {
     const long long total = g.P * (Cin / 4);
-    hipLaunchKernelGGL(wino4_input_h2_kernel, dim3((unsigned)std::min<long long>(naws_cdiv(total, 64), 256 * 32)),
-                       dim3(192), 0, s, X, g, Cin, (const unsigned*)amax_in, invA, Vp, (unsigned*)amax_out);
+    // (one slab per workgroup, 192 threads: 0.1023 vs 0.1004 ms per conv4_2 layer, bit-identical)
+    hipLaunchKernelGGL(wino4_input_h2_kernel<2>, dim3((unsigned)std::min<long long>(naws_cdiv(total, 128), 256 * 32)),
+                       dim3(384), 0, s, X, g, Cin, (const unsigned*)amax_in, invA, Vp, (unsigned*)amax_out);
     int rc = naws_check_launch();
     if (rc != NAWS_OK) return rc;
   }
