@@ -523,7 +523,8 @@ int naws_conv3x3_winograd_nhwc_f16x2_fwd(const float* X, const void* U2, const f
  * detectron/modeling/VGG16.py:33-46, conv4_x / conv5_x): 36 batched GEMMs over 6x6 input tiles,
  * 4x fewer MFMA flops than the direct sum and 0.56 of F(2x2)'s transform-domain bytes.  The
  * transforms run in fp32; the input transform scales by one power of two per tensor
- * (|B^T d B| <= 100 max|x|) and writes the f16 hi / lo planes itself.
+ * (interpolation points 0, 1, -1, 2, -1/2, inf: |B^T d B| <= 196 max|x|) and writes the f16 hi / lo
+ * planes itself.
  * naws_winograd4_weight_transform: U[36][Cout][Cin] = G g G^T of W_oihw, taken in double and
  * rounded once.  U2 / scaleU: naws_split_f16x2 of U viewed as batch 36 of [Cout][Cin] (scaleU = its
  * scales[1], [36][Cout]).  Cin % 32 == 0, Cout % 4 == 0.  amax_in (required): device word holding

@@ -28,6 +28,10 @@ def mats(m):
         BT = np.array([[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]], np.float64)
         G = np.array([[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], np.float64)
         AT = np.array([[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]], np.float64)
+    elif m == 5:   # F(4x4,3x3) on the points 0, 1, -1, 2, -1/2, inf (csrc/winograd4.hip since round 6)
+        BT = np.array([[2,3,-4,-3,2,0],[0,2,5,1,-2,0],[0,2,1,-5,2,0],[0,-1,-2,1,2,0],[0,-2,1,2,-1,0],[0,2,3,-4,-3,2]], np.float64)
+        G = np.array([[1/2,0,0],[1/6,1/6,1/6],[1/6,-1/6,1/6],[1/30,1/15,2/15],[16/15,-8/15,4/15],[0,0,1/2]], np.float64)
+        AT = np.array([[1,1,1,1,1,0],[0,1,-1,2,-1/2,0],[0,1,1,4,1/4,0],[0,1,-1,8,-1/8,1]], np.float64)
     elif m == 3:   # F(3x3,3x3): points 0, 1, -1, 2, inf  (5x5 tiles)
         BT = np.array([[2,-1,-2,1,0],[0,-2,-1,1,0],[0,2,-3,1,0],[0,-1,0,1,0],[0,2,-1,-2,1]], np.float64)
         G = np.array([[1/2,0,0],[-1/2,-1/2,-1/2],[-1/6,1/6,-1/6],[1/6,1/3,2/3],[0,0,1]], np.float64)
@@ -49,6 +53,7 @@ def wino_conv(x, w, b, m, split=False, mixed=(None, None)):
     mixed = (mh, mw) for rectangular forms."""
     mh, mw = (m, m) if mixed[0] is None else mixed
     BTh, Gh, ATh = mats(mh); BTw, Gw, ATw = mats(mw)
+    mh, mw = ATh.shape[0], ATw.shape[0]          # output tile side (m = 5 names a point set of F(4x4))
     C, H, W = x.shape; O = w.shape[0]
     th, tw = -(-H // mh), -(-W // mw)
     ah, aw = mh + 2, mw + 2
@@ -132,6 +137,7 @@ if __name__ == '__main__':
     deep = ['conv4_1', 'conv4_2', 'conv4_3', 'conv5_1', 'conv5_2', 'conv5_3']
     for label, plan in (('F2 all deep', {k: 2 for k in deep}),
                         ('F4 all deep', {k: 4 for k in deep}),
+                        ('F4 new points', {k: 5 for k in deep}),
 
                         ):
         for split in (False, True):
