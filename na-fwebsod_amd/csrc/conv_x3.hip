@@ -821,7 +821,11 @@ void conv_h2_wp_kernel(CArgs g) {
 #pragma unroll
   for (int r = 0; r < UR; ++r) {
     const int u = tid + r * 256;
-    const int hp = u >> 1, half = u & 1;
+    // 16 consecutive lanes = 8 halo pixels x the 2 k-halves, k-half major: ds_write_b128 is served in
+    // groups of 8 consecutive lanes over 32 banks, and 8 pixels of one k-half are 128 contiguous
+    // bytes (pixel-major - lanes 2 p, 2 p + 1 = the halves of pixel p - put both halves of four pixels
+    // on the same 16 banks: the kernel's 1.0-2.3 M SQ_LDS_BANK_CONFLICT cycles per launch)
+    const int hp = (u >> 4) * 8 + (u & 7), half = (u >> 3) & 1;
     const int y = ty0 - DIL + hp / HWD, x = tx0 - DIL + hp % HWD;
     const bool ok = hp < HPIX && y >= 0 && y < g.H && x >= 0 && x < g.W;
     abase[r] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)g.Cin + half * 8) * 4u : OOB;
