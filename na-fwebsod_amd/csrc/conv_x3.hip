@@ -23,6 +23,7 @@ struct CArgs {
   long long planeB, slabB;
   unsigned bytesX;
   int tiles_m, tiles_n;
+  int N_img;                 // images of the launch (conv_h2_wp_kernel's tile map)
   // fp16x2 form of the halo kernel
   const float* scaleB;       // 1/scale per output channel (naws_split_f16x2 of the weight)
   const unsigned* amax_in;   // bit pattern of an upper bound b of max|X| ...
@@ -793,9 +794,25 @@ void conv_h2_wp_kernel(CArgs g) {
   unsigned char* smA = smx;
 
   const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-  int lid = blockIdx.x;
-  const int tn = lid % g.tiles_n;
-  lid /= g.tiles_n;
+  // Workgroups go to the 8 XCDs round-robin by launch index.  The channel tiles of ONE pixel tile
+  // are given launch indices 8 apart, so that they run on one XCD and the tile's halo is fetched into
+  // one L2 (channel tile fastest, an XCD saw one channel tile of every pixel tile: the input came in
+  // tiles_n times - conv3_x's counter traffic was 3.0 x its algorithmic bytes, conv2_x's 1.9 x).  The
+  // last < 8 pixel tiles keep the channel-fastest order.
+  const int npix = g.N_img * tiles_x * tiles_y, full = npix & ~7;
+  int tn, lid;
+  {
+    const int b = blockIdx.x, span = 8 * g.tiles_n;
+    if (b < full * g.tiles_n) {
+      const int r = b % span;
+      tn = r >> 3;
+      lid = (b / span) * 8 + (r & 7);
+    } else {
+      const int b2 = b - full * g.tiles_n;
+      tn = b2 % g.tiles_n;
+      lid = full + b2 / g.tiles_n;
+    }
+  }
   const int tx0 = (lid % tiles_x) * TW;
   const int ty0 = ((lid / tiles_x) % tiles_y) * TH;
   const int img = lid / (tiles_x * tiles_y);
@@ -1416,6 +1433,7 @@ int launch_conv_h2_wp(CArgs& g, int N, hipStream_t s) {
   const long long tiles = (long long)N * naws_cdiv(g.H, 8) * naws_cdiv(g.W, 32) * g.tiles_n;
   if (tiles > 0x7fffffffLL) return NAWS_ERR_UNSUPPORTED;
   const size_t lds = (size_t)2 * NPL * 2 * NawsWpGeom<DIL>::A_HALF;
+  g.N_img = N;
   auto kern = conv_h2_wp_kernel<WR, WC, DIL, PIPE, NPL>;
   if (naws_allow_lds(kern) != NAWS_OK) return NAWS_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, g);
