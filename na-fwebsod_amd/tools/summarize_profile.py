@@ -76,8 +76,9 @@ def short(name):
 
 def template_match(prefix, kernel_name):
     """True when `kernel_name` is an instance of the template prefix: the prefix must be followed
-    by `,` (more template arguments), `>` (none) or `(` (the kernel is not a template)."""
-    return re.search(re.escape(prefix) + r'\s*[,>(]', kernel_name) is not None
+    by `,` (more template arguments), `>` (none), `(` (the kernel is not a template) or `<` (the prefix
+    is a bare template name)."""
+    return re.search(re.escape(prefix) + r'\s*[,>(<]', kernel_name) is not None
 
 
 def _find(d, pat):
