@@ -567,3 +567,29 @@ def test_per_image_pooling_on_the_conv_streams_is_bit_identical(dev):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert torch.isfinite(res[0][2]).all()
+
+
+def test_default_plan_runs_winograd4_on_the_512_channel_layers_and_f2_agrees(dev):
+    """The default plan's conv forms (engine.set_conv_blobs): conv4_1 .. conv5_3 carry the 36-frequency
+    planes of Winograd F(4x4,3x3) (csrc/winograd4.hip), conv3_x the F(2x2) planes + the direct kernel's
+    (chosen per input size), conv1_2 .. conv2_2 the direct kernel's; WINO_F4_MIN_CIN = 0 brings the
+    F(2x2) plan of rounds 1-5 back, and the two conv bodies agree to 1e-5 of max|conv5_3|."""
+    from naws_hip import ops
+    from naws_hip.engine import WsddnEngine
+    eng, mb, blobs = _setup(dev, mfma_dtype='fp16x2')
+    for name in ('conv4_1', 'conv4_2', 'conv4_3', 'conv5_1', 'conv5_2', 'conv5_3'):
+        wp = eng.conv[name][0]
+        assert isinstance(wp, ops.F16x2) and wp.planes.dim() == 5 and wp.planes.shape[1] == 36, name
+        assert name not in eng.conv_direct_h2
+    for name in ('conv3_2', 'conv3_3'):
+        assert eng.conv[name][0].planes.shape[1] == 16 and name in eng.conv_direct_h2
+    for name in ('conv1_2', 'conv2_1', 'conv2_2'):
+        assert eng.conv[name][0].planes.dim() == 4
+    data = torch.from_numpy(mb['data']).to(dev)
+    y4 = eng.conv_body(data).clone()
+    eng2 = WsddnEngine(21, dev, dropout=0.5, gpu_num=2, seed=11, mfma_dtype='fp16x2')
+    eng2.WINO_F4_MIN_CIN = 0
+    eng2.set_conv_blobs(blobs)
+    assert eng2.conv['conv4_2'][0].planes.shape[1] == 16
+    y2 = eng2.conv_body(data)
+    assert float((y4 - y2).abs().max()) <= 1e-5 * float(y2.abs().max())
